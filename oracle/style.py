@@ -1,0 +1,195 @@
+"""ORACLE (test infrastructure, NOT product code): fp32 PyTorch-CPU restatement of the
+style path — set-ViT encoder (sViT), aggregation blocks, and the layout SpatialRescaler.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+
+Reference lines followed (all under /root/reference/):
+  networks/vit_set.py:84-107    SPT: channel-stack the set, 8x8 patches '(p1 p2 c)', LayerNorm, Linear
+  networks/vit_set.py:35-67     LSA: qkv (no bias) chunks [q,k,v] each '(h d)'; logits * exp(temperature);
+                                diagonal masked to -finfo.max; softmax; out proj with bias
+  networks/vit_set.py:14-33, 69-82  PreNorm, FeedForward (exact GELU), Transformer (attn + x; ff + x)
+  networks/vit_set.py:165-208   sViT.forward (cls token, zero time token, pos emb, pool, mlp_head)
+  networks/agg_blocks.py:24-33, 45-54, 66-75, 85-86  Agg_Linear / Agg_Max / Agg_Mean / Agg_None
+  ldm/modules/encoders/modules.py:123-130  SpatialRescaler.forward
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+Params = Dict[str, torch.Tensor]
+
+
+@dataclass
+class SViTConfig:
+    """conf/style_agg/svit.yaml + networks/s_zss_dm.py:31-38."""
+    image_size: int = 512
+    patch_size: int = 8
+    num_classes: int = 512
+    dim: int = 256
+    depth: int = 6
+    heads: int = 12
+    mlp_dim: int = 256
+    pool: str = "mean"
+    channels: int = 3
+    dim_head: int = 64
+    ns: int = 1
+    t_dim: int = 256
+
+
+def svit_shapes(cfg: SViTConfig) -> Dict[str, tuple]:
+    """State-dict names/shapes of the reference sViT (vit_set.py:113-143)."""
+    S: Dict[str, tuple] = {}
+    n_patches = (cfg.image_size // cfg.patch_size) ** 2
+    patch_dim = cfg.patch_size * cfg.patch_size * cfg.ns * cfg.channels
+    inner = cfg.heads * cfg.dim_head
+    S["pos_embedding"] = (1, n_patches + 2, cfg.dim)
+    S["cls_token"] = (1, 1, cfg.dim)
+    S["to_patch_embedding.to_patch_tokens.1.weight"] = (patch_dim,)
+    S["to_patch_embedding.to_patch_tokens.1.bias"] = (patch_dim,)
+    S["to_patch_embedding.to_patch_tokens.2.weight"] = (cfg.dim, patch_dim)
+    S["to_patch_embedding.to_patch_tokens.2.bias"] = (cfg.dim,)
+    for l in range(cfg.depth):
+        a = f"transformer.layers.{l}.0."
+        f = f"transformer.layers.{l}.1."
+        S[a + "norm.weight"] = (cfg.dim,)
+        S[a + "norm.bias"] = (cfg.dim,)
+        S[a + "fn.temperature"] = ()
+        S[a + "fn.to_qkv.weight"] = (inner * 3, cfg.dim)
+        S[a + "fn.to_out.0.weight"] = (cfg.dim, inner)
+        S[a + "fn.to_out.0.bias"] = (cfg.dim,)
+        S[f + "norm.weight"] = (cfg.dim,)
+        S[f + "norm.bias"] = (cfg.dim,)
+        S[f + "fn.net.0.weight"] = (cfg.mlp_dim, cfg.dim)
+        S[f + "fn.net.0.bias"] = (cfg.mlp_dim,)
+        S[f + "fn.net.3.weight"] = (cfg.dim, cfg.mlp_dim)
+        S[f + "fn.net.3.bias"] = (cfg.dim,)
+    S["mlp_head.0.weight"] = (cfg.dim,)
+    S["mlp_head.0.bias"] = (cfg.dim,)
+    S["mlp_head.1.weight"] = (cfg.num_classes, cfg.dim)
+    S["mlp_head.1.bias"] = (cfg.num_classes,)
+    S["to_time_embedding.weight"] = (cfg.dim, cfg.t_dim)
+    S["to_time_embedding.bias"] = (cfg.dim,)
+    return S
+
+
+def spt(P: Params, cfg: SViTConfig, x_set: torch.Tensor) -> torch.Tensor:
+    """vit_set.py:98-107 + :92-96. x_set [B, ns, 3, H, W] -> tokens [B, (H/p)(W/p), dim].
+    Stacked channel = c*ns + s; patch feature index = (p1*p + p2)*(3*ns) + channel."""
+    bs, ns, ch, H, W = x_set.shape
+    p = cfg.patch_size
+    x = x_set.permute(0, 2, 1, 3, 4).reshape(bs, ch * ns, H, W)
+    C = ch * ns
+    x = x.reshape(bs, C, H // p, p, W // p, p).permute(0, 2, 4, 3, 5, 1).reshape(bs, (H // p) * (W // p), p * p * C)
+    pre = "to_patch_embedding.to_patch_tokens."
+    x = F.layer_norm(x, (p * p * C,), P[pre + "1.weight"], P[pre + "1.bias"])
+    return F.linear(x, P[pre + "2.weight"], P[pre + "2.bias"])
+
+
+def lsa(P: Params, pre: str, x: torch.Tensor, heads: int) -> torch.Tensor:
+    """vit_set.py:52-67."""
+    b, n, _ = x.shape
+    qkv = F.linear(x, P[pre + "to_qkv.weight"])
+    inner = qkv.shape[-1] // 3
+    d = inner // heads
+    q, k, v = (t.reshape(b, n, heads, d).permute(0, 2, 1, 3) for t in qkv.chunk(3, dim=-1))
+    dots = torch.matmul(q, k.transpose(-1, -2)) * P[pre + "temperature"].exp()
+    eye = torch.eye(n, dtype=torch.bool)
+    dots = dots.masked_fill(eye, -torch.finfo(dots.dtype).max)
+    attn = dots.softmax(dim=-1)
+    out = torch.matmul(attn, v).permute(0, 2, 1, 3).reshape(b, n, inner)
+    return F.linear(out, P[pre + "to_out.0.weight"], P[pre + "to_out.0.bias"])
+
+
+def transformer(P: Params, cfg: SViTConfig, x: torch.Tensor) -> torch.Tensor:
+    """vit_set.py:78-82 (dropout inactive in eval)."""
+    for l in range(cfg.depth):
+        a = f"transformer.layers.{l}.0."
+        f = f"transformer.layers.{l}.1."
+        h = F.layer_norm(x, (cfg.dim,), P[a + "norm.weight"], P[a + "norm.bias"])
+        x = lsa(P, a + "fn.", h, cfg.heads) + x
+        h = F.layer_norm(x, (cfg.dim,), P[f + "norm.weight"], P[f + "norm.bias"])
+        h = F.linear(h, P[f + "fn.net.0.weight"], P[f + "fn.net.0.bias"])
+        h = F.gelu(h)
+        h = F.linear(h, P[f + "fn.net.3.weight"], P[f + "fn.net.3.bias"])
+        x = h + x
+    return x
+
+
+@torch.no_grad()
+def svit_forward(P: Params, cfg: SViTConfig, img: torch.Tensor) -> torch.Tensor:
+    """vit_set.py:165-208 with t_emb=None, c_old=None, eval mode. img [B, ns, H, W, 3] (NHWC per image)."""
+    img = img.permute(0, 1, 4, 2, 3)
+    patches = spt(P, cfg, img)
+    b, n, dim = patches.shape
+    cls = P["cls_token"].expand(b, -1, -1)
+    t_tok = torch.zeros(b, 1, dim)
+    x = torch.cat((cls, t_tok, patches), dim=1)
+    x = x + P["pos_embedding"][:, : n + 2]
+    xs = transformer(P, cfg, x)
+    if cfg.pool == "mean":
+        x = xs.mean(dim=1)
+    elif cfg.pool == "sum":
+        x = xs.sum(dim=1)
+    elif cfg.pool == "cls":
+        x = xs[:, 0]
+    else:
+        x = xs
+    x = F.layer_norm(x, (cfg.dim,), P["mlp_head.0.weight"], P["mlp_head.0.bias"])
+    return F.linear(x, P["mlp_head.1.weight"], P["mlp_head.1.bias"])
+
+
+# ------------------------------------------------------------------------------ aggregation blocks
+def _embed(style_imgs: torch.Tensor, embedder: Callable) -> torch.Tensor:
+    """'b n h w c -> (b n) c h w' then embedder -> [(b n), f]."""
+    b, n, h, w, c = style_imgs.shape
+    x = style_imgs.permute(0, 1, 4, 2, 3).reshape(b * n, c, h, w)
+    return embedder(x)
+
+
+@torch.no_grad()
+def agg_mean(style_imgs, embedder):
+    """agg_blocks.py:66-75."""
+    b = style_imgs.shape[0]
+    f = _embed(style_imgs, embedder)
+    return f.reshape(b, -1, f.shape[-1]).mean(dim=1)
+
+
+@torch.no_grad()
+def agg_max(style_imgs, embedder):
+    """agg_blocks.py:45-54."""
+    b = style_imgs.shape[0]
+    f = _embed(style_imgs, embedder)
+    return f.reshape(b, -1, f.shape[-1]).max(dim=1)[0]
+
+
+@torch.no_grad()
+def agg_linear(P: Params, style_imgs, embedder, pre: str = "linear_block."):
+    """agg_blocks.py:24-33 — '(b1 n) f -> b1 (n f)' then ReLU, Linear(512n,512), ReLU, Linear(512,512), ReLU."""
+    b = style_imgs.shape[0]
+    f = _embed(style_imgs, embedder).reshape(b, -1)
+    h = F.relu(f)
+    h = F.relu(F.linear(h, P[pre + "1.weight"], P[pre + "1.bias"]))
+    return F.relu(F.linear(h, P[pre + "3.weight"], P[pre + "3.bias"]))
+
+
+@torch.no_grad()
+def agg_none(style_imgs):
+    """agg_blocks.py:85-86."""
+    return torch.zeros((style_imgs.shape[0], 512), dtype=style_imgs.dtype)
+
+
+# ------------------------------------------------------------------------------ layout conditioner
+@torch.no_grad()
+def spatial_rescaler(x: torch.Tensor, channel_mapper_weight: Optional[torch.Tensor], n_stages: int = 2,
+                     multiplier: float = 0.5, method: str = "bilinear") -> torch.Tensor:
+    """encoders/modules.py:123-130 — n_stages x interpolate(scale_factor) then bias-free 1x1 conv.
+    Shipped config (conf/diffusion/cond_stage_config/spatial.yaml): n_stages 2, bilinear, 0.5, 2 -> 3 channels."""
+    for _ in range(n_stages):
+        x = F.interpolate(x, scale_factor=multiplier, mode=method)
+    if channel_mapper_weight is not None:
+        x = F.conv2d(x, channel_mapper_weight)
+    return x
