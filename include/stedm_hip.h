@@ -1,0 +1,139 @@
+/*
+ * stedm_hip.h — C ABI of libstedm_hip.so, the MI355X (gfx950) implementation of STEDM's
+ * denoising hot path.
+ *
+ * The reference (OettlM/STEDM) has no FFI: its hot path is a sequence of stock PyTorch ops
+ * behind Python classes. Each entry point below therefore replaces a *PyTorch op
+ * sequence* of the reference, cited as file:line under /root/reference/. The host side
+ * (the stedm_amd python package) mirrors the reference's module surface (UNetModel, DDIMSampler, sViT, Agg_*)
+ * and binds these symbols with ctypes; see INTEGRATION.md for the stub.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; stedm_last_error() gives the text
+ *     (thread-local). Nothing is allocated for the caller; all buffers are caller-owned DEVICE
+ *     pointers unless a parameter is documented as host.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream). All launches are
+ *     asynchronous on that stream and are hipGraph-capturable (no allocation / sync inside).
+ *   - activations inside the U-Net are NHWC fp32: x[b][y][x][c]. The two I/O convs translate
+ *     from/to the reference's NCHW at the boundary.
+ *   - "mm dtype" selects the MFMA operand format: STEDM_F16 / STEDM_BF16; "npass" 1 = single
+ *     product, 3 = split-precision (hi*hi + hi*lo + lo*hi) used for fp32-parity.
+ */
+#ifndef STEDM_HIP_H
+#define STEDM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STEDM_ABI_VERSION 1
+
+#define STEDM_F16 0
+#define STEDM_BF16 1
+
+/* conv geometry modes */
+#define STEDM_CONV_S1 0   /* 3x3 (or 1x1) stride 1, pad ks/2                                  */
+#define STEDM_CONV_DOWN 1 /* 3x3 stride 2 pad 1 : Downsample.op       openaimodel.py:156-173  */
+#define STEDM_CONV_UP 2   /* nearest x2 then 3x3 pad 1 : Upsample      openaimodel.py:122-132  */
+
+int stedm_abi_version(void);
+const char* stedm_last_error(void);
+/* number of CUs of the current device (host query; used for launch heuristics / tests) */
+int stedm_device_cus(void);
+
+/* ---- weight packing (one-time, at load) -------------------------------------------------- */
+/* OIHW fp32 conv weight [cout][cin][ks][ks] -> MFMA operand planes [cout][ks*ks][cin] (16-bit).
+ * w_lo may be NULL (single-pass only). Replaces nothing in the reference (layout change only). */
+int stedm_pack_conv_weight(const float* w_oihw, void* w_hi, void* w_lo, int cout, int cin, int ks,
+                           int mm_dtype, void* stream);
+/* [rows][cols] fp32 -> [cols][rows] fp32 (Linear weights are consumed K-major). */
+int stedm_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
+
+/* ---- GroupNorm statistics -> per-(sample, channel) affine ---------------------------------- */
+/* GroupNorm32 / normalization(): util.py:199-216 (32 groups, biased variance, fp32, eps 1e-5);
+ * attention.py:76-77 uses eps 1e-6. Input is the *virtual channel concat* [x1 | x2] of two NHWC
+ * tensors (x2 may be NULL, c2 = 0), which removes th.cat([h, hs.pop()], 1) openaimodel.py:800.
+ * x2 is indexed with batch (b % x2_bmod) when x2_bmod > 0 (shared encoder skips under CFG).
+ * Writes scale[b][c] = rstd*gamma[c], shift[b][c] = beta[c] - mean*rstd*gamma[c], c in [0,c1+c2). */
+int stedm_gn_scale_shift(const float* x1, int c1, const float* x2, int c2, int x2_bmod,
+                         const float* gamma, const float* beta, float eps, int groups, int B, int HW,
+                         float* scale, float* shift, void* stream);
+
+/* ---- fused implicit-GEMM convolution on MFMA ----------------------------------------------- */
+typedef struct stedm_conv_args {
+  const float* src1; /* NHWC [B][Hin][Win][c1]                                                 */
+  const float* src2; /* NHWC [B or x2_bmod][Hin][Win][c2] or NULL : concat-free second source  */
+  int32_t c1, c2, src2_bmod;
+  int32_t B, Hin, Win;
+  int32_t mode;      /* STEDM_CONV_*                                                           */
+  int32_t ks;        /* 1 or 3                                                                 */
+  const float* scale; /* [B][c1+c2] or NULL : GroupNorm apply fused into the A-tile load       */
+  const float* shift;
+  int32_t act;       /* 0 none, 1 SiLU (after the affine)                                      */
+  const void* w_hi;  /* packed [cout][ks*ks][c1+c2] 16-bit                                     */
+  const void* w_lo;  /* low plane (npass == 3) or NULL                                         */
+  const float* bias; /* [cout] or NULL                                                         */
+  const float* emb;  /* [*][cout] or NULL : h += emb[b*emb_bstride + n]  openaimodel.py:277-286 */
+  int32_t emb_bstride;
+  const float* res;  /* NHWC [B][Hout][Wout][cout] or NULL : residual add  openaimodel.py:288   */
+  float* out;        /* NHWC [B][Hout][Wout][cout]                                             */
+  int32_t cout;
+  int32_t npass;     /* 1 or 3                                                                 */
+  int32_t mm_dtype;  /* STEDM_F16 / STEDM_BF16                                                 */
+} stedm_conv_args;
+/* Replaces: GN->SiLU->conv3x3(+bias)(+emb)(+skip) of ResBlock._forward openaimodel.py:268-288,
+ * Downsample/Upsample convs (:122-132,:156-173), 1x1 skip_connection (:254), and the 1x1
+ * Conv1d qkv / proj_out of AttentionBlock (:326,:334,:343-346). */
+int stedm_conv_igemm(const stedm_conv_args* args, void* stream);
+
+/* ---- boundary convs (NCHW <-> NHWC) ------------------------------------------------------- */
+/* input_blocks.0: conv3x3(cat([x, c_concat],1)) — DiffusionWrapper hybrid ddpm.py:1414-1417 +
+ * openaimodel.py:542. x1 NCHW [B][c1][H][W], x2 NCHW [B or bmod][c2][H][W] (may be NULL);
+ * w OIHW fp32 [cout][c1+c2][3][3]; out NHWC [B][H][W][cout]. Exact fp32 FMA. */
+int stedm_conv_in(const float* x1, int c1, const float* x2, int c2, int x2_bmod, const float* w_oihw,
+                  const float* bias, float* out, int B, int H, int W, int cout, void* stream);
+/* out: GN->SiLU->conv3x3 to out_channels openaimodel.py:729-733, 806. src NHWC [B][H][W][c];
+ * scale/shift from stedm_gn_scale_shift; w OIHW fp32 [cout][c][3][3]; out NCHW [B][cout][H][W]. */
+int stedm_conv_out(const float* src, int c, const float* scale, const float* shift, const float* w_oihw,
+                   const float* bias, float* out, int B, int H, int W, int cout, void* stream);
+
+/* ---- embedding path ---------------------------------------------------------------------- */
+/* timestep_embedding util.py:151-171 + time_embed openaimodel.py:529-534,774-775.
+ * t int64 [B]; freqs fp32 [mc/2] (host-built table, uploaded once); w0t [mc][ted], w2t [ted][ted]
+ * are TRANSPOSED Linear weights; emb [B][ted]. */
+int stedm_time_embed(const int64_t* t, const float* freqs, const float* w0t, const float* b0,
+                     const float* w2t, const float* b2, float* emb, int B, int mc, int ted, void* stream);
+/* emb_layers = SiLU -> Linear of every ResBlock at once (openaimodel.py:231-237,277):
+ * out[b][n] = bias[n] + sum_k silu(emb[b][k]) * wt[k][n]; wt is [k][ntot] (layers concatenated). */
+int stedm_emb_proj(const float* emb, const float* wt, const float* bias, float* out, int B, int k, int ntot,
+                   void* stream);
+
+/* ---- middle attention (QKVAttentionLegacy) -------------------------------------------------- */
+/* openaimodel.py:378-394. qkv [B][T][heads*3*ch] with channel = h*3*ch + {q:0,k:ch,v:2ch} + c;
+ * out [B][T][heads*ch]; scale ch^-1/4 on q and k, softmax in fp32. */
+int stedm_attn_legacy(const float* qkv, float* out, int B, int T, int heads, int ch, void* stream);
+
+/* ---- DDIM update with rescaled classifier-free guidance ----------------------------------- */
+/* ddim.py:179-184 (CFG + std rescale over dims (C,H), unbiased) and :195-210 (x0 / dir / noise).
+ * x, e_c, e_u, noise, x_prev, pred_x0: NCHW fp32 [B][C][H][W]. e_u NULL => no guidance.
+ * coefs: DEVICE table [nsteps][4] = {a_t, a_prev, sigma_t, sqrt(1-a_t)}; step_idx: DEVICE int
+ * (NULL => row 0) so that a captured graph can be replayed for every step. noise may be NULL
+ * (sigma*noise == 0). pred_x0 may be NULL. x_prev may alias x. */
+int stedm_ddim_step(const float* x, const float* e_c, const float* e_u, const float* noise,
+                    const float* coefs, const int32_t* step_idx, float cfg_scale, float rescale_phi,
+                    float* x_prev, float* pred_x0, int B, int C, int H, int W, void* stream);
+/* *step_idx += delta (device-side loop counter for graph replay). */
+int stedm_step_advance(int32_t* step_idx, int delta, void* stream);
+
+/* ---- HIP graph capture helpers (plumbing for the sampling loop) ---------------------------- */
+int stedm_graph_begin(void* stream);
+int stedm_graph_end(void* stream, void** graph_exec_out);
+int stedm_graph_launch(void* graph_exec, void* stream);
+int stedm_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STEDM_HIP_H */

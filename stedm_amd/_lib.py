@@ -1,0 +1,89 @@
+"""ctypes binding of libstedm_hip.so (the C ABI declared in include/stedm_hip.h).
+
+The library is the product: there is NO fallback. If it is missing or a call fails, an
+exception is raised (`StedmHipError`)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstedm_hip.so")
+
+ABI_VERSION = 1
+F16, BF16 = 0, 1
+CONV_S1, CONV_DOWN, CONV_UP = 0, 1, 2
+
+
+class StedmHipError(RuntimeError):
+    pass
+
+
+class ConvArgs(C.Structure):
+    """struct stedm_conv_args (include/stedm_hip.h)."""
+    _fields_ = [
+        ("src1", C.c_void_p), ("src2", C.c_void_p),
+        ("c1", C.c_int32), ("c2", C.c_int32), ("src2_bmod", C.c_int32),
+        ("B", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32),
+        ("mode", C.c_int32), ("ks", C.c_int32),
+        ("scale", C.c_void_p), ("shift", C.c_void_p),
+        ("act", C.c_int32),
+        ("w_hi", C.c_void_p), ("w_lo", C.c_void_p), ("bias", C.c_void_p),
+        ("emb", C.c_void_p), ("emb_bstride", C.c_int32),
+        ("res", C.c_void_p), ("out", C.c_void_p),
+        ("cout", C.c_int32), ("npass", C.c_int32), ("mm_dtype", C.c_int32),
+    ]
+
+
+_P, _I, _F = C.c_void_p, C.c_int, C.c_float
+# symbol -> (restype, argtypes); must list EVERY symbol of include/stedm_hip.h (tests/test_abi.py checks)
+SIGNATURES = {
+    "stedm_abi_version": (_I, []),
+    "stedm_last_error": (C.c_char_p, []),
+    "stedm_device_cus": (_I, []),
+    "stedm_pack_conv_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "stedm_transpose_f32": (_I, [_P, _P, _I, _I, _P]),
+    "stedm_gn_scale_shift": (_I, [_P, _I, _P, _I, _I, _P, _P, _F, _I, _I, _I, _P, _P, _P]),
+    "stedm_conv_igemm": (_I, [C.POINTER(ConvArgs), _P]),
+    "stedm_conv_in": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "stedm_conv_out": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "stedm_time_embed": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "stedm_emb_proj": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "stedm_attn_legacy": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "stedm_ddim_step": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _I, _I, _I, _I, _P]),
+    "stedm_step_advance": (_I, [_P, _I, _P]),
+    "stedm_graph_begin": (_I, [_P]),
+    "stedm_graph_end": (_I, [_P, C.POINTER(C.c_void_p)]),
+    "stedm_graph_launch": (_I, [_P, _P]),
+    "stedm_graph_destroy": (_I, [_P]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raises StedmHipError if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise StedmHipError(
+                f"{LIB_PATH} not found: build it with `python -m stedm_amd.build` "
+                "(there is no CPU / PyTorch fallback for the hot path)")
+        try:
+            L = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise StedmHipError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.stedm_abi_version() != ABI_VERSION:
+            raise StedmHipError(f"ABI mismatch: library {L.stedm_abi_version()} != binding {ABI_VERSION}")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().stedm_last_error().decode(errors="replace")
+        raise StedmHipError(f"{what} failed (rc={rc}): {msg}")

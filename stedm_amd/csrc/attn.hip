@@ -1,0 +1,169 @@
+// QKVAttentionLegacy (openaimodel.py:378-394) as a flash-style fp32 kernel: never materialises
+// the [T][T] weights. qkv is [B][T][heads*3*ch] (token-major, the NHWC view of the reference's
+// [B][3C][T]) with channel = h*3*ch + {q:0, k:ch, v:2*ch} + c. Softmax runs in fp32 exactly as the
+// reference's `softmax(weight.float())`; q and k are each scaled by ch^-1/4 before the product.
+//
+// v1: VALU fp32 (the U-Net's middle attention is 0.03 % of the forward's FLOPs at 32x32 latents);
+// one 256-thread block per (sample*head, 64-query tile); K/V tiles of 64 keys streamed through LDS.
+#include "common.hpp"
+using namespace stedm;
+
+constexpr int AT = 64;  // query rows per block == keys per tile
+
+__global__ void __launch_bounds__(256) attn_legacy_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T,
+                                                          int heads, int ch, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float smf[];
+  const int LD = ch + 4;       // row stride (floats), keeps 16-B alignment
+  float* Qs = smf;             // [AT][LD]
+  float* Ks = Qs + AT * LD;    // [AT][LD]
+  float* Vs = Ks + AT * LD;    // [AT][LD]
+  float* Ps = Vs + AT * LD;    // [AT][AT+4]
+  constexpr int PLD = AT + 4;
+
+  const int bh = blockIdx.x, b = bh / heads, hd = bh % heads;
+  const int q0 = blockIdx.y * AT;
+  const int C3 = heads * 3 * ch, C = heads * ch;
+  const float* base = qkv + (long)b * T * C3 + hd * 3 * ch;
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int c4n = ch >> 2;
+
+  for (int i = tid; i < AT * c4n; i += 256) {
+    const int row = i / c4n, c4 = i - row * c4n;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q0 + row < T) {
+      v = *reinterpret_cast<const float4*>(base + (long)(q0 + row) * C3 + c4 * 4);
+      v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+    }
+    *reinterpret_cast<float4*>(Qs + row * LD + c4 * 4) = v;
+  }
+
+  float m_run[4], l_run[4];
+  float4 o[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    m_run[i] = -INFINITY;
+    l_run[i] = 0.f;
+    o[i][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    o[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  for (int k0 = 0; k0 < T; k0 += AT) {
+    __syncthreads();  // previous tile fully consumed (also covers the Q stores on the first pass)
+    for (int i = tid; i < AT * c4n; i += 256) {
+      const int row = i / c4n, c4 = i - row * c4n;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (k0 + row < T) {
+        const float* pr = base + (long)(k0 + row) * C3 + c4 * 4;
+        kv = *reinterpret_cast<const float4*>(pr + ch);
+        vv = *reinterpret_cast<const float4*>(pr + 2 * ch);
+        kv.x *= scale; kv.y *= scale; kv.z *= scale; kv.w *= scale;
+      }
+      *reinterpret_cast<float4*>(Ks + row * LD + c4 * 4) = kv;
+      *reinterpret_cast<float4*>(Vs + row * LD + c4 * 4) = vv;
+    }
+    __syncthreads();
+
+    // S = Q K^T : thread owns rows ty*4+i, cols tx*4+j
+    float s[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[i][j] = 0.f;
+    for (int c = 0; c < ch; c += 4) {
+      float4 qv[4], kv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) qv[i] = *reinterpret_cast<const float4*>(Qs + (ty * 4 + i) * LD + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) kv[j] = *reinterpret_cast<const float4*>(Ks + (tx * 4 + j) * LD + c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s[i][j] = fmaf(qv[i].x, kv[j].x, s[i][j]);
+          s[i][j] = fmaf(qv[i].y, kv[j].y, s[i][j]);
+          s[i][j] = fmaf(qv[i].z, kv[j].z, s[i][j]);
+          s[i][j] = fmaf(qv[i].w, kv[j].w, s[i][j]);
+        }
+    }
+    // online softmax (row statistics shared by the 16 lanes with equal ty)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (k0 + tx * 4 + j >= T) s[i][j] = -INFINITY;
+        mx = fmaxf(mx, s[i][j]);
+      }
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+      const float m_new = fmaxf(m_run[i], mx);
+      const float alpha = __expf(m_run[i] - m_new);  // exp(-inf) = 0 on the first tile
+      float rs = 0.f;
+      float4 pv;
+      pv.x = __expf(s[i][0] - m_new); pv.y = __expf(s[i][1] - m_new);
+      pv.z = __expf(s[i][2] - m_new); pv.w = __expf(s[i][3] - m_new);
+      rs = (pv.x + pv.y) + (pv.z + pv.w);
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) rs += __shfl_xor(rs, d, 64);
+      l_run[i] = l_run[i] * alpha + rs;
+      m_run[i] = m_new;
+      o[i][0].x *= alpha; o[i][0].y *= alpha; o[i][0].z *= alpha; o[i][0].w *= alpha;
+      o[i][1].x *= alpha; o[i][1].y *= alpha; o[i][1].z *= alpha; o[i][1].w *= alpha;
+      *reinterpret_cast<float4*>(Ps + (ty * 4 + i) * PLD + tx * 4) = pv;
+    }
+    __syncthreads();
+    // O += P V : thread owns rows ty*4+i, channel quads tx + 16*jj
+    for (int sidx = 0; sidx < AT; sidx += 4) {
+      float4 pr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pr[i] = *reinterpret_cast<const float4*>(Ps + (ty * 4 + i) * PLD + sidx);
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int c4 = tx + 16 * jj;
+        if (c4 < c4n) {
+          const float4 v0 = *reinterpret_cast<const float4*>(Vs + (sidx + 0) * LD + c4 * 4);
+          const float4 v1 = *reinterpret_cast<const float4*>(Vs + (sidx + 1) * LD + c4 * 4);
+          const float4 v2 = *reinterpret_cast<const float4*>(Vs + (sidx + 2) * LD + c4 * 4);
+          const float4 v3 = *reinterpret_cast<const float4*>(Vs + (sidx + 3) * LD + c4 * 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float4& a = o[i][jj];
+            a.x = fmaf(pr[i].x, v0.x, a.x); a.y = fmaf(pr[i].x, v0.y, a.y); a.z = fmaf(pr[i].x, v0.z, a.z); a.w = fmaf(pr[i].x, v0.w, a.w);
+            a.x = fmaf(pr[i].y, v1.x, a.x); a.y = fmaf(pr[i].y, v1.y, a.y); a.z = fmaf(pr[i].y, v1.z, a.z); a.w = fmaf(pr[i].y, v1.w, a.w);
+            a.x = fmaf(pr[i].z, v2.x, a.x); a.y = fmaf(pr[i].z, v2.y, a.y); a.z = fmaf(pr[i].z, v2.z, a.z); a.w = fmaf(pr[i].z, v2.w, a.w);
+            a.x = fmaf(pr[i].w, v3.x, a.x); a.y = fmaf(pr[i].w, v3.y, a.y); a.z = fmaf(pr[i].w, v3.z, a.z); a.w = fmaf(pr[i].w, v3.w, a.w);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = q0 + ty * 4 + i;
+    if (t >= T) continue;
+    const float inv = 1.0f / l_run[i];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int c4 = tx + 16 * jj;
+      if (c4 < c4n) {
+        float4 v = o[i][jj];
+        v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+        *reinterpret_cast<float4*>(out + ((long)b * T + t) * C + hd * ch + c4 * 4) = v;
+      }
+    }
+  }
+}
+
+extern "C" int stedm_attn_legacy(const float* qkv, float* out, int B, int T, int heads, int ch, void* stream) {
+  STEDM_CHECK_ARG(qkv && out, "attn_legacy: null pointer");
+  STEDM_CHECK_ARG(B > 0 && T > 0 && heads > 0, "attn_legacy: bad sizes");
+  STEDM_CHECK_ARG(ch % 4 == 0 && ch >= 4 && ch <= 128, "attn_legacy: head width %d unsupported (need ch %% 4 == 0, ch <= 128)", ch);
+  const size_t lds = ((size_t)3 * AT * (ch + 4) + (size_t)AT * (AT + 4)) * sizeof(float);
+  if (lds > 64 * 1024)
+    STEDM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_legacy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const float scale = 1.0f / sqrtf(sqrtf((float)ch));
+  dim3 grid(B * heads, (T + AT - 1) / AT);
+  attn_legacy_kernel<<<grid, 256, lds, as_stream(stream)>>>(qkv, out, T, heads, ch, scale);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}

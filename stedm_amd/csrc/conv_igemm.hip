@@ -1,0 +1,375 @@
+// Fused implicit-GEMM convolution for gfx950 (MFMA 32x32x16, 64-wide waves).
+//
+//   out[m][n] = sum_{tap, ci} A[m][tap][ci] * W[n][tap][ci] + bias[n] (+ emb[b][n]) (+ res[m][n])
+//   A[m][tap][ci] = act( scale[b][ci] * src[b][sy][sx][ci] + shift[b][ci] )   (0 outside the image)
+//
+// GEMM view: M = B*Hout*Wout output pixels, N = cout, K = taps * cin.
+// Data layout in HBM: activations NHWC fp32; weights pre-packed [cout][tap][cin] 16-bit (hi and,
+// for the split-precision parity mode, lo = w - hi).
+//
+// Tiling: one 256-thread workgroup (4 waves, 2x2) computes a 128(M) x 128(N) tile; each wave
+// owns 64x64 = 2x2 MFMA 32x32 accumulators. K is walked chunk-major: for each chunk of BKC
+// input channels the *haloed input patch* of the tile is staged ONCE in LDS — GroupNorm affine
+// + SiLU + fp32->16-bit (hi/lo) conversion applied on the way in — and all 9 taps read shifted
+// rows of that patch, so the activation is fetched and normalised once, not 9 times. Weight tiles
+// [128][BKC] per (chunk, tap) are double-buffered in LDS with register prefetch of the next one.
+// LDS rows are padded by 16 B so 16-B fragment reads of 16 consecutive rows hit distinct banks.
+//
+// The two sources src1|src2 implement the skip concat (openaimodel.py:800) without materialising
+// it: a K-chunk comes entirely from one of them (c1 % BKC == 0).
+#include "common.hpp"
+using namespace stedm;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, NTHREADS = 256;
+
+struct ConvParams {
+  stedm_conv_args a;
+  int M, Hout, Wout, HWout, Cin, taps;
+  int whole, nsamp, trows;  // tile geometry
+  int PRs, PW, NP;          // patch rows per sample, patch cols, patch positions
+  int tiles_m, tiles_n;
+};
+
+template <typename T>
+struct MM;
+template <>
+struct MM<_Float16> {
+  using V8 = f16x8;
+  using V4 = f16x4;
+  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct MM<__bf16> {
+  using V8 = bf16x8;
+  using V4 = bf16x4;
+  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <int BKC, int NPASS, typename T>
+__global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParams p) {
+  using V8 = typename MM<T>::V8;
+  using V4 = typename MM<T>::V4;
+  constexpr int AST = BKC * 2 + 16;  // bytes per patch position (padded)
+  constexpr int BST = BKC * 2 + 16;  // bytes per weight row (padded)
+  constexpr int NPL = NPASS == 3 ? 2 : 1;  // operand planes (hi, lo)
+  constexpr int QC = BKC / 4;        // float4 quads per position
+  constexpr int POSL = NTHREADS / QC;  // positions handled per sweep
+  constexpr int PCS = BKC / 8;       // 16-B pieces per weight row
+  constexpr int BPT = BN * PCS / NTHREADS;  // weight pieces per thread per plane
+  constexpr int KSTEPS = BKC / 16;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA = smem;                                  // [NPL][NP][AST]
+  const int a_plane = p.NP * AST;
+  unsigned char* sB = smem + NPL * a_plane;                  // [2][NPL][BN][BST]
+  constexpr int b_plane = BN * BST;
+
+  const stedm_conv_args& a = p.a;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const bool is1x1 = (a.ks == 1);
+
+  // ---- tile origin in (sample, row) space
+  int b0, yo0;
+  if (p.whole) {
+    b0 = tile_m * p.nsamp;
+    yo0 = 0;
+  } else {
+    b0 = m0 / p.HWout;
+    yo0 = (m0 - b0 * p.HWout) / p.Wout;
+  }
+  int srow0;
+  if (a.mode == STEDM_CONV_S1) srow0 = yo0 - 1;
+  else if (a.mode == STEDM_CONV_DOWN) srow0 = 2 * yo0 - 1;
+  else srow0 = (yo0 - 1) >> 1;
+
+  // ---- per-lane A fragment geometry (two 32-row subtiles per wave)
+  int f_s[2], f_yl[2], f_y[2], f_x[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int ml = wm * 64 + mi * 32 + r;
+    if (is1x1) {
+      f_s[mi] = 0; f_yl[mi] = 0; f_y[mi] = 0; f_x[mi] = ml;
+    } else if (p.whole) {
+      const int s = ml / p.HWout, rem = ml - s * p.HWout;
+      f_s[mi] = s; f_yl[mi] = rem / p.Wout; f_x[mi] = rem - f_yl[mi] * p.Wout; f_y[mi] = f_yl[mi];
+    } else {
+      f_s[mi] = 0; f_yl[mi] = ml / p.Wout; f_x[mi] = ml - f_yl[mi] * p.Wout; f_y[mi] = yo0 + f_yl[mi];
+    }
+  }
+  auto patch_index = [&](int mi, int dy, int dx) -> int {
+    if (is1x1) return f_x[mi];
+    int prow, pcol;
+    if (a.mode == STEDM_CONV_S1) { prow = f_yl[mi] + dy; pcol = f_x[mi] + dx; }
+    else if (a.mode == STEDM_CONV_DOWN) { prow = 2 * f_yl[mi] + dy; pcol = 2 * f_x[mi] + dx; }
+    else { prow = ((f_y[mi] + dy - 1) >> 1) - srow0; pcol = ((f_x[mi] + dx - 1) >> 1) + 1; }
+    return (f_s[mi] * p.PRs + prow) * p.PW + pcol;
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nchunks = p.Cin / BKC;
+  const int taps = p.taps;
+  const int nsteps = nchunks * taps;
+
+  // ---- weight tile prefetch registers
+  uint4 wreg[NPL][BPT];
+  auto load_w = [&](int step) {
+    const int chunk = step / taps, tap = step - chunk * taps;
+    const int c0 = chunk * BKC;
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) {
+      const int i = tid + j * NTHREADS;
+      const int row = i / PCS, pc = i - row * PCS;
+      const int n = n0 + row;
+      const long off = ((long)n * taps + tap) * p.Cin + c0 + pc * 8;  // in 16-bit elements
+      if (n < a.cout) {
+        wreg[0][j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.w_hi) + off);
+        if (NPL == 2) wreg[NPL - 1][j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.w_lo) + off);
+      } else {
+        wreg[0][j] = make_uint4(0, 0, 0, 0);
+        if (NPL == 2) wreg[NPL - 1][j] = make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) {
+      const int i = tid + j * NTHREADS;
+      const int row = i / PCS, pc = i - row * PCS;
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+        *reinterpret_cast<uint4*>(sB + (buf * NPL + pl) * b_plane + row * BST + pc * 16) = wreg[pl][j];
+    }
+  };
+
+  // ---- patch staging (GN affine + act + convert), one chunk of BKC channels
+  const int q = tid % QC, pl0 = tid / QC;
+  auto load_patch = [&](int chunk) {
+    const int c0 = chunk * BKC;
+    const float* src;
+    int Cs, cs, bmod;
+    if (c0 < a.c1) { src = a.src1; Cs = a.c1; cs = c0; bmod = 0; }
+    else { src = a.src2; Cs = a.c2; cs = c0 - a.c1; bmod = a.src2_bmod; }
+    const bool affine = a.scale != nullptr;
+    int cur_b = -1;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    // incremental (s, prow, pcol) decode of position pos = pl0 + it*POSL
+    int pcol = pl0, prow = 0, s = 0;
+    if (!is1x1) {
+      while (pcol >= p.PW) { pcol -= p.PW; if (++prow == p.PRs) { prow = 0; ++s; } }
+    }
+    for (int pos = pl0; pos < p.NP; pos += POSL) {
+      int b;
+      long goff;
+      bool valid;
+      if (is1x1) {
+        const int m = m0 + pos;
+        valid = m < p.M;
+        b = valid ? m / p.HWout : 0;
+        const int bs = bmod > 0 ? b % bmod : b;
+        goff = ((long)bs * p.HWout + (m - b * p.HWout)) * Cs + cs + q * 4;
+      } else {
+        b = b0 + s;
+        const int sy = srow0 + prow, sx = pcol - 1;
+        valid = (b < a.B) && (sy >= 0) && (sy < a.Hin) && (sx >= 0) && (sx < a.Win);
+        const int bs = bmod > 0 ? b % bmod : b;
+        goff = (((long)bs * a.Hin + sy) * a.Win + sx) * Cs + cs + q * 4;
+      }
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (valid) {
+        v = *reinterpret_cast<const float4*>(src + goff);
+        if (affine) {
+          if (b != cur_b) {
+            cur_b = b;
+            sc = *reinterpret_cast<const float4*>(a.scale + (long)b * p.Cin + c0 + q * 4);
+            sh = *reinterpret_cast<const float4*>(a.shift + (long)b * p.Cin + c0 + q * 4);
+          }
+          v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+          v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+        }
+        if (a.act == 1) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+      }
+      V4 hi;
+      hi[0] = (T)v.x; hi[1] = (T)v.y; hi[2] = (T)v.z; hi[3] = (T)v.w;
+      *reinterpret_cast<V4*>(sA + pos * AST + q * 8) = hi;
+      if (NPL == 2) {
+        V4 lo;
+        lo[0] = (T)(v.x - (float)hi[0]); lo[1] = (T)(v.y - (float)hi[1]);
+        lo[2] = (T)(v.z - (float)hi[2]); lo[3] = (T)(v.w - (float)hi[3]);
+        *reinterpret_cast<V4*>(sA + a_plane + pos * AST + q * 8) = lo;
+      }
+      if (!is1x1) {
+        pcol += POSL;
+        while (pcol >= p.PW) { pcol -= p.PW; if (++prow == p.PRs) { prow = 0; ++s; } }
+      }
+    }
+  };
+
+  // ---- main loop
+  load_w(0);
+  for (int step = 0; step < nsteps; ++step) {
+    const int chunk = step / taps, tap = step - chunk * taps;
+    const int buf = step & 1;
+    if (tap == 0) {
+      __syncthreads();  // all reads of the previous patch are done
+      load_patch(chunk);
+    }
+    store_w(buf);       // buffer `buf` was last read two steps ago (barrier of step-1 passed)
+    __syncthreads();
+    if (step + 1 < nsteps) load_w(step + 1);
+
+    const int dy = is1x1 ? 0 : tap / 3, dx = is1x1 ? 0 : tap - (tap / 3) * 3;
+    const unsigned char* pa0 = sA + patch_index(0, dy, dx) * AST + h * 16;
+    const unsigned char* pa1 = sA + patch_index(1, dy, dx) * AST + h * 16;
+    const unsigned char* pb0 = sB + (buf * NPL) * b_plane + (wn * 64 + r) * BST + h * 16;
+    const unsigned char* pb1 = pb0 + 32 * BST;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      V8 ah[2], bh[2];
+      ah[0] = *reinterpret_cast<const V8*>(pa0 + ks * 32);
+      ah[1] = *reinterpret_cast<const V8*>(pa1 + ks * 32);
+      bh[0] = *reinterpret_cast<const V8*>(pb0 + ks * 32);
+      bh[1] = *reinterpret_cast<const V8*>(pb1 + ks * 32);
+      if (NPASS == 3) {
+        V8 al[2], bl[2];
+        al[0] = *reinterpret_cast<const V8*>(pa0 + a_plane + ks * 32);
+        al[1] = *reinterpret_cast<const V8*>(pa1 + a_plane + ks * 32);
+        bl[0] = *reinterpret_cast<const V8*>(pb0 + b_plane + ks * 32);
+        bl[1] = *reinterpret_cast<const V8*>(pb1 + b_plane + ks * 32);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = MM<T>::mfma(al[i], bh[j], acc[i][j]);
+            acc[i][j] = MM<T>::mfma(ah[i], bl[j], acc[i][j]);
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = MM<T>::mfma(ah[i], bh[j], acc[i][j]);
+    }
+  }
+
+  // ---- epilogue: bias + emb broadcast + residual, NHWC store (lanes along N -> 128-B rows)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + r;
+    if (n >= a.cout) continue;
+    const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m >= p.M) continue;
+        float v = acc[i][j][e] + bv;
+        if (a.emb) v += a.emb[(long)(m / p.HWout) * a.emb_bstride + n];
+        const long o = (long)m * a.cout + n;
+        if (a.res) v += a.res[o];
+        a.out[o] = v;
+      }
+    }
+  }
+}
+
+template <int BKC, int NPASS, typename T>
+static int launch(const ConvParams& p, hipStream_t st) {
+  constexpr int AST = BKC * 2 + 16, BST = BKC * 2 + 16, NPL = NPASS == 3 ? 2 : 1;
+  const size_t lds = (size_t)NPL * p.NP * AST + (size_t)2 * NPL * BN * BST;
+  if (lds > 160 * 1024) {
+    set_error("conv_igemm: tile needs %zu B of LDS (> 160 KiB): Hin=%d Win=%d mode=%d", lds, p.a.Hin, p.a.Win, p.a.mode);
+    return 1;
+  }
+  auto k = conv_igemm_kernel<BKC, NPASS, T>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("conv_igemm: hipFuncSetAttribute(%zu) failed: %s", lds, hipGetErrorString(e));
+      return 2;
+    }
+  }
+  k<<<p.tiles_m * p.tiles_n, NTHREADS, lds, st>>>(p);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int stedm_conv_igemm(const stedm_conv_args* args, void* stream) {
+  STEDM_CHECK_ARG(args, "conv_igemm: null args");
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.a = *args;
+  const stedm_conv_args& a = p.a;
+  STEDM_CHECK_ARG(a.src1 && a.w_hi && a.out, "conv_igemm: null src1/w_hi/out");
+  STEDM_CHECK_ARG((a.src2 != nullptr) == (a.c2 > 0), "conv_igemm: src2/c2 mismatch");
+  STEDM_CHECK_ARG(a.ks == 1 || a.ks == 3, "conv_igemm: ks must be 1 or 3");
+  STEDM_CHECK_ARG(a.mode >= 0 && a.mode <= 2, "conv_igemm: bad mode %d", a.mode);
+  STEDM_CHECK_ARG(a.ks == 3 || a.mode == STEDM_CONV_S1, "conv_igemm: 1x1 supports stride 1 only");
+  STEDM_CHECK_ARG(a.npass == 1 || a.npass == 3, "conv_igemm: npass must be 1 or 3");
+  STEDM_CHECK_ARG(a.npass == 1 || a.w_lo, "conv_igemm: npass=3 needs w_lo");
+  STEDM_CHECK_ARG((a.scale != nullptr) == (a.shift != nullptr), "conv_igemm: scale/shift must come together");
+  STEDM_CHECK_ARG(a.B > 0 && a.Hin > 0 && a.Win > 0 && a.cout > 0, "conv_igemm: bad sizes");
+  p.Cin = a.c1 + a.c2;
+  p.taps = a.ks * a.ks;
+  if (a.mode == STEDM_CONV_DOWN) {
+    STEDM_CHECK_ARG(a.Hin % 2 == 0 && a.Win % 2 == 0, "conv_igemm: stride-2 needs even Hin/Win");
+    p.Hout = a.Hin / 2; p.Wout = a.Win / 2;
+  } else if (a.mode == STEDM_CONV_UP) {
+    p.Hout = a.Hin * 2; p.Wout = a.Win * 2;
+  } else {
+    p.Hout = a.Hin; p.Wout = a.Win;
+  }
+  p.HWout = p.Hout * p.Wout;
+  p.M = a.B * p.HWout;
+  const int bkc = (a.npass == 1 && p.Cin % 64 == 0 && (a.c2 == 0 || a.c1 % 64 == 0)) ? 64 : 32;
+  STEDM_CHECK_ARG(p.Cin % bkc == 0 && (a.c2 == 0 || a.c1 % bkc == 0),
+                  "conv_igemm: channel counts must be multiples of %d (c1=%d c2=%d)", bkc, a.c1, a.c2);
+  p.tiles_n = (a.cout + BN - 1) / BN;
+  p.tiles_m = (p.M + BM - 1) / BM;
+  if (a.ks == 1) {
+    p.whole = 0; p.nsamp = 1; p.trows = 0; p.PRs = 1; p.PW = BM; p.NP = BM;
+  } else {
+    if (p.HWout <= BM) {
+      STEDM_CHECK_ARG(BM % p.HWout == 0, "conv_igemm: Hout*Wout=%d must divide %d", p.HWout, BM);
+      p.whole = 1; p.nsamp = BM / p.HWout; p.trows = p.Hout;
+      p.tiles_m = (a.B + p.nsamp - 1) / p.nsamp;
+    } else {
+      STEDM_CHECK_ARG(BM % p.Wout == 0 && p.HWout % BM == 0,
+                      "conv_igemm: unsupported spatial shape %dx%d (need Wout | %d and %d | Hout*Wout)", p.Hout, p.Wout, BM, BM);
+      p.whole = 0; p.nsamp = 1; p.trows = BM / p.Wout;
+    }
+    if (a.mode == STEDM_CONV_S1) p.PRs = p.trows + 2;
+    else if (a.mode == STEDM_CONV_DOWN) p.PRs = 2 * p.trows + 1;
+    else p.PRs = (p.trows + 1) / 2 + 2;
+    p.PW = a.Win + 2;
+    p.NP = p.nsamp * p.PRs * p.PW;
+  }
+  hipStream_t st = as_stream(stream);
+  const bool f16 = a.mm_dtype == STEDM_F16;
+  STEDM_CHECK_ARG(f16 || a.mm_dtype == STEDM_BF16, "conv_igemm: bad mm_dtype %d", a.mm_dtype);
+  if (a.npass == 3) return f16 ? launch<32, 3, _Float16>(p, st) : launch<32, 3, __bf16>(p, st);
+  if (bkc == 64) return f16 ? launch<64, 1, _Float16>(p, st) : launch<64, 1, __bf16>(p, st);
+  return f16 ? launch<32, 1, _Float16>(p, st) : launch<32, 1, __bf16>(p, st);
+}

@@ -1,0 +1,298 @@
+// Error plumbing, weight packing, transposes, graph helpers, embedding path, DDIM update.
+#include <stdarg.h>
+
+#include "common.hpp"
+
+namespace stedm {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace stedm
+using namespace stedm;
+
+extern "C" int stedm_abi_version(void) { return STEDM_ABI_VERSION; }
+extern "C" const char* stedm_last_error(void) { return g_err; }
+extern "C" int stedm_device_cus(void) {
+  int dev = 0;
+  hipDeviceProp_t p;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) {
+    set_error("no HIP device");
+    return -1;
+  }
+  return p.multiProcessorCount;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight packing: OIHW fp32 -> [cout][tap][cin] 16-bit hi (+ lo = round(w - float(hi))).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ hi, T* __restrict__ lo, int cout,
+                                        int cin, int taps) {
+  const long total = (long)cout * taps * cin;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % cin);
+    const long r = i / cin;
+    const int tap = (int)(r % taps);
+    const int co = (int)(r / taps);
+    const float v = w[((long)co * cin + ci) * taps + tap];
+    const T h = (T)v;
+    hi[i] = h;
+    if (lo) lo[i] = (T)(v - (float)h);
+  }
+}
+
+extern "C" int stedm_pack_conv_weight(const float* w, void* w_hi, void* w_lo, int cout, int cin, int ks, int mm_dtype,
+                                      void* stream) {
+  STEDM_CHECK_ARG(w && w_hi, "pack_conv_weight: null pointer");
+  STEDM_CHECK_ARG(ks == 1 || ks == 3, "pack_conv_weight: ks must be 1 or 3 (got %d)", ks);
+  STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "pack_conv_weight: bad mm_dtype %d", mm_dtype);
+  const long total = (long)cout * cin * ks * ks;
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (mm_dtype == STEDM_F16)
+    pack_conv_weight_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(w, (_Float16*)w_hi, (_Float16*)w_lo, cout, cin,
+                                                                         ks * ks);
+  else
+    pack_conv_weight_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(w, (__bf16*)w_hi, (__bf16*)w_lo, cout, cin,
+                                                                       ks * ks);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int r = by + j, c = bx + threadIdx.x;
+    if (r < rows && c < cols) tile[j][threadIdx.x] = in[(long)r * cols + c];
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int c = bx + j, r = by + threadIdx.x;
+    if (r < rows && c < cols) out[(long)c * rows + r] = tile[threadIdx.x][j];
+  }
+}
+
+extern "C" int stedm_transpose_f32(const float* in, float* out, int rows, int cols, void* stream) {
+  STEDM_CHECK_ARG(in && out && rows > 0 && cols > 0, "transpose: bad args");
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32), block(32, 8);
+  transpose_kernel<<<grid, block, 0, as_stream(stream)>>>(in, out, rows, cols);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Embedding path
+// ------------------------------------------------------------------------------------------------
+// One block per sample: sinusoid [mc] -> Linear(mc, ted) -> SiLU -> Linear(ted, ted).
+__global__ void __launch_bounds__(256) time_embed_kernel(const int64_t* __restrict__ t, const float* __restrict__ freqs,
+                                                         const float* __restrict__ w0t, const float* __restrict__ b0,
+                                                         const float* __restrict__ w2t, const float* __restrict__ b2,
+                                                         float* __restrict__ emb, int mc, int ted) {
+  extern __shared__ float sm[];
+  float* te = sm;        // [mc]
+  float* h1 = sm + mc;   // [ted]
+  const int b = blockIdx.x;
+  const float tv = (float)t[b];
+  const int half = mc / 2;
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    const float a = tv * freqs[i];
+    te[i] = cosf(a);         // cos half first (util.py:166)
+    te[half + i] = sinf(a);
+  }
+  if ((mc & 1) && threadIdx.x == 0) te[mc - 1] = 0.f;
+  __syncthreads();
+  for (int n = threadIdx.x; n < ted; n += blockDim.x) {
+    float acc = b0[n];
+    for (int k = 0; k < mc; ++k) acc = fmaf(te[k], w0t[(long)k * ted + n], acc);
+    h1[n] = silu_f(acc);
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < ted; n += blockDim.x) {
+    float acc = b2[n];
+    for (int k = 0; k < ted; ++k) acc = fmaf(h1[k], w2t[(long)k * ted + n], acc);
+    emb[(long)b * ted + n] = acc;
+  }
+}
+
+extern "C" int stedm_time_embed(const int64_t* t, const float* freqs, const float* w0t, const float* b0, const float* w2t,
+                                const float* b2, float* emb, int B, int mc, int ted, void* stream) {
+  STEDM_CHECK_ARG(t && freqs && w0t && b0 && w2t && b2 && emb, "time_embed: null pointer");
+  STEDM_CHECK_ARG(B > 0 && mc > 0 && ted > 0 && (mc + ted) * 4 <= 64 * 1024, "time_embed: bad sizes B=%d mc=%d ted=%d", B, mc, ted);
+  time_embed_kernel<<<B, 256, (mc + ted) * sizeof(float), as_stream(stream)>>>(t, freqs, w0t, b0, w2t, b2, emb, mc, ted);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[b][n] = bias[n] + sum_k silu(emb[b][k]) * wt[k][n]; 8 batch rows per block share each weight read.
+constexpr int EP_ROWS = 8;
+__global__ void __launch_bounds__(256) emb_proj_kernel(const float* __restrict__ emb, const float* __restrict__ wt,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int B, int K,
+                                                       int ntot) {
+  extern __shared__ float se[];  // [EP_ROWS][K]
+  const int b0 = blockIdx.y * EP_ROWS;
+  for (int i = threadIdx.x; i < EP_ROWS * K; i += blockDim.x) {
+    const int r = i / K, k = i - r * K;
+    se[i] = (b0 + r < B) ? silu_f(emb[(long)(b0 + r) * K + k]) : 0.f;
+  }
+  __syncthreads();
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= ntot) return;
+  float acc[EP_ROWS];
+  const float bv = bias[n];
+#pragma unroll
+  for (int r = 0; r < EP_ROWS; ++r) acc[r] = bv;
+  for (int k = 0; k < K; ++k) {
+    const float w = wt[(long)k * ntot + n];
+#pragma unroll
+    for (int r = 0; r < EP_ROWS; ++r) acc[r] = fmaf(se[r * K + k], w, acc[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < EP_ROWS; ++r)
+    if (b0 + r < B) out[(long)(b0 + r) * ntot + n] = acc[r];
+}
+
+extern "C" int stedm_emb_proj(const float* emb, const float* wt, const float* bias, float* out, int B, int k, int ntot,
+                              void* stream) {
+  STEDM_CHECK_ARG(emb && wt && bias && out, "emb_proj: null pointer");
+  STEDM_CHECK_ARG(B > 0 && k > 0 && ntot > 0 && EP_ROWS * k * 4 <= 64 * 1024, "emb_proj: bad sizes B=%d k=%d ntot=%d", B, k, ntot);
+  dim3 grid((ntot + 255) / 256, (B + EP_ROWS - 1) / EP_ROWS);
+  emb_proj_kernel<<<grid, 256, EP_ROWS * k * sizeof(float), as_stream(stream)>>>(emb, wt, bias, out, B, k, ntot);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// DDIM update + rescaled CFG. One block per sample; thread = (w, part) with part striding (c,h).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ e_c,
+                                                        const float* __restrict__ e_u, const float* __restrict__ noise,
+                                                        const float* __restrict__ coefs, const int32_t* __restrict__ step_idx,
+                                                        float s, float phi, float* __restrict__ x_prev,
+                                                        float* __restrict__ pred_x0, int C, int H, int W) {
+  __shared__ float red[2][256];
+  __shared__ float ratio_w[256];
+  const int b = blockIdx.x;
+  const int idx = step_idx ? *step_idx : 0;
+  const float a_t = coefs[idx * 4 + 0], a_prev = coefs[idx * 4 + 1], sigma = coefs[idx * 4 + 2], sq1m = coefs[idx * 4 + 3];
+  const int CH = C * H;
+  const long base = (long)b * CH * W;
+  const int parts = 256 / W;  // W <= 256 checked on host
+  const int w = threadIdx.x % W, part = threadIdx.x / W;
+  const bool active = part < parts;
+
+  if (e_u) {
+    // pass A: means over (c,h) for column w
+    float sc = 0.f, sw = 0.f;
+    if (active)
+      for (int r = part; r < CH; r += parts) {
+        const float ec = e_c[base + (long)r * W + w], eu = e_u[base + (long)r * W + w];
+        sc += ec;
+        sw += eu + s * (ec - eu);
+      }
+    red[0][threadIdx.x] = active ? sc : 0.f;
+    red[1][threadIdx.x] = active ? sw : 0.f;
+    __syncthreads();
+    float mc = 0.f, mw = 0.f;
+    for (int p = 0; p < parts; ++p) {
+      mc += red[0][p * W + w];
+      mw += red[1][p * W + w];
+    }
+    mc /= (float)CH;
+    mw /= (float)CH;
+    __syncthreads();
+    // pass B: centred sums of squares -> unbiased std (torch.std default, ddim.py:183)
+    float qc = 0.f, qw = 0.f;
+    if (active)
+      for (int r = part; r < CH; r += parts) {
+        const float ec = e_c[base + (long)r * W + w], eu = e_u[base + (long)r * W + w];
+        const float ew = eu + s * (ec - eu);
+        qc += (ec - mc) * (ec - mc);
+        qw += (ew - mw) * (ew - mw);
+      }
+    red[0][threadIdx.x] = active ? qc : 0.f;
+    red[1][threadIdx.x] = active ? qw : 0.f;
+    __syncthreads();
+    if (threadIdx.x < W) {
+      float vc = 0.f, vw = 0.f;
+      for (int p = 0; p < parts; ++p) {
+        vc += red[0][p * W + threadIdx.x];
+        vw += red[1][p * W + threadIdx.x];
+      }
+      ratio_w[threadIdx.x] = sqrtf(vc / (float)(CH - 1)) / sqrtf(vw / (float)(CH - 1));
+    }
+    __syncthreads();
+  }
+  const float sqrt_at = sqrtf(a_t);
+  const float dir_c = sqrtf(1.0f - a_prev - sigma * sigma);
+  const float sqrt_ap = sqrtf(a_prev);
+  if (active)
+    for (int r = part; r < CH; r += parts) {
+      const long o = base + (long)r * W + w;
+      float e = e_c[o];
+      if (e_u) {
+        const float eu = e_u[o];
+        const float ew = eu + s * (e - eu);
+        e = (ew * ratio_w[w]) * phi + (1.0f - phi) * e;
+      }
+      const float x0 = (x[o] - sq1m * e) / sqrt_at;
+      float xp = sqrt_ap * x0 + dir_c * e;
+      if (noise) xp += sigma * noise[o];
+      x_prev[o] = xp;
+      if (pred_x0) pred_x0[o] = x0;
+    }
+}
+
+extern "C" int stedm_ddim_step(const float* x, const float* e_c, const float* e_u, const float* noise, const float* coefs,
+                               const int32_t* step_idx, float cfg_scale, float rescale_phi, float* x_prev, float* pred_x0,
+                               int B, int C, int H, int W, void* stream) {
+  STEDM_CHECK_ARG(x && e_c && coefs && x_prev, "ddim_step: null pointer");
+  STEDM_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && W <= 256, "ddim_step: bad shape B=%d C=%d H=%d W=%d (W <= 256)", B, C, H, W);
+  STEDM_CHECK_ARG(!e_u || C * H > 1, "ddim_step: std over (C,H) needs C*H > 1");
+  ddim_step_kernel<<<B, 256, 0, as_stream(stream)>>>(x, e_c, e_u, noise, coefs, step_idx, cfg_scale, rescale_phi, x_prev,
+                                                     pred_x0, C, H, W);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void step_advance_kernel(int32_t* p, int d) { *p += d; }
+extern "C" int stedm_step_advance(int32_t* step_idx, int delta, void* stream) {
+  STEDM_CHECK_ARG(step_idx, "step_advance: null pointer");
+  step_advance_kernel<<<1, 1, 0, as_stream(stream)>>>(step_idx, delta);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Graph helpers
+// ------------------------------------------------------------------------------------------------
+extern "C" int stedm_graph_begin(void* stream) {
+  STEDM_HIP_TRY(hipStreamBeginCapture(as_stream(stream), hipStreamCaptureModeThreadLocal));
+  return 0;
+}
+extern "C" int stedm_graph_end(void* stream, void** graph_exec_out) {
+  STEDM_CHECK_ARG(graph_exec_out, "graph_end: null out pointer");
+  hipGraph_t g = nullptr;
+  STEDM_HIP_TRY(hipStreamEndCapture(as_stream(stream), &g));
+  hipGraphExec_t ge = nullptr;
+  hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) {
+    set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    return 2;
+  }
+  *graph_exec_out = (void*)ge;
+  return 0;
+}
+extern "C" int stedm_graph_launch(void* graph_exec, void* stream) {
+  STEDM_CHECK_ARG(graph_exec, "graph_launch: null graph");
+  STEDM_HIP_TRY(hipGraphLaunch((hipGraphExec_t)graph_exec, as_stream(stream)));
+  return 0;
+}
+extern "C" int stedm_graph_destroy(void* graph_exec) {
+  if (graph_exec) STEDM_HIP_TRY(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  return 0;
+}

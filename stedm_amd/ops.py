@@ -1,0 +1,229 @@
+"""Thin torch-tensor front end over the C ABI (include/stedm_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every function below
+forwards raw device pointers to libstedm_hip.so and raises on error. No function in this
+module computes anything with torch ops."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import BF16, CONV_DOWN, CONV_S1, CONV_UP, F16, ConvArgs, check, lib
+
+
+@dataclass(frozen=True)
+class Precision:
+    """MFMA operand format of the contraction kernels.
+    parity: fp16 operands, 3 split products (hi*hi + hi*lo + lo*hi), fp32 accumulate — the mode
+            checked against the oracle at 1e-3 (SURVEY.md §7 precision budget).
+    fast:   single product (fp16 or bf16 operands), fp32 accumulate / activations / GN / softmax."""
+    mm_dtype: int = F16
+    npass: int = 3
+
+    @staticmethod
+    def parse(name: str) -> "Precision":
+        table = {"parity": Precision(F16, 3), "parity_bf16": Precision(BF16, 3),
+                 "fast": Precision(F16, 1), "f16": Precision(F16, 1), "bf16": Precision(BF16, 1)}
+        if name not in table:
+            raise ValueError(f"unknown precision {name!r}; choose from {sorted(table)}")
+        return table[name]
+
+    @property
+    def label(self) -> str:
+        return ("f16" if self.mm_dtype == F16 else "bf16") + ("x3" if self.npass == 3 else "")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype=torch.float32, name="tensor"):
+    if not t.is_cuda:
+        raise _lib.StedmHipError(f"{name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+
+
+def device_cus() -> int:
+    return lib().stedm_device_cus()
+
+
+# ------------------------------------------------------------------------------------------- weights
+def pack_conv_weight(w: torch.Tensor, prec: Precision) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """OIHW (or [O][I][1] Conv1d) fp32 -> ([O][taps][I] 16-bit hi, lo or None)."""
+    if w.dim() == 3:
+        w = w.unsqueeze(-1)
+    w = w.detach().contiguous()
+    _chk(w, name="conv weight")
+    cout, cin, ks, ks2 = w.shape
+    assert ks == ks2
+    hi = torch.empty((cout, ks * ks, cin), dtype=torch.int16, device=w.device)
+    lo = torch.empty_like(hi) if prec.npass == 3 else None
+    check(lib().stedm_pack_conv_weight(w.data_ptr(), hi.data_ptr(), _ptr(lo), cout, cin, ks, prec.mm_dtype, _stream()),
+          "stedm_pack_conv_weight")
+    return hi, lo
+
+
+def transpose(w: torch.Tensor) -> torch.Tensor:
+    w = w.detach().contiguous()
+    _chk(w, name="matrix")
+    rows, cols = w.shape
+    out = torch.empty((cols, rows), dtype=torch.float32, device=w.device)
+    check(lib().stedm_transpose_f32(w.data_ptr(), out.data_ptr(), rows, cols, _stream()), "stedm_transpose_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------- GroupNorm
+def gn_scale_shift(x1: torch.Tensor, x2: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, eps: float,
+                   scale: torch.Tensor, shift: torch.Tensor, groups: int = 32, x2_bmod: int = 0) -> None:
+    """x1 [B,H,W,c1] (+ x2 [B|bmod,H,W,c2]) NHWC -> scale/shift [B, c1+c2]."""
+    _chk(x1, name="x1")
+    B = x1.shape[0]
+    HW = x1.numel() // (B * x1.shape[-1])
+    c1 = x1.shape[-1]
+    c2 = 0
+    if x2 is not None:
+        _chk(x2, name="x2")
+        c2 = x2.shape[-1]
+    assert scale.shape == (B, c1 + c2) and shift.shape == (B, c1 + c2)
+    check(lib().stedm_gn_scale_shift(x1.data_ptr(), c1, _ptr(x2), c2, x2_bmod, gamma.data_ptr(), beta.data_ptr(),
+                                     float(eps), groups, B, HW, scale.data_ptr(), shift.data_ptr(), _stream()),
+          "stedm_gn_scale_shift")
+
+
+# ------------------------------------------------------------------------------------------- conv
+def conv_igemm(src1: torch.Tensor, w_hi: torch.Tensor, w_lo: Optional[torch.Tensor], out: torch.Tensor, *, prec: Precision,
+               ks: int = 3, mode: int = CONV_S1, src2: Optional[torch.Tensor] = None, src2_bmod: int = 0,
+               scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, act: int = 0,
+               bias: Optional[torch.Tensor] = None, emb: Optional[torch.Tensor] = None, emb_offset: int = 0,
+               emb_bstride: int = 0, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """src1 [B,Hin,Win,c1] NHWC fp32 -> out [B,Hout,Wout,cout] NHWC fp32 (see stedm_conv_igemm)."""
+    _chk(src1, name="src1")
+    _chk(out, name="out")
+    B, Hin, Win, c1 = src1.shape
+    a = ConvArgs()
+    a.src1 = src1.data_ptr()
+    a.src2 = _ptr(src2)
+    a.c1, a.c2, a.src2_bmod = c1, (0 if src2 is None else src2.shape[-1]), src2_bmod
+    a.B, a.Hin, a.Win = B, Hin, Win
+    a.mode, a.ks = mode, ks
+    a.scale, a.shift, a.act = _ptr(scale), _ptr(shift), act
+    a.w_hi, a.w_lo = w_hi.data_ptr(), (_ptr(w_lo) if prec.npass == 3 else None)
+    a.bias = _ptr(bias)
+    a.emb = None if emb is None else emb.data_ptr() + 4 * emb_offset
+    a.emb_bstride = emb_bstride
+    a.res = _ptr(res)
+    a.out = out.data_ptr()
+    a.cout = out.shape[-1]
+    a.npass, a.mm_dtype = prec.npass, prec.mm_dtype
+    assert w_hi.shape == (a.cout, ks * ks, a.c1 + a.c2), (w_hi.shape, a.cout, ks, a.c1, a.c2)
+    check(lib().stedm_conv_igemm(C.byref(a), _stream()), "stedm_conv_igemm")
+    return out
+
+
+def conv_in(x1: torch.Tensor, x2: Optional[torch.Tensor], w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor,
+            x2_bmod: int = 0) -> torch.Tensor:
+    """x1 [B,c1,H,W] NCHW (+ x2 [B,c2,H,W]) -> out [B,H,W,cout] NHWC."""
+    _chk(x1, name="x1")
+    B, c1, H, W = x1.shape
+    c2 = 0 if x2 is None else x2.shape[1]
+    if x2 is not None:
+        _chk(x2, name="x2")
+    check(lib().stedm_conv_in(x1.data_ptr(), c1, _ptr(x2), c2, x2_bmod, w.data_ptr(), _ptr(bias), out.data_ptr(), B, H, W,
+                              out.shape[-1], _stream()), "stedm_conv_in")
+    return out
+
+
+def conv_out(src: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
+             out: torch.Tensor) -> torch.Tensor:
+    """src [B,H,W,c] NHWC -> out [B,cout,H,W] NCHW (GN affine + SiLU fused)."""
+    _chk(src, name="src")
+    B, H, W, c = src.shape
+    check(lib().stedm_conv_out(src.data_ptr(), c, scale.data_ptr(), shift.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(),
+                               B, H, W, out.shape[1], _stream()), "stedm_conv_out")
+    return out
+
+
+# ------------------------------------------------------------------------------------------- embeddings
+def time_embed(t: torch.Tensor, freqs: torch.Tensor, w0t: torch.Tensor, b0: torch.Tensor, w2t: torch.Tensor, b2: torch.Tensor,
+               out: torch.Tensor) -> torch.Tensor:
+    _chk(t, torch.int64, "timesteps")
+    B = t.shape[0]
+    mc, ted = w0t.shape
+    check(lib().stedm_time_embed(t.data_ptr(), freqs.data_ptr(), w0t.data_ptr(), b0.data_ptr(), w2t.data_ptr(), b2.data_ptr(),
+                                 out.data_ptr(), B, mc, ted, _stream()), "stedm_time_embed")
+    return out
+
+
+def emb_proj(emb: torch.Tensor, wt: torch.Tensor, bias: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    _chk(emb, name="emb")
+    B, K = emb.shape
+    assert wt.shape[0] == K and out.shape == (B, wt.shape[1])
+    check(lib().stedm_emb_proj(emb.data_ptr(), wt.data_ptr(), bias.data_ptr(), out.data_ptr(), B, K, wt.shape[1], _stream()),
+          "stedm_emb_proj")
+    return out
+
+
+# ------------------------------------------------------------------------------------------- attention
+def attn_legacy(qkv: torch.Tensor, out: torch.Tensor, heads: int) -> torch.Tensor:
+    """qkv [B,T,heads*3*ch] -> out [B,T,heads*ch]."""
+    _chk(qkv, name="qkv")
+    B, T, C3 = qkv.shape
+    ch = C3 // (3 * heads)
+    check(lib().stedm_attn_legacy(qkv.data_ptr(), out.data_ptr(), B, T, heads, ch, _stream()), "stedm_attn_legacy")
+    return out
+
+
+# ------------------------------------------------------------------------------------------- DDIM
+def ddim_step(x: torch.Tensor, e_c: torch.Tensor, e_u: Optional[torch.Tensor], coefs: torch.Tensor, x_prev: torch.Tensor,
+              pred_x0: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
+              step_idx: Optional[torch.Tensor] = None, cfg_scale: float = 1.0, rescale_phi: float = 0.7) -> torch.Tensor:
+    _chk(x, name="x")
+    _chk(e_c, name="e_c")
+    B, Cc, H, W = x.shape
+    check(lib().stedm_ddim_step(x.data_ptr(), e_c.data_ptr(), _ptr(e_u), _ptr(noise), coefs.data_ptr(), _ptr(step_idx),
+                                float(cfg_scale), float(rescale_phi), x_prev.data_ptr(), _ptr(pred_x0), B, Cc, H, W, _stream()),
+          "stedm_ddim_step")
+    return x_prev
+
+
+def step_advance(step_idx: torch.Tensor, delta: int = 1) -> None:
+    check(lib().stedm_step_advance(step_idx.data_ptr(), delta, _stream()), "stedm_step_advance")
+
+
+# ------------------------------------------------------------------------------------------- graphs
+class Graph:
+    """hipGraph captured on the current torch stream (all buffers must be allocated beforehand)."""
+
+    def __init__(self):
+        self._exec = C.c_void_p()
+
+    def __enter__(self):
+        check(lib().stedm_graph_begin(_stream()), "stedm_graph_begin")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        rc = lib().stedm_graph_end(_stream(), C.byref(self._exec))
+        if et is None:
+            check(rc, "stedm_graph_end")
+        return False
+
+    def launch(self):
+        check(lib().stedm_graph_launch(self._exec, _stream()), "stedm_graph_launch")
+
+    def __del__(self):
+        try:
+            if self._exec:
+                lib().stedm_graph_destroy(self._exec)
+        except Exception:
+            pass

@@ -1,0 +1,428 @@
+"""HIP-backed denoising U-Net with the reference's module surface.
+
+Drop-in for `ldm.modules.diffusionmodules.openaimodel.UNetModel` (reference openaimodel.py:435-806):
+same constructor kwargs, same `forward(x, timesteps, context, y)` contract, same state-dict names
+and fp32 OIHW parameter shapes — so reference checkpoints load with `load_state_dict` — but
+`forward` runs entirely in hand-written HIP kernels through the C ABI (stedm_amd/ops.py).
+torch.nn modules below are *parameter containers*; their own forward is never used.
+
+Internal data layout: activations NHWC fp32 in HBM; conv weights pre-packed [cout][tap][cin]
+16-bit (hi/lo planes); GroupNorm is turned into per-(sample, channel) scale/shift by a statistics
+kernel and applied inside the consuming conv's A-tile load together with SiLU; the skip concat is
+never materialised (the conv reads two sources).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import CONV_DOWN, CONV_S1, CONV_UP, StedmHipError
+from .ops import Precision
+
+
+def zero_module(module: nn.Module) -> nn.Module:
+    """util.py:174-180."""
+    for p in module.parameters():
+        p.detach().zero_()
+    return module
+
+
+class GroupNorm32(nn.GroupNorm):
+    """util.py:214-216 (container; eps 1e-5, 32 groups)."""
+
+
+class TimestepBlock(nn.Module):
+    """openaimodel.py:64-73 marker: forward(x, emb)."""
+
+
+class StyleBlock(nn.Module):
+    """openaimodel.py:75-84 marker: forward(x, context)."""
+
+
+class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
+    """openaimodel.py:87-101 (container; routing is done by UNetModel._run_block)."""
+
+
+class Upsample(nn.Module):
+    """openaimodel.py:104-132: nearest x2 then 3x3 conv (fused: the conv's patch loader reads src//2)."""
+
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        assert dims == 2 and use_conv, "only the conv_resample=True 2-D form is implemented (shipped configs)"
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.conv = nn.Conv2d(self.channels, self.out_channels, 3, padding=padding)
+
+
+class Downsample(nn.Module):
+    """openaimodel.py:147-173: 3x3 stride-2 pad-1 conv."""
+
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        assert dims == 2 and use_conv, "only the conv_resample=True 2-D form is implemented (shipped configs)"
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.op = nn.Conv2d(self.channels, self.out_channels, 3, stride=2, padding=padding)
+
+
+class ResBlock(TimestepBlock):
+    """openaimodel.py:176-288 with the options the shipped configs use (no scale-shift norm, no up/down)."""
+
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False, use_scale_shift_norm=False,
+                 dims=2, use_checkpoint=False, up=False, down=False):
+        super().__init__()
+        if use_scale_shift_norm or up or down or dims != 2 or use_conv:
+            raise NotImplementedError("ResBlock: use_scale_shift_norm / up / down / use_conv / dims != 2 are not "
+                                      "exercised by the reference configs and are not implemented in the HIP path")
+        self.channels = channels
+        self.emb_channels = emb_channels
+        self.dropout = dropout
+        self.out_channels = out_channels or channels
+        self.in_layers = nn.Sequential(GroupNorm32(32, channels), nn.SiLU(), nn.Conv2d(channels, self.out_channels, 3, padding=1))
+        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, self.out_channels))
+        self.out_layers = nn.Sequential(GroupNorm32(32, self.out_channels), nn.SiLU(), nn.Dropout(p=dropout),
+                                        zero_module(nn.Conv2d(self.out_channels, self.out_channels, 3, padding=1)))
+        if self.out_channels == channels:
+            self.skip_connection = nn.Identity()
+        else:
+            self.skip_connection = nn.Conv2d(channels, self.out_channels, 1)
+
+
+class ResBlockStyle(StyleBlock):
+    """openaimodel.py:291-297."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        self.block = ResBlock(*args, **kwargs)
+
+
+class AttentionBlock(nn.Module):
+    """openaimodel.py:300-346 with QKVAttentionLegacy (use_new_attention_order=False)."""
+
+    def __init__(self, channels, num_heads=1, num_head_channels=-1, use_checkpoint=False, use_new_attention_order=False):
+        super().__init__()
+        if use_new_attention_order:
+            raise NotImplementedError("QKVAttention (new order) is unused by the reference configs")
+        self.channels = channels
+        if num_head_channels == -1:
+            self.num_heads = num_heads
+        else:
+            assert channels % num_head_channels == 0
+            self.num_heads = channels // num_head_channels
+        self.norm = GroupNorm32(32, channels)
+        self.qkv = nn.Conv1d(channels, channels * 3, 1)
+        self.proj_out = zero_module(nn.Conv1d(channels, channels, 1))
+
+
+class _Packed:
+    __slots__ = ("hi", "lo", "bias")
+
+    def __init__(self, hi, lo, bias):
+        self.hi, self.lo, self.bias = hi, lo, bias
+
+
+class UNetModel(nn.Module):
+    """openaimodel.py:435-806. Extra (non-reference) attribute: `precision` (ops.Precision)."""
+
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None, use_checkpoint=False,
+                 use_fp16=False, num_heads=-1, num_head_channels=-1, num_heads_upsample=-1, use_scale_shift_norm=False,
+                 resblock_updown=False, use_new_attention_order=False, use_spatial_transformer=False, transformer_depth=1,
+                 context_dim=None, n_embed=None, legacy=True, style_imgs=1, precision: str = "parity"):
+        super().__init__()
+        if use_spatial_transformer:
+            assert context_dim is not None, "context_dim is required with use_spatial_transformer (openaimodel.py:494-495)"
+            raise NotImplementedError("SpatialTransformer middle block: HIP kernels not built yet (SURVEY.md §8a A8)")
+        if context_dim is not None:
+            raise AssertionError("context_dim requires use_spatial_transformer (openaimodel.py:497-498)")
+        if num_classes is not None or n_embed is not None or resblock_updown or not conv_resample or dims != 2 or dropout != 0:
+            raise NotImplementedError("num_classes / n_embed / resblock_updown / conv_resample=False / dims != 2 / dropout: "
+                                      "not used by the reference configs, not implemented")
+        if num_heads_upsample == -1:
+            num_heads_upsample = num_heads
+        if num_heads == -1:
+            assert num_head_channels != -1, "Either num_heads or num_head_channels has to be set"
+        if num_head_channels == -1:
+            assert num_heads != -1, "Either num_heads or num_head_channels has to be set"
+
+        self.image_size = image_size
+        self.in_channels = in_channels
+        self.model_channels = model_channels
+        self.out_channels = out_channels
+        self.num_res_blocks = num_res_blocks
+        self.attention_resolutions = attention_resolutions
+        self.dropout = dropout
+        self.channel_mult = channel_mult
+        self.conv_resample = conv_resample
+        self.num_classes = num_classes
+        self.use_checkpoint = use_checkpoint
+        self.dtype = torch.float32
+        self.num_heads = num_heads
+        self.num_head_channels = num_head_channels
+        self.num_heads_upsample = num_heads_upsample
+        self.predict_codebook_ids = False
+        self.precision = Precision.parse(precision) if isinstance(precision, str) else precision
+
+        ted = model_channels * 4
+        self.time_embed = nn.Sequential(nn.Linear(model_channels, ted), nn.SiLU(), nn.Linear(ted, ted))
+        self.input_blocks = nn.ModuleList([TimestepEmbedSequential(nn.Conv2d(in_channels, model_channels, 3, padding=1))])
+        input_block_chans = [model_channels]
+        ch, ds = model_channels, 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                if ds in attention_resolutions:
+                    # the reference executes `layers.append()` here (openaimodel.py:580-590) -> TypeError
+                    raise TypeError("list.append() takes exactly one argument (0 given) "
+                                    "[reference openaimodel.py:580: ds in attention_resolutions is not constructible]")
+                self.input_blocks.append(TimestepEmbedSequential(ResBlock(ch, ted, dropout, out_channels=mult * model_channels)))
+                ch = mult * model_channels
+                input_block_chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(TimestepEmbedSequential(Downsample(ch, conv_resample, out_channels=ch)))
+                input_block_chans.append(ch)
+                ds *= 2
+        if num_head_channels != -1:
+            num_heads = ch // num_head_channels
+        dim_head = num_head_channels  # legacy=True, no spatial transformer (openaimodel.py:624-626)
+        self.middle_block = TimestepEmbedSequential(
+            ResBlock(ch, ted, dropout),
+            ResBlockStyle(ch, ted, dropout),
+            AttentionBlock(ch, num_heads=num_heads, num_head_channels=dim_head),
+            ResBlock(ch, ted, dropout),
+        )
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                ich = input_block_chans.pop()
+                layers: List[nn.Module] = [ResBlock(ch + ich, ted, dropout, out_channels=model_channels * mult)]
+                ch = model_channels * mult
+                if ds in attention_resolutions:
+                    raise TypeError("reference output block with ds in attention_resolutions is not runnable (openaimodel.py:689-698)")
+                if level and i == num_res_blocks:
+                    layers.append(Upsample(ch, conv_resample, out_channels=ch))
+                    ds //= 2
+                self.output_blocks.append(TimestepEmbedSequential(*layers))
+        self.out = nn.Sequential(GroupNorm32(32, ch), nn.SiLU(), zero_module(nn.Conv2d(model_channels, out_channels, 3, padding=1)))
+
+        # ---- engine state (not part of the state dict)
+        self._packed: Dict[int, _Packed] = {}
+        self._pack_key = None
+        self._bufs: Dict[Tuple, torch.Tensor] = {}
+        self._emb_layout: List[Tuple[ResBlock, int]] = []
+        self._consts: Dict[str, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------------------------ engine plumbing
+    def convert_to_fp16(self):  # openaimodel.py:745-751 — a no-op in the reference too (openaimodel.py:25-29)
+        pass
+
+    def convert_to_fp32(self):
+        pass
+
+    def set_precision(self, precision) -> None:
+        self.precision = Precision.parse(precision) if isinstance(precision, str) else precision
+        self.invalidate()
+
+    def invalidate(self) -> None:
+        """Drop packed weights (call after changing parameters in place without bumping their version)."""
+        self._packed.clear()
+        self._consts.clear()
+        self._pack_key = None
+
+    def _buf(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
+        key = (name, tuple(shape), dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            dev = next(self.parameters()).device
+            t = torch.empty(tuple(shape), dtype=dtype, device=dev)
+            self._bufs[key] = t
+        return t
+
+    def _timestep_blocks(self) -> List[ResBlock]:
+        """ResBlocks conditioned on the timestep embedding, in execution order."""
+        out = []
+        for blk in list(self.input_blocks) + [self.middle_block] + list(self.output_blocks):
+            for layer in blk:
+                if isinstance(layer, ResBlock):
+                    out.append(layer)
+        return out
+
+    def _prepare(self) -> None:
+        """(Re)pack weights when any parameter changed (cheap version fingerprint)."""
+        params = list(self.parameters())
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise StedmHipError("UNetModel.forward needs its parameters on the GPU; there is no CPU fallback")
+        key = (self.precision, dev, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        if key == self._pack_key:
+            return
+        self._packed.clear()
+        self._consts.clear()
+        prec = self.precision
+
+        def pack(conv):
+            hi, lo = ops.pack_conv_weight(conv.weight.float(), prec)
+            self._packed[id(conv)] = _Packed(hi, lo, None if conv.bias is None else conv.bias.detach().float().contiguous())
+
+        for m in self.modules():
+            if isinstance(m, ResBlock):
+                pack(m.in_layers[2])
+                pack(m.out_layers[3])
+                if not isinstance(m.skip_connection, nn.Identity):
+                    pack(m.skip_connection)
+            elif isinstance(m, Downsample):
+                pack(m.op)
+            elif isinstance(m, Upsample):
+                pack(m.conv)
+            elif isinstance(m, AttentionBlock):
+                pack(m.qkv)
+                pack(m.proj_out)
+        c = self._consts
+        half = self.model_channels // 2
+        # host-built frequency table (util.py:162-164 builds it on the CPU in fp32)
+        c["freqs"] = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(dev)
+        c["te_w0t"] = ops.transpose(self.time_embed[0].weight.float())
+        c["te_b0"] = self.time_embed[0].bias.detach().float().contiguous()
+        c["te_w2t"] = ops.transpose(self.time_embed[2].weight.float())
+        c["te_b2"] = self.time_embed[2].bias.detach().float().contiguous()
+        # all timestep emb_layers concatenated along N (SiLU -> Linear, openaimodel.py:231-237)
+        tblocks = self._timestep_blocks()
+        self._emb_layout = []
+        off = 0
+        for rb in tblocks:
+            self._emb_layout.append((rb, off))
+            off += rb.out_channels
+        wcat = torch.cat([rb.emb_layers[1].weight.detach().float() for rb in tblocks], dim=0)  # [Ntot, ted]
+        c["emb_wt"] = ops.transpose(wcat.contiguous())
+        c["emb_b"] = torch.cat([rb.emb_layers[1].bias.detach().float() for rb in tblocks]).contiguous()
+        self._emb_off = {id(rb): o for rb, o in self._emb_layout}
+        self._emb_ntot = off
+        srb = self.middle_block[1].block
+        c["style_wt"] = ops.transpose(srb.emb_layers[1].weight.float())
+        c["style_b"] = srb.emb_layers[1].bias.detach().float().contiguous()
+        self._pack_key = key
+
+    # ------------------------------------------------------------------------------------ block runners (NHWC)
+    def _gn(self, tag, norm: nn.GroupNorm, x1, x2=None, x2_bmod=0):
+        B = x1.shape[0]
+        C = x1.shape[-1] + (0 if x2 is None else x2.shape[-1])
+        sc = self._buf(tag + ".sc", (B, C))
+        sh = self._buf(tag + ".sh", (B, C))
+        ops.gn_scale_shift(x1, x2, norm.weight, norm.bias, norm.eps, sc, sh, norm.num_groups, x2_bmod)
+        return sc, sh
+
+    def _res(self, tag: str, rb: ResBlock, x1, x2, emb_all, emb_off, emb_bstride, x2_bmod=0):
+        """ResBlock._forward openaimodel.py:268-288 on NHWC tensors; [x1|x2] is the virtual concat input."""
+        prec = self.precision
+        B, H, W, _ = x1.shape
+        co = rb.out_channels
+        sc, sh = self._gn(tag + ".gn1", rb.in_layers[0], x1, x2, x2_bmod)
+        pk = self._packed[id(rb.in_layers[2])]
+        h = self._buf(f"h.{B}x{H}x{W}x{co}", (B, H, W, co))
+        ops.conv_igemm(x1, pk.hi, pk.lo, h, prec=prec, src2=x2, src2_bmod=x2_bmod, scale=sc, shift=sh, act=1, bias=pk.bias,
+                       emb=emb_all, emb_offset=emb_off, emb_bstride=emb_bstride)
+        sc2, sh2 = self._gn(tag + ".gn2", rb.out_layers[0], h)
+        out = self._buf(tag + ".out", (B, H, W, co))
+        if isinstance(rb.skip_connection, nn.Identity):
+            assert x2 is None
+            res = x1
+        else:
+            ps = self._packed[id(rb.skip_connection)]
+            ops.conv_igemm(x1, ps.hi, ps.lo, out, prec=prec, ks=1, src2=x2, src2_bmod=x2_bmod, bias=ps.bias)
+            res = out
+        pk2 = self._packed[id(rb.out_layers[3])]
+        ops.conv_igemm(h, pk2.hi, pk2.lo, out, prec=prec, scale=sc2, shift=sh2, act=1, bias=pk2.bias, res=res)
+        return out
+
+    def _attn(self, tag: str, ab: AttentionBlock, x):
+        """AttentionBlock._forward openaimodel.py:340-346 on NHWC (tokens = H*W)."""
+        prec = self.precision
+        B, H, W, Cc = x.shape
+        sc, sh = self._gn(tag + ".gn", ab.norm, x)
+        pq = self._packed[id(ab.qkv)]
+        qkv = self._buf(tag + ".qkv", (B, H, W, 3 * Cc))
+        ops.conv_igemm(x, pq.hi, pq.lo, qkv, prec=prec, ks=1, scale=sc, shift=sh, act=0, bias=pq.bias)
+        a = self._buf(tag + ".a", (B, H, W, Cc))
+        ops.attn_legacy(qkv.view(B, H * W, 3 * Cc), a.view(B, H * W, Cc), ab.num_heads)
+        pp = self._packed[id(ab.proj_out)]
+        out = self._buf(tag + ".out", (B, H, W, Cc))
+        ops.conv_igemm(a, pp.hi, pp.lo, out, prec=prec, ks=1, bias=pp.bias, res=x)
+        return out
+
+    def _run_block(self, tag: str, blk, h, skip, emb_all, emb_bstride, style_all):
+        """TimestepEmbedSequential.forward openaimodel.py:93-101 (+ the th.cat of :800 folded into the first layer)."""
+        for li, layer in enumerate(blk):
+            ltag = f"{tag}.{li}"
+            if isinstance(layer, ResBlock):
+                h = self._res(ltag, layer, h, skip, emb_all, self._emb_off[id(layer)], emb_bstride)
+                skip = None
+            elif isinstance(layer, ResBlockStyle):
+                h = self._res(ltag, layer.block, h, None, style_all, 0, style_all.shape[1])
+            elif isinstance(layer, AttentionBlock):
+                h = self._attn(ltag, layer, h)
+            elif isinstance(layer, Downsample):
+                pk = self._packed[id(layer.op)]
+                B, H, W, _ = h.shape
+                out = self._buf(ltag + ".out", (B, H // 2, W // 2, layer.out_channels))
+                h = ops.conv_igemm(h, pk.hi, pk.lo, out, prec=self.precision, mode=CONV_DOWN, bias=pk.bias)
+            elif isinstance(layer, Upsample):
+                pk = self._packed[id(layer.conv)]
+                B, H, W, _ = h.shape
+                out = self._buf(ltag + ".out", (B, H * 2, W * 2, layer.out_channels))
+                h = ops.conv_igemm(h, pk.hi, pk.lo, out, prec=self.precision, mode=CONV_UP, bias=pk.bias)
+            else:
+                raise TypeError(f"unexpected layer {type(layer).__name__} in {tag}")
+        return h
+
+    # ------------------------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
+        """openaimodel.py:761-806. x [B,C,H,W] fp32 NCHW (already concatenated with c_concat by the
+        DiffusionWrapper), timesteps int64 [B], context [B, 4*model_channels] style vector -> eps [B,out,H,W]."""
+        assert (y is not None) == (self.num_classes is not None), \
+            "must specify y if and only if the model is class-conditional"
+        return self.forward_parts(x, None, timesteps, context)
+
+    @torch.no_grad()
+    def forward_parts(self, x, c_concat, timesteps, context, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Same as forward, but takes the latent and the concat-conditioning separately (the cat of
+        ddpm.py:1415 is folded into the first conv's loader)."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            pass  # decorated no_grad: gradients are not produced by the HIP path (training backward is a later row)
+        self._prepare()
+        x = x.float().contiguous()
+        B, c1, H, W = x.shape
+        c2 = 0
+        if c_concat is not None:
+            c_concat = c_concat.float().contiguous()
+            c2 = c_concat.shape[1]
+        assert c1 + c2 == self.in_channels, f"expected {self.in_channels} input channels, got {c1}+{c2}"
+        if context is None:
+            raise ValueError("context (style vector) is required: middle_block[1] is a ResBlockStyle (openaimodel.py:636-643)")
+        timesteps = timesteps.to(device=x.device, dtype=torch.int64).contiguous()
+        context = context.float().contiguous()
+        c = self._consts
+        ted = self.model_channels * 4
+        assert context.shape == (B, ted), f"context must be [B,{ted}] (ResBlockStyle uses it as the embedding)"
+
+        emb = ops.time_embed(timesteps, c["freqs"], c["te_w0t"], c["te_b0"], c["te_w2t"], c["te_b2"], self._buf("emb", (B, ted)))
+        emb_all = ops.emb_proj(emb, c["emb_wt"], c["emb_b"], self._buf("emb_all", (B, self._emb_ntot)))
+        style_all = ops.emb_proj(context, c["style_wt"], c["style_b"], self._buf("style_all", (B, c["style_wt"].shape[1])))
+
+        conv0 = self.input_blocks[0][0]
+        h = ops.conv_in(x, c_concat, conv0.weight, conv0.bias, self._buf("in0.out", (B, H, W, self.model_channels)))
+        hs = [h]
+        for i, blk in enumerate(self.input_blocks[1:], start=1):
+            h = self._run_block(f"in{i}", blk, h, None, emb_all, self._emb_ntot, style_all)
+            hs.append(h)
+        h = self._run_block("mid", self.middle_block, h, None, emb_all, self._emb_ntot, style_all)
+        for i, blk in enumerate(self.output_blocks):
+            h = self._run_block(f"out{i}", blk, h, hs.pop(), emb_all, self._emb_ntot, style_all)
+        sc, sh = self._gn("outn", self.out[0], h)
+        if out is None:
+            out = torch.empty((B, self.out_channels, H, W), dtype=torch.float32, device=x.device)
+        ops.conv_out(h, sc, sh, self.out[2].weight, self.out[2].bias, out)
+        return out

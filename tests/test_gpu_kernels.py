@@ -1,0 +1,253 @@
+"""GPU tier (-m gpu): every HIP kernel, called through the C ABI, against the CPU oracle / plain
+fp32 torch ops on the same seeded inputs. Tolerances (relative to the reference tensor's std):
+  parity mode (fp16 x3 split products, fp32 accumulate)  : 2e-4 per op
+  fast modes  (single fp16 / bf16 product)                : 5e-3 / 3e-2 per op (reported, loose)
+  pure-fp32 kernels (GN, embeddings, attention, DDIM, I/O convs): 2e-5 .. 1e-4
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from stedm_amd.utils import prng
+
+pytestmark = pytest.mark.gpu
+
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from stedm_amd import _lib
+    _lib.lib()  # must load: no fallback
+    return torch.device("cuda:0")
+
+
+def rel_err(got, ref):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return float((got - ref).abs().max()) / (float(ref.std()) + 1e-12)
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+PRECS = [("parity", 2e-4), ("f16", 5e-3), ("bf16", 3e-2)]
+
+
+# ------------------------------------------------------------------------------------------------ GroupNorm
+@pytest.mark.parametrize("B,H,W,c1,c2,bmod", [(2, 8, 8, 64, 0, 0), (3, 16, 16, 128, 0, 0), (2, 8, 8, 1024, 512, 0),
+                                              (2, 4, 4, 32, 64, 0), (4, 8, 8, 128, 128, 2), (2, 32, 32, 128, 0, 0)])
+def test_gn_scale_shift(dev, B, H, W, c1, c2, bmod):
+    from stedm_amd import ops
+    C = c1 + c2
+    x1 = prng.normal(1, "gn.x1", (B, c1, H, W)) * 1.7 + 0.3
+    x2 = prng.normal(1, "gn.x2", (bmod or B, c2, H, W)) * 0.6 - 0.2 if c2 else None
+    g = prng.normal(1, "gn.g", (C,), 0.1, 1.0)
+    b = prng.normal(1, "gn.b", (C,), 0.1)
+    x2f = None if x2 is None else (x2 if not bmod else x2.repeat(B // bmod, 1, 1, 1))
+    xin = x1 if x2 is None else torch.cat([x1, x2f], 1)
+    ref = F.group_norm(xin, 32, g, b, 1e-5)
+    sc = torch.empty((B, C), device=dev)
+    sh = torch.empty((B, C), device=dev)
+    ops.gn_scale_shift(nhwc(x1).to(dev), None if x2 is None else nhwc(x2).to(dev), g.to(dev), b.to(dev), 1e-5, sc, sh, 32, bmod)
+    got = xin * sc.cpu()[:, :, None, None] + sh.cpu()[:, :, None, None]
+    assert rel_err(got, ref) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ conv_igemm
+def _conv_case(dev, prec_name, tol, B, Hin, Win, c1, c2, cout, mode, ks, gn, act, use_emb, use_res, bmod=0, seed=2):
+    from stedm_amd import ops
+    from stedm_amd._lib import CONV_DOWN, CONV_S1, CONV_UP
+    prec = ops.Precision.parse(prec_name)
+    cin = c1 + c2
+    x1 = prng.normal(seed, "cv.x1", (B, c1, Hin, Win))
+    x2 = prng.normal(seed, "cv.x2", (bmod or B, c2, Hin, Win)) if c2 else None
+    w = prng.normal(seed, "cv.w", (cout, cin, ks, ks), 1.0 / math.sqrt(cin * ks * ks))
+    bias = prng.normal(seed, "cv.b", (cout,), 0.05)
+    x2f = None if x2 is None else (x2 if not bmod else x2.repeat(B // bmod, 1, 1, 1))
+    xin = x1 if x2 is None else torch.cat([x1, x2f], 1)
+    sc = sh = None
+    a = xin
+    if gn:
+        sc = prng.normal(seed, "cv.sc", (B, cin), 0.2, 1.0)
+        sh = prng.normal(seed, "cv.sh", (B, cin), 0.2)
+        a = a * sc[:, :, None, None] + sh[:, :, None, None]
+    if act:
+        a = F.silu(a)
+    if mode == "s1":
+        ref = F.conv2d(a, w, bias, padding=ks // 2)
+        m = CONV_S1
+    elif mode == "down":
+        ref = F.conv2d(a, w, bias, stride=2, padding=1)
+        m = CONV_DOWN
+    else:
+        ref = F.conv2d(F.interpolate(a, scale_factor=2, mode="nearest"), w, bias, padding=1)
+        m = CONV_UP
+    Bo, _, Ho, Wo = ref.shape
+    emb = None
+    if use_emb:
+        emb = prng.normal(seed, "cv.emb", (B, cout + 24))
+        ref = ref + emb[:, 8:8 + cout, None, None]
+    res = None
+    if use_res:
+        res = prng.normal(seed, "cv.res", (B, cout, Ho, Wo))
+        ref = ref + res
+    hi, lo = ops.pack_conv_weight(w.to(dev), prec)
+    out = torch.full((B, Ho, Wo, cout), float("nan"), device=dev)
+    ops.conv_igemm(nhwc(x1).to(dev), hi, lo, out, prec=prec, ks=ks, mode=m,
+                   src2=None if x2 is None else nhwc(x2).to(dev), src2_bmod=bmod,
+                   scale=None if sc is None else sc.to(dev), shift=None if sh is None else sh.to(dev), act=act,
+                   bias=bias.to(dev), emb=None if emb is None else emb.to(dev), emb_offset=8,
+                   emb_bstride=0 if emb is None else emb.shape[1], res=None if res is None else nhwc(res).to(dev))
+    torch.cuda.synchronize()
+    err = rel_err(nchw(out), ref)
+    assert err < tol, f"{prec_name}: rel err {err:.3e} >= {tol}"
+    return err
+
+
+@pytest.mark.parametrize("prec,tol", PRECS)
+@pytest.mark.parametrize("B,H,W,c1,c2,cout", [
+    (2, 8, 8, 64, 0, 64),       # whole-image tiles, 2 samples per tile
+    (3, 8, 8, 128, 64, 96),     # odd batch (partial tile), concat, cout < 128 (N mask)
+    (2, 16, 16, 128, 0, 256),   # row tiles, 2 N tiles
+    (1, 32, 32, 128, 0, 128),   # level-0 shape
+    (5, 4, 4, 32, 32, 32),      # 4x4 images, 8 per tile, partial
+    (1, 64, 64, 32, 0, 32),     # 2 rows per tile
+])
+def test_conv3x3_s1(dev, prec, tol, B, H, W, c1, c2, cout):
+    _conv_case(dev, prec, tol, B, H, W, c1, c2, cout, "s1", 3, gn=True, act=1, use_emb=True, use_res=True)
+
+
+@pytest.mark.parametrize("prec,tol", PRECS[:2])
+def test_conv3x3_plain_and_bmod(dev, prec, tol):
+    _conv_case(dev, prec, tol, 2, 16, 16, 64, 0, 64, "s1", 3, gn=False, act=0, use_emb=False, use_res=False)
+    _conv_case(dev, prec, tol, 4, 8, 8, 64, 64, 128, "s1", 3, gn=True, act=1, use_emb=True, use_res=False, bmod=2)
+
+
+@pytest.mark.parametrize("prec,tol", PRECS[:2])
+@pytest.mark.parametrize("B,H,W,c,cout", [(2, 16, 16, 64, 64), (2, 32, 32, 128, 128), (3, 8, 8, 32, 32), (1, 64, 64, 32, 64)])
+def test_conv_down(dev, prec, tol, B, H, W, c, cout):
+    _conv_case(dev, prec, tol, B, H, W, c, 0, cout, "down", 3, gn=False, act=0, use_emb=False, use_res=False)
+
+
+@pytest.mark.parametrize("prec,tol", PRECS[:2])
+@pytest.mark.parametrize("B,H,W,c,cout", [(2, 8, 8, 64, 64), (2, 16, 16, 128, 128), (3, 4, 4, 32, 32), (1, 32, 32, 32, 32)])
+def test_conv_up(dev, prec, tol, B, H, W, c, cout):
+    _conv_case(dev, prec, tol, B, H, W, c, 0, cout, "up", 3, gn=False, act=0, use_emb=False, use_res=False)
+
+
+@pytest.mark.parametrize("prec,tol", PRECS)
+@pytest.mark.parametrize("B,H,W,c1,c2,cout,gn", [(2, 8, 8, 128, 64, 128, False), (3, 4, 4, 128, 0, 384, True), (1, 10, 10, 64, 0, 64, True)])
+def test_conv1x1(dev, prec, tol, B, H, W, c1, c2, cout, gn):
+    _conv_case(dev, prec, tol, B, H, W, c1, c2, cout, "s1", 1, gn=gn, act=0, use_emb=False, use_res=True)
+
+
+def test_conv_rejects_bad_args(dev):
+    from stedm_amd import _lib, ops
+    prec = ops.Precision.parse("f16")
+    x = torch.zeros((1, 8, 8, 48), device=dev)   # 48 channels: not a multiple of 32
+    w = torch.zeros((32, 9, 48), dtype=torch.int16, device=dev)
+    with pytest.raises(_lib.StedmHipError):
+        ops.conv_igemm(x, w, None, torch.zeros((1, 8, 8, 32), device=dev), prec=prec)
+
+
+# ------------------------------------------------------------------------------------------------ boundary convs
+@pytest.mark.parametrize("B,H,W,c1,c2,cout", [(2, 32, 32, 4, 3, 128), (3, 16, 16, 7, 0, 32), (1, 128, 128, 3, 3, 128)])
+def test_conv_in(dev, B, H, W, c1, c2, cout):
+    from stedm_amd import ops
+    x1 = prng.normal(3, "ci.x1", (B, c1, H, W))
+    x2 = prng.normal(3, "ci.x2", (B, c2, H, W)) if c2 else None
+    w = prng.normal(3, "ci.w", (cout, c1 + c2, 3, 3), 0.1)
+    b = prng.normal(3, "ci.b", (cout,), 0.05)
+    ref = F.conv2d(x1 if x2 is None else torch.cat([x1, x2], 1), w, b, padding=1)
+    out = torch.empty((B, H, W, cout), device=dev)
+    ops.conv_in(x1.to(dev), None if x2 is None else x2.to(dev), w.to(dev), b.to(dev), out)
+    assert rel_err(nchw(out), ref) < 2e-5
+
+
+@pytest.mark.parametrize("B,H,W,c,cout", [(2, 32, 32, 128, 4), (2, 16, 16, 32, 4), (1, 128, 128, 128, 3), (1, 40, 40, 64, 3)])
+def test_conv_out(dev, B, H, W, c, cout):
+    from stedm_amd import ops
+    x = prng.normal(4, "co.x", (B, c, H, W))
+    sc = prng.normal(4, "co.sc", (B, c), 0.2, 1.0)
+    sh = prng.normal(4, "co.sh", (B, c), 0.2)
+    w = prng.normal(4, "co.w", (cout, c, 3, 3), 0.03)
+    b = prng.normal(4, "co.b", (cout,), 0.05)
+    ref = F.conv2d(F.silu(x * sc[:, :, None, None] + sh[:, :, None, None]), w, b, padding=1)
+    out = torch.empty((B, cout, H, W), device=dev)
+    ops.conv_out(nhwc(x).to(dev), sc.to(dev), sh.to(dev), w.to(dev), b.to(dev), out)
+    assert rel_err(out, ref) < 5e-5
+
+
+# ------------------------------------------------------------------------------------------------ embeddings
+@pytest.mark.parametrize("mc", [128, 32])
+def test_time_embed_and_proj(dev, mc):
+    from oracle import unet as ou
+    from stedm_amd import ops
+    ted = mc * 4
+    t = torch.tensor([0, 1, 500, 999, 951, 21, 7, 333, 2], dtype=torch.long)
+    B = t.shape[0]
+    w0 = prng.normal(5, "te.w0", (ted, mc), 1 / math.sqrt(mc)); b0 = prng.normal(5, "te.b0", (ted,), 0.05)
+    w2 = prng.normal(5, "te.w2", (ted, ted), 1 / math.sqrt(ted)); b2 = prng.normal(5, "te.b2", (ted,), 0.05)
+    ref = F.linear(F.silu(F.linear(ou.timestep_embedding(t, mc), w0, b0)), w2, b2)
+    half = mc // 2
+    freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(dev)
+    emb = torch.empty((B, ted), device=dev)
+    ops.time_embed(t.to(dev), freqs, ops.transpose(w0.to(dev)), b0.to(dev), ops.transpose(w2.to(dev)), b2.to(dev), emb)
+    assert rel_err(emb, ref) < 1e-4
+    ntot = 1000
+    we = prng.normal(5, "ep.w", (ntot, ted), 1 / math.sqrt(ted)); be = prng.normal(5, "ep.b", (ntot,), 0.05)
+    ref2 = F.linear(F.silu(ref), we, be)
+    out = torch.empty((B, ntot), device=dev)
+    ops.emb_proj(ref.to(dev), ops.transpose(we.to(dev)), be.to(dev), out)
+    assert rel_err(out, ref2) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("B,T,heads,ch", [(2, 64, 8, 128), (2, 16, 4, 32), (1, 256, 4, 32), (1, 100, 2, 64), (1, 1024, 8, 128)])
+def test_attn_legacy(dev, B, T, heads, ch):
+    from oracle import unet as ou
+    from stedm_amd import ops
+    qkv = prng.normal(6, "at.qkv", (B, heads * 3 * ch, T)) * 1.5   # reference layout [B, 3C, T]
+    ref = ou.qkv_attention_legacy(qkv, heads)                       # [B, C, T]
+    out = torch.empty((B, T, heads * ch), device=dev)
+    ops.attn_legacy(qkv.permute(0, 2, 1).contiguous().to(dev), out, heads)
+    assert rel_err(out.permute(0, 2, 1), ref) < 5e-5
+
+
+# ------------------------------------------------------------------------------------------------ DDIM
+@pytest.mark.parametrize("B,C,H,W,cfg,eta", [(2, 4, 32, 32, True, 0.0), (3, 3, 16, 16, True, 1.0), (2, 4, 8, 8, False, 1.0),
+                                             (1, 3, 128, 128, True, 0.0), (2, 4, 12, 24, True, 0.5)])
+def test_ddim_step(dev, B, C, H, W, cfg, eta):
+    from oracle import ddim as od
+    from stedm_amd import ops
+    sched = od.Schedule()
+    ds = od.DDIMSchedule(sched, 20, eta)
+    x = prng.normal(7, "dd.x", (B, C, H, W))
+    ec = prng.normal(7, "dd.ec", (B, C, H, W))
+    eu = prng.normal(7, "dd.eu", (B, C, H, W)) * 0.8 + 0.1 * ec
+    nz = prng.normal(7, "dd.nz", (B, C, H, W))
+    idx = 10
+    e = od.cfg_combine(ec, eu, 1.5) if cfg else ec
+    xp_ref, x0_ref = od.ddim_update(x, e, *ds.scalars(idx), noise=nz)
+    table = torch.tensor([ds.scalars(i) for i in range(20)], dtype=torch.float32, device=dev)
+    step = torch.tensor([idx], dtype=torch.int32, device=dev)
+    xp = torch.empty((B, C, H, W), device=dev)
+    x0 = torch.empty((B, C, H, W), device=dev)
+    ops.ddim_step(x.to(dev), ec.to(dev), eu.to(dev) if cfg else None, table, xp, pred_x0=x0, noise=nz.to(dev), step_idx=step,
+                  cfg_scale=1.5, rescale_phi=0.7)
+    assert rel_err(xp, xp_ref) < 2e-5
+    assert rel_err(x0, x0_ref) < 2e-5
+    ops.step_advance(step, -1)
+    assert int(step.item()) == idx - 1
