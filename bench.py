@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""Headline benchmark: U-Net denoising steps/sec (32x32x4 latent, bs=64 per GPU) on MI355X.
+
+One "step" = one iteration of the reference's DDIM loop (ddim.py:139-160) for a batch of 64 latents with
+classifier-free guidance: both U-Net evaluations (cond + uncond, ddim.py:177-178) + the fused CFG-rescale /
+DDIM update. Synthetic inputs resident in HBM, PRNG-recipe weights of the NS32 architecture.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision bf16|f16|parity] [--batch 64]
+
+N > 1: launched by torch.distributed.run, one rank per GPU; every rank denoises its own 64 latents (weak
+scaling, no collective inside the loop — samples are independent); the final latents are all-gathered over
+RCCL once after the timed region. Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+NS32 = dict(image_size=32, in_channels=7, model_channels=128, out_channels=4, num_res_blocks=2,
+            attention_resolutions=[32, 16, 8], channel_mult=[1, 4, 8], num_heads=8)
+# algorithmic work: 54.288 GFLOP per U-Net sample-forward at 32x32 (hooks on the reference module)
+GFLOP_PER_SAMPLE_FORWARD = 54.288
+PEAK_MFMA_TFLOPS = 2500.0     # dense bf16/f16, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0
+
+
+def build_model(dev, precision, use_graph=True):
+    from stedm_amd.latent_diffusion import LatentDiffusion
+    from stedm_amd.unet import UNetModel
+    from stedm_amd.utils import prng
+    unet = UNetModel(precision=precision, **NS32).eval()
+    prng.fill_module_(unet, seed=0)
+    ld = LatentDiffusion(unet, linear_start=0.0015, linear_end=0.0205, image_size=32, channels=4,
+                         conditioning_key="hybrid", loss_type="l1", use_graph=use_graph)
+    return ld.to(dev)
+
+
+def synth_inputs(dev, B, rank):
+    from stedm_amd.utils import prng
+    s = 1000 * rank
+    xT = prng.normal(1 + s, "bench.xT", (B, 4, 32, 32)).to(dev)
+    layout = (prng.uniform(2 + s, "bench.layout", (B, 3, 32, 32)) > 0).float().to(dev)   # stand-in for the rescaled layout
+    ctx = prng.normal(3 + s, "bench.ctx", (B, 512)).to(dev)
+    ctx_u = prng.normal(4, "bench.ctx_u", (1, 512)).repeat(B, 1).contiguous().to(dev)     # uncond style: one constant vector
+    cond = {"c_concat": [layout], "c_crossattn": [ctx]}
+    unc = {"c_concat": [layout], "c_crossattn": [ctx_u]}
+    return xT, cond, unc
+
+
+class ConvTimer:
+    """Brackets every stedm_conv_igemm launch with HIP events on the launch stream (torch's current stream is
+    the stream ops.py launches on) and records its algorithmic FLOPs = 2*M*N*K."""
+
+    def __init__(self):
+        self.rec = []
+
+    def install(self):
+        from stedm_amd import ops
+        self._orig = ops.conv_igemm
+        timer = self
+
+        def timed(src1, w_hi, w_lo, out, **kw):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = timer._orig(src1, w_hi, w_lo, out, **kw)
+            e1.record()
+            M = out.numel() // out.shape[-1]
+            flops = 2.0 * M * out.shape[-1] * w_hi.shape[1] * w_hi.shape[2]
+            timer.rec.append((e0, e1, flops))
+            return r
+
+        ops.conv_igemm = timed
+
+    def remove(self):
+        from stedm_amd import ops
+        ops.conv_igemm = self._orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.rec)
+        fl = sum(f for _, _, f in self.rec)
+        return {"launches": len(self.rec), "total_ms": ms, "avg_us": 1e3 * ms / max(1, len(self.rec)),
+                "flops_per_launch": fl / max(1, len(self.rec)), "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
+
+
+def run_steps(ld, xT, cond, unc, warmup, steps, world):
+    """W untimed + K timed denoising steps (hipGraph replay). Returns (seconds for K steps, final latents)."""
+    from stedm_amd.ddim import DDIMSampler, StepGraph
+    smp = DDIMSampler(ld, use_graph=True)
+    smp.make_schedule(50, ddim_eta=0.0, verbose=False)      # BASELINE config 3: DDIM-50, eta 0, cfg 1.5
+    n = smp.ddim_timesteps.shape[0]
+    img = xT.clone()
+    sg = StepGraph(smp, img, cond, unc, 1.5)
+    sg.reset(n - 1)
+    sg.step_eager()
+    with sg.stream_ctx():
+        sg.capture()
+        left = n - 2
+        for _ in range(max(0, warmup - 1)):
+            if left < 0:
+                sg.reset(n - 1); left = n - 1
+            sg.replay(); left -= 1
+        torch.cuda.current_stream().synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            if left < 0:
+                sg.reset(n - 1); left = n - 1
+            sg.replay(); left -= 1
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    sg.join()
+    return dt, img
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The CPU oracle (fixture-pinned restatement of the reference's PyTorch-CPU path) on this host's cores:
+    CFG denoising steps (2 sequential U-Net forwards + update, as the reference does) at a bounded batch."""
+    from oracle import ddim as od
+    from oracle import unet as ou
+    from stedm_amd.utils import prng
+    torch.set_grad_enabled(False)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    # a 1-GPU box share is 16 host cores (the affinity mask shows the whole 256-thread host; using all of them
+    # oversubscribes the share and runs ~50x slower). STEDM_CPU_THREADS overrides.
+    cores = int(os.environ.get("STEDM_CPU_THREADS", min(cores, 16)))
+    torch.set_num_threads(cores)
+    cfg = ou.UNetConfig()
+    plan = ou.build_plan(cfg)
+    P = prng.fill_state_dict(plan.shapes, 0)
+    Bc = 4
+    x = prng.normal(1, "cpu.x", (Bc, 4, 32, 32)); cc = prng.normal(2, "cpu.cc", (Bc, 3, 32, 32))
+    ctx = prng.normal(3, "cpu.ctx", (Bc, 512)); ctx_u = prng.normal(4, "cpu.ctxu", (Bc, 512))
+    t = torch.full((Bc,), 951, dtype=torch.long)
+    ds = od.DDIMSchedule(od.Schedule(), 50, 0.0)
+
+    def step(xx):
+        e_c = ou.unet_forward(P, cfg, torch.cat([xx, cc], 1), t, ctx, plan=plan)
+        e_u = ou.unet_forward(P, cfg, torch.cat([xx, cc], 1), t, ctx_u, plan=plan)
+        return od.ddim_update(xx, od.cfg_combine(e_c, e_u, 1.5), *ds.scalars(49))[0]
+
+    x = step(x)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        x = step(x); n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or n >= 12:
+            break
+    sample_steps_per_s = n * Bc / el
+    return {"value": sample_steps_per_s / 64.0, "unit": "steps/s (bs=64 equivalent)", "cores": cores, "kind": "port",
+            "sample": f"{n} CFG denoising steps at batch {Bc} (fp32 torch-CPU oracle, {cores} threads), "
+                      f"{el:.1f} s; scaled by {Bc}/64", "sample_steps_per_s": sample_steps_per_s}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--precision", default=os.environ.get("STEDM_BENCH_PRECISION", "bf16"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-leg", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=dev)
+    torch.set_grad_enabled(False)
+
+    B = args.batch
+    ld = build_model(dev, args.precision)
+    xT, cond, unc = synth_inputs(dev, B, rank)
+    dt, final = run_steps(ld, xT, cond, unc, args.warmup, args.steps, world)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        gathered = [torch.empty_like(final) for _ in range(world)]       # prediction-side RCCL all-gather of the samples
+        torch.distributed.all_gather(gathered, final)
+        assert all(torch.isfinite(g).all() for g in gathered)
+    dt = float(t.item())
+    steps_per_s = world * args.steps / dt
+    ms_per_step = 1e3 * dt / args.steps
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel (conv_igemm): live HIP-event timing of every launch of one eager step
+        from stedm_amd.ddim import DDIMSampler, StepGraph
+        smp = DDIMSampler(ld)
+        smp.make_schedule(50, ddim_eta=0.0, verbose=False)
+        sg = StepGraph(smp, xT.clone(), cond, unc, 1.5)
+        sg.reset(49)
+        sg.step_eager()
+        torch.cuda.synchronize()
+        ct = ConvTimer(); ct.install()
+        for _ in range(2):
+            sg.step_eager()
+        cs = ct.summary(); ct.remove()
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("conv_igemm_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (all instantiations)", "achieved": round(cs["tflops"], 2),
+                    "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(cs["tflops"] / PEAK_MFMA_TFLOPS, 4),
+                    "traffic": traffic, "launches_per_step": cs["launches"] // 2, "avg_launch_us": round(cs["avg_us"], 2),
+                    "algorithmic_gflop_per_launch": round(cs["flops_per_launch"] / 1e9, 3),
+                    "conv_ms_per_step": round(cs["total_ms"] / 2, 3)}
+        # whole-step figure against the same peak (2 reference forwards of algorithmic work per step)
+        step_tflops = 2 * B * GFLOP_PER_SAMPLE_FORWARD / 1e3 / (ms_per_step * 1e-3) * 1.0
+        out = {
+            "metric": "U-Net denoising steps/sec (32x32x4 latent, bs=64)", "value": round(steps_per_s, 3), "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ld.model.diffusion_model.precision.label,
+            "data": "synthetic",
+            "config": {"workload": "HER2-style DDIM-50 + CFG 1.5 (rescale 0.7) denoising step, NS32 U-Net (234.6M params, "
+                                   "random-init PRNG weights), 32x32x4 latents + 3-ch layout concat, style vector 512",
+                       "batch_per_gpu": B, "global_batch": B * world, "latent": "32x32x4", "cfg": "cond+uncond per step",
+                       "parallelism": f"dp{world} (independent latents, no in-loop collective)"},
+            "sample_steps_per_s": round(steps_per_s * B, 1),
+            "step_algorithmic_tflops": round(step_tflops, 1), "step_frac_of_mfma_peak": round(step_tflops / PEAK_MFMA_TFLOPS, 4),
+            "roofline": roofline,
+        }
+        if not args.no_parity_leg and world == 1:
+            # fp32-parity mode (fp16 x3 split products) throughput next to the fast mode, same workload
+            del sg, smp
+            ld.model.diffusion_model.set_precision("parity")
+            dtp, _ = run_steps(ld, xT, cond, unc, 2, max(4, args.steps // 2), 1)
+            out["parity_mode"] = {"dtype": "f16x3", "value": round(max(4, args.steps // 2) / dtp, 3), "unit": "steps/s",
+                                  "note": "split-precision mode that meets the 1e-3 fp32 parity tolerance (tests/test_gpu_unet.py)"}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        elif world == 1:
+            out["cpu_baseline"] = None
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -126,6 +126,9 @@ int stedm_ddim_step(const float* x, const float* e_c, const float* e_u, const fl
                     float* x_prev, float* pred_x0, int B, int C, int H, int W, void* stream);
 /* *step_idx += delta (device-side loop counter for graph replay). */
 int stedm_step_advance(int32_t* step_idx, int delta, void* stream);
+/* t_buf[0..B) = ts_table[*step_idx] : ts = torch.full((b,), step) of ddim.py:141, device-side so that one
+ * captured graph serves every step. ts_table: DEVICE int64 [nsteps] (ddim_timesteps, ascending). */
+int stedm_step_set_t(const int64_t* ts_table, const int32_t* step_idx, int64_t* t_buf, int B, void* stream);
 
 /* ---- HIP graph capture helpers (plumbing for the sampling loop) ---------------------------- */
 int stedm_graph_begin(void* stream);

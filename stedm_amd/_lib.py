@@ -52,6 +52,7 @@ SIGNATURES = {
     "stedm_attn_legacy": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "stedm_ddim_step": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _I, _I, _I, _I, _P]),
     "stedm_step_advance": (_I, [_P, _I, _P]),
+    "stedm_step_set_t": (_I, [_P, _P, _P, _I, _P]),
     "stedm_graph_begin": (_I, [_P]),
     "stedm_graph_end": (_I, [_P, C.POINTER(C.c_void_p)]),
     "stedm_graph_launch": (_I, [_P, _P]),
@@ -69,6 +70,13 @@ def lib() -> C.CDLL:
             raise StedmHipError(
                 f"{LIB_PATH} not found: build it with `python -m stedm_amd.build` "
                 "(there is no CPU / PyTorch fallback for the hot path)")
+        try:
+            # One HIP runtime per process: the PyTorch-ROCm wheel bundles libamdhip64.so (soname .so.7) under
+            # torch/lib. Loaded first, it satisfies this library's NEEDED libamdhip64.so.7 by soname; loaded second,
+            # /opt/rocm's copy would already be in and torch would add its own -> two runtimes, "no device".
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         try:
             L = C.CDLL(LIB_PATH)
         except OSError as e:  # pragma: no cover

@@ -266,6 +266,17 @@ extern "C" int stedm_step_advance(int32_t* step_idx, int delta, void* stream) {
   return 0;
 }
 
+__global__ void step_set_t_kernel(const int64_t* __restrict__ ts, const int32_t* __restrict__ idx, int64_t* __restrict__ t, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) t[i] = ts[*idx];
+}
+extern "C" int stedm_step_set_t(const int64_t* ts_table, const int32_t* step_idx, int64_t* t_buf, int B, void* stream) {
+  STEDM_CHECK_ARG(ts_table && step_idx && t_buf && B > 0, "step_set_t: bad args");
+  step_set_t_kernel<<<(B + 255) / 256, 256, 0, as_stream(stream)>>>(ts_table, step_idx, t_buf, B);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Graph helpers
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,195 @@
+"""Model surface that `modules/ldm_diffusion.py::LDM_Diffusion` drives (SURVEY.md §8b seam 2), HIP-backed.
+
+  DiffusionWrapper   ddpm.py:1398-1424  (hybrid conditioning: cat([x]+c_concat,1), cat(c_crossattn,1))
+  LatentDiffusion    ddpm.py:424-…     subset on the hot path: register_schedule :120-172, q_sample :277-280,
+                                        apply_model :894-995 (live lines), p_losses :1015-1048 (forward value),
+                                        sample_log :1237-1250, get_learned_conditioning :554-565
+The first stage (VQ-f4 autoencoder) is outside this round's scope: `first_stage_model`
+is an optional caller-supplied module; `decode_first_stage` raises if it is absent.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ddim import DDIMSampler
+from .schedule import NoiseSchedule
+from .unet import UNetModel
+
+
+def instantiate_from_config(config):
+    """ldm/util.py:78-93 restricted to targets this package provides (reference target strings are mapped)."""
+    import importlib
+    if "target" not in config:
+        raise KeyError("Expected key `target` to instantiate.")
+    alias = {
+        "ldm.modules.diffusionmodules.openaimodel.UNetModel": "stedm_amd.unet.UNetModel",
+        "ldm.modules.encoders.modules.SpatialRescaler": "stedm_amd.style.SpatialRescaler",
+    }
+    target = alias.get(config["target"], config["target"])
+    module, cls = target.rsplit(".", 1)
+    return getattr(importlib.import_module(module), cls)(**config.get("params", dict()))
+
+
+class DiffusionWrapper(nn.Module):
+    """ddpm.py:1398-1424."""
+
+    def __init__(self, diff_model_config, conditioning_key):
+        super().__init__()
+        self.diffusion_model = diff_model_config if isinstance(diff_model_config, nn.Module) else instantiate_from_config(diff_model_config)
+        self.conditioning_key = conditioning_key
+        assert self.conditioning_key in [None, 'concat', 'crossattn', 'hybrid', 'adm']
+        if self.conditioning_key != 'hybrid':
+            raise NotImplementedError("only conditioning_key='hybrid' is used by STEDM (conf/diffusion/ldm_based.yaml:12)")
+
+    @torch.no_grad()
+    def forward(self, x, t, c_concat: list = None, c_crossattn: list = None, out=None):
+        cc = c_crossattn[0] if len(c_crossattn) == 1 else torch.cat(c_crossattn, 1)
+        xc = c_concat[0] if len(c_concat) == 1 else torch.cat(c_concat, 1)
+        return self.diffusion_model.forward_parts(x, xc, t, cc, out=out)   # cat([x]+c_concat) folded into the first conv
+
+    def _same_tensor(self, a, b) -> bool:
+        """Content equality of two conditioning tensors, decided once per (storage, version) pair (no per-step sync)."""
+        if a is b or (a.shape == b.shape and a.data_ptr() == b.data_ptr()):
+            return True
+        if a.shape != b.shape:
+            return False
+        key = (a.data_ptr(), a._version, b.data_ptr(), b._version, tuple(a.shape))
+        cache = self.__dict__.setdefault("_eq_cache", {})
+        if key not in cache:
+            if len(cache) > 64:
+                cache.clear()
+            cache[key] = bool(torch.equal(a, b))
+        return cache[key]
+
+    @torch.no_grad()
+    def forward_cfg(self, x, t, cond: dict, uncond: dict, out=None):
+        """cond/uncond evaluations of ddim.py:177-178 in one shared-encoder pass. Requires equal c_concat (the
+        reference's unconditional batch keeps the segmentation, ldm_diffusion.py:86); otherwise two passes."""
+        cc_c, cc_u = cond["c_concat"], uncond["c_concat"]
+        same = len(cc_c) == len(cc_u) and all(self._same_tensor(a, b) for a, b in zip(cc_c, cc_u))
+        if not same:
+            B = x.shape[0]
+            if out is None:
+                out = torch.empty((2 * B, self.diffusion_model.out_channels) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+            self.forward(x, t, **cond, out=out[:B])
+            self.forward(x, t, **uncond, out=out[B:])
+            return out[:B], out[B:]
+        xc = cc_c[0] if len(cc_c) == 1 else torch.cat(cc_c, 1)
+        ca = cond["c_crossattn"]; cu = uncond["c_crossattn"]
+        ca = ca[0] if len(ca) == 1 else torch.cat(ca, 1)
+        cu = cu[0] if len(cu) == 1 else torch.cat(cu, 1)
+        return self.diffusion_model.forward_cfg(x, xc, t, ca, cu, out=out)
+
+
+class LatentDiffusion(nn.Module):
+    """Hot-path subset of ddpm.py::LatentDiffusion / DDPM with the attribute names its callers read."""
+
+    def __init__(self, unet_config, timesteps=1000, beta_schedule="linear", linear_start=1e-4, linear_end=2e-2,
+                 loss_type="l2", image_size=256, channels=3, conditioning_key=None, parameterization="eps",
+                 cond_stage_config=None, first_stage_config=None, cond_stage_trainable=False, first_stage_key="image",
+                 cond_stage_key="image", log_every_t=100, scale_factor=1.0, use_graph=False, **ignored):
+        super().__init__()
+        assert parameterization == "eps", "the reference configs use eps-prediction"
+        self.parameterization = parameterization
+        self.image_size = image_size
+        self.channels = channels
+        self.first_stage_key = first_stage_key
+        self.cond_stage_key = cond_stage_key
+        self.cond_stage_trainable = cond_stage_trainable
+        self.log_every_t = log_every_t
+        self.loss_type = loss_type
+        self.scale_factor = scale_factor
+        self.learn_logvar = False
+        self.use_graph = use_graph
+        self.model = DiffusionWrapper(unet_config, conditioning_key)
+        self.cond_stage_model = None
+        if cond_stage_config is not None:
+            self.cond_stage_model = cond_stage_config if isinstance(cond_stage_config, nn.Module) else instantiate_from_config(cond_stage_config)
+        self.first_stage_model = first_stage_config if isinstance(first_stage_config, nn.Module) else None
+        self.register_schedule(beta_schedule=beta_schedule, timesteps=timesteps, linear_start=linear_start, linear_end=linear_end)
+        self.register_buffer("logvar", torch.zeros(self.num_timesteps))
+
+    # ------------------------------------------------------------------------------------------ schedule
+    def register_schedule(self, given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=1e-4,
+                          linear_end=2e-2, cosine_s=8e-3):
+        """ddpm.py:120-172 (the buffers the hot path reads)."""
+        assert given_betas is None
+        ns = NoiseSchedule.make(timesteps, linear_start, linear_end, beta_schedule)
+        self.num_timesteps = ns.num_timesteps
+        self.linear_start, self.linear_end = linear_start, linear_end
+        for name in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod"):
+            self.register_buffer(name, torch.from_numpy(getattr(ns, name).copy()))
+
+    @property
+    def device(self):
+        return self.betas.device
+
+    # ------------------------------------------------------------------------------------------ conditioning
+    def get_learned_conditioning(self, c):
+        """ddpm.py:554-565 with a module cond stage (SpatialRescaler has `encode`)."""
+        if hasattr(self.cond_stage_model, 'encode') and callable(self.cond_stage_model.encode):
+            return self.cond_stage_model.encode(c)
+        return self.cond_stage_model(c)
+
+    # ------------------------------------------------------------------------------------------ denoiser
+    @staticmethod
+    def _as_cond_dict(cond, key='c_crossattn'):
+        if isinstance(cond, dict):
+            return cond
+        if not isinstance(cond, list):
+            cond = [cond]
+        return {key: cond}
+
+    @torch.no_grad()
+    def apply_model(self, x_noisy, t, cond, return_ids=False, out=None):
+        """ddpm.py:894-903 + 989-995."""
+        return self.model(x_noisy, t, **self._as_cond_dict(cond), out=out)
+
+    @torch.no_grad()
+    def apply_model_cfg(self, x_noisy, t, cond, uncond, out=None):
+        """(e_t, e_t_uncond) of ddim.py:177-178 in one pass (see UNetModel.forward_cfg)."""
+        return self.model.forward_cfg(x_noisy, t, self._as_cond_dict(cond), self._as_cond_dict(uncond), out=out)
+
+    # ------------------------------------------------------------------------------------------ training-side forward values
+    @torch.no_grad()
+    def q_sample(self, x_start, t, noise=None):
+        """ddpm.py:277-280 (+ extract_into_tensor util.py:96-99). Elementwise; torch ops on the caller's device."""
+        noise = torch.randn_like(x_start) if noise is None else noise
+        sh = (x_start.shape[0],) + (1,) * (x_start.dim() - 1)
+        return (self.sqrt_alphas_cumprod.gather(-1, t).reshape(sh) * x_start
+                + self.sqrt_one_minus_alphas_cumprod.gather(-1, t).reshape(sh) * noise)
+
+    @torch.no_grad()
+    def p_losses(self, x_start, cond, t, noise=None):
+        """ddpm.py:1015-1048, forward value only (loss_type l1/l2, logvar == 0). The backward kernels are a later
+        row; calling this under autograd does not produce gradients."""
+        noise = torch.randn_like(x_start) if noise is None else noise
+        x_noisy = self.q_sample(x_start, t, noise)
+        model_output = self.apply_model(x_noisy, t, cond)
+        if self.loss_type == 'l1':
+            loss_simple = (noise - model_output).abs().mean([1, 2, 3])
+        else:
+            loss_simple = ((noise - model_output) ** 2).mean([1, 2, 3])
+        loss = loss_simple.mean()
+        return loss, {"val/loss_simple": loss, "val/loss": loss}
+
+    # ------------------------------------------------------------------------------------------ sampling
+    @torch.no_grad()
+    def sample_log(self, cond, batch_size, ddim, ddim_steps, **kwargs):
+        """ddpm.py:1237-1250."""
+        if not ddim:
+            raise NotImplementedError("ancestral DDPM sampling is dead code for the shipped configs (SURVEY.md §2.1 #5)")
+        sampler = DDIMSampler(self, use_graph=self.use_graph)
+        shape = (self.channels, self.image_size, self.image_size)
+        return sampler.sample(ddim_steps, batch_size, shape, cond, verbose=False, **kwargs)
+
+    def decode_first_stage(self, z, **kw):
+        if self.first_stage_model is None:
+            raise NotImplementedError("first stage (VQ-f4 decoder) is out of this round's scope (SURVEY.md §8f next-1); "
+                                      "pass a first_stage module to LatentDiffusion to use decode_first_stage")
+        return self.first_stage_model.decode(z / self.scale_factor)

@@ -201,6 +201,13 @@ def step_advance(step_idx: torch.Tensor, delta: int = 1) -> None:
     check(lib().stedm_step_advance(step_idx.data_ptr(), delta, _stream()), "stedm_step_advance")
 
 
+def step_set_t(ts_table: torch.Tensor, step_idx: torch.Tensor, t_buf: torch.Tensor) -> None:
+    _chk(ts_table, torch.int64, "ts_table")
+    _chk(t_buf, torch.int64, "t_buf")
+    check(lib().stedm_step_set_t(ts_table.data_ptr(), step_idx.data_ptr(), t_buf.data_ptr(), t_buf.shape[0], _stream()),
+          "stedm_step_set_t")
+
+
 # ------------------------------------------------------------------------------------------- graphs
 class Graph:
     """hipGraph captured on the current torch stream (all buffers must be allocated beforehand)."""

@@ -352,12 +352,12 @@ class UNetModel(nn.Module):
         ops.conv_igemm(a, pp.hi, pp.lo, out, prec=prec, ks=1, bias=pp.bias, res=x)
         return out
 
-    def _run_block(self, tag: str, blk, h, skip, emb_all, emb_bstride, style_all):
+    def _run_block(self, tag: str, blk, h, skip, emb_all, emb_bstride, style_all, skip_bmod=0, li0=0):
         """TimestepEmbedSequential.forward openaimodel.py:93-101 (+ the th.cat of :800 folded into the first layer)."""
-        for li, layer in enumerate(blk):
+        for li, layer in enumerate(blk, start=li0):
             ltag = f"{tag}.{li}"
             if isinstance(layer, ResBlock):
-                h = self._res(ltag, layer, h, skip, emb_all, self._emb_off[id(layer)], emb_bstride)
+                h = self._res(ltag, layer, h, skip, emb_all, self._emb_off[id(layer)], emb_bstride, x2_bmod=skip_bmod)
                 skip = None
             elif isinstance(layer, ResBlockStyle):
                 h = self._res(ltag, layer.block, h, None, style_all, 0, style_all.shape[1])
@@ -390,39 +390,76 @@ class UNetModel(nn.Module):
     def forward_parts(self, x, c_concat, timesteps, context, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Same as forward, but takes the latent and the concat-conditioning separately (the cat of
         ddpm.py:1415 is folded into the first conv's loader)."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            pass  # decorated no_grad: gradients are not produced by the HIP path (training backward is a later row)
+        return self._forward_impl(x, c_concat, timesteps, [context], out)
+
+    @torch.no_grad()
+    def forward_cfg(self, x, c_concat, timesteps, context_cond, context_uncond, out: Optional[torch.Tensor] = None):
+        """Both classifier-free-guidance evaluations of ddim.py:177-178 in one pass: returns (e_t, e_t_uncond).
+
+        The reference runs the U-Net twice on the same (x, t, c_concat) with two style vectors. The style vector only
+        enters at middle_block[1] (ResBlockStyle, openaimodel.py:636-643), so everything before it — the 9 input blocks
+        and middle_block[0] — is bit-identical in the two runs and is evaluated once (batch B); from the style block on
+        the batch is 2B = [cond | uncond], with the skip tensors of the shared encoder read modulo B. Per-sample
+        arithmetic (GroupNorm is per sample) is exactly that of two sequential forwards."""
+        o = self._forward_impl(x, c_concat, timesteps, [context_cond, context_uncond], out)
+        B = x.shape[0]
+        return o[:B], o[B:]
+
+    def _forward_impl(self, x, c_concat, timesteps, contexts, out):
         self._prepare()
         x = x.float().contiguous()
         B, c1, H, W = x.shape
+        nrep = len(contexts)
+        Bd = B * nrep                      # decoder batch
         c2 = 0
         if c_concat is not None:
             c_concat = c_concat.float().contiguous()
             c2 = c_concat.shape[1]
         assert c1 + c2 == self.in_channels, f"expected {self.in_channels} input channels, got {c1}+{c2}"
-        if context is None:
+        if any(cx is None for cx in contexts):
             raise ValueError("context (style vector) is required: middle_block[1] is a ResBlockStyle (openaimodel.py:636-643)")
         timesteps = timesteps.to(device=x.device, dtype=torch.int64).contiguous()
-        context = context.float().contiguous()
         c = self._consts
         ted = self.model_channels * 4
-        assert context.shape == (B, ted), f"context must be [B,{ted}] (ResBlockStyle uses it as the embedding)"
+        for cx in contexts:
+            assert tuple(cx.shape) == (B, ted), f"context must be [B,{ted}] (ResBlockStyle uses it as the embedding)"
+        if nrep == 1:
+            ctx_all = contexts[0].float().contiguous()
+        else:
+            ctx_all = self._buf("ctx_all", (Bd, ted))
+            for r, cx in enumerate(contexts):
+                ctx_all[r * B:(r + 1) * B].copy_(cx)
 
         emb = ops.time_embed(timesteps, c["freqs"], c["te_w0t"], c["te_b0"], c["te_w2t"], c["te_b2"], self._buf("emb", (B, ted)))
-        emb_all = ops.emb_proj(emb, c["emb_wt"], c["emb_b"], self._buf("emb_all", (B, self._emb_ntot)))
-        style_all = ops.emb_proj(context, c["style_wt"], c["style_b"], self._buf("style_all", (B, c["style_wt"].shape[1])))
+        emb_e = ops.emb_proj(emb, c["emb_wt"], c["emb_b"], self._buf("emb_all", (B, self._emb_ntot)))
+        if nrep == 1:
+            emb_d = emb_e
+        else:  # decoder rows b and b+B share timestep row b
+            emb_d = self._buf("emb_all_d", (Bd, self._emb_ntot))
+            for r in range(nrep):
+                emb_d[r * B:(r + 1) * B].copy_(emb_e)
+        style_all = ops.emb_proj(ctx_all, c["style_wt"], c["style_b"], self._buf("style_all", (Bd, c["style_wt"].shape[1])))
 
         conv0 = self.input_blocks[0][0]
         h = ops.conv_in(x, c_concat, conv0.weight, conv0.bias, self._buf("in0.out", (B, H, W, self.model_channels)))
         hs = [h]
         for i, blk in enumerate(self.input_blocks[1:], start=1):
-            h = self._run_block(f"in{i}", blk, h, None, emb_all, self._emb_ntot, style_all)
+            h = self._run_block(f"in{i}", blk, h, None, emb_e, self._emb_ntot, None)
             hs.append(h)
-        h = self._run_block("mid", self.middle_block, h, None, emb_all, self._emb_ntot, style_all)
+        # middle block: [0] shared, then replicate the batch for the style-conditioned remainder
+        mid = list(self.middle_block)
+        h = self._run_block("mid.a", mid[:1], h, None, emb_e, self._emb_ntot, None)
+        if nrep > 1:
+            h2 = self._buf("mid.rep", (Bd,) + tuple(h.shape[1:]))
+            for r in range(nrep):
+                h2[r * B:(r + 1) * B].copy_(h)
+            h = h2
+        h = self._run_block("mid.b", mid[1:], h, None, emb_d, self._emb_ntot, style_all, li0=1)
+        bmod = B if nrep > 1 else 0
         for i, blk in enumerate(self.output_blocks):
-            h = self._run_block(f"out{i}", blk, h, hs.pop(), emb_all, self._emb_ntot, style_all)
+            h = self._run_block(f"out{i}", blk, h, hs.pop(), emb_d, self._emb_ntot, style_all, skip_bmod=bmod)
         sc, sh = self._gn("outn", self.out[0], h)
         if out is None:
-            out = torch.empty((B, self.out_channels, H, W), dtype=torch.float32, device=x.device)
+            out = torch.empty((Bd, self.out_channels, H, W), dtype=torch.float32, device=x.device)
         ops.conv_out(h, sc, sh, self.out[2].weight, self.out[2].bias, out)
         return out

@@ -1,0 +1,112 @@
+"""GPU tier (-m gpu): DDIM + rescaled-CFG sampling loop (reference module surface: LatentDiffusion.sample_log ->
+DDIMSampler.sample) against the CPU oracle loop on identical x_T / conditioning / injected noise."""
+import pytest
+import torch
+
+from stedm_amd.utils import prng
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+TINY = dict(image_size=16, in_channels=7, model_channels=32, out_channels=4, num_res_blocks=2,
+            attention_resolutions=[32, 16, 8], channel_mult=[1, 2, 4], num_heads=4)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def make(dev, use_graph=False, precision="parity"):
+    from stedm_amd.latent_diffusion import LatentDiffusion
+    from stedm_amd.unet import UNetModel
+    unet = UNetModel(precision=precision, **TINY).eval()
+    prng.fill_module_(unet, seed=6)
+    ld = LatentDiffusion(unet, linear_start=0.0015, linear_end=0.0205, image_size=16, channels=4, conditioning_key="hybrid",
+                         loss_type="l1", use_graph=use_graph)
+    return ld.to(dev)
+
+
+def oracle_sample(xT, cc, ctx, ctx_u, S, eta, scale, noises=None):
+    from oracle import ddim as od
+    from oracle import unet as ou
+    cfg = ou.UNetConfig(image_size=16, in_channels=7, model_channels=32, out_channels=4, channel_mult=(1, 2, 4), num_heads=4)
+    plan = ou.build_plan(cfg)
+    P = prng.fill_state_dict(plan.shapes, 6)
+
+    def apply_model(x, t, c):
+        return ou.unet_forward(P, cfg, torch.cat([x, c["c_concat"][0]], 1), t, c["c_crossattn"][0], plan=plan)
+
+    cond = {"c_concat": [cc], "c_crossattn": [ctx]}
+    unc = None if ctx_u is None else {"c_concat": [cc], "c_crossattn": [ctx_u]}
+    return od.ddim_sample(apply_model, od.Schedule(), xT, cond, S, eta, uncond=unc, scale=scale, noises=noises)
+
+
+def inputs(B=2):
+    xT = prng.normal(30, "s.xT", (B, 4, 16, 16))
+    cc = prng.normal(30, "s.cc", (B, 3, 16, 16)) * 0.5
+    ctx = prng.normal(30, "s.ctx", (B, 128))
+    ctx_u = prng.normal(30, "s.ctxu", (B, 128))
+    return xT, cc, ctx, ctx_u
+
+
+def rel(a, b):
+    return float((a.double().cpu() - b.double()).abs().max() / b.double().std())
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_ddim_cfg_loop_vs_oracle(dev, use_graph):
+    xT, cc, ctx, ctx_u = inputs()
+    ref = oracle_sample(xT, cc, ctx, ctx_u, 5, 0.0, 1.5)
+    ld = make(dev, use_graph)
+    cond = {"c_concat": [cc.to(dev)], "c_crossattn": [ctx.to(dev)]}
+    unc = {"c_concat": [cc.to(dev).clone()], "c_crossattn": [ctx_u.to(dev)]}   # equal content, different storage
+    s, inter = ld.sample_log(cond, 2, True, 5, eta=0.0, x_T=xT.to(dev), unconditional_conditioning=unc,
+                             unconditional_guidance_scale=1.5, log_every_t=1000)
+    err = rel(s, ref)
+    print(f"[ddim cfg x5, graph={use_graph}] rel err vs oracle loop: {err:.3e}")
+    assert err < 1e-3
+    assert len(inter["x_inter"]) == 3   # initial, index 4 (== total-1), index 0
+
+
+def test_graph_equals_eager_bits(dev):
+    xT, cc, ctx, ctx_u = inputs()
+    outs = []
+    for g in (False, True):
+        ld = make(dev, g, "f16")
+        cond = {"c_concat": [cc.to(dev)], "c_crossattn": [ctx.to(dev)]}
+        unc = {"c_concat": [cc.to(dev)], "c_crossattn": [ctx_u.to(dev)]}
+        s, _ = ld.sample_log(cond, 2, True, 4, eta=0.0, x_T=xT.to(dev), unconditional_conditioning=unc,
+                             unconditional_guidance_scale=1.5)
+        outs.append(s.clone())
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_ddim_eta1_injected_noise_and_no_cfg(dev):
+    xT, cc, ctx, _ = inputs()
+    S = 4
+    noises = [prng.normal(31, f"nz{i}", (2, 4, 16, 16)) for i in range(S)]
+    ref = oracle_sample(xT, cc, ctx, None, S, 1.0, 1.0, noises=noises)
+    ld = make(dev)
+    cond = {"c_concat": [cc.to(dev)], "c_crossattn": [ctx.to(dev)]}
+    s, _ = ld.sample_log(cond, 2, True, S, eta=1.0, x_T=xT.to(dev), noises=noises)
+    assert rel(s, ref) < 1e-3
+
+
+def test_cfg_pass_equals_two_sequential_forwards(dev):
+    """The shared-encoder CFG pass must give the same values as the reference's two sequential apply_model calls."""
+    xT, cc, ctx, ctx_u = inputs(3)
+    ld = make(dev, precision="f16")
+    t = torch.tensor([951, 951, 951], dtype=torch.long, device=dev)
+    cond = {"c_concat": [cc.to(dev)], "c_crossattn": [ctx.to(dev)]}
+    unc = {"c_concat": [cc.to(dev)], "c_crossattn": [ctx_u.to(dev)]}
+    e_c = ld.apply_model(xT.to(dev), t, cond).clone()
+    e_u = ld.apply_model(xT.to(dev), t, unc).clone()
+    f_c, f_u = ld.apply_model_cfg(xT.to(dev), t, cond, unc)
+    assert torch.equal(e_c, f_c) and torch.equal(e_u, f_u)
+    # different c_concat -> falls back to two passes
+    unc2 = {"c_concat": [cc.to(dev) * 0.5], "c_crossattn": [ctx_u.to(dev)]}
+    g_c, g_u = ld.apply_model_cfg(xT.to(dev), t, cond, unc2)
+    assert torch.equal(g_c, e_c) and not torch.equal(g_u, e_u)

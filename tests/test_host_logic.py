@@ -1,0 +1,47 @@
+"""CPU tier: product host logic (schedules, DDIM tables, module surface) against the reference's golden vectors."""
+import numpy as np
+import torch
+
+from stedm_amd import schedule as sch
+
+
+def test_schedule_matches_reference_bits(golden):
+    fx = golden("f2_schedule")
+    ns = sch.NoiseSchedule.make(1000, 0.0015, 0.0205)
+    assert np.array_equal(ns.betas, fx["betas_f32"])
+    assert np.array_equal(ns.alphas_cumprod, fx["alphas_cumprod_f32"])
+    assert ns.alphas_cumprod_prev[0] == np.float32(1.0)
+    for S, n in ((20, 20), (50, 50), (128, 143)):
+        ts = sch.make_ddim_timesteps(S)
+        assert ts.dtype == np.int64 and ts.shape[0] == n
+        assert np.array_equal(ts, fx[f"ts_{S}"])            # integer indexing: bit-exact
+        for eta in (0.0, 1.0):
+            tb = sch.make_ddim_tables(ns.alphas_cumprod, S, eta)
+            f32 = lambda a: np.asarray(a, dtype=np.float64).astype(np.float32)
+            assert np.array_equal(tb.alphas, f32(fx[f"a_{S}_{eta}"]))
+            assert np.array_equal(tb.alphas_prev, f32(fx[f"ap_{S}_{eta}"]))
+            assert np.array_equal(tb.sigmas, f32(fx[f"sig_{S}_{eta}"]))
+            assert np.array_equal(tb.sqrt_one_minus_alphas, np.sqrt(np.float32(1.0) - tb.alphas))
+            assert tb.coef_table().shape == (n, 4) and tb.coef_table().dtype == np.float32
+
+
+def test_unet_module_surface_cpu():
+    """Construction, state-dict names and zero-initialised layers follow the reference (no GPU needed)."""
+    from oracle import unet as ou
+    from stedm_amd.unet import UNetModel
+    m = UNetModel(image_size=16, in_channels=7, model_channels=32, out_channels=4, num_res_blocks=2,
+                  attention_resolutions=[32, 16, 8], channel_mult=[1, 2, 4], num_heads=4)
+    plan = ou.build_plan(ou.UNetConfig(image_size=16, model_channels=32, channel_mult=(1, 2, 4), num_heads=4))
+    sd = m.state_dict()
+    assert set(sd) == set(plan.shapes)
+    for k in ("input_blocks.1.0.out_layers.3.weight", "middle_block.2.proj_out.weight", "out.2.weight"):
+        assert float(sd[k].abs().max()) == 0.0            # zero_module (openaimodel.py:242-244,334,732)
+    # reference raises TypeError when ds hits attention_resolutions (openaimodel.py:580-590)
+    import pytest
+    with pytest.raises(TypeError):
+        UNetModel(image_size=16, in_channels=7, model_channels=32, out_channels=4, num_res_blocks=2,
+                  attention_resolutions=[1], channel_mult=[1, 2], num_heads=4)
+    # fails loudly on CPU: no fallback
+    from stedm_amd._lib import StedmHipError
+    with pytest.raises(StedmHipError):
+        m(torch.zeros(1, 7, 16, 16), torch.zeros(1, dtype=torch.long), context=torch.zeros(1, 128))
