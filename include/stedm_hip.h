@@ -61,6 +61,18 @@ int stedm_gn_scale_shift(const float* x1, int c1, const float* x2, int c2, int x
                          const float* gamma, const float* beta, float eps, int groups, int B, int HW,
                          float* scale, float* shift, void* stream);
 
+/* Two-kernel form used by the DMA convolution path. (1) stats: per-(sample, pixel slab, group) sum and sum of
+ * squares of the virtual concat [x1 | x2] (coalesced full-row reads) written to stats[B][nslab][groups][2] with
+ * nslab = stedm_gn_nslab(c1+c2, HW); no atomics: apply adds the slabs in order, results are bitwise reproducible. (2) apply: y = act(GroupNorm(x)) written ONCE as 16-bit NHWC operand planes [B][HW][c1+c2]
+ * (hi, and lo = y - hi when out_lo != NULL) — the concat is materialised in 16-bit, the conv then streams it by
+ * LDS-DMA with no per-tile re-normalisation. act: 0 none, 1 SiLU. gamma == NULL: plain conversion (no norm). */
+int stedm_gn_nslab(int C, int HW);
+int stedm_gn_stats(const float* x1, int c1, const float* x2, int c2, int x2_bmod, int groups, int B, int HW,
+                   double* stats, void* stream);
+int stedm_gn_apply16(const float* x1, int c1, const float* x2, int c2, int x2_bmod, const float* gamma,
+                     const float* beta, float eps, int groups, int act, const double* stats, int B, int HW,
+                     void* out_hi, void* out_lo, int mm_dtype, void* stream);
+
 /* ---- fused implicit-GEMM convolution on MFMA ----------------------------------------------- */
 typedef struct stedm_conv_args {
   const float* src1; /* NHWC [B][Hin][Win][c1]                                                 */
@@ -82,6 +94,10 @@ typedef struct stedm_conv_args {
   int32_t cout;
   int32_t npass;     /* 1 or 3                                                                 */
   int32_t mm_dtype;  /* STEDM_F16 / STEDM_BF16                                                 */
+  /* DMA path: when src16_hi != NULL the A operand is read from these pre-normalised 16-bit NHWC planes
+   * [B][Hin][Win][c1+c2] (from stedm_gn_apply16) and src1/src2/scale/shift/act are ignored.              */
+  const void* src16_hi;
+  const void* src16_lo;
 } stedm_conv_args;
 /* Replaces: GN->SiLU->conv3x3(+bias)(+emb)(+skip) of ResBlock._forward openaimodel.py:268-288,
  * Downsample/Upsample convs (:122-132,:156-173), 1x1 skip_connection (:254), and the 1x1

@@ -32,6 +32,7 @@ class ConvArgs(C.Structure):
         ("emb", C.c_void_p), ("emb_bstride", C.c_int32),
         ("res", C.c_void_p), ("out", C.c_void_p),
         ("cout", C.c_int32), ("npass", C.c_int32), ("mm_dtype", C.c_int32),
+        ("src16_hi", C.c_void_p), ("src16_lo", C.c_void_p),
     ]
 
 
@@ -44,6 +45,9 @@ SIGNATURES = {
     "stedm_pack_conv_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "stedm_transpose_f32": (_I, [_P, _P, _I, _I, _P]),
     "stedm_gn_scale_shift": (_I, [_P, _I, _P, _I, _I, _P, _P, _F, _I, _I, _I, _P, _P, _P]),
+    "stedm_gn_nslab": (_I, [_I, _I]),
+    "stedm_gn_stats": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "stedm_gn_apply16": (_I, [_P, _I, _P, _I, _I, _P, _P, _F, _I, _I, _P, _I, _I, _P, _P, _I, _P]),
     "stedm_conv_igemm": (_I, [C.POINTER(ConvArgs), _P]),
     "stedm_conv_in": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "stedm_conv_out": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -1,0 +1,50 @@
+// Shared definitions of the implicit-GEMM convolution kernels (v1: conv_igemm.hip, v2: conv_igemm_ws.hip).
+#pragma once
+#include "common.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BN = 128;
+
+struct ConvParams {
+  stedm_conv_args a;
+  int M, Hout, Wout, HWout, Cin, taps;
+  int whole, nsamp, trows;  // tile geometry
+  int PRs, PW, NP;          // patch rows per sample, patch cols, patch positions
+  int tiles_m, tiles_n;
+  int dbg;  // ablation bits (STEDM_CONV_DBG, timing experiments only): 1 no weight DMA, 2 no patch staging, 4 no MFMA, 8 no LDS frag reads
+};
+
+template <typename T>
+struct MM;
+template <>
+struct MM<_Float16> {
+  using V8 = f16x8;
+  using V4 = f16x4;
+  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct MM<__bf16> {
+  using V8 = bf16x8;
+  using V4 = bf16x4;
+  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+
+namespace stedm {
+// Fills the tile geometry of `p` for an M-tile of `bm` output pixels. Returns false (with the error set) when the
+// spatial shape cannot be tiled that way.
+bool conv_geometry(ConvParams& p, int bm);
+// v2 (warp-specialised) launcher; returns -1 when v2 does not support this problem (caller falls back to v1).
+int conv_launch_ws(ConvParams& p, hipStream_t st);
+// v3 (LDS-DMA operands from 16-bit activation planes); 0 ok, > 0 error (message set).
+int conv_launch_dma(ConvParams& p, hipStream_t st);
+}  // namespace stedm

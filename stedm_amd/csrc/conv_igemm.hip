@@ -17,43 +17,12 @@
 //
 // The two sources src1|src2 implement the skip concat (openaimodel.py:800) without materialising
 // it: a K-chunk comes entirely from one of them (c1 % BKC == 0).
-#include "common.hpp"
+#include <stdlib.h>
+
+#include "conv_common.hpp"
 using namespace stedm;
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-constexpr int BM = 128, BN = 128, NTHREADS = 256;
-
-struct ConvParams {
-  stedm_conv_args a;
-  int M, Hout, Wout, HWout, Cin, taps;
-  int whole, nsamp, trows;  // tile geometry
-  int PRs, PW, NP;          // patch rows per sample, patch cols, patch positions
-  int tiles_m, tiles_n;
-};
-
-template <typename T>
-struct MM;
-template <>
-struct MM<_Float16> {
-  using V8 = f16x8;
-  using V4 = f16x4;
-  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-  }
-};
-template <>
-struct MM<__bf16> {
-  using V8 = bf16x8;
-  using V4 = bf16x4;
-  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
-};
+constexpr int BM = 128, NTHREADS = 256;
 
 template <int BKC, int NPASS, typename T>
 __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParams p) {
@@ -316,14 +285,42 @@ static int launch(const ConvParams& p, hipStream_t st) {
   return 0;
 }
 
+bool stedm::conv_geometry(ConvParams& p, int bm) {
+  const stedm_conv_args& a = p.a;
+  p.tiles_n = (a.cout + BN - 1) / BN;
+  p.tiles_m = (p.M + bm - 1) / bm;
+  if (a.ks == 1) {
+    p.whole = 0; p.nsamp = 1; p.trows = 0; p.PRs = 1; p.PW = bm; p.NP = bm;
+    return true;
+  }
+  if (p.HWout <= bm) {
+    if (bm % p.HWout != 0) { set_error("conv_igemm: Hout*Wout=%d must divide %d", p.HWout, bm); return false; }
+    p.whole = 1; p.nsamp = bm / p.HWout; p.trows = p.Hout;
+    p.tiles_m = (a.B + p.nsamp - 1) / p.nsamp;
+  } else {
+    if (bm % p.Wout != 0 || p.HWout % bm != 0) {
+      set_error("conv_igemm: unsupported spatial shape %dx%d (need Wout | %d and %d | Hout*Wout)", p.Hout, p.Wout, bm, bm);
+      return false;
+    }
+    p.whole = 0; p.nsamp = 1; p.trows = bm / p.Wout;
+  }
+  if (a.mode == STEDM_CONV_S1) p.PRs = p.trows + 2;
+  else if (a.mode == STEDM_CONV_DOWN) p.PRs = 2 * p.trows + 1;
+  else p.PRs = (p.trows + 1) / 2 + 2;
+  p.PW = a.Win + 2;
+  p.NP = p.nsamp * p.PRs * p.PW;
+  return true;
+}
+
 extern "C" int stedm_conv_igemm(const stedm_conv_args* args, void* stream) {
   STEDM_CHECK_ARG(args, "conv_igemm: null args");
   ConvParams p;
   memset(&p, 0, sizeof(p));
   p.a = *args;
   const stedm_conv_args& a = p.a;
-  STEDM_CHECK_ARG(a.src1 && a.w_hi && a.out, "conv_igemm: null src1/w_hi/out");
-  STEDM_CHECK_ARG((a.src2 != nullptr) == (a.c2 > 0), "conv_igemm: src2/c2 mismatch");
+  STEDM_CHECK_ARG((a.src1 || a.src16_hi) && a.w_hi && a.out, "conv_igemm: null src/w_hi/out");
+  STEDM_CHECK_ARG(!a.src1 || (a.src2 != nullptr) == (a.c2 > 0), "conv_igemm: src2/c2 mismatch");
+  STEDM_CHECK_ARG(!a.src16_hi || a.npass == 1 || a.src16_lo, "conv_igemm: npass=3 needs src16_lo");
   STEDM_CHECK_ARG(a.ks == 1 || a.ks == 3, "conv_igemm: ks must be 1 or 3");
   STEDM_CHECK_ARG(a.mode >= 0 && a.mode <= 2, "conv_igemm: bad mode %d", a.mode);
   STEDM_CHECK_ARG(a.ks == 3 || a.mode == STEDM_CONV_S1, "conv_igemm: 1x1 supports stride 1 only");
@@ -331,6 +328,7 @@ extern "C" int stedm_conv_igemm(const stedm_conv_args* args, void* stream) {
   STEDM_CHECK_ARG(a.npass == 1 || a.w_lo, "conv_igemm: npass=3 needs w_lo");
   STEDM_CHECK_ARG((a.scale != nullptr) == (a.shift != nullptr), "conv_igemm: scale/shift must come together");
   STEDM_CHECK_ARG(a.B > 0 && a.Hin > 0 && a.Win > 0 && a.cout > 0, "conv_igemm: bad sizes");
+  STEDM_CHECK_ARG(a.mm_dtype == STEDM_F16 || a.mm_dtype == STEDM_BF16, "conv_igemm: bad mm_dtype %d", a.mm_dtype);
   p.Cin = a.c1 + a.c2;
   p.taps = a.ks * a.ks;
   if (a.mode == STEDM_CONV_DOWN) {
@@ -343,32 +341,27 @@ extern "C" int stedm_conv_igemm(const stedm_conv_args* args, void* stream) {
   }
   p.HWout = p.Hout * p.Wout;
   p.M = a.B * p.HWout;
-  const int bkc = (a.npass == 1 && p.Cin % 64 == 0 && (a.c2 == 0 || a.c1 % 64 == 0)) ? 64 : 32;
-  STEDM_CHECK_ARG(p.Cin % bkc == 0 && (a.c2 == 0 || a.c1 % bkc == 0),
-                  "conv_igemm: channel counts must be multiples of %d (c1=%d c2=%d)", bkc, a.c1, a.c2);
-  p.tiles_n = (a.cout + BN - 1) / BN;
-  p.tiles_m = (p.M + BM - 1) / BM;
-  if (a.ks == 1) {
-    p.whole = 0; p.nsamp = 1; p.trows = 0; p.PRs = 1; p.PW = BM; p.NP = BM;
-  } else {
-    if (p.HWout <= BM) {
-      STEDM_CHECK_ARG(BM % p.HWout == 0, "conv_igemm: Hout*Wout=%d must divide %d", p.HWout, BM);
-      p.whole = 1; p.nsamp = BM / p.HWout; p.trows = p.Hout;
-      p.tiles_m = (a.B + p.nsamp - 1) / p.nsamp;
-    } else {
-      STEDM_CHECK_ARG(BM % p.Wout == 0 && p.HWout % BM == 0,
-                      "conv_igemm: unsupported spatial shape %dx%d (need Wout | %d and %d | Hout*Wout)", p.Hout, p.Wout, BM, BM);
-      p.whole = 0; p.nsamp = 1; p.trows = BM / p.Wout;
-    }
-    if (a.mode == STEDM_CONV_S1) p.PRs = p.trows + 2;
-    else if (a.mode == STEDM_CONV_DOWN) p.PRs = 2 * p.trows + 1;
-    else p.PRs = (p.trows + 1) / 2 + 2;
-    p.PW = a.Win + 2;
-    p.NP = p.nsamp * p.PRs * p.PW;
-  }
+  STEDM_CHECK_ARG(p.Cin % 32 == 0 && (a.c2 == 0 || a.c1 % 32 == 0),
+                  "conv_igemm: channel counts must be multiples of 32 (c1=%d c2=%d)", a.c1, a.c2);
   hipStream_t st = as_stream(stream);
+  static const int dbg0 = getenv("STEDM_CONV_DBG") ? atoi(getenv("STEDM_CONV_DBG")) : 0;
+  p.dbg = dbg0;
+  if (a.src16_hi) {   // v3: both operands by LDS-DMA from pre-normalised 16-bit planes
+    const int rc = conv_launch_dma(p, st);
+    if (rc == 0 || !a.src1) return rc;
+    // otherwise fall through to the fused fp32-source kernels
+  }
+  // v2 (warp-specialised, 256/128 x 128 tiles) when it supports the problem; v1 otherwise
+  static const bool force_v1 = getenv("STEDM_CONV_V1") != nullptr;
+  static const int dbg = getenv("STEDM_CONV_DBG") ? atoi(getenv("STEDM_CONV_DBG")) : 0;
+  p.dbg = dbg;
+  if (!force_v1) {
+    const int rc = conv_launch_ws(p, st);
+    if (rc >= 0) return rc;
+  }
+  const int bkc = (a.npass == 1 && p.Cin % 64 == 0 && (a.c2 == 0 || a.c1 % 64 == 0)) ? 64 : 32;
+  if (!conv_geometry(p, BM)) return 1;
   const bool f16 = a.mm_dtype == STEDM_F16;
-  STEDM_CHECK_ARG(f16 || a.mm_dtype == STEDM_BF16, "conv_igemm: bad mm_dtype %d", a.mm_dtype);
   if (a.npass == 3) return f16 ? launch<32, 3, _Float16>(p, st) : launch<32, 3, __bf16>(p, st);
   if (bkc == 64) return f16 ? launch<64, 1, _Float16>(p, st) : launch<64, 1, __bf16>(p, st);
   return f16 ? launch<32, 1, _Float16>(p, st) : launch<32, 1, __bf16>(p, st);

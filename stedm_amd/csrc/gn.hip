@@ -87,3 +87,204 @@ extern "C" int stedm_gn_scale_shift(const float* x1, int c1, const float* x2, in
   STEDM_LAUNCH_CHECK();
   return 0;
 }
+
+// ================================================================================================
+// Two-kernel GroupNorm for the DMA convolution path
+// ================================================================================================
+// (1) stats: block = (sample, slab of pixels); threads sweep whole NHWC rows with 16-B loads (coalesced),
+//     accumulate per-group partial sums in LDS and add them to stats[b][g] = {sum, sumsq} with fp64 atomics.
+struct GnStatsArgs {
+  const float* x1;
+  const float* x2;
+  int c1, c2, bmod, groups, HW, slab;
+  double* stats;
+};
+
+constexpr int GN_MAX_SLOTS = 4;   // channel quads owned by one thread (C <= 4096)
+
+__global__ void __launch_bounds__(256) gn_stats_kernel(GnStatsArgs a) {
+  // Every thread owns fixed channel quads (so its running sums never change group) and strides over the slab's
+  // pixels; per-channel partials go to LDS and one thread per group adds them in a fixed order: no atomics, the
+  // result is bitwise reproducible.
+  extern __shared__ float part[];   // [slots][256][8] : {sum x4, sumsq x4} per thread and slot
+  const int b = blockIdx.x, slab = blockIdx.y;
+  const int C = a.c1 + a.c2, Q = C >> 2;
+  const int cpg = C / a.groups;
+  const float* p1 = a.x1 + (long)b * a.HW * a.c1;
+  const float* p2 = a.x2 ? a.x2 + (long)(a.bmod > 0 ? b % a.bmod : b) * a.HW * a.c2 : nullptr;
+  const int px0 = slab * a.slab, px1 = min(a.HW, px0 + a.slab);
+  const int t = threadIdx.x;
+  int npl, slots, tq, tp;
+  if (Q <= 256) { npl = 256 / Q; slots = 1; tq = t % Q; tp = t / Q; }
+  else { npl = 1; slots = (Q + 255) / 256; tq = t; tp = 0; }
+  float s4[GN_MAX_SLOTS][4], q4[GN_MAX_SLOTS][4];
+#pragma unroll
+  for (int k = 0; k < GN_MAX_SLOTS; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s4[k][j] = 0.f; q4[k][j] = 0.f; }
+  if (tp < npl) {
+    for (int pix = px0 + tp; pix < px1; pix += npl) {
+#pragma unroll
+      for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+        const int c = (tq + 256 * k) * 4;
+        if (k < slots && c < C) {
+          const float4 v = c < a.c1 ? *reinterpret_cast<const float4*>(p1 + (long)pix * a.c1 + c)
+                                    : *reinterpret_cast<const float4*>(p2 + (long)pix * a.c2 + (c - a.c1));
+          s4[k][0] += v.x; s4[k][1] += v.y; s4[k][2] += v.z; s4[k][3] += v.w;
+          q4[k][0] += v.x * v.x; q4[k][1] += v.y * v.y; q4[k][2] += v.z * v.z; q4[k][3] += v.w * v.w;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < GN_MAX_SLOTS; ++k)
+    if (k < slots) {
+      float* d = part + ((long)k * 256 + t) * 8;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { d[j] = s4[k][j]; d[4 + j] = q4[k][j]; }
+    }
+  __syncthreads();
+  if (t < a.groups) {
+    double su = 0.0, sq = 0.0;
+    for (int c = t * cpg; c < (t + 1) * cpg; ++c) {       // fixed order: channel, then pixel lane
+      const int quad = c >> 2, j = c & 3;
+      const int k = Q <= 256 ? 0 : quad / 256, tqq = Q <= 256 ? quad : quad % 256;
+      for (int l = 0; l < npl; ++l) {
+        const float* d = part + ((long)k * 256 + (l * (Q <= 256 ? Q : 0) + tqq)) * 8;
+        su += (double)d[j];
+        sq += (double)d[4 + j];
+      }
+    }
+    a.stats[(((long)b * gridDim.y + slab) * a.groups + t) * 2] = su;
+    a.stats[(((long)b * gridDim.y + slab) * a.groups + t) * 2 + 1] = sq;
+  }
+}
+
+static int gn_slab_pixels(int C, int HW) {
+  int slab = (16384 + C - 1) / C;   // ~64 KB of fp32 per block
+  if (slab < 1) slab = 1;
+  if (slab > HW) slab = HW;
+  return slab;
+}
+extern "C" int stedm_gn_nslab(int C, int HW) {
+  const int slab = gn_slab_pixels(C, HW);
+  return (HW + slab - 1) / slab;
+}
+
+extern "C" int stedm_gn_stats(const float* x1, int c1, const float* x2, int c2, int x2_bmod, int groups, int B, int HW,
+                              double* stats, void* stream) {
+  STEDM_CHECK_ARG(x1 && stats, "gn_stats: null pointer");
+  STEDM_CHECK_ARG((x2 != nullptr) == (c2 > 0), "gn_stats: x2/c2 mismatch");
+  const int C = c1 + c2;
+  STEDM_CHECK_ARG(groups > 0 && groups <= 64 && C % groups == 0 && C % 4 == 0 && c1 % 4 == 0 && C <= 1024 * GN_MAX_SLOTS,
+                  "gn_stats: need groups <= 64, C %% groups == 0, C %% 4 == 0, c1 %% 4 == 0, C <= %d (C=%d c1=%d groups=%d)",
+                  1024 * GN_MAX_SLOTS, C, c1, groups);
+  const int slab = gn_slab_pixels(C, HW);
+  GnStatsArgs a{x1, x2, c1, c2, x2_bmod, groups, HW, slab, stats};
+  dim3 grid(B, (HW + slab - 1) / slab);
+  const int slots = (C / 4 + 255) / 256;
+  gn_stats_kernel<<<grid, 256, (size_t)slots * 256 * 8 * sizeof(float), as_stream(stream)>>>(a);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+// (2) apply: elementwise over the virtual concat; 16 B in, 8 B (+8 B) out per lane, fully coalesced.
+struct GnApplyArgs {
+  const float* x1;
+  const float* x2;
+  int c1, c2, bmod, groups, HW, act;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  const double* stats;
+  void* out_hi;
+  void* out_lo;
+  long total_q;  // B*HW*C/4
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) gn_apply16_kernel(GnApplyArgs a, int slab, int nslab_stats) {
+  typedef T V4 __attribute__((ext_vector_type(4)));
+  __shared__ float lmean[64], lrstd[64];
+  const int b = blockIdx.x, sl = blockIdx.y;
+  const int C = a.c1 + a.c2, Q = C >> 2;
+  const int cpg = C / a.groups;
+  if (a.gamma && threadIdx.x < a.groups) {
+    const double inv_n = 1.0 / ((double)cpg * a.HW);
+    double su = 0.0, sq = 0.0;
+    for (int k = 0; k < nslab_stats; ++k) {   // fixed order
+      su += a.stats[(((long)b * nslab_stats + k) * a.groups + threadIdx.x) * 2];
+      sq += a.stats[(((long)b * nslab_stats + k) * a.groups + threadIdx.x) * 2 + 1];
+    }
+    const double mean = su * inv_n;
+    double var = sq * inv_n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    lmean[threadIdx.x] = (float)mean;
+    lrstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)a.eps));
+  }
+  __syncthreads();
+  const float* p1 = a.x1 + (long)b * a.HW * a.c1;
+  const float* p2 = a.x2 ? a.x2 + (long)(a.bmod > 0 ? b % a.bmod : b) * a.HW * a.c2 : nullptr;
+  const int px0 = sl * slab, px1 = min(a.HW, px0 + slab);
+  const int total = (px1 - px0) * Q;
+  int pix = px0 + threadIdx.x / Q, q = threadIdx.x % Q;
+  const int dpix = 256 / Q, dq = 256 % Q;
+  V4* oh = reinterpret_cast<V4*>(a.out_hi) + (long)b * a.HW * Q;
+  V4* ol = a.out_lo ? reinterpret_cast<V4*>(a.out_lo) + (long)b * a.HW * Q : nullptr;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int c = q * 4;
+    float4 v = c < a.c1 ? *reinterpret_cast<const float4*>(p1 + (long)pix * a.c1 + c)
+                        : *reinterpret_cast<const float4*>(p2 + (long)pix * a.c2 + (c - a.c1));
+    if (a.gamma) {
+      const float4 gm = *reinterpret_cast<const float4*>(a.gamma + c);
+      const float4 bt = *reinterpret_cast<const float4*>(a.beta + c);
+      if (cpg & 3) {
+        const int g0 = c / cpg, g1 = (c + 1) / cpg, g2 = (c + 2) / cpg, g3 = (c + 3) / cpg;
+        v.x = (v.x - lmean[g0]) * lrstd[g0] * gm.x + bt.x; v.y = (v.y - lmean[g1]) * lrstd[g1] * gm.y + bt.y;
+        v.z = (v.z - lmean[g2]) * lrstd[g2] * gm.z + bt.z; v.w = (v.w - lmean[g3]) * lrstd[g3] * gm.w + bt.w;
+      } else {
+        const int g = c / cpg;
+        const float mf = lmean[g], rstd = lrstd[g];
+        v.x = (v.x - mf) * rstd * gm.x + bt.x; v.y = (v.y - mf) * rstd * gm.y + bt.y;
+        v.z = (v.z - mf) * rstd * gm.z + bt.z; v.w = (v.w - mf) * rstd * gm.w + bt.w;
+      }
+    }
+    if (a.act == 1) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+    V4 hi;
+    hi[0] = (T)v.x; hi[1] = (T)v.y; hi[2] = (T)v.z; hi[3] = (T)v.w;
+    const long o = (long)pix * Q + q;
+    oh[o] = hi;
+    if (ol) {
+      V4 lo;
+      lo[0] = (T)(v.x - (float)hi[0]); lo[1] = (T)(v.y - (float)hi[1]);
+      lo[2] = (T)(v.z - (float)hi[2]); lo[3] = (T)(v.w - (float)hi[3]);
+      ol[o] = lo;
+    }
+    pix += dpix; q += dq;
+    if (q >= Q) { q -= Q; ++pix; }
+  }
+}
+
+extern "C" int stedm_gn_apply16(const float* x1, int c1, const float* x2, int c2, int x2_bmod, const float* gamma,
+                                const float* beta, float eps, int groups, int act, const double* stats, int B, int HW,
+                                void* out_hi, void* out_lo, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(x1 && out_hi, "gn_apply16: null pointer");
+  STEDM_CHECK_ARG((x2 != nullptr) == (c2 > 0), "gn_apply16: x2/c2 mismatch");
+  STEDM_CHECK_ARG((gamma == nullptr) || (beta && stats && groups > 0), "gn_apply16: gamma needs beta, stats, groups");
+  const int C = c1 + c2;
+  STEDM_CHECK_ARG(C % 4 == 0 && c1 % 4 == 0, "gn_apply16: channels must be multiples of 4");
+  STEDM_CHECK_ARG(!gamma || C % groups == 0, "gn_apply16: C %% groups != 0");
+  STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "gn_apply16: bad mm_dtype");
+  GnApplyArgs a{x1, x2, c1, c2, x2_bmod, groups > 0 ? groups : 1, HW, act, gamma, beta, eps, stats, out_hi, out_lo,
+                (long)B * HW * (C / 4)};
+  STEDM_CHECK_ARG(!gamma || groups <= 64, "gn_apply16: groups <= 64");
+  const int slab = gn_slab_pixels(C, HW);
+  const int nslab = (HW + slab - 1) / slab;
+  dim3 grid(B, nslab);
+  if (mm_dtype == STEDM_F16)
+    gn_apply16_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(a, slab, nslab);
+  else
+    gn_apply16_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(a, slab, nslab);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}

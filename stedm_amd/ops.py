@@ -101,20 +101,60 @@ def gn_scale_shift(x1: torch.Tensor, x2: Optional[torch.Tensor], gamma: torch.Te
           "stedm_gn_scale_shift")
 
 
+def gn_nslab(C: int, HW: int) -> int:
+    return lib().stedm_gn_nslab(C, HW)
+
+
+def gn_stats(x1: torch.Tensor, x2: Optional[torch.Tensor], stats: torch.Tensor, groups: int = 32, x2_bmod: int = 0) -> None:
+    """Per-slab {sum, sumsq} of the virtual concat [x1|x2] into stats (float64, >= B*gn_nslab(C,HW)*groups*2 elements)."""
+    _chk(x1, name="x1")
+    _chk(stats, torch.float64, "stats")
+    B = x1.shape[0]
+    HW = x1.numel() // (B * x1.shape[-1])
+    c2 = 0 if x2 is None else x2.shape[-1]
+    assert stats.numel() >= B * gn_nslab(x1.shape[-1] + c2, HW) * groups * 2
+    check(lib().stedm_gn_stats(x1.data_ptr(), x1.shape[-1], _ptr(x2), c2, x2_bmod, groups, B, HW, stats.data_ptr(), _stream()),
+          "stedm_gn_stats")
+
+
+def gn_apply16(x1: torch.Tensor, x2: Optional[torch.Tensor], out_hi: torch.Tensor, out_lo: Optional[torch.Tensor], prec: Precision,
+               gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None, eps: float = 1e-5, groups: int = 32,
+               act: int = 0, stats: Optional[torch.Tensor] = None, x2_bmod: int = 0) -> None:
+    """y = act(GroupNorm([x1|x2])) (or plain conversion when gamma is None) -> 16-bit NHWC planes out_hi (/out_lo)."""
+    _chk(x1, name="x1")
+    B = x1.shape[0]
+    HW = x1.numel() // (B * x1.shape[-1])
+    c2 = 0 if x2 is None else x2.shape[-1]
+    check(lib().stedm_gn_apply16(x1.data_ptr(), x1.shape[-1], _ptr(x2), c2, x2_bmod, _ptr(gamma), _ptr(beta), float(eps), groups,
+                                 act, _ptr(stats), B, HW, out_hi.data_ptr(), _ptr(out_lo), prec.mm_dtype, _stream()),
+          "stedm_gn_apply16")
+
+
 # ------------------------------------------------------------------------------------------- conv
-def conv_igemm(src1: torch.Tensor, w_hi: torch.Tensor, w_lo: Optional[torch.Tensor], out: torch.Tensor, *, prec: Precision,
+def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[torch.Tensor], out: torch.Tensor, *, prec: Precision,
                ks: int = 3, mode: int = CONV_S1, src2: Optional[torch.Tensor] = None, src2_bmod: int = 0,
                scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, act: int = 0,
                bias: Optional[torch.Tensor] = None, emb: Optional[torch.Tensor] = None, emb_offset: int = 0,
-               emb_bstride: int = 0, res: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """src1 [B,Hin,Win,c1] NHWC fp32 -> out [B,Hout,Wout,cout] NHWC fp32 (see stedm_conv_igemm)."""
-    _chk(src1, name="src1")
+               emb_bstride: int = 0, res: Optional[torch.Tensor] = None,
+               src16: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None) -> torch.Tensor:
+    """src1 [B,Hin,Win,c1] NHWC fp32 (fused path) and/or src16 = (hi, lo) 16-bit NHWC planes [B,Hin,Win,Cin] from
+    gn_apply16 (DMA path) -> out [B,Hout,Wout,cout] NHWC fp32 (see stedm_conv_igemm)."""
     _chk(out, name="out")
-    B, Hin, Win, c1 = src1.shape
     a = ConvArgs()
-    a.src1 = src1.data_ptr()
-    a.src2 = _ptr(src2)
-    a.c1, a.c2, a.src2_bmod = c1, (0 if src2 is None else src2.shape[-1]), src2_bmod
+    if src1 is not None:
+        _chk(src1, name="src1")
+        B, Hin, Win, c1 = src1.shape
+        a.src1 = src1.data_ptr()
+        a.src2 = _ptr(src2)
+        c2 = 0 if src2 is None else src2.shape[-1]
+    else:
+        B, Hin, Win, c1 = src16[0].shape
+        c2 = 0
+    if src16 is not None:
+        assert src16[0].dtype == torch.int16 and src16[0].is_contiguous() and tuple(src16[0].shape) == (B, Hin, Win, c1 + c2)
+        a.src16_hi = src16[0].data_ptr()
+        a.src16_lo = _ptr(src16[1]) if prec.npass == 3 else None
+    a.c1, a.c2, a.src2_bmod = c1, c2, src2_bmod
     a.B, a.Hin, a.Win = B, Hin, Win
     a.mode, a.ks = mode, ks
     a.scale, a.shift, a.act = _ptr(scale), _ptr(shift), act

@@ -214,6 +214,11 @@ class UNetModel(nn.Module):
         self._bufs: Dict[Tuple, torch.Tensor] = {}
         self._emb_layout: List[Tuple[ResBlock, int]] = []
         self._consts: Dict[str, torch.Tensor] = {}
+        # "dma": GroupNorm statistics kernel + one normalise/activate/convert pass to 16-bit planes, convolution with
+        #        LDS-DMA operands (default). "fused": GroupNorm applied inside the conv's patch loader (v1/v2 kernels).
+        import os as _os
+        self.conv_path = _os.environ.get("STEDM_CONV_PATH", "dma")
+        self._gn_slot = 0
 
     # ------------------------------------------------------------------------------------ engine plumbing
     def convert_to_fp16(self):  # openaimodel.py:745-751 — a no-op in the reference too (openaimodel.py:25-29)
@@ -314,42 +319,82 @@ class UNetModel(nn.Module):
         ops.gn_scale_shift(x1, x2, norm.weight, norm.bias, norm.eps, sc, sh, norm.num_groups, x2_bmod)
         return sc, sh
 
+    # ---- DMA path helpers: 16-bit operand planes -------------------------------------------------------------
+    def _planes(self, B, H, W, C):
+        hi = self._buf(f"a16hi.{B}x{H}x{W}x{C}", (B, H, W, C), torch.int16)
+        lo = self._buf(f"a16lo.{B}x{H}x{W}x{C}", (B, H, W, C), torch.int16) if self.precision.npass == 3 else None
+        return hi, lo
+
+    def _norm16(self, norm: Optional[nn.GroupNorm], act: int, x1, x2=None, x2_bmod=0):
+        """act(GroupNorm([x1|x2])) (norm None: plain conversion) written once as 16-bit planes."""
+        B, H, W, _ = x1.shape
+        C = x1.shape[-1] + (0 if x2 is None else x2.shape[-1])
+        hi, lo = self._planes(B, H, W, C)
+        if norm is None:
+            ops.gn_apply16(x1, x2, hi, lo, self.precision, x2_bmod=x2_bmod)
+        else:
+            stats = self._buf("gn_partials", (B * ops.gn_nslab(C, H * W) * norm.num_groups * 2,), torch.float64)
+            ops.gn_stats(x1, x2, stats, norm.num_groups, x2_bmod)
+            ops.gn_apply16(x1, x2, hi, lo, self.precision, norm.weight, norm.bias, norm.eps, norm.num_groups, act, stats, x2_bmod)
+        return hi, lo
+
     def _res(self, tag: str, rb: ResBlock, x1, x2, emb_all, emb_off, emb_bstride, x2_bmod=0):
         """ResBlock._forward openaimodel.py:268-288 on NHWC tensors; [x1|x2] is the virtual concat input."""
         prec = self.precision
         B, H, W, _ = x1.shape
         co = rb.out_channels
-        sc, sh = self._gn(tag + ".gn1", rb.in_layers[0], x1, x2, x2_bmod)
+        dma = self.conv_path == "dma"
         pk = self._packed[id(rb.in_layers[2])]
         h = self._buf(f"h.{B}x{H}x{W}x{co}", (B, H, W, co))
-        ops.conv_igemm(x1, pk.hi, pk.lo, h, prec=prec, src2=x2, src2_bmod=x2_bmod, scale=sc, shift=sh, act=1, bias=pk.bias,
-                       emb=emb_all, emb_offset=emb_off, emb_bstride=emb_bstride)
-        sc2, sh2 = self._gn(tag + ".gn2", rb.out_layers[0], h)
+        if dma:
+            a16 = self._norm16(rb.in_layers[0], 1, x1, x2, x2_bmod)
+            ops.conv_igemm(None, pk.hi, pk.lo, h, prec=prec, src16=a16, bias=pk.bias, emb=emb_all, emb_offset=emb_off,
+                           emb_bstride=emb_bstride)
+        else:
+            sc, sh = self._gn(tag + ".gn1", rb.in_layers[0], x1, x2, x2_bmod)
+            ops.conv_igemm(x1, pk.hi, pk.lo, h, prec=prec, src2=x2, src2_bmod=x2_bmod, scale=sc, shift=sh, act=1, bias=pk.bias,
+                           emb=emb_all, emb_offset=emb_off, emb_bstride=emb_bstride)
         out = self._buf(tag + ".out", (B, H, W, co))
         if isinstance(rb.skip_connection, nn.Identity):
             assert x2 is None
             res = x1
         else:
             ps = self._packed[id(rb.skip_connection)]
-            ops.conv_igemm(x1, ps.hi, ps.lo, out, prec=prec, ks=1, src2=x2, src2_bmod=x2_bmod, bias=ps.bias)
+            if dma:
+                x16 = self._norm16(None, 0, x1, x2, x2_bmod)
+                ops.conv_igemm(None, ps.hi, ps.lo, out, prec=prec, ks=1, src16=x16, bias=ps.bias)
+            else:
+                ops.conv_igemm(x1, ps.hi, ps.lo, out, prec=prec, ks=1, src2=x2, src2_bmod=x2_bmod, bias=ps.bias)
             res = out
         pk2 = self._packed[id(rb.out_layers[3])]
-        ops.conv_igemm(h, pk2.hi, pk2.lo, out, prec=prec, scale=sc2, shift=sh2, act=1, bias=pk2.bias, res=res)
+        if dma:
+            h16 = self._norm16(rb.out_layers[0], 1, h)
+            ops.conv_igemm(None, pk2.hi, pk2.lo, out, prec=prec, src16=h16, bias=pk2.bias, res=res)
+        else:
+            sc2, sh2 = self._gn(tag + ".gn2", rb.out_layers[0], h)
+            ops.conv_igemm(h, pk2.hi, pk2.lo, out, prec=prec, scale=sc2, shift=sh2, act=1, bias=pk2.bias, res=res)
         return out
 
     def _attn(self, tag: str, ab: AttentionBlock, x):
         """AttentionBlock._forward openaimodel.py:340-346 on NHWC (tokens = H*W)."""
         prec = self.precision
         B, H, W, Cc = x.shape
-        sc, sh = self._gn(tag + ".gn", ab.norm, x)
+        dma = self.conv_path == "dma"
         pq = self._packed[id(ab.qkv)]
         qkv = self._buf(tag + ".qkv", (B, H, W, 3 * Cc))
-        ops.conv_igemm(x, pq.hi, pq.lo, qkv, prec=prec, ks=1, scale=sc, shift=sh, act=0, bias=pq.bias)
+        if dma:
+            ops.conv_igemm(None, pq.hi, pq.lo, qkv, prec=prec, ks=1, src16=self._norm16(ab.norm, 0, x), bias=pq.bias)
+        else:
+            sc, sh = self._gn(tag + ".gn", ab.norm, x)
+            ops.conv_igemm(x, pq.hi, pq.lo, qkv, prec=prec, ks=1, scale=sc, shift=sh, act=0, bias=pq.bias)
         a = self._buf(tag + ".a", (B, H, W, Cc))
         ops.attn_legacy(qkv.view(B, H * W, 3 * Cc), a.view(B, H * W, Cc), ab.num_heads)
         pp = self._packed[id(ab.proj_out)]
         out = self._buf(tag + ".out", (B, H, W, Cc))
-        ops.conv_igemm(a, pp.hi, pp.lo, out, prec=prec, ks=1, bias=pp.bias, res=x)
+        if dma:
+            ops.conv_igemm(None, pp.hi, pp.lo, out, prec=prec, ks=1, src16=self._norm16(None, 0, a), bias=pp.bias, res=x)
+        else:
+            ops.conv_igemm(a, pp.hi, pp.lo, out, prec=prec, ks=1, bias=pp.bias, res=x)
         return out
 
     def _run_block(self, tag: str, blk, h, skip, emb_all, emb_bstride, style_all, skip_bmod=0, li0=0):
@@ -367,12 +412,17 @@ class UNetModel(nn.Module):
                 pk = self._packed[id(layer.op)]
                 B, H, W, _ = h.shape
                 out = self._buf(ltag + ".out", (B, H // 2, W // 2, layer.out_channels))
+                # stride-2 patches do not fit the DMA kernel's LDS budget: fused fp32-source kernel
                 h = ops.conv_igemm(h, pk.hi, pk.lo, out, prec=self.precision, mode=CONV_DOWN, bias=pk.bias)
             elif isinstance(layer, Upsample):
                 pk = self._packed[id(layer.conv)]
                 B, H, W, _ = h.shape
                 out = self._buf(ltag + ".out", (B, H * 2, W * 2, layer.out_channels))
-                h = ops.conv_igemm(h, pk.hi, pk.lo, out, prec=self.precision, mode=CONV_UP, bias=pk.bias)
+                if self.conv_path == "dma":
+                    h = ops.conv_igemm(None, pk.hi, pk.lo, out, prec=self.precision, mode=CONV_UP, src16=self._norm16(None, 0, h),
+                                       bias=pk.bias)
+                else:
+                    h = ops.conv_igemm(h, pk.hi, pk.lo, out, prec=self.precision, mode=CONV_UP, bias=pk.bias)
             else:
                 raise TypeError(f"unexpected layer {type(layer).__name__} in {tag}")
         return h
@@ -411,6 +461,7 @@ class UNetModel(nn.Module):
         B, c1, H, W = x.shape
         nrep = len(contexts)
         Bd = B * nrep                      # decoder batch
+
         c2 = 0
         if c_concat is not None:
             c_concat = c_concat.float().contiguous()

@@ -251,3 +251,90 @@ def test_ddim_step(dev, B, C, H, W, cfg, eta):
     assert rel_err(x0, x0_ref) < 2e-5
     ops.step_advance(step, -1)
     assert int(step.item()) == idx - 1
+
+
+# ------------------------------------------------------------------------------------------------ two-kernel GN + DMA conv (v3)
+def _as_float(t16, prec):
+    from stedm_amd._lib import F16
+    return t16.view(torch.float16 if prec.mm_dtype == F16 else torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("B,H,W,c1,c2,bmod", [(2, 8, 8, 64, 0, 0), (3, 16, 16, 128, 0, 0), (2, 8, 8, 1024, 512, 0),
+                                              (4, 8, 8, 128, 128, 2), (2, 32, 32, 128, 0, 0), (2, 16, 16, 512, 128, 0)])
+def test_gn_stats_apply16(dev, B, H, W, c1, c2, bmod):
+    from stedm_amd import ops
+    prec = ops.Precision.parse("parity")
+    C = c1 + c2
+    x1 = prng.normal(11, "g2.x1", (B, c1, H, W)) * 1.7 + 0.3
+    x2 = prng.normal(11, "g2.x2", (bmod or B, c2, H, W)) * 0.6 - 0.2 if c2 else None
+    g = prng.normal(11, "g2.g", (C,), 0.1, 1.0)
+    b = prng.normal(11, "g2.b", (C,), 0.1)
+    x2f = None if x2 is None else (x2 if not bmod else x2.repeat(B // bmod, 1, 1, 1))
+    xin = x1 if x2 is None else torch.cat([x1, x2f], 1)
+    ref = F.silu(F.group_norm(xin, 32, g, b, 1e-5))
+    stats = torch.empty((B * ops.gn_nslab(C, H * W) * 32 * 2,), dtype=torch.float64, device=dev)
+    d1 = nhwc(x1).to(dev); d2 = None if x2 is None else nhwc(x2).to(dev)
+    ops.gn_stats(d1, d2, stats, 32, bmod)
+    hi = torch.empty((B, H, W, C), dtype=torch.int16, device=dev); lo = torch.empty_like(hi)
+    ops.gn_apply16(d1, d2, hi, lo, prec, g.to(dev), b.to(dev), 1e-5, 32, 1, stats, bmod)
+    got = nchw(_as_float(hi, prec) + _as_float(lo, prec))
+    assert rel_err(got, ref) < 2e-5
+    assert rel_err(nchw(_as_float(hi, prec)), ref) < 1e-2   # hi plane alone: fp16 rounding of values up to ~8 std
+    # plain conversion (no norm, no act)
+    ops.gn_apply16(d1, d2, hi, lo, prec, x2_bmod=bmod)
+    assert rel_err(nchw(_as_float(hi, prec) + _as_float(lo, prec)), xin) < 1e-6
+
+
+def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_emb=True, use_res=True, seed=12):
+    from stedm_amd import ops
+    from stedm_amd._lib import CONV_DOWN, CONV_S1, CONV_UP
+    prec = ops.Precision.parse(prec_name)
+    x = prng.normal(seed, "cd.x", (B, cin, Hin, Win))
+    a = F.silu(x * 1.3 + 0.1)                      # stands for the normalised + activated activation
+    w = prng.normal(seed, "cd.w", (cout, cin, ks, ks), 1.0 / math.sqrt(cin * ks * ks))
+    bias = prng.normal(seed, "cd.b", (cout,), 0.05)
+    if mode == "s1":
+        ref = F.conv2d(a, w, bias, padding=ks // 2); m = CONV_S1
+    elif mode == "down":
+        ref = F.conv2d(a, w, bias, stride=2, padding=1); m = CONV_DOWN
+    else:
+        ref = F.conv2d(F.interpolate(a, scale_factor=2, mode="nearest"), w, bias, padding=1); m = CONV_UP
+    _, _, Ho, Wo = ref.shape
+    emb = res = None
+    if use_emb:
+        emb = prng.normal(seed, "cd.emb", (B, cout + 24)); ref = ref + emb[:, 8:8 + cout, None, None]
+    if use_res:
+        res = prng.normal(seed, "cd.res", (B, cout, Ho, Wo)); ref = ref + res
+    hi16 = torch.empty((B, Hin, Win, cin), dtype=torch.int16, device=dev); lo16 = torch.empty_like(hi16)
+    ops.gn_apply16(nhwc(a).to(dev), None, hi16, lo16, prec)
+    whi, wlo = ops.pack_conv_weight(w.to(dev), prec)
+    out = torch.full((B, Ho, Wo, cout), float("nan"), device=dev)
+    # stride-2 patches can exceed LDS in the DMA kernel: pass the fp32 source too so the dispatcher may fall back
+    src1 = nhwc(a).to(dev) if mode == "down" else None
+    ops.conv_igemm(src1, whi, wlo, out, prec=prec, ks=ks, mode=m, src16=(hi16, lo16), bias=bias.to(dev),
+                   emb=None if emb is None else emb.to(dev), emb_offset=8, emb_bstride=0 if emb is None else emb.shape[1],
+                   res=None if res is None else nhwc(res).to(dev))
+    torch.cuda.synchronize()
+    err = rel_err(nchw(out), ref)
+    assert err < tol, f"{prec_name}: rel err {err:.3e} >= {tol}"
+
+
+@pytest.mark.parametrize("prec,tol", PRECS)
+@pytest.mark.parametrize("B,H,W,cin,cout", [
+    (2, 8, 8, 64, 64), (5, 8, 8, 192, 96), (2, 16, 16, 128, 256), (1, 32, 32, 128, 128), (9, 4, 4, 64, 32),
+    (1, 64, 64, 32, 32), (64, 8, 8, 128, 128), (8, 32, 32, 64, 128), (1, 128, 128, 32, 32)])
+def test_conv_dma_3x3(dev, prec, tol, B, H, W, cin, cout):
+    _conv_dma_case(dev, prec, tol, B, H, W, cin, cout, "s1", 3)
+
+
+@pytest.mark.parametrize("prec,tol", PRECS[:2])
+@pytest.mark.parametrize("B,H,W,c,mode", [(2, 8, 8, 64, "up"), (16, 16, 16, 128, "up"), (3, 4, 4, 32, "up"), (1, 32, 32, 32, "up"),
+                                          (2, 16, 16, 64, "down"), (8, 32, 32, 128, "down"), (3, 8, 8, 32, "down")])
+def test_conv_dma_updown(dev, prec, tol, B, H, W, c, mode):
+    _conv_dma_case(dev, prec, tol, B, H, W, c, c, mode, 3, use_emb=False, use_res=False)
+
+
+@pytest.mark.parametrize("prec,tol", PRECS)
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 8, 8, 192, 128), (3, 4, 4, 128, 384), (1, 10, 10, 64, 64), (32, 8, 8, 256, 128)])
+def test_conv_dma_1x1(dev, prec, tol, B, H, W, cin, cout):
+    _conv_dma_case(dev, prec, tol, B, H, W, cin, cout, "s1", 1, use_emb=False)
