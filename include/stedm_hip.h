@@ -110,17 +110,19 @@ int stedm_conv_igemm(const stedm_conv_args* args, void* stream);
  * w OIHW fp32 [cout][c1+c2][3][3]; out NHWC [B][H][W][cout]. Exact fp32 FMA. */
 int stedm_conv_in(const float* x1, int c1, const float* x2, int c2, int x2_bmod, const float* w_oihw,
                   const float* bias, float* out, int B, int H, int W, int cout, void* stream);
-/* out: GN->SiLU->conv3x3 to out_channels openaimodel.py:729-733, 806. src NHWC [B][H][W][c];
- * scale/shift from stedm_gn_scale_shift; w OIHW fp32 [cout][c][3][3]; out NCHW [B][cout][H][W]. */
-int stedm_conv_out(const float* src, int c, const float* scale, const float* shift, const float* w_oihw,
-                   const float* bias, float* out, int B, int H, int W, int cout, void* stream);
+/* out: GN->SiLU->conv3x3 to out_channels openaimodel.py:729-733, 806. src NHWC [B][H][W][c]; GroupNorm statistics as
+ * the slab partials of stedm_gn_stats (stats[B][nslab][groups][2]); w OIHW fp32 [cout][c][3][3]; out NCHW. */
+int stedm_conv_out(const float* src, int c, const double* stats, int nslab, const float* gamma, const float* beta,
+                   float eps, int groups, const float* w_oihw, const float* bias, float* out, int B, int H, int W,
+                   int cout, void* stream);
 
 /* ---- embedding path ---------------------------------------------------------------------- */
 /* timestep_embedding util.py:151-171 + time_embed openaimodel.py:529-534,774-775.
  * t int64 [B]; freqs fp32 [mc/2] (host-built table, uploaded once); w0t [mc][ted], w2t [ted][ted]
- * are TRANSPOSED Linear weights; emb [B][ted]. */
+ * are TRANSPOSED Linear weights; emb [B][ted]; ws: scratch of B*(mc+ted) floats. */
 int stedm_time_embed(const int64_t* t, const float* freqs, const float* w0t, const float* b0,
-                     const float* w2t, const float* b2, float* emb, int B, int mc, int ted, void* stream);
+                     const float* w2t, const float* b2, float* emb, float* ws, int B, int mc, int ted,
+                     void* stream);
 /* emb_layers = SiLU -> Linear of every ResBlock at once (openaimodel.py:231-237,277):
  * out[b][n] = bias[n] + sum_k silu(emb[b][k]) * wt[k][n]; wt is [k][ntot] (layers concatenated). */
 int stedm_emb_proj(const float* emb, const float* wt, const float* bias, float* out, int B, int k, int ntot,

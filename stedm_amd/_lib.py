@@ -50,8 +50,8 @@ SIGNATURES = {
     "stedm_gn_apply16": (_I, [_P, _I, _P, _I, _I, _P, _P, _F, _I, _I, _P, _I, _I, _P, _P, _I, _P]),
     "stedm_conv_igemm": (_I, [C.POINTER(ConvArgs), _P]),
     "stedm_conv_in": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "stedm_conv_out": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "stedm_time_embed": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "stedm_conv_out": (_I, [_P, _I, _P, _I, _P, _P, _F, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "stedm_time_embed": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "stedm_emb_proj": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "stedm_attn_legacy": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "stedm_ddim_step": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _I, _I, _I, _I, _P]),

@@ -29,7 +29,7 @@ def _newer(src_paths, target):
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "stedm_hip.h"))
     objs, jobs = [], []
     for f in sources():
@@ -52,7 +52,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if jobs:
         if verbose:
             print(f"[stedm_amd.build] compiling {len(jobs)} file(s) for gfx950 ...", flush=True)
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(cc, jobs))
     if jobs or force or _newer(objs, LIB):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs

@@ -46,11 +46,67 @@ __global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ 
   }
 }
 
+// Fast path (256 % cout == 0, cin <= 8): a thread owns one output channel and keeps its 9*cin weights in registers;
+// a block covers 8 image rows, the haloed input patch sits in LDS padded to 8 floats per position (two 16-B
+// broadcast reads per tap).
+constexpr int CI_ROWS = 8;
+__global__ void __launch_bounds__(256) conv_in_fast_kernel(const float* __restrict__ x1, int c1, const float* __restrict__ x2,
+                                                           int c2, int bmod, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ out, int H, int W,
+                                                           int cout, int rblocks) {
+  extern __shared__ __attribute__((aligned(16))) float smi[];   // [CI_ROWS+2][W+2][8]
+  const int cin = c1 + c2;
+  const int PW = W + 2;
+  const int b = blockIdx.x / rblocks, y0 = (blockIdx.x % rblocks) * CI_ROWS;
+  const int b2 = bmod > 0 ? b % bmod : b;
+  for (int i = threadIdx.x; i < (CI_ROWS + 2) * PW * 8; i += 256) {
+    const int ci = i & 7;
+    const int pc = (i >> 3) % PW;
+    const int pr = (i >> 3) / PW;
+    const int sy = y0 + pr - 1, sxx = pc - 1;
+    float v = 0.f;
+    if (ci < cin && sy >= 0 && sy < H && sxx >= 0 && sxx < W)
+      v = ci < c1 ? x1[(((long)b * c1 + ci) * H + sy) * W + sxx] : x2[(((long)b2 * c2 + (ci - c1)) * H + sy) * W + sxx];
+    smi[i] = v;
+  }
+  const int co = threadIdx.x % cout, pl = threadIdx.x / cout, npl = 256 / cout;
+  float wr[9][8];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci) wr[tap][ci] = ci < cin ? w[((long)co * cin + ci) * 9 + tap] : 0.f;
+  const float bv = bias ? bias[co] : 0.f;
+  __syncthreads();
+  const int rows = min(CI_ROWS, H - y0);
+  for (int pix = pl; pix < rows * W; pix += npl) {
+    const int yl = pix / W, x = pix - yl * W;
+    float acc = bv;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap % 3;
+      const float4* pp = reinterpret_cast<const float4*>(smi + ((yl + dy) * PW + x + dx) * 8);
+      const float4 u = pp[0], v = pp[1];
+      acc = fmaf(u.x, wr[tap][0], acc); acc = fmaf(u.y, wr[tap][1], acc); acc = fmaf(u.z, wr[tap][2], acc); acc = fmaf(u.w, wr[tap][3], acc);
+      acc = fmaf(v.x, wr[tap][4], acc); acc = fmaf(v.y, wr[tap][5], acc); acc = fmaf(v.z, wr[tap][6], acc); acc = fmaf(v.w, wr[tap][7], acc);
+    }
+    out[(((long)b * H + y0 + yl) * W + x) * cout + co] = acc;
+  }
+}
+
 extern "C" int stedm_conv_in(const float* x1, int c1, const float* x2, int c2, int x2_bmod, const float* w,
                              const float* bias, float* out, int B, int H, int W, int cout, void* stream) {
   STEDM_CHECK_ARG(x1 && w && out, "conv_in: null pointer");
   STEDM_CHECK_ARG((x2 != nullptr) == (c2 > 0), "conv_in: x2/c2 mismatch");
   const int cin = c1 + c2;
+  if (cin <= 8 && cout <= 256 && 256 % cout == 0) {
+    const size_t ldsf = (size_t)(CI_ROWS + 2) * (W + 2) * 8 * sizeof(float);
+    if (ldsf <= 64 * 1024) {
+      const int rblocks = (H + CI_ROWS - 1) / CI_ROWS;
+      conv_in_fast_kernel<<<B * rblocks, 256, ldsf, as_stream(stream)>>>(x1, c1, x2, c2, x2_bmod, w, bias, out, H, W, cout, rblocks);
+      STEDM_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   const size_t lds = ((size_t)3 * (W + 2) * cin + (size_t)9 * cin * cout) * sizeof(float);
   STEDM_CHECK_ARG(lds <= 64 * 1024, "conv_in: cin=%d cout=%d W=%d needs %zu B LDS (> 64 KiB)", cin, cout, W, lds);
   conv_in_kernel<<<B * H, 256, lds, as_stream(stream)>>>(x1, c1, x2, c2, x2_bmod, w, bias, out, H, W, cout);
@@ -58,86 +114,113 @@ extern "C" int stedm_conv_in(const float* x1, int c1, const float* x2, int c2, i
   return 0;
 }
 
-// One block per (b, y, 32-pixel segment). Each output pixel's K = 9*c reduction is split over PARTS
-// lanes (channel-interleaved: lane part takes channels part, part+PARTS, ...) and combined by shuffles.
-constexpr int CO_PARTS = 8;
+// conv_out: block = (sample, 4 rows x 32 columns of output pixels). GroupNorm mean/rstd are reduced from the stats
+// partials of stedm_gn_stats in the block prologue (fixed order). Channels are walked in chunks of 32: the haloed,
+// normalised + activated patch chunk [6][34][32(+1 pad)] and the weight chunk [9][32][cout<=8 as 2 float4] sit in
+// LDS; a thread owns one pixel and half of the chunk's channels for all output channels; halves meet in LDS.
 constexpr int CO_MAXOUT = 8;
-constexpr int CO_SEG = 32;
-__global__ void __launch_bounds__(256) conv_out_kernel(const float* __restrict__ src, int c, const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, const float* __restrict__ w,
+constexpr int CO_TR = 4, CO_TC = 32, CO_CH = 32;
+__global__ void __launch_bounds__(256) conv_out_kernel(const float* __restrict__ src, int c, const double* __restrict__ stats,
+                                                       int nslab, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, int groups, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ out, int H, int W,
-                                                       int cout, int nseg) {
-  extern __shared__ float sm[];
-  constexpr int PW = CO_SEG + 2;
-  const int CST = c + 8;                   // padded channel stride (bank spread across pixels)
-  float* sx = sm;                          // [3][PW][CST]  (post GN+SiLU)
-  float* sw = sm + 3 * PW * CST;           // [cout][9][c]
-  const int seg = blockIdx.x % nseg;
-  const int by = blockIdx.x / nseg;
-  const int b = by / H, y = by % H;
-  const int x0 = seg * CO_SEG;
-  const int c4 = c >> 2;
-  for (int i = threadIdx.x; i < 3 * PW * c4; i += blockDim.x) {
-    const int q = i % c4;
-    const int pc = (i / c4) % PW;
-    const int dy = i / (c4 * PW);
-    const int sy = y + dy - 1, sxx = x0 + pc - 1;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (sy >= 0 && sy < H && sxx >= 0 && sxx < W) {
-      v = *reinterpret_cast<const float4*>(src + (((long)b * H + sy) * W + sxx) * c + q * 4);
-      const float4 sc = *reinterpret_cast<const float4*>(scale + (long)b * c + q * 4);
-      const float4 sh = *reinterpret_cast<const float4*>(shift + (long)b * c + q * 4);
-      v.x = silu_f(fmaf(v.x, sc.x, sh.x)); v.y = silu_f(fmaf(v.y, sc.y, sh.y));
-      v.z = silu_f(fmaf(v.z, sc.z, sh.z)); v.w = silu_f(fmaf(v.w, sc.w, sh.w));
+                                                       int cout, int tr, int tc) {
+  extern __shared__ __attribute__((aligned(16))) float smo[];
+  constexpr int PR = CO_TR + 2, PC = CO_TC + 2, PST = CO_CH + 1;
+  float* sscale = smo;                       // [c]
+  float* sshift = sscale + c;                // [c]
+  float* sx = sshift + c;                    // [PR][PC][PST]
+  float* sw = sx + PR * PC * PST;            // [9][CO_CH][8]
+  float* sred = sw + 9 * CO_CH * 8;          // [128][8]
+  const int tiles = tr * tc;
+  const int b = blockIdx.x / tiles, t = blockIdx.x % tiles;
+  const int y0 = (t / tc) * CO_TR, x0 = (t % tc) * CO_TC;
+  const int cpg = c / groups;
+  const int HW = H * W;
+  for (int ch = threadIdx.x; ch < c; ch += 256) {
+    const int g = ch / cpg;
+    double su = 0.0, sq = 0.0;
+    for (int k = 0; k < nslab; ++k) {
+      su += stats[(((long)b * nslab + k) * groups + g) * 2];
+      sq += stats[(((long)b * nslab + k) * groups + g) * 2 + 1];
     }
-    *reinterpret_cast<float4*>(sx + (dy * PW + pc) * CST + q * 4) = v;
+    const double inv_n = 1.0 / ((double)cpg * HW);
+    const double mean = su * inv_n;
+    double var = sq * inv_n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float gm = gamma[ch] * rstd;
+    sscale[ch] = gm;
+    sshift[ch] = beta[ch] - (float)mean * gm;
   }
-  for (int i = threadIdx.x; i < cout * 9 * c; i += blockDim.x) {
-    const int ci = i % c;
-    const int tap = (i / c) % 9;
-    const int co = i / (c * 9);
-    sw[i] = w[((long)co * c + ci) * 9 + tap];
-  }
-  __syncthreads();
-  const int part = threadIdx.x % CO_PARTS;
-  const int xl = threadIdx.x / CO_PARTS;   // 0..31: pixel within the segment
-  const int x = x0 + xl;
+  const int pix = threadIdx.x & 127, half = threadIdx.x >> 7;
+  const int yl = pix / CO_TC, xl = pix % CO_TC;
   float acc[CO_MAXOUT];
 #pragma unroll
   for (int o = 0; o < CO_MAXOUT; ++o) acc[o] = 0.f;
-  if (x < W) {
+  for (int c0 = 0; c0 < c; c0 += CO_CH) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < PR * PC * (CO_CH / 4); i += 256) {
+      const int q = i % (CO_CH / 4);
+      const int pc = (i / (CO_CH / 4)) % PC;
+      const int pr = i / ((CO_CH / 4) * PC);
+      const int sy = y0 + pr - 1, sxx = x0 + pc - 1;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (sy >= 0 && sy < H && sxx >= 0 && sxx < W && c0 + q * 4 < c) {
+        v = *reinterpret_cast<const float4*>(src + (((long)b * H + sy) * W + sxx) * c + c0 + q * 4);
+        const int cc = c0 + q * 4;
+        v.x = silu_f(fmaf(v.x, sscale[cc], sshift[cc])); v.y = silu_f(fmaf(v.y, sscale[cc + 1], sshift[cc + 1]));
+        v.z = silu_f(fmaf(v.z, sscale[cc + 2], sshift[cc + 2])); v.w = silu_f(fmaf(v.w, sscale[cc + 3], sshift[cc + 3]));
+      }
+      float* d = sx + (pr * PC + pc) * PST + q * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    for (int i = threadIdx.x; i < 9 * CO_CH * 8; i += 256) {
+      const int o = i & 7, ci = (i >> 3) % CO_CH, tap = i / (8 * CO_CH);
+      sw[i] = (o < cout && c0 + ci < c) ? w[((long)o * c + c0 + ci) * 9 + tap] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int dy = tap / 3, dx = tap % 3;
-      const float* px = sx + (dy * PW + xl + dx) * CST;
-      const float* pw = sw + tap * c;
-      for (int ci = part; ci < c; ci += CO_PARTS) {
+      const float* px = sx + ((yl + dy) * PC + xl + dx) * PST + half * (CO_CH / 2);
+      const float4* pw = reinterpret_cast<const float4*>(sw + (tap * CO_CH + half * (CO_CH / 2)) * 8);
+#pragma unroll 4
+      for (int ci = 0; ci < CO_CH / 2; ++ci) {
         const float v = px[ci];
-#pragma unroll
-        for (int o = 0; o < CO_MAXOUT; ++o)
-          if (o < cout) acc[o] = fmaf(v, pw[o * 9 * c + ci], acc[o]);
+        const float4 wa = pw[ci * 2], wb = pw[ci * 2 + 1];
+        acc[0] = fmaf(v, wa.x, acc[0]); acc[1] = fmaf(v, wa.y, acc[1]); acc[2] = fmaf(v, wa.z, acc[2]); acc[3] = fmaf(v, wa.w, acc[3]);
+        acc[4] = fmaf(v, wb.x, acc[4]); acc[5] = fmaf(v, wb.y, acc[5]); acc[6] = fmaf(v, wb.z, acc[6]); acc[7] = fmaf(v, wb.w, acc[7]);
       }
     }
   }
+  __syncthreads();
+  if (half == 1) {
 #pragma unroll
-  for (int o = 0; o < CO_MAXOUT; ++o) {
-    float v = acc[o];
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    if (o < cout && part == 0 && x < W) out[(((long)b * cout + o) * H + y) * W + x] = v + (bias ? bias[o] : 0.f);
+    for (int o = 0; o < CO_MAXOUT; ++o) sred[pix * 8 + o] = acc[o];
+  }
+  __syncthreads();
+  if (half == 0) {
+    const int y = y0 + yl, x = x0 + xl;
+    if (y < H && x < W) {
+#pragma unroll
+      for (int o = 0; o < CO_MAXOUT; ++o)
+        if (o < cout) out[(((long)b * cout + o) * H + y) * W + x] = acc[o] + sred[pix * 8 + o] + (bias ? bias[o] : 0.f);
+    }
   }
 }
 
-extern "C" int stedm_conv_out(const float* src, int c, const float* scale, const float* shift, const float* w,
-                              const float* bias, float* out, int B, int H, int W, int cout, void* stream) {
-  STEDM_CHECK_ARG(src && scale && shift && w && out, "conv_out: null pointer");
-  STEDM_CHECK_ARG(c % 4 == 0 && cout >= 1 && cout <= CO_MAXOUT, "conv_out: need c %% 4 == 0 and cout <= %d (c=%d cout=%d)", CO_MAXOUT, c, cout);
-  const size_t lds = ((size_t)3 * (CO_SEG + 2) * (c + 8) + (size_t)cout * 9 * c) * sizeof(float);
-  STEDM_CHECK_ARG(lds <= 160 * 1024, "conv_out: needs %zu B LDS", lds);
-  if (lds > 64 * 1024)
-    STEDM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_out_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int nseg = (W + CO_SEG - 1) / CO_SEG;
-  conv_out_kernel<<<B * H * nseg, 256, lds, as_stream(stream)>>>(src, c, scale, shift, w, bias, out, H, W, cout, nseg);
+extern "C" int stedm_conv_out(const float* src, int c, const double* stats, int nslab, const float* gamma, const float* beta,
+                              float eps, int groups, const float* w, const float* bias, float* out, int B, int H, int W,
+                              int cout, void* stream) {
+  STEDM_CHECK_ARG(src && stats && gamma && beta && w && out, "conv_out: null pointer");
+  STEDM_CHECK_ARG(c % 4 == 0 && cout >= 1 && cout <= CO_MAXOUT && groups > 0 && c % groups == 0,
+                  "conv_out: need c %% 4 == 0, c %% groups == 0 and cout <= %d (c=%d cout=%d)", CO_MAXOUT, c, cout);
+  const size_t lds = ((size_t)2 * c + (size_t)(CO_TR + 2) * (CO_TC + 2) * (CO_CH + 1) + 9 * CO_CH * 8 + 128 * 8) * sizeof(float);
+  STEDM_CHECK_ARG(lds <= 64 * 1024, "conv_out: needs %zu B LDS", lds);
+  const int tr = (H + CO_TR - 1) / CO_TR, tc = (W + CO_TC - 1) / CO_TC;
+  conv_out_kernel<<<B * tr * tc, 256, lds, as_stream(stream)>>>(src, c, stats, nslab, gamma, beta, eps, groups, w, bias, out, H, W,
+                                                             cout, tr, tc);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

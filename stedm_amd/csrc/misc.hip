@@ -87,82 +87,93 @@ extern "C" int stedm_transpose_f32(const float* in, float* out, int rows, int co
 // ------------------------------------------------------------------------------------------------
 // Embedding path
 // ------------------------------------------------------------------------------------------------
-// One block per sample: sinusoid [mc] -> Linear(mc, ted) -> SiLU -> Linear(ted, ted).
-__global__ void __launch_bounds__(256) time_embed_kernel(const int64_t* __restrict__ t, const float* __restrict__ freqs,
-                                                         const float* __restrict__ w0t, const float* __restrict__ b0,
-                                                         const float* __restrict__ w2t, const float* __restrict__ b2,
-                                                         float* __restrict__ emb, int mc, int ted) {
-  extern __shared__ float sm[];
-  float* te = sm;        // [mc]
-  float* h1 = sm + mc;   // [ted]
-  const int b = blockIdx.x;
-  const float tv = (float)t[b];
-  const int half = mc / 2;
-  for (int i = threadIdx.x; i < half; i += blockDim.x) {
-    const float a = tv * freqs[i];
-    te[i] = cosf(a);         // cos half first (util.py:166)
-    te[half + i] = sinf(a);
-  }
-  if ((mc & 1) && threadIdx.x == 0) te[mc - 1] = 0.f;
-  __syncthreads();
-  for (int n = threadIdx.x; n < ted; n += blockDim.x) {
-    float acc = b0[n];
-    for (int k = 0; k < mc; ++k) acc = fmaf(te[k], w0t[(long)k * ted + n], acc);
-    h1[n] = silu_f(acc);
+// out[b][n] = act_out( bias[n] + sum_k act_in(x[b][k]) * wt[k][n] ),  wt K-major ([K][N]).
+// Block = 64 outputs x 4 K-slices (256 threads), up to 8 batch rows per block share each weight read;
+// the K split keeps the dependent-load chain short (these GEMVs are latency-, not bandwidth-bound).
+constexpr int LIN_ROWS = 8;
+__global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                     const float* __restrict__ bias, float* __restrict__ out, int B, int K, int N,
+                                                     int act_in, int act_out) {
+  extern __shared__ float sx[];                 // [LIN_ROWS][K] then [4][LIN_ROWS][64] partials
+  float* part = sx + LIN_ROWS * K;
+  const int b0 = blockIdx.y * LIN_ROWS;
+  for (int i = threadIdx.x; i < LIN_ROWS * K; i += 256) {
+    const int r = i / K, k = i - r * K;
+    float v = (b0 + r < B) ? x[(long)(b0 + r) * K + k] : 0.f;
+    sx[i] = act_in ? silu_f(v) : v;
   }
   __syncthreads();
-  for (int n = threadIdx.x; n < ted; n += blockDim.x) {
-    float acc = b2[n];
-    for (int k = 0; k < ted; ++k) acc = fmaf(h1[k], w2t[(long)k * ted + n], acc);
-    emb[(long)b * ted + n] = acc;
+  const int nl = threadIdx.x & 63, ks = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + nl;
+  float acc[LIN_ROWS];
+#pragma unroll
+  for (int r = 0; r < LIN_ROWS; ++r) acc[r] = 0.f;
+  if (n < N) {
+    const int k0 = ks * ((K + 3) / 4), k1 = min(K, k0 + (K + 3) / 4);
+    for (int k = k0; k < k1; ++k) {
+      const float w = wt[(long)k * N + n];
+#pragma unroll
+      for (int r = 0; r < LIN_ROWS; ++r) acc[r] = fmaf(sx[r * K + k], w, acc[r]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < LIN_ROWS; ++r) part[(ks * LIN_ROWS + r) * 64 + nl] = acc[r];
+  __syncthreads();
+  if (ks == 0 && n < N) {
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < LIN_ROWS; ++r) {
+      if (b0 + r < B) {
+        float v = bv + ((part[(0 * LIN_ROWS + r) * 64 + nl] + part[(1 * LIN_ROWS + r) * 64 + nl]) +
+                        (part[(2 * LIN_ROWS + r) * 64 + nl] + part[(3 * LIN_ROWS + r) * 64 + nl]));
+        out[(long)(b0 + r) * N + n] = act_out ? silu_f(v) : v;
+      }
+    }
   }
 }
 
-extern "C" int stedm_time_embed(const int64_t* t, const float* freqs, const float* w0t, const float* b0, const float* w2t,
-                                const float* b2, float* emb, int B, int mc, int ted, void* stream) {
-  STEDM_CHECK_ARG(t && freqs && w0t && b0 && w2t && b2 && emb, "time_embed: null pointer");
-  STEDM_CHECK_ARG(B > 0 && mc > 0 && ted > 0 && (mc + ted) * 4 <= 64 * 1024, "time_embed: bad sizes B=%d mc=%d ted=%d", B, mc, ted);
-  time_embed_kernel<<<B, 256, (mc + ted) * sizeof(float), as_stream(stream)>>>(t, freqs, w0t, b0, w2t, b2, emb, mc, ted);
+static int launch_linear(const float* x, const float* wt, const float* bias, float* out, int B, int K, int N, int act_in,
+                         int act_out, hipStream_t st) {
+  const size_t lds = ((size_t)LIN_ROWS * K + 4 * LIN_ROWS * 64) * sizeof(float);
+  if (lds > 64 * 1024) { set_error("linear: K=%d too large", K); return 1; }
+  dim3 grid((N + 63) / 64, (B + LIN_ROWS - 1) / LIN_ROWS);
+  linear_kernel<<<grid, 256, lds, st>>>(x, wt, bias, out, B, K, N, act_in, act_out);
   STEDM_LAUNCH_CHECK();
   return 0;
 }
 
-// out[b][n] = bias[n] + sum_k silu(emb[b][k]) * wt[k][n]; 8 batch rows per block share each weight read.
-constexpr int EP_ROWS = 8;
-__global__ void __launch_bounds__(256) emb_proj_kernel(const float* __restrict__ emb, const float* __restrict__ wt,
-                                                       const float* __restrict__ bias, float* __restrict__ out, int B, int K,
-                                                       int ntot) {
-  extern __shared__ float se[];  // [EP_ROWS][K]
-  const int b0 = blockIdx.y * EP_ROWS;
-  for (int i = threadIdx.x; i < EP_ROWS * K; i += blockDim.x) {
-    const int r = i / K, k = i - r * K;
-    se[i] = (b0 + r < B) ? silu_f(emb[(long)(b0 + r) * K + k]) : 0.f;
+// sinusoid [B][mc]: cos half first (util.py:166)
+__global__ void sinusoid_kernel(const int64_t* __restrict__ t, const float* __restrict__ freqs, float* __restrict__ te, int mc) {
+  const int b = blockIdx.x, half = mc / 2;
+  const float tv = (float)t[b];
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    const float a = tv * freqs[i];
+    te[(long)b * mc + i] = cosf(a);
+    te[(long)b * mc + half + i] = sinf(a);
   }
-  __syncthreads();
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= ntot) return;
-  float acc[EP_ROWS];
-  const float bv = bias[n];
-#pragma unroll
-  for (int r = 0; r < EP_ROWS; ++r) acc[r] = bv;
-  for (int k = 0; k < K; ++k) {
-    const float w = wt[(long)k * ntot + n];
-#pragma unroll
-    for (int r = 0; r < EP_ROWS; ++r) acc[r] = fmaf(se[r * K + k], w, acc[r]);
-  }
-#pragma unroll
-  for (int r = 0; r < EP_ROWS; ++r)
-    if (b0 + r < B) out[(long)(b0 + r) * ntot + n] = acc[r];
+  if ((mc & 1) && threadIdx.x == 0) te[(long)b * mc + mc - 1] = 0.f;
+}
+
+// emb [B][ted]; ws: caller-provided scratch of B*(mc+ted) floats (sinusoid + hidden layer).
+extern "C" int stedm_time_embed(const int64_t* t, const float* freqs, const float* w0t, const float* b0, const float* w2t,
+                                const float* b2, float* emb, float* ws, int B, int mc, int ted, void* stream) {
+  STEDM_CHECK_ARG(t && freqs && w0t && b0 && w2t && b2 && emb && ws, "time_embed: null pointer");
+  STEDM_CHECK_ARG(B > 0 && mc > 0 && ted > 0, "time_embed: bad sizes B=%d mc=%d ted=%d", B, mc, ted);
+  float* te = ws;
+  float* h1 = ws + (size_t)B * mc;
+  hipStream_t st = as_stream(stream);
+  sinusoid_kernel<<<B, 64, 0, st>>>(t, freqs, te, mc);
+  STEDM_LAUNCH_CHECK();
+  int rc = launch_linear(te, w0t, b0, h1, B, mc, ted, 0, 1, st);
+  if (rc) return rc;
+  return launch_linear(h1, w2t, b2, emb, B, ted, ted, 0, 0, st);
 }
 
 extern "C" int stedm_emb_proj(const float* emb, const float* wt, const float* bias, float* out, int B, int k, int ntot,
                               void* stream) {
   STEDM_CHECK_ARG(emb && wt && bias && out, "emb_proj: null pointer");
-  STEDM_CHECK_ARG(B > 0 && k > 0 && ntot > 0 && EP_ROWS * k * 4 <= 64 * 1024, "emb_proj: bad sizes B=%d k=%d ntot=%d", B, k, ntot);
-  dim3 grid((ntot + 255) / 256, (B + EP_ROWS - 1) / EP_ROWS);
-  emb_proj_kernel<<<grid, 256, EP_ROWS * k * sizeof(float), as_stream(stream)>>>(emb, wt, bias, out, B, k, ntot);
-  STEDM_LAUNCH_CHECK();
-  return 0;
+  STEDM_CHECK_ARG(B > 0 && k > 0 && ntot > 0, "emb_proj: bad sizes B=%d k=%d ntot=%d", B, k, ntot);
+  return launch_linear(emb, wt, bias, out, B, k, ntot, 1, 0, as_stream(stream));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -100,7 +100,8 @@ class DDIMSampler(object):
             elif self._eta != 0.0:
                 nz = torch.randn(shape, device=device)     # ddim.py:206 (when sigma == 0 the draw cannot change x)
             img, pred_x0 = self.p_sample_ddim(img, cond, ts, index=index, unconditional_guidance_scale=unconditional_guidance_scale,
-                                              unconditional_conditioning=unconditional_conditioning, _noise=nz, _out=(img, pred_x0))
+                                              unconditional_conditioning=unconditional_conditioning, _noise=nz, _out=(img, pred_x0),
+                                              _uniform_t=True)
             if callback:
                 callback(i)
             if img_callback:
@@ -114,16 +115,18 @@ class DDIMSampler(object):
     def p_sample_ddim(self, x, c, t, index, repeat_noise=False, use_original_steps=False, quantize_denoised=False,
                       temperature=1., noise_dropout=0., score_corrector=None, corrector_kwargs=None,
                       unconditional_guidance_scale=1., unconditional_conditioning=None, rescale_phi=0.7,
-                      _noise: Optional[torch.Tensor] = None, _out=None):
+                      _noise: Optional[torch.Tensor] = None, _out=None, _uniform_t: bool = False):
         """ddim.py:164-210. Returns (x_prev, pred_x0)."""
         if use_original_steps or quantize_denoised or score_corrector is not None or repeat_noise:
             raise NotImplementedError("use_original_steps / quantize_denoised / score_corrector / repeat_noise not implemented")
         x = x.float().contiguous()
         e_u = None
+        ours = hasattr(self.model, "apply_model_cfg")
+        kw = {"uniform_t": True} if (ours and _uniform_t) else {}
         if unconditional_conditioning is None or unconditional_guidance_scale == 1.:
-            e_c = self.model.apply_model(x, t, c)
-        elif hasattr(self.model, "apply_model_cfg"):
-            e_c, e_u = self.model.apply_model_cfg(x, t, c, unconditional_conditioning)
+            e_c = self.model.apply_model(x, t, c, **kw)
+        elif ours:
+            e_c, e_u = self.model.apply_model_cfg(x, t, c, unconditional_conditioning, **kw)
         else:
             e_c = self.model.apply_model(x, t, c)                           # cond first, then uncond (ddim.py:177-178)
             e_u = self.model.apply_model(x, t, unconditional_conditioning)
@@ -181,9 +184,9 @@ class StepGraph:
         s, m = self.s, self.s.model
         ops.step_set_t(s._ts_table, self.step, self.t_buf)
         if self.cfg:
-            e_c, e_u = m.apply_model_cfg(self.img, self.t_buf, self.cond, self.uncond, out=self.eps)
+            e_c, e_u = m.apply_model_cfg(self.img, self.t_buf, self.cond, self.uncond, out=self.eps, uniform_t=True)
         else:
-            e_c, e_u = m.apply_model(self.img, self.t_buf, self.cond, out=self.eps), None
+            e_c, e_u = m.apply_model(self.img, self.t_buf, self.cond, out=self.eps, uniform_t=True), None
         ops.ddim_step(self.img, e_c, e_u, s._coefs, self.img, pred_x0=self.pred_x0, step_idx=self.step,
                       cfg_scale=self.scale, rescale_phi=self.phi)
         ops.step_advance(self.step, -1)

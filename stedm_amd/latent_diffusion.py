@@ -47,10 +47,10 @@ class DiffusionWrapper(nn.Module):
             raise NotImplementedError("only conditioning_key='hybrid' is used by STEDM (conf/diffusion/ldm_based.yaml:12)")
 
     @torch.no_grad()
-    def forward(self, x, t, c_concat: list = None, c_crossattn: list = None, out=None):
+    def forward(self, x, t, c_concat: list = None, c_crossattn: list = None, out=None, uniform_t=False):
         cc = c_crossattn[0] if len(c_crossattn) == 1 else torch.cat(c_crossattn, 1)
         xc = c_concat[0] if len(c_concat) == 1 else torch.cat(c_concat, 1)
-        return self.diffusion_model.forward_parts(x, xc, t, cc, out=out)   # cat([x]+c_concat) folded into the first conv
+        return self.diffusion_model.forward_parts(x, xc, t, cc, out=out, uniform_t=uniform_t)   # cat folded into the first conv
 
     def _same_tensor(self, a, b) -> bool:
         """Content equality of two conditioning tensors, decided once per (storage, version) pair (no per-step sync)."""
@@ -67,7 +67,7 @@ class DiffusionWrapper(nn.Module):
         return cache[key]
 
     @torch.no_grad()
-    def forward_cfg(self, x, t, cond: dict, uncond: dict, out=None):
+    def forward_cfg(self, x, t, cond: dict, uncond: dict, out=None, uniform_t=False):
         """cond/uncond evaluations of ddim.py:177-178 in one shared-encoder pass. Requires equal c_concat (the
         reference's unconditional batch keeps the segmentation, ldm_diffusion.py:86); otherwise two passes."""
         cc_c, cc_u = cond["c_concat"], uncond["c_concat"]
@@ -76,14 +76,14 @@ class DiffusionWrapper(nn.Module):
             B = x.shape[0]
             if out is None:
                 out = torch.empty((2 * B, self.diffusion_model.out_channels) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
-            self.forward(x, t, **cond, out=out[:B])
-            self.forward(x, t, **uncond, out=out[B:])
+            self.forward(x, t, **cond, out=out[:B], uniform_t=uniform_t)
+            self.forward(x, t, **uncond, out=out[B:], uniform_t=uniform_t)
             return out[:B], out[B:]
         xc = cc_c[0] if len(cc_c) == 1 else torch.cat(cc_c, 1)
         ca = cond["c_crossattn"]; cu = uncond["c_crossattn"]
         ca = ca[0] if len(ca) == 1 else torch.cat(ca, 1)
         cu = cu[0] if len(cu) == 1 else torch.cat(cu, 1)
-        return self.diffusion_model.forward_cfg(x, xc, t, ca, cu, out=out)
+        return self.diffusion_model.forward_cfg(x, xc, t, ca, cu, out=out, uniform_t=uniform_t)
 
 
 class LatentDiffusion(nn.Module):
@@ -146,14 +146,14 @@ class LatentDiffusion(nn.Module):
         return {key: cond}
 
     @torch.no_grad()
-    def apply_model(self, x_noisy, t, cond, return_ids=False, out=None):
-        """ddpm.py:894-903 + 989-995."""
-        return self.model(x_noisy, t, **self._as_cond_dict(cond), out=out)
+    def apply_model(self, x_noisy, t, cond, return_ids=False, out=None, uniform_t=False):
+        """ddpm.py:894-903 + 989-995. uniform_t: all entries of t are equal (the DDIM loop, ddim.py:141)."""
+        return self.model(x_noisy, t, **self._as_cond_dict(cond), out=out, uniform_t=uniform_t)
 
     @torch.no_grad()
-    def apply_model_cfg(self, x_noisy, t, cond, uncond, out=None):
+    def apply_model_cfg(self, x_noisy, t, cond, uncond, out=None, uniform_t=False):
         """(e_t, e_t_uncond) of ddim.py:177-178 in one pass (see UNetModel.forward_cfg)."""
-        return self.model.forward_cfg(x_noisy, t, self._as_cond_dict(cond), self._as_cond_dict(uncond), out=out)
+        return self.model.forward_cfg(x_noisy, t, self._as_cond_dict(cond), self._as_cond_dict(uncond), out=out, uniform_t=uniform_t)
 
     # ------------------------------------------------------------------------------------------ training-side forward values
     @torch.no_grad()

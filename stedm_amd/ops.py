@@ -184,24 +184,32 @@ def conv_in(x1: torch.Tensor, x2: Optional[torch.Tensor], w: torch.Tensor, bias:
     return out
 
 
-def conv_out(src: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
-             out: torch.Tensor) -> torch.Tensor:
-    """src [B,H,W,c] NHWC -> out [B,cout,H,W] NCHW (GN affine + SiLU fused)."""
+def conv_out(src: torch.Tensor, norm_weight: torch.Tensor, norm_bias: torch.Tensor, eps: float, groups: int, w: torch.Tensor,
+             bias: Optional[torch.Tensor], out: torch.Tensor, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """src [B,H,W,c] NHWC -> out [B,cout,H,W] NCHW with GroupNorm + SiLU fused into the patch load (statistics from
+    gn_stats; computed here when `stats` is None)."""
     _chk(src, name="src")
     B, H, W, c = src.shape
-    check(lib().stedm_conv_out(src.data_ptr(), c, scale.data_ptr(), shift.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(),
-                               B, H, W, out.shape[1], _stream()), "stedm_conv_out")
+    nslab = gn_nslab(c, H * W)
+    if stats is None:
+        stats = torch.empty((B * nslab * groups * 2,), dtype=torch.float64, device=src.device)
+    gn_stats(src, None, stats, groups)
+    check(lib().stedm_conv_out(src.data_ptr(), c, stats.data_ptr(), nslab, norm_weight.data_ptr(), norm_bias.data_ptr(), float(eps),
+                               groups, w.data_ptr(), _ptr(bias), out.data_ptr(), B, H, W, out.shape[1], _stream()), "stedm_conv_out")
     return out
 
 
 # ------------------------------------------------------------------------------------------- embeddings
 def time_embed(t: torch.Tensor, freqs: torch.Tensor, w0t: torch.Tensor, b0: torch.Tensor, w2t: torch.Tensor, b2: torch.Tensor,
-               out: torch.Tensor) -> torch.Tensor:
+               out: torch.Tensor, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(t, torch.int64, "timesteps")
     B = t.shape[0]
     mc, ted = w0t.shape
+    if ws is None:
+        ws = torch.empty((B * (mc + ted),), dtype=torch.float32, device=t.device)
+    assert ws.numel() >= B * (mc + ted)
     check(lib().stedm_time_embed(t.data_ptr(), freqs.data_ptr(), w0t.data_ptr(), b0.data_ptr(), w2t.data_ptr(), b2.data_ptr(),
-                                 out.data_ptr(), B, mc, ted, _stream()), "stedm_time_embed")
+                                 out.data_ptr(), ws.data_ptr(), B, mc, ted, _stream()), "stedm_time_embed")
     return out
 
 

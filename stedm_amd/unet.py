@@ -219,6 +219,7 @@ class UNetModel(nn.Module):
         import os as _os
         self.conv_path = _os.environ.get("STEDM_CONV_PATH", "dma")
         self._gn_slot = 0
+        self._style_cache: Dict[Tuple, torch.Tensor] = {}
 
     # ------------------------------------------------------------------------------------ engine plumbing
     def convert_to_fp16(self):  # openaimodel.py:745-751 — a no-op in the reference too (openaimodel.py:25-29)
@@ -234,6 +235,7 @@ class UNetModel(nn.Module):
     def invalidate(self) -> None:
         """Drop packed weights (call after changing parameters in place without bumping their version)."""
         self._packed.clear()
+        self._style_cache.clear()
         self._consts.clear()
         self._pack_key = None
 
@@ -266,6 +268,7 @@ class UNetModel(nn.Module):
             return
         self._packed.clear()
         self._consts.clear()
+        self._style_cache.clear()
         prec = self.precision
 
         def pack(conv):
@@ -437,13 +440,15 @@ class UNetModel(nn.Module):
         return self.forward_parts(x, None, timesteps, context)
 
     @torch.no_grad()
-    def forward_parts(self, x, c_concat, timesteps, context, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward_parts(self, x, c_concat, timesteps, context, out: Optional[torch.Tensor] = None, uniform_t: bool = False) -> torch.Tensor:
         """Same as forward, but takes the latent and the concat-conditioning separately (the cat of
-        ddpm.py:1415 is folded into the first conv's loader)."""
-        return self._forward_impl(x, c_concat, timesteps, [context], out)
+        ddpm.py:1415 is folded into the first conv's loader). uniform_t=True promises that all timesteps are equal
+        (DDIM sampling, ddim.py:141): the timestep-embedding path is then evaluated for one row and broadcast."""
+        return self._forward_impl(x, c_concat, timesteps, [context], out, uniform_t)
 
     @torch.no_grad()
-    def forward_cfg(self, x, c_concat, timesteps, context_cond, context_uncond, out: Optional[torch.Tensor] = None):
+    def forward_cfg(self, x, c_concat, timesteps, context_cond, context_uncond, out: Optional[torch.Tensor] = None,
+                    uniform_t: bool = False):
         """Both classifier-free-guidance evaluations of ddim.py:177-178 in one pass: returns (e_t, e_t_uncond).
 
         The reference runs the U-Net twice on the same (x, t, c_concat) with two style vectors. The style vector only
@@ -451,11 +456,31 @@ class UNetModel(nn.Module):
         and middle_block[0] — is bit-identical in the two runs and is evaluated once (batch B); from the style block on
         the batch is 2B = [cond | uncond], with the skip tensors of the shared encoder read modulo B. Per-sample
         arithmetic (GroupNorm is per sample) is exactly that of two sequential forwards."""
-        o = self._forward_impl(x, c_concat, timesteps, [context_cond, context_uncond], out)
+        o = self._forward_impl(x, c_concat, timesteps, [context_cond, context_uncond], out, uniform_t)
         B = x.shape[0]
         return o[:B], o[B:]
 
-    def _forward_impl(self, x, c_concat, timesteps, contexts, out):
+    def _style_proj(self, contexts, B, ted):
+        """emb_layers of the ResBlockStyle applied to the style vector(s) (openaimodel.py:277 with emb = context). The
+        style vectors do not change during a sampling run: cached per (storage, version) of the context tensors."""
+        c = self._consts
+        key = tuple((cx.data_ptr(), cx._version, tuple(cx.shape)) for cx in contexts) + (self._pack_key is not None and id(c["style_wt"]),)
+        hit = self._style_cache.get(key)
+        if hit is not None:
+            return hit
+        nrep = len(contexts)
+        if nrep == 1:
+            ctx_all = contexts[0].float().contiguous()
+        else:
+            ctx_all = torch.cat([cx.float() for cx in contexts], dim=0).contiguous()
+        style_all = ops.emb_proj(ctx_all, c["style_wt"], c["style_b"],
+                                 torch.empty((B * nrep, c["style_wt"].shape[1]), dtype=torch.float32, device=ctx_all.device))
+        if len(self._style_cache) > 8:
+            self._style_cache.clear()
+        self._style_cache[key] = style_all
+        return style_all
+
+    def _forward_impl(self, x, c_concat, timesteps, contexts, out, uniform_t=False):
         self._prepare()
         x = x.float().contiguous()
         B, c1, H, W = x.shape
@@ -474,43 +499,40 @@ class UNetModel(nn.Module):
         ted = self.model_channels * 4
         for cx in contexts:
             assert tuple(cx.shape) == (B, ted), f"context must be [B,{ted}] (ResBlockStyle uses it as the embedding)"
-        if nrep == 1:
-            ctx_all = contexts[0].float().contiguous()
-        else:
-            ctx_all = self._buf("ctx_all", (Bd, ted))
-            for r, cx in enumerate(contexts):
-                ctx_all[r * B:(r + 1) * B].copy_(cx)
-
-        emb = ops.time_embed(timesteps, c["freqs"], c["te_w0t"], c["te_b0"], c["te_w2t"], c["te_b2"], self._buf("emb", (B, ted)))
-        emb_e = ops.emb_proj(emb, c["emb_wt"], c["emb_b"], self._buf("emb_all", (B, self._emb_ntot)))
-        if nrep == 1:
+        Bt = 1 if uniform_t else B          # rows of the timestep-embedding path
+        emb = ops.time_embed(timesteps[:Bt], c["freqs"], c["te_w0t"], c["te_b0"], c["te_w2t"], c["te_b2"], self._buf("emb", (Bt, ted)),
+                             self._buf("emb_ws", (Bt * (self.model_channels + ted),)))
+        emb_e = ops.emb_proj(emb, c["emb_wt"], c["emb_b"], self._buf("emb_all", (Bt, self._emb_ntot)))
+        emb_stride = 0 if uniform_t else self._emb_ntot
+        if nrep == 1 or uniform_t:
             emb_d = emb_e
         else:  # decoder rows b and b+B share timestep row b
             emb_d = self._buf("emb_all_d", (Bd, self._emb_ntot))
             for r in range(nrep):
                 emb_d[r * B:(r + 1) * B].copy_(emb_e)
-        style_all = ops.emb_proj(ctx_all, c["style_wt"], c["style_b"], self._buf("style_all", (Bd, c["style_wt"].shape[1])))
+        style_all = self._style_proj(contexts, B, ted)
 
         conv0 = self.input_blocks[0][0]
         h = ops.conv_in(x, c_concat, conv0.weight, conv0.bias, self._buf("in0.out", (B, H, W, self.model_channels)))
         hs = [h]
         for i, blk in enumerate(self.input_blocks[1:], start=1):
-            h = self._run_block(f"in{i}", blk, h, None, emb_e, self._emb_ntot, None)
+            h = self._run_block(f"in{i}", blk, h, None, emb_e, emb_stride, None)
             hs.append(h)
         # middle block: [0] shared, then replicate the batch for the style-conditioned remainder
         mid = list(self.middle_block)
-        h = self._run_block("mid.a", mid[:1], h, None, emb_e, self._emb_ntot, None)
+        h = self._run_block("mid.a", mid[:1], h, None, emb_e, emb_stride, None)
         if nrep > 1:
             h2 = self._buf("mid.rep", (Bd,) + tuple(h.shape[1:]))
             for r in range(nrep):
                 h2[r * B:(r + 1) * B].copy_(h)
             h = h2
-        h = self._run_block("mid.b", mid[1:], h, None, emb_d, self._emb_ntot, style_all, li0=1)
+        h = self._run_block("mid.b", mid[1:], h, None, emb_d, emb_stride, style_all, li0=1)
         bmod = B if nrep > 1 else 0
         for i, blk in enumerate(self.output_blocks):
-            h = self._run_block(f"out{i}", blk, h, hs.pop(), emb_d, self._emb_ntot, style_all, skip_bmod=bmod)
-        sc, sh = self._gn("outn", self.out[0], h)
+            h = self._run_block(f"out{i}", blk, h, hs.pop(), emb_d, emb_stride, style_all, skip_bmod=bmod)
         if out is None:
             out = torch.empty((Bd, self.out_channels, H, W), dtype=torch.float32, device=x.device)
-        ops.conv_out(h, sc, sh, self.out[2].weight, self.out[2].bias, out)
+        gn = self.out[0]
+        stats = self._buf("gn_partials_out", (Bd * ops.gn_nslab(h.shape[-1], H * W) * gn.num_groups * 2,), torch.float64)
+        ops.conv_out(h, gn.weight, gn.bias, gn.eps, gn.num_groups, self.out[2].weight, self.out[2].bias, out, stats)
         return out

@@ -179,14 +179,14 @@ def test_conv_in(dev, B, H, W, c1, c2, cout):
 @pytest.mark.parametrize("B,H,W,c,cout", [(2, 32, 32, 128, 4), (2, 16, 16, 32, 4), (1, 128, 128, 128, 3), (1, 40, 40, 64, 3)])
 def test_conv_out(dev, B, H, W, c, cout):
     from stedm_amd import ops
-    x = prng.normal(4, "co.x", (B, c, H, W))
-    sc = prng.normal(4, "co.sc", (B, c), 0.2, 1.0)
-    sh = prng.normal(4, "co.sh", (B, c), 0.2)
+    x = prng.normal(4, "co.x", (B, c, H, W)) * 1.4 + 0.2
+    g = prng.normal(4, "co.g", (c,), 0.1, 1.0)
+    bt = prng.normal(4, "co.bt", (c,), 0.1)
     w = prng.normal(4, "co.w", (cout, c, 3, 3), 0.03)
     b = prng.normal(4, "co.b", (cout,), 0.05)
-    ref = F.conv2d(F.silu(x * sc[:, :, None, None] + sh[:, :, None, None]), w, b, padding=1)
+    ref = F.conv2d(F.silu(F.group_norm(x, 32, g, bt, 1e-5)), w, b, padding=1)
     out = torch.empty((B, cout, H, W), device=dev)
-    ops.conv_out(nhwc(x).to(dev), sc.to(dev), sh.to(dev), w.to(dev), b.to(dev), out)
+    ops.conv_out(nhwc(x).to(dev), g.to(dev), bt.to(dev), 1e-5, 32, w.to(dev), b.to(dev), out)
     assert rel_err(out, ref) < 5e-5
 
 
