@@ -98,6 +98,11 @@ typedef struct stedm_conv_args {
    * [B][Hin][Win][c1+c2] (from stedm_gn_apply16) and src1/src2/scale/shift/act are ignored.              */
   const void* src16_hi;
   const void* src16_lo;
+  /* epilogue extras (DMA path): act_out 0 none, 2 exact (erf) GELU applied after bias/emb/res; when out16_hi != NULL
+   * the result is ALSO/ONLY written as 16-bit planes [M][cout] (hi, lo = v - hi); `out` may then be NULL.        */
+  int32_t act_out;
+  void* out16_hi;
+  void* out16_lo;
 } stedm_conv_args;
 /* Replaces: GN->SiLU->conv3x3(+bias)(+emb)(+skip) of ResBlock._forward openaimodel.py:268-288,
  * Downsample/Upsample convs (:122-132,:156-173), 1x1 skip_connection (:254), and the 1x1
@@ -128,6 +133,11 @@ int stedm_time_embed(const int64_t* t, const float* freqs, const float* w0t, con
 int stedm_emb_proj(const float* emb, const float* wt, const float* bias, float* out, int B, int k, int ntot,
                    void* stream);
 
+/* out[b][n] = act_out(bias[n] + sum_k act_in(x[b][k]) * wt[k][n]); act: 0 none, 1 SiLU, 2 ReLU. wt K-major [k][n].
+ * Used for Agg_Linear's MLP (agg_blocks.py:14-18, 28-31). */
+int stedm_linear(const float* x, const float* wt, const float* bias, float* out, int B, int k, int n, int act_in,
+                 int act_out, void* stream);
+
 /* ---- middle attention (QKVAttentionLegacy) -------------------------------------------------- */
 /* openaimodel.py:378-394. qkv [B][T][heads*3*ch] with channel = h*3*ch + {q:0,k:ch,v:2ch} + c;
  * out [B][T][heads*ch]; scale ch^-1/4 on q and k, softmax in fp32. */
@@ -147,6 +157,35 @@ int stedm_step_advance(int32_t* step_idx, int delta, void* stream);
 /* t_buf[0..B) = ts_table[*step_idx] : ts = torch.full((b,), step) of ddim.py:141, device-side so that one
  * captured graph serves every step. ts_table: DEVICE int64 [nsteps] (ddim_timesteps, ascending). */
 int stedm_step_set_t(const int64_t* ts_table, const int32_t* step_idx, int64_t* t_buf, int B, void* stream);
+
+/* ---- style path: set-ViT encoder (networks/vit_set.py), aggregation blocks, layout rescaler -------------------- */
+/* SPT vit_set.py:84-107 + token assembly :175-186. img [B][ns][H][W][3] fp32 -> x [B][ntok+2][dim]:
+ * x[:,2+t] = Linear(LayerNorm(patch_t)) + pos[2+t]; x[:,0] = cls + pos[0]; x[:,1] = pos[1] (zero time token).
+ * wt is the TRANSPOSED Linear weight [patch_dim][dim]; patch feature index = (p1*p + p2)*(3*ns) + c*ns + s. */
+int stedm_svit_patch_embed(const float* img, int B, int ns, int H, int W, int patch, const float* ln_w,
+                           const float* ln_b, float eps, const float* wt, const float* bias, const float* pos,
+                           const float* cls, float* x, int dim, void* stream);
+/* PreNorm LayerNorm vit_set.py:14-20 -> 16-bit operand planes [rows][dim] for the MFMA GEMMs (out_lo may be NULL). */
+int stedm_ln_apply16(const float* x, const float* gamma, const float* beta, float eps, void* out_hi, void* out_lo,
+                     long rows, int dim, int mm_dtype, void* stream);
+/* to_qkv output [B][T][3*heads*64] ('(h d)' per chunk, vit_set.py:53-54) -> q/k [B*heads][Tp][64] (q scaled by
+ * qscale = exp(temperature), vit_set.py:56; rows >= T zero) and V^T [B*heads][64][Tp]; Tp multiple of 128. */
+int stedm_qkv_pack(const float* qkv, float qscale, void* q_hi, void* q_lo, void* k_hi, void* k_lo, void* vt_hi,
+                   void* vt_lo, int B, int T, int Tp, int heads, int mm_dtype, void* stream);
+/* LSA attention vit_set.py:56-66: softmax over keys of q.k with the DIAGONAL masked to -FLT_MAX, times v; flash-style
+ * on MFMA (head dim 64). out planes [B][T][heads*64] ('b h n d -> b n (h d)'). */
+int stedm_lsa_flash(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi,
+                    const void* vt_lo, void* out_hi, void* out_lo, int B, int T, int Tp, int heads, int npass,
+                    int mm_dtype, void* stream);
+/* pool (0 mean, 1 cls, 2 sum) over tokens (+ c_old) -> mlp_head LayerNorm + Linear, vit_set.py:191-206. wt [dim][ncls]. */
+int stedm_svit_head(const float* x, int B, int T, int dim, int pool, const float* c_old, const float* ln_w,
+                    const float* ln_b, float eps, const float* wt, const float* bias, float* out, int ncls, void* stream);
+/* Agg_Mean (mode 0) / Agg_Max (mode 1) over the set: feats [B*n][F] -> out [B][F]; agg_blocks.py:52,73. */
+int stedm_agg_reduce(const float* feats, float* out, int B, int n, int F, int mode, void* stream);
+/* SpatialRescaler encoders/modules.py:123-130: n_stages x bilinear 1/2 (== box mean for divisible sizes) then bias-free
+ * 1x1 conv w [cout][cin] (NULL: none). x NCHW [B][cin][H][W] -> out NCHW [B][cout][H>>n][W>>n]. */
+int stedm_spatial_rescale(const float* x, const float* w, float* out, int B, int cin, int cout, int H, int W,
+                          int n_stages, void* stream);
 
 /* ---- HIP graph capture helpers (plumbing for the sampling loop) ---------------------------- */
 int stedm_graph_begin(void* stream);

@@ -33,6 +33,7 @@ class ConvArgs(C.Structure):
         ("res", C.c_void_p), ("out", C.c_void_p),
         ("cout", C.c_int32), ("npass", C.c_int32), ("mm_dtype", C.c_int32),
         ("src16_hi", C.c_void_p), ("src16_lo", C.c_void_p),
+        ("act_out", C.c_int32), ("out16_hi", C.c_void_p), ("out16_lo", C.c_void_p),
     ]
 
 
@@ -53,10 +54,18 @@ SIGNATURES = {
     "stedm_conv_out": (_I, [_P, _I, _P, _I, _P, _P, _F, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "stedm_time_embed": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "stedm_emb_proj": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "stedm_linear": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "stedm_attn_legacy": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "stedm_ddim_step": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _I, _I, _I, _I, _P]),
     "stedm_step_advance": (_I, [_P, _I, _P]),
     "stedm_step_set_t": (_I, [_P, _P, _P, _I, _P]),
+    "stedm_svit_patch_embed": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _I, _P]),
+    "stedm_ln_apply16": (_I, [_P, _P, _P, _F, _P, _P, C.c_long, _I, _I, _P]),
+    "stedm_qkv_pack": (_I, [_P, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "stedm_lsa_flash": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "stedm_svit_head": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _I, _P]),
+    "stedm_agg_reduce": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "stedm_spatial_rescale": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "stedm_graph_begin": (_I, [_P]),
     "stedm_graph_end": (_I, [_P, C.POINTER(C.c_void_p)]),
     "stedm_graph_launch": (_I, [_P, _P]),

@@ -318,7 +318,8 @@ extern "C" int stedm_conv_igemm(const stedm_conv_args* args, void* stream) {
   memset(&p, 0, sizeof(p));
   p.a = *args;
   const stedm_conv_args& a = p.a;
-  STEDM_CHECK_ARG((a.src1 || a.src16_hi) && a.w_hi && a.out, "conv_igemm: null src/w_hi/out");
+  STEDM_CHECK_ARG((a.src1 || a.src16_hi) && a.w_hi && (a.out || a.out16_hi), "conv_igemm: null src/w_hi/out");
+  STEDM_CHECK_ARG((!a.act_out && !a.out16_hi) || (a.src16_hi && !a.src1), "conv_igemm: act_out/out16 need the DMA path (src16 only)");
   STEDM_CHECK_ARG(!a.src1 || (a.src2 != nullptr) == (a.c2 > 0), "conv_igemm: src2/c2 mismatch");
   STEDM_CHECK_ARG(!a.src16_hi || a.npass == 1 || a.src16_lo, "conv_igemm: npass=3 needs src16_lo");
   STEDM_CHECK_ARG(a.ks == 1 || a.ks == 3, "conv_igemm: ks must be 1 or 3");

@@ -91,29 +91,35 @@ extern "C" int stedm_transpose_f32(const float* in, float* out, int rows, int co
 // Block = 64 outputs x 4 K-slices (256 threads), up to 8 batch rows per block share each weight read;
 // the K split keeps the dependent-load chain short (these GEMVs are latency-, not bandwidth-bound).
 constexpr int LIN_ROWS = 8;
+constexpr int LIN_KC = 1024;   // K chunk staged in LDS
 __global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                      const float* __restrict__ bias, float* __restrict__ out, int B, int K, int N,
                                                      int act_in, int act_out) {
-  extern __shared__ float sx[];                 // [LIN_ROWS][K] then [4][LIN_ROWS][64] partials
-  float* part = sx + LIN_ROWS * K;
+  __shared__ float sx[LIN_ROWS * LIN_KC];
+  __shared__ float part[4 * LIN_ROWS * 64];
   const int b0 = blockIdx.y * LIN_ROWS;
-  for (int i = threadIdx.x; i < LIN_ROWS * K; i += 256) {
-    const int r = i / K, k = i - r * K;
-    float v = (b0 + r < B) ? x[(long)(b0 + r) * K + k] : 0.f;
-    sx[i] = act_in ? silu_f(v) : v;
-  }
-  __syncthreads();
   const int nl = threadIdx.x & 63, ks = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + nl;
   float acc[LIN_ROWS];
 #pragma unroll
   for (int r = 0; r < LIN_ROWS; ++r) acc[r] = 0.f;
-  if (n < N) {
-    const int k0 = ks * ((K + 3) / 4), k1 = min(K, k0 + (K + 3) / 4);
-    for (int k = k0; k < k1; ++k) {
-      const float w = wt[(long)k * N + n];
+  for (int kc = 0; kc < K; kc += LIN_KC) {
+    const int kn = min(LIN_KC, K - kc);
+    __syncthreads();
+    for (int i = threadIdx.x; i < LIN_ROWS * kn; i += 256) {
+      const int r = i / kn, k = i - r * kn;
+      float v = (b0 + r < B) ? x[(long)(b0 + r) * K + kc + k] : 0.f;
+      sx[r * LIN_KC + k] = act_in == 1 ? silu_f(v) : (act_in == 2 ? fmaxf(v, 0.f) : v);
+    }
+    __syncthreads();
+    if (n < N) {
+      const int per = (kn + 3) / 4;
+      const int k0 = ks * per, k1 = min(kn, k0 + per);
+      for (int k = k0; k < k1; ++k) {
+        const float w = wt[(long)(kc + k) * N + n];
 #pragma unroll
-      for (int r = 0; r < LIN_ROWS; ++r) acc[r] = fmaf(sx[r * K + k], w, acc[r]);
+        for (int r = 0; r < LIN_ROWS; ++r) acc[r] = fmaf(sx[r * LIN_KC + k], w, acc[r]);
+      }
     }
   }
 #pragma unroll
@@ -126,7 +132,7 @@ __global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ x
       if (b0 + r < B) {
         float v = bv + ((part[(0 * LIN_ROWS + r) * 64 + nl] + part[(1 * LIN_ROWS + r) * 64 + nl]) +
                         (part[(2 * LIN_ROWS + r) * 64 + nl] + part[(3 * LIN_ROWS + r) * 64 + nl]));
-        out[(long)(b0 + r) * N + n] = act_out ? silu_f(v) : v;
+        out[(long)(b0 + r) * N + n] = act_out == 1 ? silu_f(v) : (act_out == 2 ? fmaxf(v, 0.f) : v);
       }
     }
   }
@@ -134,10 +140,8 @@ __global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ x
 
 static int launch_linear(const float* x, const float* wt, const float* bias, float* out, int B, int K, int N, int act_in,
                          int act_out, hipStream_t st) {
-  const size_t lds = ((size_t)LIN_ROWS * K + 4 * LIN_ROWS * 64) * sizeof(float);
-  if (lds > 64 * 1024) { set_error("linear: K=%d too large", K); return 1; }
   dim3 grid((N + 63) / 64, (B + LIN_ROWS - 1) / LIN_ROWS);
-  linear_kernel<<<grid, 256, lds, st>>>(x, wt, bias, out, B, K, N, act_in, act_out);
+  linear_kernel<<<grid, 256, 0, st>>>(x, wt, bias, out, B, K, N, act_in, act_out);
   STEDM_LAUNCH_CHECK();
   return 0;
 }
@@ -167,6 +171,13 @@ extern "C" int stedm_time_embed(const int64_t* t, const float* freqs, const floa
   int rc = launch_linear(te, w0t, b0, h1, B, mc, ted, 0, 1, st);
   if (rc) return rc;
   return launch_linear(h1, w2t, b2, emb, B, ted, ted, 0, 0, st);
+}
+
+// generic small Linear with optional input / output activation (0 none, 1 SiLU, 2 ReLU): Agg_Linear agg_blocks.py:14-18
+extern "C" int stedm_linear(const float* x, const float* wt, const float* bias, float* out, int B, int k, int n, int act_in,
+                            int act_out, void* stream) {
+  STEDM_CHECK_ARG(x && wt && out && B > 0 && k > 0 && n > 0, "linear: bad args");
+  return launch_linear(x, wt, bias, out, B, k, n, act_in, act_out, as_stream(stream));
 }
 
 extern "C" int stedm_emb_proj(const float* emb, const float* wt, const float* bias, float* out, int B, int k, int ntot,

@@ -1,0 +1,484 @@
+// Set-ViT style encoder (networks/vit_set.py) and the small style-path kernels (agg blocks, SpatialRescaler).
+//
+//   svit_patch_embed : SPT (vit_set.py:84-107): channel-stack the set, 8x8 patches '(p1 p2 c)', LayerNorm, Linear,
+//                      + pos_embedding, written at token index 2.. (tokens 0/1 = cls / zero time token, :175-186)
+//   ln_apply16       : PreNorm LayerNorm (vit_set.py:14-20) -> 16-bit operand planes for the MFMA GEMMs
+//   qkv_pack         : to_qkv output chunks [q|k|v] '(h d)' (vit_set.py:53-54) -> per-head q/k rows and V^T, logits
+//                      scale exp(temperature) folded into q (vit_set.py:56)
+//   lsa_flash        : softmax(mask_diag(q k^T)) v (vit_set.py:56-66) flash-style on MFMA, never materialising T x T
+//   svit_head        : pool (mean / sum / cls) + mlp_head LayerNorm + Linear (vit_set.py:191-206)
+//   agg_reduce       : Agg_Mean / Agg_Max over the set dimension (agg_blocks.py:52,73)
+//   spatial_rescale  : SpatialRescaler (encoders/modules.py:123-130): n x bilinear 1/2 (== 2x2 box mean for even sizes)
+//                      then bias-free 1x1 conv
+#include <float.h>
+
+#include "conv_common.hpp"
+using namespace stedm;
+
+// ------------------------------------------------------------------------------------------------ patch embed
+struct PatchArgs {
+  const float* img;   // [B][ns][H][W][3]
+  const float* ln_w;  // [pd]
+  const float* ln_b;
+  const float* wt;    // [pd][dim]
+  const float* bias;  // [dim]
+  const float* pos;   // [ntok+2][dim]
+  const float* cls;   // [dim]
+  float* x;           // [B][ntok+2][dim]
+  int ns, H, W, p, dim, tg;
+  float eps;
+};
+
+__global__ void __launch_bounds__(256) svit_patch_embed_kernel(PatchArgs a) {
+  extern __shared__ float sf[];   // [tg][pd]
+  const int pw = a.W / a.p, ph = a.H / a.p;
+  const int C = 3 * a.ns, pd = a.p * a.p * C;
+  const int groups_per_row = pw / a.tg;
+  const int b = blockIdx.x / (ph * groups_per_row);
+  const int rem = blockIdx.x % (ph * groups_per_row);
+  const int hp = rem / groups_per_row, w0 = (rem % groups_per_row) * a.tg;
+  const int ntok = ph * pw;
+  // gather: for every image s and patch row p1 one contiguous run of tg*p pixels x 3 channels
+  const int run = a.tg * a.p * 3;
+  for (int i = threadIdx.x; i < a.ns * a.p * run; i += 256) {
+    const int e = i % run;
+    const int p1 = (i / run) % a.p;
+    const int s = i / (run * a.p);
+    const int px = e / 3, c = e - px * 3;
+    const int t = px / a.p, p2 = px - t * a.p;
+    const float v = a.img[((((long)b * a.ns + s) * a.H + hp * a.p + p1) * a.W + w0 * a.p) * 3 + e];
+    sf[t * pd + (p1 * a.p + p2) * C + c * a.ns + s] = v;   // stacked channel = c*ns + s (vit_set.py:105-106)
+  }
+  __syncthreads();
+  // LayerNorm per token (wave w handles tokens w, w+4, ...)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int t = wave; t < a.tg; t += 4) {
+    float s1 = 0.f;
+    for (int k = lane; k < pd; k += 64) s1 += sf[t * pd + k];
+    const float mean = wave_sum(s1) / pd;
+    float s2 = 0.f;
+    for (int k = lane; k < pd; k += 64) { const float d = sf[t * pd + k] - mean; s2 += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(s2) / pd + a.eps);
+    for (int k = lane; k < pd; k += 64) sf[t * pd + k] = (sf[t * pd + k] - mean) * rstd * a.ln_w[k] + a.ln_b[k];
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < a.dim; n += 256) {
+    float acc[32];
+#pragma unroll
+    for (int t = 0; t < 32; ++t) acc[t] = 0.f;
+    for (int k = 0; k < pd; ++k) {
+      const float w = a.wt[(long)k * a.dim + n];
+#pragma unroll
+      for (int t = 0; t < 32; ++t)
+        if (t < a.tg) acc[t] = fmaf(sf[t * pd + k], w, acc[t]);
+    }
+    const float bv = a.bias[n];
+#pragma unroll
+    for (int t = 0; t < 32; ++t)
+      if (t < a.tg) {
+        const int tok = hp * pw + w0 + t + 2;
+        a.x[((long)b * (ntok + 2) + tok) * a.dim + n] = acc[t] + bv + a.pos[(long)tok * a.dim + n];
+      }
+    if (rem == 0) {   // cls token and the zero time token (t_emb=None, vit_set.py:177-178)
+      a.x[((long)b * (ntok + 2) + 0) * a.dim + n] = a.cls[n] + a.pos[n];
+      a.x[((long)b * (ntok + 2) + 1) * a.dim + n] = a.pos[a.dim + n];
+    }
+  }
+}
+
+extern "C" int stedm_svit_patch_embed(const float* img, int B, int ns, int H, int W, int patch, const float* ln_w,
+                                      const float* ln_b, float eps, const float* wt, const float* bias, const float* pos,
+                                      const float* cls, float* x, int dim, void* stream) {
+  STEDM_CHECK_ARG(img && ln_w && ln_b && wt && bias && pos && cls && x, "svit_patch_embed: null pointer");
+  STEDM_CHECK_ARG(H % patch == 0 && W % patch == 0, "svit_patch_embed: image not divisible by patch");
+  const int pd = patch * patch * 3 * ns, pw = W / patch;
+  int tg = 32;
+  while (tg > 1 && ((size_t)tg * pd * 4 > 96 * 1024 || pw % tg != 0)) tg >>= 1;
+  STEDM_CHECK_ARG(pw % tg == 0 && (size_t)tg * pd * 4 <= 160 * 1024, "svit_patch_embed: patch_dim %d too large", pd);
+  PatchArgs a{img, ln_w, ln_b, wt, bias, pos, cls, x, ns, H, W, patch, dim, tg, eps};
+  const size_t lds = (size_t)tg * pd * sizeof(float);
+  if (lds > 64 * 1024)
+    STEDM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(svit_patch_embed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  svit_patch_embed_kernel<<<B * (H / patch) * (pw / tg), 256, lds, as_stream(stream)>>>(a);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm -> 16-bit
+template <typename T>
+__global__ void __launch_bounds__(256) ln_apply16_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                         const float* __restrict__ bt, float eps, T* __restrict__ hi,
+                                                         T* __restrict__ lo, long rows, int dim) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* px = x + row * dim;
+  float s1 = 0.f;
+  for (int k = lane; k < dim; k += 64) s1 += px[k];
+  const float mean = wave_sum(s1) / dim;
+  float s2 = 0.f;
+  for (int k = lane; k < dim; k += 64) { const float d = px[k] - mean; s2 += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum(s2) / dim + eps);
+  for (int k = lane; k < dim; k += 64) {
+    const float v = (px[k] - mean) * rstd * g[k] + bt[k];
+    const T h = (T)v;
+    hi[row * dim + k] = h;
+    if (lo) lo[row * dim + k] = (T)(v - (float)h);
+  }
+}
+
+extern "C" int stedm_ln_apply16(const float* x, const float* gamma, const float* beta, float eps, void* out_hi, void* out_lo,
+                                long rows, int dim, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(x && gamma && beta && out_hi && rows > 0 && dim > 0, "ln_apply16: bad args");
+  const int grid = (int)((rows + 3) / 4);
+  if (mm_dtype == STEDM_F16)
+    ln_apply16_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(x, gamma, beta, eps, (_Float16*)out_hi, (_Float16*)out_lo, rows, dim);
+  else
+    ln_apply16_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(x, gamma, beta, eps, (__bf16*)out_hi, (__bf16*)out_lo, rows, dim);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ qkv pack
+// qkv fp32 [B][T][3*H*64] -> q16/k16 [B*H][Tp][64] (rows >= T zero), vT16 [B*H][64][Tp] (cols >= T zero)
+template <typename T>
+__global__ void __launch_bounds__(256) qkv_pack_kernel(const float* __restrict__ qkv, float qscale, T* __restrict__ qh,
+                                                       T* __restrict__ ql, T* __restrict__ kh, T* __restrict__ kl,
+                                                       T* __restrict__ vh, T* __restrict__ vl, int Tn, int Tp, int H) {
+  __shared__ float sv[64][65];
+  const int bh = blockIdx.x, b = bh / H, hd = bh % H;
+  const int t0 = blockIdx.y * 64;
+  const int HD = H * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int tl = i >> 6, d = i & 63;
+    const int t = t0 + tl;
+    float q = 0.f, k = 0.f, v = 0.f;
+    if (t < Tn) {
+      const float* p = qkv + ((long)b * Tn + t) * (3 * HD) + hd * 64 + d;
+      q = p[0] * qscale; k = p[HD]; v = p[2 * HD];
+    }
+    const long o = ((long)bh * Tp + t) * 64 + d;
+    const T q16 = (T)q, k16 = (T)k;
+    qh[o] = q16; kh[o] = k16;
+    if (ql) { ql[o] = (T)(q - (float)q16); kl[o] = (T)(k - (float)k16); }
+    sv[tl][d] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int d = i >> 6, tl = i & 63;
+    const float v = sv[tl][d];
+    const long o = ((long)bh * 64 + d) * Tp + t0 + tl;
+    const T v16 = (T)v;
+    vh[o] = v16;
+    if (vl) vl[o] = (T)(v - (float)v16);
+  }
+}
+
+extern "C" int stedm_qkv_pack(const float* qkv, float qscale, void* q_hi, void* q_lo, void* k_hi, void* k_lo, void* vt_hi,
+                              void* vt_lo, int B, int T, int Tp, int heads, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(qkv && q_hi && k_hi && vt_hi, "qkv_pack: null pointer");
+  STEDM_CHECK_ARG(Tp % 128 == 0 && Tp >= T, "qkv_pack: Tp must be a multiple of 128 and >= T");
+  dim3 grid(B * heads, Tp / 64);
+  if (mm_dtype == STEDM_F16)
+    qkv_pack_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(qkv, qscale, (_Float16*)q_hi, (_Float16*)q_lo, (_Float16*)k_hi,
+                                                                  (_Float16*)k_lo, (_Float16*)vt_hi, (_Float16*)vt_lo, T, Tp, heads);
+  else
+    qkv_pack_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(qkv, qscale, (__bf16*)q_hi, (__bf16*)q_lo, (__bf16*)k_hi, (__bf16*)k_lo,
+                                                                (__bf16*)vt_hi, (__bf16*)vt_lo, T, Tp, heads);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ LSA flash attention
+// One block = 128 queries of one (sample, head): 4 waves x 32 queries. Keys/values stream in tiles of 64.
+// S^T = K Q^T is computed "swapped" (keys on the accumulator rows, the wave's 32 queries on the lanes), so that the
+// row statistics of a query are lane-local and the exponentiated tile is directly the B operand of O^T += V^T P^T
+// (cdna guide: "an accumulator tile as the next MFMA's operand"; its k order is 16s + 8(j>>2) + 4h + (j&3)).
+struct FlashArgs {
+  const void *qh, *ql, *kh, *kl, *vh, *vl;
+  void *oh, *ol;   // [B][T][H*64]
+  int T, Tp, H;
+};
+
+template <typename T, int NPASS>
+__global__ void __launch_bounds__(256, 2) lsa_flash_kernel(FlashArgs a) {
+  using V8 = typename MM<T>::V8;
+  typedef T V4t __attribute__((ext_vector_type(4)));
+  constexpr int NPL = NPASS == 3 ? 2 : 1;
+  constexpr int RS = 72;                          // LDS row stride in elements (64 + 8 pad -> 144 B)
+  // one LDS block: K and V^T tiles during the loop, the O^T transpose buffer afterwards
+  constexpr int TILE = 64 * RS;
+  constexpr int KV_BYTES = 2 * NPL * TILE * (int)sizeof(T);
+  constexpr int O_BYTES = 4 * 32 * 65 * (int)sizeof(float);
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[KV_BYTES > O_BYTES ? KV_BYTES : O_BYTES];
+  T (*sK)[TILE] = reinterpret_cast<T (*)[TILE]>(lds_raw);
+  T (*sV)[TILE] = reinterpret_cast<T (*)[TILE]>(lds_raw + NPL * TILE * sizeof(T));
+  float (*sO)[32][65] = reinterpret_cast<float (*)[32][65]>(lds_raw);
+  const int bh = blockIdx.x, b = bh / a.H, hd = bh % a.H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.y * 128 + wave * 32;
+  const T* qg[2] = {reinterpret_cast<const T*>(a.qh), reinterpret_cast<const T*>(a.ql)};
+  const T* kg[2] = {reinterpret_cast<const T*>(a.kh), reinterpret_cast<const T*>(a.kl)};
+  const T* vg[2] = {reinterpret_cast<const T*>(a.vh), reinterpret_cast<const T*>(a.vl)};
+
+  V8 qf[NPL][4];
+#pragma unroll
+  for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      qf[pl][ks] = *reinterpret_cast<const V8*>(qg[pl] + ((long)bh * a.Tp + q0 + r) * 64 + ks * 16 + h * 8);
+
+  f32x16 o[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int qidx = q0 + r;
+
+  const int ntiles = (a.T + 63) / 64;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();
+    // stage K rows and V^T rows of this tile (64 x 128 B each per plane)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int pc = tid + it * 256;
+      const int row = pc >> 3, c = pc & 7;
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        *reinterpret_cast<uint4*>(&sK[pl][row * RS + c * 8]) =
+            *reinterpret_cast<const uint4*>(kg[pl] + ((long)bh * a.Tp + kt * 64 + row) * 64 + c * 8);
+        *reinterpret_cast<uint4*>(&sV[pl][row * RS + c * 8]) =
+            *reinterpret_cast<const uint4*>(vg[pl] + ((long)bh * 64 + row) * a.Tp + kt * 64 + c * 8);
+      }
+    }
+    __syncthreads();
+    // ---- S^T tiles (2 x 32 keys) x 32 queries
+    f32x16 s[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[sub][e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const V8 kf = *reinterpret_cast<const V8*>(&sK[0][(sub * 32 + r) * RS + ks * 16 + h * 8]);
+        if (NPASS == 3) {
+          const V8 kfl = *reinterpret_cast<const V8*>(&sK[NPL - 1][(sub * 32 + r) * RS + ks * 16 + h * 8]);
+          s[sub] = MM<T>::mfma(kfl, qf[0][ks], s[sub]);
+          s[sub] = MM<T>::mfma(kf, qf[NPL - 1][ks], s[sub]);
+        }
+        s[sub] = MM<T>::mfma(kf, qf[0][ks], s[sub]);
+      }
+    }
+    // ---- mask (diagonal: a token never attends to itself, vit_set.py:58-60; padding keys) + online softmax
+    float mx = -INFINITY;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = kt * 64 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        float v = s[sub][e];
+        if (key == qidx) v = -FLT_MAX;
+        if (key >= a.T) v = -INFINITY;
+        s[sub][e] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = __expf(s[sub][e] - m_new);
+        s[sub][e] = pv;
+        rs += pv;
+      }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        V8 ph, pl8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float pv = s[sub][8 * s2 + j];
+          const T hv = (T)pv;
+          ph[j] = hv;
+          if (NPASS == 3) pl8[j] = (T)(pv - (float)hv);
+        }
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          // A fragment of V^T: row = d*32 + r, keys 32*sub + 16*s2 + {4h .. 4h+3} and {8 + 4h .. 8 + 4h + 3}
+          const int base = (d * 32 + r) * RS + sub * 32 + s2 * 16 + h * 4;
+          V8 vf, vfl;
+          const V4t v0 = *reinterpret_cast<const V4t*>(&sV[0][base]);
+          const V4t v1 = *reinterpret_cast<const V4t*>(&sV[0][base + 8]);
+          vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
+          vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+          if (NPASS == 3) {
+            const V4t w0 = *reinterpret_cast<const V4t*>(&sV[NPL - 1][base]);
+            const V4t w1 = *reinterpret_cast<const V4t*>(&sV[NPL - 1][base + 8]);
+            vfl[0] = w0[0]; vfl[1] = w0[1]; vfl[2] = w0[2]; vfl[3] = w0[3];
+            vfl[4] = w1[0]; vfl[5] = w1[1]; vfl[6] = w1[2]; vfl[7] = w1[3];
+            o[d] = MM<T>::mfma(vfl, ph, o[d]);
+            o[d] = MM<T>::mfma(vf, pl8, o[d]);
+          }
+          o[d] = MM<T>::mfma(vf, ph, o[d]);
+        }
+      }
+  }
+  // ---- epilogue: O^T / l through LDS so that every token row is written contiguously (token-major [B][T][H*64])
+  __syncthreads();   // all waves are done with the K / V^T tiles: the block is reused for the transpose
+  const float inv = 1.0f / l_run;
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sO[wave][r][d * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] = o[d][e] * inv;
+  __syncthreads();
+  {
+    const int row = lane >> 1, half = lane & 1;
+    const int t = q0 + row;
+    if (t < a.T) {
+      T* oh = reinterpret_cast<T*>(a.oh) + ((long)b * a.T + t) * (a.H * 64) + hd * 64 + half * 32;
+      T* ol = a.ol ? reinterpret_cast<T*>(a.ol) + ((long)b * a.T + t) * (a.H * 64) + hd * 64 + half * 32 : nullptr;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        const float v = sO[wave][row][half * 32 + j];
+        const T hv = (T)v;
+        oh[j] = hv;
+        if (ol) ol[j] = (T)(v - (float)hv);
+      }
+    }
+  }
+}
+
+extern "C" int stedm_lsa_flash(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi,
+                               const void* vt_lo, void* out_hi, void* out_lo, int B, int T, int Tp, int heads, int npass,
+                               int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(q_hi && k_hi && vt_hi && out_hi, "lsa_flash: null pointer");
+  STEDM_CHECK_ARG(npass == 1 || (q_lo && k_lo && vt_lo && out_lo), "lsa_flash: npass=3 needs lo planes");
+  STEDM_CHECK_ARG(Tp % 128 == 0 && Tp >= T && T > 1, "lsa_flash: need Tp %% 128 == 0, Tp >= T > 1");
+  FlashArgs a{q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out_hi, npass == 3 ? out_lo : nullptr, T, Tp, heads};
+  dim3 grid(B * heads, Tp / 128);
+  hipStream_t st = as_stream(stream);
+  if (mm_dtype == STEDM_F16) {
+    if (npass == 3) lsa_flash_kernel<_Float16, 3><<<grid, 256, 0, st>>>(a);
+    else lsa_flash_kernel<_Float16, 1><<<grid, 256, 0, st>>>(a);
+  } else {
+    if (npass == 3) lsa_flash_kernel<__bf16, 3><<<grid, 256, 0, st>>>(a);
+    else lsa_flash_kernel<__bf16, 1><<<grid, 256, 0, st>>>(a);
+  }
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ pooled head
+__global__ void __launch_bounds__(256) svit_head_kernel(const float* __restrict__ x, int Tn, int dim, int pool,
+                                                        const float* __restrict__ c_old, const float* __restrict__ g,
+                                                        const float* __restrict__ bt, float eps, const float* __restrict__ wt,
+                                                        const float* __restrict__ bias, float* __restrict__ out, int ncls) {
+  extern __shared__ float sp[];   // [dim] pooled, then normalised
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const float* px = x + (long)b * Tn * dim;
+  for (int n = threadIdx.x; n < dim; n += 256) {
+    float s = 0.f;
+    if (pool == 1) s = px[n];
+    else {
+      for (int t = 0; t < Tn; ++t) s += px[(long)t * dim + n];
+      if (pool == 0) s /= (float)Tn;
+    }
+    if (c_old) s += c_old[(long)b * dim + n];
+    sp[n] = s;
+  }
+  __syncthreads();
+  float s1 = 0.f;
+  for (int n = threadIdx.x; n < dim; n += 256) s1 += sp[n];
+  const float mean = block_sum_256(s1, red) / dim;
+  float s2 = 0.f;
+  for (int n = threadIdx.x; n < dim; n += 256) { const float d = sp[n] - mean; s2 += d * d; }
+  const float rstd = 1.0f / sqrtf(block_sum_256(s2, red) / dim + eps);
+  __syncthreads();
+  for (int n = threadIdx.x; n < dim; n += 256) sp[n] = (sp[n] - mean) * rstd * g[n] + bt[n];
+  __syncthreads();
+  for (int n = threadIdx.x; n < ncls; n += 256) {
+    float acc = bias[n];
+    for (int k = 0; k < dim; ++k) acc = fmaf(sp[k], wt[(long)k * ncls + n], acc);
+    out[(long)b * ncls + n] = acc;
+  }
+}
+
+extern "C" int stedm_svit_head(const float* x, int B, int T, int dim, int pool, const float* c_old, const float* ln_w,
+                               const float* ln_b, float eps, const float* wt, const float* bias, float* out, int ncls,
+                               void* stream) {
+  STEDM_CHECK_ARG(x && ln_w && ln_b && wt && bias && out, "svit_head: null pointer");
+  STEDM_CHECK_ARG(pool >= 0 && pool <= 2, "svit_head: pool must be 0 (mean), 1 (cls) or 2 (sum)");
+  svit_head_kernel<<<B, 256, dim * sizeof(float), as_stream(stream)>>>(x, T, dim, pool, c_old, ln_w, ln_b, eps, wt, bias, out, ncls);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ agg blocks / rescaler
+__global__ void agg_reduce_kernel(const float* __restrict__ f, float* __restrict__ out, int n, int F, int mode, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long b = i / F;
+  const int k = (int)(i - b * F);
+  float acc = f[(b * n) * F + k];
+  for (int j = 1; j < n; ++j) {
+    const float v = f[(b * n + j) * F + k];
+    acc = mode == 1 ? fmaxf(acc, v) : acc + v;
+  }
+  out[i] = mode == 1 ? acc : acc / (float)n;
+}
+
+extern "C" int stedm_agg_reduce(const float* feats, float* out, int B, int n, int F, int mode, void* stream) {
+  STEDM_CHECK_ARG(feats && out && B > 0 && n > 0 && F > 0 && (mode == 0 || mode == 1), "agg_reduce: bad args");
+  const long total = (long)B * F;
+  agg_reduce_kernel<<<(int)((total + 255) / 256), 256, 0, as_stream(stream)>>>(feats, out, n, F, mode, total);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void spatial_rescale_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ out, int cin,
+                                       int cout, int H, int W, int f, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int Wo = W / f, Ho = H / f;
+  const int xo = (int)(i % Wo);
+  const int yo = (int)((i / Wo) % Ho);
+  const int co = (int)((i / ((long)Wo * Ho)) % cout);
+  const long b = i / ((long)Wo * Ho * cout);
+  float acc = 0.f;
+  for (int ci = 0; ci < cin; ++ci) {
+    // n stages of 2x2 box means == one f x f box mean, but keep the staged summation order of the reference
+    float s = 0.f;
+    const float* p = x + ((b * cin + ci) * H + (long)yo * f) * W + (long)xo * f;
+    for (int dy = 0; dy < f; ++dy)
+      for (int dx = 0; dx < f; ++dx) s += p[(long)dy * W + dx];
+    acc = fmaf(s / (float)(f * f), w ? w[co * cin + ci] : (ci == co ? 1.f : 0.f), acc);
+  }
+  out[i] = acc;
+}
+
+extern "C" int stedm_spatial_rescale(const float* x, const float* w, float* out, int B, int cin, int cout, int H, int W,
+                                     int n_stages, void* stream) {
+  STEDM_CHECK_ARG(x && out && n_stages >= 0 && n_stages < 8, "spatial_rescale: bad args");
+  const int f = 1 << n_stages;
+  STEDM_CHECK_ARG(H % f == 0 && W % f == 0, "spatial_rescale: H, W must be divisible by 2^n_stages (bilinear 1/2 == box mean only then)");
+  STEDM_CHECK_ARG(w || cin == cout, "spatial_rescale: no channel mapper needs cin == cout");
+  const long total = (long)B * cout * (H / f) * (W / f);
+  spatial_rescale_kernel<<<(int)((total + 255) / 256), 256, 0, as_stream(stream)>>>(x, w, out, cin, cout, H, W, f, total);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}

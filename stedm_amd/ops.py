@@ -136,11 +136,18 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
                scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, act: int = 0,
                bias: Optional[torch.Tensor] = None, emb: Optional[torch.Tensor] = None, emb_offset: int = 0,
                emb_bstride: int = 0, res: Optional[torch.Tensor] = None,
-               src16: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None) -> torch.Tensor:
+               src16: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None, act_out: int = 0,
+               out16: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None) -> torch.Tensor:
     """src1 [B,Hin,Win,c1] NHWC fp32 (fused path) and/or src16 = (hi, lo) 16-bit NHWC planes [B,Hin,Win,Cin] from
     gn_apply16 (DMA path) -> out [B,Hout,Wout,cout] NHWC fp32 (see stedm_conv_igemm)."""
-    _chk(out, name="out")
+    if out is not None:
+        _chk(out, name="out")
     a = ConvArgs()
+    a.act_out = act_out
+    if out16 is not None:
+        a.out16_hi = out16[0].data_ptr()
+        a.out16_lo = _ptr(out16[1]) if prec.npass == 3 else None
+    oshape = out.shape if out is not None else out16[0].shape
     if src1 is not None:
         _chk(src1, name="src1")
         B, Hin, Win, c1 = src1.shape
@@ -163,8 +170,8 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
     a.emb = None if emb is None else emb.data_ptr() + 4 * emb_offset
     a.emb_bstride = emb_bstride
     a.res = _ptr(res)
-    a.out = out.data_ptr()
-    a.cout = out.shape[-1]
+    a.out = _ptr(out)
+    a.cout = oshape[-1]
     a.npass, a.mm_dtype = prec.npass, prec.mm_dtype
     assert w_hi.shape == (a.cout, ks * ks, a.c1 + a.c2), (w_hi.shape, a.cout, ks, a.c1, a.c2)
     check(lib().stedm_conv_igemm(C.byref(a), _stream()), "stedm_conv_igemm")
@@ -219,6 +226,66 @@ def emb_proj(emb: torch.Tensor, wt: torch.Tensor, bias: torch.Tensor, out: torch
     assert wt.shape[0] == K and out.shape == (B, wt.shape[1])
     check(lib().stedm_emb_proj(emb.data_ptr(), wt.data_ptr(), bias.data_ptr(), out.data_ptr(), B, K, wt.shape[1], _stream()),
           "stedm_emb_proj")
+    return out
+
+
+def linear(x: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, act_in: int = 0, act_out: int = 0):
+    """out = act_out(bias + act_in(x) @ wt); wt K-major [K, N]; act 0 none / 1 SiLU / 2 ReLU."""
+    _chk(x, name="x")
+    B, K = x.shape
+    check(lib().stedm_linear(x.data_ptr(), wt.data_ptr(), _ptr(bias), out.data_ptr(), B, K, wt.shape[1], act_in, act_out, _stream()),
+          "stedm_linear")
+    return out
+
+
+# ------------------------------------------------------------------------------------------- style path
+def svit_patch_embed(img, ln_w, ln_b, eps, wt, bias, pos, cls, x, patch: int):
+    _chk(img, name="style images")
+    B, ns, H, W, C3 = img.shape
+    assert C3 == 3
+    check(lib().stedm_svit_patch_embed(img.data_ptr(), B, ns, H, W, patch, ln_w.data_ptr(), ln_b.data_ptr(), float(eps), wt.data_ptr(),
+                                       bias.data_ptr(), pos.data_ptr(), cls.data_ptr(), x.data_ptr(), x.shape[-1], _stream()),
+          "stedm_svit_patch_embed")
+    return x
+
+
+def ln_apply16(x, gamma, beta, eps, hi, lo, prec: Precision):
+    _chk(x, name="x")
+    rows = x.numel() // x.shape[-1]
+    check(lib().stedm_ln_apply16(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), hi.data_ptr(), _ptr(lo), rows, x.shape[-1],
+                                 prec.mm_dtype, _stream()), "stedm_ln_apply16")
+
+
+def qkv_pack(qkv, qscale: float, q, k, vt, B: int, T: int, Tp: int, heads: int, prec: Precision):
+    """q, k, vt: (hi, lo) tuples of int16 tensors [B*heads, Tp, 64] / [B*heads, 64, Tp]."""
+    check(lib().stedm_qkv_pack(qkv.data_ptr(), float(qscale), q[0].data_ptr(), _ptr(q[1]), k[0].data_ptr(), _ptr(k[1]),
+                               vt[0].data_ptr(), _ptr(vt[1]), B, T, Tp, heads, prec.mm_dtype, _stream()), "stedm_qkv_pack")
+
+
+def lsa_flash(q, k, vt, out, B: int, T: int, Tp: int, heads: int, prec: Precision):
+    check(lib().stedm_lsa_flash(q[0].data_ptr(), _ptr(q[1]), k[0].data_ptr(), _ptr(k[1]), vt[0].data_ptr(), _ptr(vt[1]),
+                                out[0].data_ptr(), _ptr(out[1]), B, T, Tp, heads, prec.npass, prec.mm_dtype, _stream()), "stedm_lsa_flash")
+
+
+def svit_head(x, pool: int, c_old, ln_w, ln_b, eps, wt, bias, out):
+    B, T, dim = x.shape
+    check(lib().stedm_svit_head(x.data_ptr(), B, T, dim, pool, _ptr(c_old), ln_w.data_ptr(), ln_b.data_ptr(), float(eps), wt.data_ptr(),
+                                bias.data_ptr(), out.data_ptr(), out.shape[-1], _stream()), "stedm_svit_head")
+    return out
+
+
+def agg_reduce(feats, out, n: int, mode: int):
+    _chk(feats, name="features")
+    Bn, Fd = feats.shape
+    check(lib().stedm_agg_reduce(feats.data_ptr(), out.data_ptr(), Bn // n, n, Fd, mode, _stream()), "stedm_agg_reduce")
+    return out
+
+
+def spatial_rescale(x, w, out, n_stages: int):
+    _chk(x, name="x")
+    B, cin, H, W = x.shape
+    check(lib().stedm_spatial_rescale(x.data_ptr(), _ptr(w), out.data_ptr(), B, cin, out.shape[1], H, W, n_stages, _stream()),
+          "stedm_spatial_rescale")
     return out
 
 

@@ -1,0 +1,296 @@
+"""Style path with the reference's module surface, HIP-backed.
+
+  sViT, SPT, LSA, Transformer, PreNorm, FeedForward   networks/vit_set.py (state-dict names kept)
+  Agg_Linear / Agg_Max / Agg_Mean / Agg_None          networks/agg_blocks.py
+  SpatialRescaler                                      ldm/modules/encoders/modules.py:104-133
+
+torch.nn modules are parameter containers; `forward` launches HIP kernels through the C ABI.
+The swin_v2_t embedder of Agg_* is third-party torchvision code (parity unpinned): it stays a
+caller-supplied nn.Module; only the set aggregation after it runs here.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import StedmHipError
+from .ops import Precision
+
+
+def pair(t):
+    return t if isinstance(t, tuple) else (t, t)
+
+
+class PreNorm(nn.Module):
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.fn = fn
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, hidden_dim, dropout=0.):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(dim, hidden_dim), nn.GELU(), nn.Dropout(dropout), nn.Linear(hidden_dim, dim), nn.Dropout(dropout))
+
+
+class LSA(nn.Module):
+    """vit_set.py:35-67 (container)."""
+
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0.):
+        super().__init__()
+        inner_dim = dim_head * heads
+        self.heads = heads
+        self.dim_head = dim_head
+        self.temperature = nn.Parameter(torch.log(torch.tensor(dim_head ** -0.5)))
+        self.to_qkv = nn.Linear(dim, inner_dim * 3, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner_dim, dim), nn.Dropout(dropout))
+
+
+class Transformer(nn.Module):
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout=0.):
+        super().__init__()
+        self.layers = nn.ModuleList([])
+        for _ in range(depth):
+            self.layers.append(nn.ModuleList([PreNorm(dim, LSA(dim, heads=heads, dim_head=dim_head, dropout=dropout)),
+                                              PreNorm(dim, FeedForward(dim, mlp_dim, dropout=dropout))]))
+
+
+class SPT(nn.Module):
+    """vit_set.py:84-107 (container; index 0 stands for the parameter-free Rearrange)."""
+
+    def __init__(self, *, dim, patch_size, channels=3, sample_size=5):
+        super().__init__()
+        patch_dim = patch_size * patch_size * sample_size * channels
+        self.to_patch_tokens = nn.Sequential(nn.Identity(), nn.LayerNorm(patch_dim), nn.Linear(patch_dim, dim))
+
+
+class sViT(nn.Module):
+    """Set-ViT style encoder, vit_set.py:109-208. forward(img [B, ns, H, W, 3]) -> [B, num_classes]."""
+
+    def __init__(self, *, image_size, patch_size, num_classes, dim, depth, heads, mlp_dim, pool='cls', channels=3, dim_head=64,
+                 dropout=0., emb_dropout=0., ns=5, t_dim=256, precision: str = "parity"):
+        super().__init__()
+        image_height, image_width = pair(image_size)
+        patch_height, patch_width = pair(patch_size)
+        assert image_height % patch_height == 0 and image_width % patch_width == 0, \
+            'Image dimensions must be divisible by the patch size.'
+        assert pool in {'cls', 'mean', 'none'}, 'pool type must be either cls (cls token) or mean (mean pooling)'
+        if pool == 'none':
+            raise NotImplementedError("pool='none' (per-token output) is not used by STEDM (svit.yaml: pool mean)")
+        if dim_head != 64 or channels != 3 or patch_height != patch_width:
+            raise NotImplementedError("HIP sViT: dim_head 64, 3 channels and square patches only (conf/style_agg/svit.yaml)")
+        self.ns = ns
+        self.np = (image_height // patch_height) * (image_width // patch_width)
+        self.patch_size = patch_height
+        self.dim, self.heads, self.depth = dim, heads, depth
+        self.to_patch_embedding = SPT(dim=dim, patch_size=patch_height, channels=channels, sample_size=ns)
+        self.pos_embedding = nn.Parameter(torch.randn(1, self.np + 2, dim))
+        self.cls_token = nn.Parameter(torch.randn(1, 1, dim))
+        self.dropout = nn.Dropout(emb_dropout)
+        self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, dropout)
+        self.pool = pool
+        self.to_latent = nn.Identity()
+        self.mlp_head = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, num_classes))
+        self.to_time_embedding = nn.Linear(t_dim, dim)
+        self.precision = Precision.parse(precision) if isinstance(precision, str) else precision
+        self._packed: Dict = {}
+        self._pack_key = None
+        self._bufs: Dict[Tuple, torch.Tensor] = {}
+
+    # ---------------------------------------------------------------------------------------------- engine
+    def set_precision(self, precision):
+        self.precision = Precision.parse(precision) if isinstance(precision, str) else precision
+        self._pack_key = None
+
+    def _buf(self, name, shape, dtype=torch.float32, zero=False):
+        key = (name, tuple(shape), dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            dev = self.pos_embedding.device
+            t = (torch.zeros if zero else torch.empty)(tuple(shape), dtype=dtype, device=dev)
+            self._bufs[key] = t
+        return t
+
+    def _prepare(self):
+        params = list(self.parameters())
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise StedmHipError("sViT.forward needs its parameters on the GPU; there is no CPU fallback")
+        key = (self.precision, dev, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        if key == self._pack_key:
+            return
+        P = {}
+        prec = self.precision
+        tp = self.to_patch_embedding.to_patch_tokens
+        P["pe_wt"] = ops.transpose(tp[2].weight.float())
+        for l, (attn, ff) in enumerate(self.transformer.layers):
+            P[f"qkv{l}"] = ops.pack_conv_weight(attn.fn.to_qkv.weight.float().unsqueeze(-1), prec)
+            P[f"out{l}"] = ops.pack_conv_weight(attn.fn.to_out[0].weight.float().unsqueeze(-1), prec)
+            P[f"ff1{l}"] = ops.pack_conv_weight(ff.fn.net[0].weight.float().unsqueeze(-1), prec)
+            P[f"ff2{l}"] = ops.pack_conv_weight(ff.fn.net[3].weight.float().unsqueeze(-1), prec)
+            P[f"tau{l}"] = float(attn.fn.temperature.detach().exp().item())
+        P["head_wt"] = ops.transpose(self.mlp_head[1].weight.float())
+        self._packed = P
+        self._pack_key = key
+
+    def _gemm(self, a16, w, M, N, bias=None, res=None, out=None, act_out=0, out16=None):
+        """[M, K] 16-bit planes x packed [N][1][K] weights on the DMA conv kernel (1x1 conv view [1, 1, M, K])."""
+        K = a16[0].shape[-1]
+        v = lambda t: None if t is None else t.view(1, 1, M, -1)
+        ops.conv_igemm(None, w[0], w[1], v(out), prec=self.precision, ks=1, src16=(v(a16[0]), v(a16[1])), bias=bias, res=v(res),
+                       act_out=act_out, out16=None if out16 is None else (v(out16[0]), v(out16[1])))
+
+    @torch.no_grad()
+    def forward(self, img, t_emb=None, c_old=None):
+        """vit_set.py:165-208. img [B, ns, H, W, 3] fp32 (NHWC per image, as LDM_Diffusion.prepare_batch emits it)."""
+        if t_emb is not None:
+            raise NotImplementedError("t_emb is always None in STEDM (networks/s_zss_dm.py:55)")
+        if self.training and (self.dropout.p > 0):
+            raise NotImplementedError("HIP sViT runs in eval mode (dropout is inactive at prediction time)")
+        self._prepare()
+        P, prec = self._packed, self.precision
+        img = img.float().contiguous()
+        B, ns, H, W, _ = img.shape
+        assert ns == self.ns, f"sViT built for ns={self.ns} style images, got {ns}"
+        dim, heads = self.dim, self.heads
+        n = (H // self.patch_size) * (W // self.patch_size)
+        assert n == self.np, "image size does not match the sViT's pos_embedding"
+        T = n + 2
+        Tp = ((T + 127) // 128) * 128
+        M = B * T
+        tp = self.to_patch_embedding.to_patch_tokens
+        x = self._buf("x", (B, T, dim))
+        ops.svit_patch_embed(img, tp[1].weight, tp[1].bias, tp[1].eps, P["pe_wt"], tp[2].bias, self.pos_embedding, self.cls_token, x,
+                             self.patch_size)
+        i16 = torch.int16
+        lo_ok = prec.npass == 3
+        ln = (self._buf("ln.hi", (M, dim), i16), self._buf("ln.lo", (M, dim), i16) if lo_ok else None)
+        qkv = self._buf("qkv", (M, 3 * heads * 64))
+        mk = lambda nm, shp: (self._buf(nm + ".hi", shp, i16, zero=True), self._buf(nm + ".lo", shp, i16, zero=True) if lo_ok else None)
+        q, k, vt = mk("q", (B * heads, Tp, 64)), mk("k", (B * heads, Tp, 64)), mk("vt", (B * heads, 64, Tp))
+        att = (self._buf("att.hi", (M, heads * 64), i16), self._buf("att.lo", (M, heads * 64), i16) if lo_ok else None)
+        for l, (attn, ff) in enumerate(self.transformer.layers):
+            mlp = ff.fn.net[0].out_features
+            ops.ln_apply16(x, attn.norm.weight, attn.norm.bias, attn.norm.eps, ln[0], ln[1], prec)
+            self._gemm(ln, P[f"qkv{l}"], M, 3 * heads * 64, out=qkv)
+            ops.qkv_pack(qkv, P[f"tau{l}"], q, k, vt, B, T, Tp, heads, prec)
+            ops.lsa_flash(q, k, vt, att, B, T, Tp, heads, prec)
+            self._gemm(att, P[f"out{l}"], M, dim, bias=attn.fn.to_out[0].bias, res=x, out=x)          # x = attn(x) + x
+            ops.ln_apply16(x, ff.norm.weight, ff.norm.bias, ff.norm.eps, ln[0], ln[1], prec)
+            h16 = (self._buf("h.hi", (M, mlp), i16), self._buf("h.lo", (M, mlp), i16) if lo_ok else None)
+            self._gemm(ln, P[f"ff1{l}"], M, mlp, bias=ff.fn.net[0].bias, act_out=2, out16=h16)       # GELU(Linear)
+            self._gemm(h16, P[f"ff2{l}"], M, dim, bias=ff.fn.net[3].bias, res=x, out=x)              # x = ff(x) + x
+        out = torch.empty((B, self.mlp_head[1].out_features), dtype=torch.float32, device=img.device)
+        pool = {"mean": 0, "cls": 1, "sum": 2}[self.pool]
+        ops.svit_head(x, pool, None if c_old is None else c_old.float().contiguous(), self.mlp_head[0].weight, self.mlp_head[0].bias,
+                      self.mlp_head[0].eps, P["head_wt"], self.mlp_head[1].bias, out)
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------- agg blocks
+def _embed(embedder: nn.Module, style_imgs: torch.Tensor) -> torch.Tensor:
+    """'b n h w c -> (b n) c h w' then the caller's embedder -> [(b n), f] (agg_blocks.py:26-28)."""
+    b, n, h, w, c = style_imgs.shape
+    x = style_imgs.permute(0, 1, 4, 2, 3).reshape(b * n, c, h, w)
+    return embedder(x).float().contiguous()
+
+
+class Agg_Linear(nn.Module):
+    """agg_blocks.py:6-33."""
+
+    def __init__(self, sampling_cfg, embedder):
+        super().__init__()
+        self._sampling_cfg = sampling_cfg
+        self._embedder = embedder
+        num = self._sampling_cfg.num_patches if self._sampling_cfg.name == "mp" else 1
+        self._linear_block = nn.Sequential(nn.ReLU(), nn.Linear(512 * num, 512), nn.ReLU(), nn.Linear(512, 512), nn.ReLU())
+        self.register_module("embedder", self._embedder)
+        self.register_module("linear_block", self._linear_block)
+
+    @torch.no_grad()
+    def forward(self, style_imgs):
+        b = style_imgs.shape[0]
+        f = _embed(self._embedder, style_imgs).reshape(b, -1)        # '(b1 n) f -> b1 (n f)'
+        l1, l2 = self._linear_block[1], self._linear_block[3]
+        h = ops.linear(f, ops.transpose(l1.weight.float()), l1.bias, torch.empty((b, 512), device=f.device), act_in=2, act_out=2)
+        return ops.linear(h, ops.transpose(l2.weight.float()), l2.bias, torch.empty((b, 512), device=f.device), act_in=0, act_out=2)
+
+
+class Agg_Max(nn.Module):
+    """agg_blocks.py:36-54."""
+
+    def __init__(self, sampling_cfg, embedder):
+        super().__init__()
+        self._sampling_cfg = sampling_cfg
+        self._embedder = embedder
+        self.register_module("embedder", self._embedder)
+
+    @torch.no_grad()
+    def forward(self, style_imgs):
+        b, n = style_imgs.shape[:2]
+        f = _embed(self._embedder, style_imgs)
+        return ops.agg_reduce(f, torch.empty((b, f.shape[-1]), device=f.device), n, 1)
+
+
+class Agg_Mean(nn.Module):
+    """agg_blocks.py:57-75."""
+
+    def __init__(self, sampling_cfg, embedder):
+        super().__init__()
+        self._sampling_cfg = sampling_cfg
+        self._embedder = embedder
+        self.register_module("embedder", self._embedder)
+
+    @torch.no_grad()
+    def forward(self, style_imgs):
+        b, n = style_imgs.shape[:2]
+        f = _embed(self._embedder, style_imgs)
+        return ops.agg_reduce(f, torch.empty((b, f.shape[-1]), device=f.device), n, 0)
+
+
+class Agg_None(nn.Module):
+    """agg_blocks.py:78-86."""
+
+    def __init__(self, sampling_cfg, embedder):
+        super().__init__()
+        self._sampling_cfg = sampling_cfg
+        self._embedder = embedder
+
+    def forward(self, style_imgs):
+        return torch.zeros((style_imgs.shape[0], 512), dtype=style_imgs.dtype, device=style_imgs.device)
+
+
+# ---------------------------------------------------------------------------------------------------- layout conditioner
+class SpatialRescaler(nn.Module):
+    """encoders/modules.py:104-133 — n_stages x bilinear 1/2, then a bias-free 1x1 conv (channel_mapper)."""
+
+    def __init__(self, n_stages=1, method='bilinear', multiplier=0.5, in_channels=3, out_channels=None, bias=False):
+        super().__init__()
+        self.n_stages = n_stages
+        assert self.n_stages >= 0
+        assert method in ['nearest', 'linear', 'bilinear', 'trilinear', 'bicubic', 'area']
+        if method != 'bilinear' or multiplier != 0.5 or bias:
+            raise NotImplementedError("HIP SpatialRescaler: bilinear x0.5 stages without bias (conf/diffusion/cond_stage_config/spatial.yaml)")
+        self.multiplier = multiplier
+        self.in_channels = in_channels
+        self.remap_output = out_channels is not None
+        if self.remap_output:
+            self.channel_mapper = nn.Conv2d(in_channels, out_channels, 1, bias=bias)
+
+    @torch.no_grad()
+    def forward(self, x):
+        x = x.float().contiguous()
+        B, cin, H, W = x.shape
+        cout = self.channel_mapper.out_channels if self.remap_output else cin
+        f = 1 << self.n_stages
+        out = torch.empty((B, cout, H // f, W // f), dtype=torch.float32, device=x.device)
+        w = self.channel_mapper.weight.detach().float().reshape(cout, cin).contiguous() if self.remap_output else None
+        return ops.spatial_rescale(x, w, out, self.n_stages)
+
+    def encode(self, x):
+        return self(x)
