@@ -43,12 +43,14 @@ def build_model(dev, precision, use_graph=True):
     return ld.to(dev)
 
 
-def synth_inputs(dev, B, rank):
+def synth_inputs(dev, B, rank, world=1):
+    from stedm_amd import parallel as par
     from stedm_amd.utils import prng
-    s = 1000 * rank
-    xT = prng.normal(1 + s, "bench.xT", (B, 4, 32, 32)).to(dev)
-    layout = (prng.uniform(2 + s, "bench.layout", (B, 3, 32, 32)) > 0).float().to(dev)   # stand-in for the rescaled layout
-    ctx = prng.normal(3 + s, "bench.ctx", (B, 512)).to(dev)
+    lo, hi = par.shard_range(B * world, rank, world)            # this rank's slice of the global batch
+    ids = list(range(lo, hi))
+    xT = par.per_sample_normal(1, ids, (4, 32, 32)).to(dev)       # per-sample streams: identical samples for any N
+    layout = (par.per_sample_normal(2, ids, (3, 32, 32)) > 0).float().to(dev)   # stand-in for the rescaled layout
+    ctx = par.per_sample_normal(3, ids, (512,)).to(dev)
     ctx_u = prng.normal(4, "bench.ctx_u", (1, 512)).repeat(B, 1).contiguous().to(dev)     # uncond style: one constant vector
     cond = {"c_concat": [layout], "c_crossattn": [ctx]}
     unc = {"c_concat": [layout], "c_crossattn": [ctx_u]}
@@ -195,14 +197,14 @@ def main():
 
     B = args.batch
     ld = build_model(dev, args.precision)
-    xT, cond, unc = synth_inputs(dev, B, rank)
+    xT, cond, unc = synth_inputs(dev, B, rank, world)
     dt, final = run_steps(ld, xT, cond, unc, args.warmup, args.steps, world)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        gathered = [torch.empty_like(final) for _ in range(world)]       # prediction-side RCCL all-gather of the samples
-        torch.distributed.all_gather(gathered, final)
-        assert all(torch.isfinite(g).all() for g in gathered)
+        from stedm_amd import parallel as par
+        gathered = par.all_gather_samples(final, B * world)                # prediction-side RCCL all-gather of the samples
+        assert gathered.shape[0] == B * world and bool(torch.isfinite(gathered).all())
     dt = float(t.item())
     steps_per_s = world * args.steps / dt
     ms_per_step = 1e3 * dt / args.steps

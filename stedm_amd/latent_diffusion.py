@@ -193,3 +193,87 @@ class LatentDiffusion(nn.Module):
             raise NotImplementedError("first stage (VQ-f4 decoder) is out of this round's scope (SURVEY.md §8f next-1); "
                                       "pass a first_stage module to LatentDiffusion to use decode_first_stage")
         return self.first_stage_model.decode(z / self.scale_factor)
+
+
+class S_ZSS_DM(LatentDiffusion):
+    """networks/s_zss_dm.py:11-60 — LatentDiffusion + style aggregation block; `get_input` emits the hybrid conditioning
+    dict {"c_concat": [layout], "c_crossattn": [style]}.
+
+    `encoder` names the torchvision embedder of the mean/max/linear aggregators in the reference ("swin_v2_t", third-party,
+    SURVEY.md §8c); here it must be supplied as a module through `embedder=` for those modes. `style_agg: svit` and
+    `style_sampling: none` need no embedder."""
+
+    def __init__(self, encoder, sampling_cfg, agg_cfg, cfg, *args, embedder: Optional[nn.Module] = None, **kwargs):
+        super().__init__(*args, **kwargs)
+        from . import style as st
+        self._sampling_cfg = sampling_cfg
+        self._agg_cfg = agg_cfg
+        self._cfg = cfg
+        self.embed_key = "style_imgs"
+        name = lambda c: c["name"] if isinstance(c, dict) else c.name
+        get = lambda c, k: c[k] if isinstance(c, dict) else getattr(c, k)
+        if name(sampling_cfg) == "none":
+            self._agg_block = st.Agg_None(sampling_cfg, embedder)
+        elif name(agg_cfg) == "svit":
+            a = dict(agg_cfg) if isinstance(agg_cfg, dict) else {k: getattr(agg_cfg, k) for k in
+                                                               ("patch_size", "dim", "depth", "heads", "mlp_dim", "pool", "channels",
+                                                                "dropout", "emb_dropout", "t_dim")}
+            a.pop("name", None)
+            data = cfg["data"] if isinstance(cfg, dict) else cfg.data
+            img = data["patch_size"] if isinstance(data, dict) else data.patch_size
+            ns = get(sampling_cfg, "num_patches") if name(sampling_cfg) == "mp" else 1
+            self._agg_block = st.sViT(image_size=img, num_classes=512, ns=ns, **a)
+        else:
+            if embedder is None:
+                raise NotImplementedError(f"style_agg={name(agg_cfg)!r} needs the torchvision {encoder!r} embedder (third-party, not "
+                                          "part of this package): pass it as S_ZSS_DM(..., embedder=module)")
+            cls = {"linear": st.Agg_Linear, "max": st.Agg_Max, "mean": st.Agg_Mean}.get(name(agg_cfg))
+            if cls is None:
+                raise Exception("Unkown aggregation function!")
+            self._agg_block = cls(sampling_cfg, embedder)
+        self.register_module("agg_block", self._agg_block)
+
+    @torch.no_grad()
+    def get_input(self, batch, k, cond_key=None, bs=None, **kwargs):
+        """s_zss_dm.py:45-60 + ddpm.py:656-706. batch tensors are NHWC (LDM_Diffusion.prepare_batch, ldm_diffusion.py:51-60).
+        Returns [z, {"c_concat": [c], "c_crossattn": [style]}]. Without a first stage, z is a zero placeholder of the latent
+        shape (predict_step only uses len(z), ldm_diffusion.py:79-90)."""
+        x = batch[k]
+        if bs is not None:
+            x = x[:bs]
+        x = x.permute(0, 3, 1, 2).float()
+        dev = self.device
+        if self.first_stage_model is not None:
+            z = self.first_stage_model.encode(x.to(dev)) * self.scale_factor
+        else:
+            z = torch.zeros((x.shape[0], self.channels, self.image_size, self.image_size), device=dev)
+        xc = batch[cond_key or self.cond_stage_key]
+        if bs is not None:
+            xc = xc[:bs]
+        xc = xc.permute(0, 3, 1, 2).float().contiguous().to(dev)
+        self.cond_stage_trainable = True
+        c = self.get_learned_conditioning(xc)
+        self.cond_stage_trainable = False
+        style_imgs = batch[self.embed_key]
+        if bs is not None:
+            style_imgs = style_imgs[:bs]
+        style_features = self._agg_block(style_imgs.to(dev))
+        return [z, {"c_concat": [c], "c_crossattn": [style_features]}]
+
+
+@torch.no_grad()
+def predict_latents(model: S_ZSS_DM, ldm_batch: dict, ddim_steps: int, eta: float = 0.0, cfg_scale: float = 1.0,
+                    style_sampling: str = "nearby", x_T: Optional[torch.Tensor] = None):
+    """Lightning-free restatement of LDM_Diffusion.predict_step (modules/ldm_diffusion.py:76-91) up to the sampled latents:
+    conditional get_input, unconditional batch {image: 0, segmentation: same, style_imgs: -2}, DDIM + CFG."""
+    z, c_0 = model.get_input(ldm_batch, "image")
+    kw = {} if x_T is None else {"x_T": x_T}
+    if cfg_scale == 1 or style_sampling == "none":
+        out, _ = model.sample_log(c_0, batch_size=len(z), ddim=True, ddim_steps=ddim_steps, eta=eta, log_every_t=1000, **kw)
+    else:
+        unc_batch = {"image": torch.zeros_like(ldm_batch["image"]), "segmentation": ldm_batch["segmentation"],
+                     "style_imgs": torch.zeros_like(ldm_batch["style_imgs"]) - 2}
+        z, c_uncond = model.get_input(unc_batch, "image")
+        out, _ = model.sample_log(c_0, batch_size=len(z), ddim=True, ddim_steps=ddim_steps, eta=eta, log_every_t=1000,
+                                  unconditional_conditioning=c_uncond, unconditional_guidance_scale=cfg_scale, **kw)
+    return out

@@ -1,0 +1,42 @@
+"""Data-parallel sharding of the sampling workload: latents are independent, so the global batch is
+cut into contiguous per-rank shards with NO collective inside the denoising loop; one all-gather of the final latents
+(RCCL over xGMI with backend "nccl", gloo on CPU) after the loop. Noise is drawn from per-SAMPLE streams keyed by the
+global sample id, so a run with 1, 2, 4 or 8 ranks produces the same latents sample for sample (the reference's
+batch-shaped global-RNG draw, ddim.py:122, cannot give that)."""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+
+def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [lo, hi) of samples owned by `rank`; sizes differ by at most one (first ranks take the remainder)."""
+    base, rem = divmod(global_batch, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def per_sample_normal(seed: int, sample_ids, shape, stream: int = 0) -> torch.Tensor:
+    """N(0,1) tensor [len(ids), *shape] whose row i depends only on (seed, stream, sample_ids[i])."""
+    rows = []
+    for sid in sample_ids:
+        g = np.random.Generator(np.random.Philox(key=[seed & 0xFFFFFFFF, (int(sid) << 8 | (stream & 0xFF)) & 0xFFFFFFFFFFFFFFFF]))
+        rows.append(g.standard_normal(size=tuple(shape), dtype=np.float32))
+    return torch.from_numpy(np.stack(rows)) if rows else torch.empty((0,) + tuple(shape))
+
+
+def all_gather_samples(local: torch.Tensor, global_batch: int, group=None) -> torch.Tensor:
+    """Concatenate the per-rank shards (possibly of unequal length) in rank order -> [global_batch, ...] on every rank."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    sizes = [shard_range(global_batch, r, world) for r in range(world)]
+    maxn = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((maxn,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)

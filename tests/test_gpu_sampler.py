@@ -1,5 +1,6 @@
 """GPU tier (-m gpu): DDIM + rescaled-CFG sampling loop (reference module surface: LatentDiffusion.sample_log ->
 DDIMSampler.sample) against the CPU oracle loop on identical x_T / conditioning / injected noise."""
+import numpy as np
 import pytest
 import torch
 
@@ -110,3 +111,51 @@ def test_cfg_pass_equals_two_sequential_forwards(dev):
     unc2 = {"c_concat": [cc.to(dev) * 0.5], "c_crossattn": [ctx_u.to(dev)]}
     g_c, g_u = ld.apply_model_cfg(xT.to(dev), t, cond, unc2)
     assert torch.equal(g_c, e_c) and not torch.equal(g_u, e_u)
+
+
+def test_predict_step_surface_end_to_end(dev):
+    """S_ZSS_DM.get_input + predict_step call sequence (ldm_diffusion.py:76-91) with the HIP sViT / SpatialRescaler / U-Net /
+    DDIM sampler, against the same pipeline assembled from the CPU oracle pieces."""
+    from oracle import ddim as od
+    from oracle import style as ost
+    from oracle import unet as ou
+    from stedm_amd.latent_diffusion import S_ZSS_DM, predict_latents
+    from stedm_amd.unet import UNetModel
+    B, P, ns = 2, 64, 4
+    ucfg = dict(image_size=16, in_channels=7, model_channels=128, out_channels=4, num_res_blocks=1,
+                attention_resolutions=[32, 16, 8], channel_mult=[1, 2], num_heads=4)
+    unet = UNetModel(**ucfg).eval()
+    prng.fill_module_(unet, seed=50)
+    agg = dict(name="svit", patch_size=8, dim=256, depth=2, heads=12, mlp_dim=256, pool="mean", channels=3, dropout=0.1,
+               emb_dropout=0.1, t_dim=256)
+    model = S_ZSS_DM("swin_v2_t", dict(name="mp", num_patches=ns), agg, {"data": {"patch_size": P}}, unet,
+                     linear_start=0.0015, linear_end=0.0205, image_size=16, channels=4, conditioning_key="hybrid", loss_type="l1",
+                     cond_stage_key="segmentation", cond_stage_config={"target": "ldm.modules.encoders.modules.SpatialRescaler",
+                                                                      "params": {"n_stages": 2, "in_channels": 2, "out_channels": 3}})
+    prng.fill_module_(model.agg_block, seed=51)
+    prng.fill_module_(model.cond_stage_model, seed=52)
+    model = model.to(dev).eval()
+    img = prng.uniform(53, "ps.img", (B, P, P, 3))
+    seg = (prng.uniform(53, "ps.seg", (B, P, P, 2)) > 0).float()
+    sty = prng.uniform(53, "ps.sty", (B, ns, P, P, 3))
+    xT = prng.normal(53, "ps.xT", (B, 4, 16, 16))
+    batch = {"image": img.to(dev), "segmentation": seg.to(dev), "style_imgs": sty.to(dev)}
+    got = predict_latents(model, batch, ddim_steps=4, eta=0.0, cfg_scale=1.5, x_T=xT.to(dev))
+    # ---- oracle pipeline
+    ocfg = ou.UNetConfig(image_size=16, in_channels=7, model_channels=128, out_channels=4, num_res_blocks=1, channel_mult=(1, 2), num_heads=4)
+    plan = ou.build_plan(ocfg)
+    PU = prng.fill_state_dict(plan.shapes, 50)
+    scfg = ost.SViTConfig(image_size=P, ns=ns, depth=2)
+    PS = prng.fill_state_dict(ost.svit_shapes(scfg), 51)
+    for l in range(2):
+        PS[f"transformer.layers.{l}.0.fn.temperature"] = torch.tensor(float(np.log(64 ** -0.5)))
+    wmap = prng.fill_value(52, "channel_mapper.weight", (3, 2, 1, 1))
+    cc = ost.spatial_rescaler(seg.permute(0, 3, 1, 2), wmap)
+    ctx = ost.svit_forward(PS, scfg, sty)
+    ctx_u = ost.svit_forward(PS, scfg, torch.zeros_like(sty) - 2)
+    am = lambda x, t, c: ou.unet_forward(PU, ocfg, torch.cat([x, c["c_concat"][0]], 1), t, c["c_crossattn"][0], plan=plan)
+    ref = od.ddim_sample(am, od.Schedule(), xT, {"c_concat": [cc], "c_crossattn": [ctx]}, 4, 0.0,
+                         uncond={"c_concat": [cc], "c_crossattn": [ctx_u]}, scale=1.5)
+    err = rel(got, ref)
+    print(f"[predict_step surface] rel err vs oracle pipeline: {err:.3e}")
+    assert err < 1e-3
