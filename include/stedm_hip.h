@@ -180,6 +180,8 @@ int stedm_lsa_flash(const void* q_hi, const void* q_lo, const void* k_hi, const 
 /* pool (0 mean, 1 cls, 2 sum) over tokens (+ c_old) -> mlp_head LayerNorm + Linear, vit_set.py:191-206. wt [dim][ncls]. */
 int stedm_svit_head(const float* x, int B, int T, int dim, int pool, const float* c_old, const float* ln_w,
                     const float* ln_b, float eps, const float* wt, const float* bias, float* out, int ncls, void* stream);
+/* GEGLU attention.py:37-44: g [M][2*I] fp32 (value | gate) -> value * gelu_erf(gate) as 16-bit planes [M][I]. */
+int stedm_geglu16(const float* g, void* out_hi, void* out_lo, long M, int I, int mm_dtype, void* stream);
 /* Agg_Mean (mode 0) / Agg_Max (mode 1) over the set: feats [B*n][F] -> out [B][F]; agg_blocks.py:52,73. */
 int stedm_agg_reduce(const float* feats, float* out, int B, int n, int F, int mode, void* stream);
 /* SpatialRescaler encoders/modules.py:123-130: n_stages x bilinear 1/2 (== box mean for divisible sizes) then bias-free

@@ -482,3 +482,35 @@ extern "C" int stedm_spatial_rescale(const float* x, const float* w, float* out,
   STEDM_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ GEGLU
+// attention.py:37-44: x, gate = proj(x).chunk(2, -1); out = x * gelu(gate) (exact erf GELU) -> 16-bit planes
+template <typename T>
+__global__ void __launch_bounds__(256) geglu16_kernel(const float* __restrict__ g, T* __restrict__ hi, T* __restrict__ lo, long M,
+                                                      int I) {
+  const long total = M * (I / 4);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long row = i / (I / 4);
+    const int q = (int)(i - row * (I / 4));
+    const float4 x = *reinterpret_cast<const float4*>(g + row * 2 * I + q * 4);
+    const float4 t = *reinterpret_cast<const float4*>(g + row * 2 * I + I + q * 4);
+    const float xs[4] = {x.x, x.y, x.z, x.w}, ts[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float v = xs[j] * (0.5f * ts[j] * (1.0f + erff(ts[j] * 0.70710678118654752f)));
+      const T h = (T)v;
+      hi[row * I + q * 4 + j] = h;
+      if (lo) lo[row * I + q * 4 + j] = (T)(v - (float)h);
+    }
+  }
+}
+
+extern "C" int stedm_geglu16(const float* g, void* out_hi, void* out_lo, long M, int I, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(g && out_hi && M > 0 && I > 0 && I % 4 == 0, "geglu16: bad args");
+  long blocks = (M * (I / 4) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (mm_dtype == STEDM_F16) geglu16_kernel<_Float16><<<(int)blocks, 256, 0, as_stream(stream)>>>(g, (_Float16*)out_hi, (_Float16*)out_lo, M, I);
+  else geglu16_kernel<__bf16><<<(int)blocks, 256, 0, as_stream(stream)>>>(g, (__bf16*)out_hi, (__bf16*)out_lo, M, I);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}

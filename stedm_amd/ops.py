@@ -274,6 +274,12 @@ def svit_head(x, pool: int, c_old, ln_w, ln_b, eps, wt, bias, out):
     return out
 
 
+def geglu16(g, hi, lo, prec: Precision):
+    _chk(g, name="g")
+    M = g.numel() // g.shape[-1]
+    check(lib().stedm_geglu16(g.data_ptr(), hi.data_ptr(), _ptr(lo), M, g.shape[-1] // 2, prec.mm_dtype, _stream()), "stedm_geglu16")
+
+
 def agg_reduce(feats, out, n: int, mode: int):
     _chk(feats, name="features")
     Bn, Fd = feats.shape

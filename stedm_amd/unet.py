@@ -135,10 +135,11 @@ class UNetModel(nn.Module):
                  context_dim=None, n_embed=None, legacy=True, style_imgs=1, precision: str = "parity"):
         super().__init__()
         if use_spatial_transformer:
-            assert context_dim is not None, "context_dim is required with use_spatial_transformer (openaimodel.py:494-495)"
-            raise NotImplementedError("SpatialTransformer middle block: HIP kernels not built yet (SURVEY.md §8a A8)")
+            assert context_dim is not None, 'Fool!! You forgot to include the dimension of your cross-attention conditioning...'
         if context_dim is not None:
-            raise AssertionError("context_dim requires use_spatial_transformer (openaimodel.py:497-498)")
+            assert use_spatial_transformer, 'Fool!! You forgot to use the spatial transformer for your cross-attention conditioning...'
+            if not isinstance(context_dim, int):
+                context_dim = list(context_dim)
         if num_classes is not None or n_embed is not None or resblock_updown or not conv_resample or dims != 2 or dropout != 0:
             raise NotImplementedError("num_classes / n_embed / resblock_updown / conv_resample=False / dims != 2 / dropout: "
                                       "not used by the reference configs, not implemented")
@@ -187,11 +188,17 @@ class UNetModel(nn.Module):
                 ds *= 2
         if num_head_channels != -1:
             num_heads = ch // num_head_channels
-        dim_head = num_head_channels  # legacy=True, no spatial transformer (openaimodel.py:624-626)
+        # legacy=True (openaimodel.py:624-626): dim_head = ch // num_heads with the spatial transformer, else num_head_channels
+        dim_head = ch // num_heads if use_spatial_transformer else num_head_channels
+        if use_spatial_transformer:
+            from .attention import SpatialTransformer
+            mid_attn = SpatialTransformer(ch, num_heads, dim_head, depth=transformer_depth, context_dim=context_dim)
+        else:
+            mid_attn = AttentionBlock(ch, num_heads=num_heads, num_head_channels=dim_head)
         self.middle_block = TimestepEmbedSequential(
             ResBlock(ch, ted, dropout),
             ResBlockStyle(ch, ted, dropout),
-            AttentionBlock(ch, num_heads=num_heads, num_head_channels=dim_head),
+            mid_attn,
             ResBlock(ch, ted, dropout),
         )
         self.output_blocks = nn.ModuleList([])
@@ -288,6 +295,8 @@ class UNetModel(nn.Module):
             elif isinstance(m, AttentionBlock):
                 pack(m.qkv)
                 pack(m.proj_out)
+            elif type(m).__name__ == "SpatialTransformer":
+                self._packed[id(m)] = m.pack(prec)
         c = self._consts
         half = self.model_channels // 2
         # host-built frequency table (util.py:162-164 builds it on the CPU in fp32)
@@ -411,6 +420,9 @@ class UNetModel(nn.Module):
                 h = self._res(ltag, layer.block, h, None, style_all, 0, style_all.shape[1])
             elif isinstance(layer, AttentionBlock):
                 h = self._attn(ltag, layer, h)
+            elif type(layer).__name__ == "SpatialTransformer":
+                # routed without context, exactly like the reference (openaimodel.py:99-100)
+                h = layer.run(h, self._packed[id(layer)], self.precision, self._buf)
             elif isinstance(layer, Downsample):
                 pk = self._packed[id(layer.op)]
                 B, H, W, _ = h.shape
