@@ -37,6 +37,8 @@ extern "C" {
 #define STEDM_CONV_S1 0   /* 3x3 (or 1x1) stride 1, pad ks/2                                  */
 #define STEDM_CONV_DOWN 1 /* 3x3 stride 2 pad 1 : Downsample.op       openaimodel.py:156-173  */
 #define STEDM_CONV_UP 2   /* nearest x2 then 3x3 pad 1 : Upsample      openaimodel.py:122-132  */
+#define STEDM_CONV_UP_SUBPIXEL 3 /* same operator evaluated as 4 output-parity 2x2 convs on the low-res input with
+                                  * pre-summed taps (weights from stedm_pack_conv_weight_up): 4/9 of the MACs; DMA path */
 
 int stedm_abi_version(void);
 const char* stedm_last_error(void);
@@ -48,6 +50,10 @@ int stedm_device_cus(void);
  * w_lo may be NULL (single-pass only). Replaces nothing in the reference (layout change only). */
 int stedm_pack_conv_weight(const float* w_oihw, void* w_hi, void* w_lo, int cout, int cin, int ks,
                            int mm_dtype, void* stream);
+/* Upsample conv weights for STEDM_CONV_UP_SUBPIXEL: OIHW 3x3 fp32 -> [4 parities (py*2+px)][cout][4 taps (a*2+b)][cin]
+ * with W_eff[py][px][a][b] = sum of the 3x3 taps that read the same low-res pixel (rows: py=0 -> {0},{1,2}; py=1 -> {0,1},{2}). */
+int stedm_pack_conv_weight_up(const float* w_oihw, void* w_hi, void* w_lo, int cout, int cin, int mm_dtype,
+                              void* stream);
 /* [rows][cols] fp32 -> [cols][rows] fp32 (Linear weights are consumed K-major). */
 int stedm_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
 

@@ -304,7 +304,7 @@ bool stedm::conv_geometry(ConvParams& p, int bm) {
     }
     p.whole = 0; p.nsamp = 1; p.trows = bm / p.Wout;
   }
-  if (a.mode == STEDM_CONV_S1) p.PRs = p.trows + 2;
+  if (a.mode == STEDM_CONV_S1 || a.mode == STEDM_CONV_UP_SUBPIXEL) p.PRs = p.trows + 2;
   else if (a.mode == STEDM_CONV_DOWN) p.PRs = 2 * p.trows + 1;
   else p.PRs = (p.trows + 1) / 2 + 2;
   p.PW = a.Win + 2;
@@ -323,7 +323,8 @@ extern "C" int stedm_conv_igemm(const stedm_conv_args* args, void* stream) {
   STEDM_CHECK_ARG(!a.src1 || (a.src2 != nullptr) == (a.c2 > 0), "conv_igemm: src2/c2 mismatch");
   STEDM_CHECK_ARG(!a.src16_hi || a.npass == 1 || a.src16_lo, "conv_igemm: npass=3 needs src16_lo");
   STEDM_CHECK_ARG(a.ks == 1 || a.ks == 3, "conv_igemm: ks must be 1 or 3");
-  STEDM_CHECK_ARG(a.mode >= 0 && a.mode <= 2, "conv_igemm: bad mode %d", a.mode);
+  STEDM_CHECK_ARG(a.mode >= 0 && a.mode <= 3, "conv_igemm: bad mode %d", a.mode);
+  STEDM_CHECK_ARG(a.mode != STEDM_CONV_UP_SUBPIXEL || (a.src16_hi && !a.src1 && a.ks == 3), "conv_igemm: sub-pixel upsample needs the DMA path (src16) and ks=3");
   STEDM_CHECK_ARG(a.ks == 3 || a.mode == STEDM_CONV_S1, "conv_igemm: 1x1 supports stride 1 only");
   STEDM_CHECK_ARG(a.npass == 1 || a.npass == 3, "conv_igemm: npass must be 1 or 3");
   STEDM_CHECK_ARG(a.npass == 1 || a.w_lo, "conv_igemm: npass=3 needs w_lo");
@@ -331,8 +332,10 @@ extern "C" int stedm_conv_igemm(const stedm_conv_args* args, void* stream) {
   STEDM_CHECK_ARG(a.B > 0 && a.Hin > 0 && a.Win > 0 && a.cout > 0, "conv_igemm: bad sizes");
   STEDM_CHECK_ARG(a.mm_dtype == STEDM_F16 || a.mm_dtype == STEDM_BF16, "conv_igemm: bad mm_dtype %d", a.mm_dtype);
   p.Cin = a.c1 + a.c2;
-  p.taps = a.ks * a.ks;
-  if (a.mode == STEDM_CONV_DOWN) {
+  p.taps = a.mode == STEDM_CONV_UP_SUBPIXEL ? 4 : a.ks * a.ks;
+  if (a.mode == STEDM_CONV_UP_SUBPIXEL) {
+    p.Hout = a.Hin; p.Wout = a.Win;     // tiles are cut on the LOW-RES grid; each tile is computed for the 4 output parities
+  } else if (a.mode == STEDM_CONV_DOWN) {
     STEDM_CHECK_ARG(a.Hin % 2 == 0 && a.Win % 2 == 0, "conv_igemm: stride-2 needs even Hin/Win");
     p.Hout = a.Hin / 2; p.Wout = a.Win / 2;
   } else if (a.mode == STEDM_CONV_UP) {

@@ -62,6 +62,41 @@ extern "C" int stedm_pack_conv_weight(const float* w, void* w_hi, void* w_lo, in
   return 0;
 }
 
+template <typename T>
+__global__ void pack_conv_weight_up_kernel(const float* __restrict__ w, T* __restrict__ hi, T* __restrict__ lo, int cout, int cin) {
+  const long total = (long)4 * cout * 4 * cin;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % cin);
+    long r = i / cin;
+    const int tap = (int)(r % 4); r /= 4;
+    const int co = (int)(r % cout);
+    const int par = (int)(r / cout);
+    const int py = par >> 1, px = par & 1, a = tap >> 1, b = tap & 1;
+    // 3x3 taps that land on low-res neighbour (a, b) for output parity (py, px)
+    const int dy0 = py == 0 ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), dy1 = py == 0 ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
+    const int dx0 = px == 0 ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), dx1 = px == 0 ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
+    float v = 0.f;
+    for (int dy = dy0; dy <= dy1; ++dy)
+      for (int dx = dx0; dx <= dx1; ++dx) v += w[((long)co * cin + ci) * 9 + dy * 3 + dx];
+    const T h = (T)v;
+    hi[i] = h;
+    if (lo) lo[i] = (T)(v - (float)h);
+  }
+}
+
+extern "C" int stedm_pack_conv_weight_up(const float* w, void* w_hi, void* w_lo, int cout, int cin, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(w && w_hi, "pack_conv_weight_up: null pointer");
+  STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "pack_conv_weight_up: bad mm_dtype %d", mm_dtype);
+  const long total = (long)16 * cout * cin;
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (mm_dtype == STEDM_F16)
+    pack_conv_weight_up_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(w, (_Float16*)w_hi, (_Float16*)w_lo, cout, cin);
+  else
+    pack_conv_weight_up_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(w, (__bf16*)w_hi, (__bf16*)w_lo, cout, cin);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
   __shared__ float tile[32][33];
   const int bx = blockIdx.x * 32, by = blockIdx.y * 32;

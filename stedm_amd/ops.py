@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import BF16, CONV_DOWN, CONV_S1, CONV_UP, F16, ConvArgs, check, lib
+from ._lib import BF16, CONV_DOWN, CONV_S1, CONV_UP, CONV_UP_SUBPIXEL, F16, ConvArgs, check, lib
 
 
 @dataclass(frozen=True)
@@ -71,6 +71,19 @@ def pack_conv_weight(w: torch.Tensor, prec: Precision) -> Tuple[torch.Tensor, Op
     lo = torch.empty_like(hi) if prec.npass == 3 else None
     check(lib().stedm_pack_conv_weight(w.data_ptr(), hi.data_ptr(), _ptr(lo), cout, cin, ks, prec.mm_dtype, _stream()),
           "stedm_pack_conv_weight")
+    return hi, lo
+
+
+def pack_conv_weight_up(w: torch.Tensor, prec: Precision) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """OIHW 3x3 fp32 -> sub-pixel upsample planes [4*O][4][I] (parity-major), see stedm_pack_conv_weight_up."""
+    w = w.detach().contiguous()
+    _chk(w, name="conv weight")
+    cout, cin, ks, _ = w.shape
+    assert ks == 3
+    hi = torch.empty((4 * cout, 4, cin), dtype=torch.int16, device=w.device)
+    lo = torch.empty_like(hi) if prec.npass == 3 else None
+    check(lib().stedm_pack_conv_weight_up(w.data_ptr(), hi.data_ptr(), _ptr(lo), cout, cin, prec.mm_dtype, _stream()),
+          "stedm_pack_conv_weight_up")
     return hi, lo
 
 
@@ -173,7 +186,10 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
     a.out = _ptr(out)
     a.cout = oshape[-1]
     a.npass, a.mm_dtype = prec.npass, prec.mm_dtype
-    assert w_hi.shape == (a.cout, ks * ks, a.c1 + a.c2), (w_hi.shape, a.cout, ks, a.c1, a.c2)
+    if mode == CONV_UP_SUBPIXEL:
+        assert w_hi.shape == (4 * a.cout, 4, a.c1 + a.c2), (w_hi.shape, a.cout, a.c1, a.c2)
+    else:
+        assert w_hi.shape == (a.cout, ks * ks, a.c1 + a.c2), (w_hi.shape, a.cout, ks, a.c1, a.c2)
     check(lib().stedm_conv_igemm(C.byref(a), _stream()), "stedm_conv_igemm")
     return out
 

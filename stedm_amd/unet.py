@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._lib import CONV_DOWN, CONV_S1, CONV_UP, StedmHipError
+from ._lib import CONV_DOWN, CONV_S1, CONV_UP, CONV_UP_SUBPIXEL, StedmHipError
 from .ops import Precision
 
 
@@ -292,6 +292,9 @@ class UNetModel(nn.Module):
                 pack(m.op)
             elif isinstance(m, Upsample):
                 pack(m.conv)
+                if self.conv_path == "dma":   # sub-pixel form: 4 parity 2x2 convs with pre-summed taps
+                    hi, lo = ops.pack_conv_weight_up(m.conv.weight.float(), prec)
+                    self._packed[(id(m.conv), "up")] = _Packed(hi, lo, self._packed[id(m.conv)].bias)
             elif isinstance(m, AttentionBlock):
                 pack(m.qkv)
                 pack(m.proj_out)
@@ -434,8 +437,9 @@ class UNetModel(nn.Module):
                 B, H, W, _ = h.shape
                 out = self._buf(ltag + ".out", (B, H * 2, W * 2, layer.out_channels))
                 if self.conv_path == "dma":
-                    h = ops.conv_igemm(None, pk.hi, pk.lo, out, prec=self.precision, mode=CONV_UP, src16=self._norm16(None, 0, h),
-                                       bias=pk.bias)
+                    pu = self._packed[(id(layer.conv), "up")]
+                    h = ops.conv_igemm(None, pu.hi, pu.lo, out, prec=self.precision, mode=CONV_UP_SUBPIXEL,
+                                       src16=self._norm16(None, 0, h), bias=pu.bias)
                 else:
                     h = ops.conv_igemm(h, pk.hi, pk.lo, out, prec=self.precision, mode=CONV_UP, bias=pk.bias)
             else:

@@ -287,7 +287,7 @@ def test_gn_stats_apply16(dev, B, H, W, c1, c2, bmod):
 
 def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_emb=True, use_res=True, seed=12):
     from stedm_amd import ops
-    from stedm_amd._lib import CONV_DOWN, CONV_S1, CONV_UP
+    from stedm_amd._lib import CONV_DOWN, CONV_S1, CONV_UP, CONV_UP_SUBPIXEL
     prec = ops.Precision.parse(prec_name)
     x = prng.normal(seed, "cd.x", (B, cin, Hin, Win))
     a = F.silu(x * 1.3 + 0.1)                      # stands for the normalised + activated activation
@@ -298,7 +298,8 @@ def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_em
     elif mode == "down":
         ref = F.conv2d(a, w, bias, stride=2, padding=1); m = CONV_DOWN
     else:
-        ref = F.conv2d(F.interpolate(a, scale_factor=2, mode="nearest"), w, bias, padding=1); m = CONV_UP
+        ref = F.conv2d(F.interpolate(a, scale_factor=2, mode="nearest"), w, bias, padding=1)
+        m = CONV_UP_SUBPIXEL if mode == "up2" else CONV_UP
     _, _, Ho, Wo = ref.shape
     emb = res = None
     if use_emb:
@@ -307,7 +308,7 @@ def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_em
         res = prng.normal(seed, "cd.res", (B, cout, Ho, Wo)); ref = ref + res
     hi16 = torch.empty((B, Hin, Win, cin), dtype=torch.int16, device=dev); lo16 = torch.empty_like(hi16)
     ops.gn_apply16(nhwc(a).to(dev), None, hi16, lo16, prec)
-    whi, wlo = ops.pack_conv_weight(w.to(dev), prec)
+    whi, wlo = ops.pack_conv_weight_up(w.to(dev), prec) if mode == "up2" else ops.pack_conv_weight(w.to(dev), prec)
     out = torch.full((B, Ho, Wo, cout), float("nan"), device=dev)
     # stride-2 patches can exceed LDS in the DMA kernel: pass the fp32 source too so the dispatcher may fall back
     src1 = nhwc(a).to(dev) if mode == "down" else None
@@ -332,6 +333,13 @@ def test_conv_dma_3x3(dev, prec, tol, B, H, W, cin, cout):
                                           (2, 16, 16, 64, "down"), (8, 32, 32, 128, "down"), (3, 8, 8, 32, "down")])
 def test_conv_dma_updown(dev, prec, tol, B, H, W, c, mode):
     _conv_dma_case(dev, prec, tol, B, H, W, c, c, mode, 3, use_emb=False, use_res=False)
+
+
+@pytest.mark.parametrize("prec,tol", PRECS[:2])
+@pytest.mark.parametrize("B,H,W,c,cout", [(2, 8, 8, 64, 64), (16, 16, 16, 128, 96), (3, 4, 4, 32, 32), (1, 32, 32, 32, 64), (5, 8, 8, 128, 128)])
+def test_conv_dma_up_subpixel(dev, prec, tol, B, H, W, c, cout):
+    """nearest x2 + 3x3 evaluated as four parity 2x2 convs with pre-summed taps (STEDM_CONV_UP_SUBPIXEL)."""
+    _conv_dma_case(dev, prec, tol, B, H, W, c, cout, "up2", 3, use_emb=True, use_res=True)
 
 
 @pytest.mark.parametrize("prec,tol", PRECS)

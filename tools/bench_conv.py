@@ -5,7 +5,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from stedm_amd import ops
-from stedm_amd._lib import CONV_S1, CONV_UP, CONV_DOWN
+from stedm_amd._lib import CONV_S1, CONV_UP, CONV_DOWN, CONV_UP_SUBPIXEL
 
 SHAPES = [  # name, B, H, W, c1, c2, cout, mode, ks, gn
     ("L0 128->128 @32 B64", 64, 32, 32, 128, 0, 128, CONV_S1, 3, True),
@@ -19,6 +19,8 @@ SHAPES = [  # name, B, H, W, c1, c2, cout, mode, ks, gn
     ("L2 2048->1024 @8 B128", 128, 8, 8, 1024, 1024, 1024, CONV_S1, 3, True),
     ("UP 1024 8->16 B128", 128, 8, 8, 1024, 0, 1024, CONV_UP, 3, False),
     ("UP 512 16->32 B128", 128, 16, 16, 512, 0, 512, CONV_UP, 3, False),
+    ("UPSUB 1024 8->16 B128", 128, 8, 8, 1024, 0, 1024, CONV_UP_SUBPIXEL, 3, False),
+    ("UPSUB 512 16->32 B128", 128, 16, 16, 512, 0, 512, CONV_UP_SUBPIXEL, 3, False),
     ("DOWN 512 16->8 B64", 64, 16, 16, 512, 0, 512, CONV_DOWN, 3, False),
     ("1x1 2048->1024 @8 B128", 128, 8, 8, 1024, 1024, 1024, CONV_S1, 1, False),
     ("1x1 qkv 1024->3072 @8 B128", 128, 8, 8, 1024, 0, 3072, CONV_S1, 1, True),
@@ -36,10 +38,10 @@ def main():
         x1 = torch.randn(B, H, W, c1, device=dev)
         x2 = torch.randn(B, H, W, c2, device=dev) if c2 else None
         w = torch.randn(cout, cin, ks, ks, device=dev) / (cin * ks * ks) ** 0.5
-        hi, lo = ops.pack_conv_weight(w, prec)
+        hi, lo = ops.pack_conv_weight_up(w, prec) if mode == CONV_UP_SUBPIXEL else ops.pack_conv_weight(w, prec)
         sc = torch.rand(B, cin, device=dev) + 0.5 if gn else None
         sh = torch.randn(B, cin, device=dev) * 0.1 if gn else None
-        Ho, Wo = (H * 2, W * 2) if mode == CONV_UP else ((H // 2, W // 2) if mode == CONV_DOWN else (H, W))
+        Ho, Wo = (H * 2, W * 2) if mode in (CONV_UP, CONV_UP_SUBPIXEL) else ((H // 2, W // 2) if mode == CONV_DOWN else (H, W))
         out = torch.empty(B, Ho, Wo, cout, device=dev)
         bias = torch.randn(cout, device=dev)
         if os.environ.get("BENCH_DMA"):
@@ -57,7 +59,7 @@ def main():
         for _ in range(n): run()
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
-        fl = 2.0 * B * Ho * Wo * cout * cin * ks * ks
+        fl = 2.0 * B * Ho * Wo * cout * cin * (4 if mode == CONV_UP_SUBPIXEL else ks * ks)
         tot_f += fl; tot_t += ms
         print(f"{name:32s} {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TFLOP/s  ({fl/ms/1e9/2500*100:5.1f}% of peak)", flush=True)
     print(f"{'SUM':32s} {tot_t*1e3:9.1f} us  {tot_f/tot_t/1e9:8.1f} TFLOP/s")
