@@ -54,6 +54,10 @@ int stedm_pack_conv_weight(const float* w_oihw, void* w_hi, void* w_lo, int cout
  * with W_eff[py][px][a][b] = sum of the 3x3 taps that read the same low-res pixel (rows: py=0 -> {0},{1,2}; py=1 -> {0,1},{2}). */
 int stedm_pack_conv_weight_up(const float* w_oihw, void* w_hi, void* w_lo, int cout, int cin, int mm_dtype,
                               void* stream);
+/* OIHW 3x3 fp32 -> MFMA-fragment order [ceil(cout/128)][cin/16][9 taps][4][64 lanes][8] 16-bit (single product): the
+ * layout the register-streamed 3x3 kernel reads with one coalesced 16-B load per lane and fragment. Passed to
+ * stedm_conv_igemm as w_frag (optional; the kernel falls back to w_hi through LDS when it is NULL). */
+int stedm_pack_conv_weight_frag(const float* w_oihw, void* out, int cout, int cin, int mm_dtype, void* stream);
 /* [rows][cols] fp32 -> [cols][rows] fp32 (Linear weights are consumed K-major). */
 int stedm_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
 
@@ -109,6 +113,7 @@ typedef struct stedm_conv_args {
   int32_t act_out;
   void* out16_hi;
   void* out16_lo;
+  const void* w_frag; /* optional: fragment-order weights (stedm_pack_conv_weight_frag) for 3x3, npass 1, DMA path */
 } stedm_conv_args;
 /* Replaces: GN->SiLU->conv3x3(+bias)(+emb)(+skip) of ResBlock._forward openaimodel.py:268-288,
  * Downsample/Upsample convs (:122-132,:156-173), 1x1 skip_connection (:254), and the 1x1
@@ -200,6 +205,11 @@ int stedm_graph_begin(void* stream);
 int stedm_graph_end(void* stream, void** graph_exec_out);
 int stedm_graph_launch(void* graph_exec, void* stream);
 int stedm_graph_destroy(void* graph_exec);
+
+/* ---- diagnostics (no reference counterpart) ----
+ * With STEDM_CONV_DBG & 1024 the bf16 register-streamed 3x3 kernel records 5 phase stamps (100 MHz clock) per block:
+ * entry, tables built, first patch landed, main loop done, stores retired. Copies 8 x nblocks u64 to host memory. */
+int stedm_debug_conv_stamps(unsigned long long* host_out, int nblocks);
 
 #ifdef __cplusplus
 }

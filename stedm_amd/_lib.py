@@ -34,6 +34,7 @@ class ConvArgs(C.Structure):
         ("cout", C.c_int32), ("npass", C.c_int32), ("mm_dtype", C.c_int32),
         ("src16_hi", C.c_void_p), ("src16_lo", C.c_void_p),
         ("act_out", C.c_int32), ("out16_hi", C.c_void_p), ("out16_lo", C.c_void_p),
+        ("w_frag", C.c_void_p),
     ]
 
 
@@ -45,6 +46,7 @@ SIGNATURES = {
     "stedm_device_cus": (_I, []),
     "stedm_pack_conv_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "stedm_pack_conv_weight_up": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "stedm_pack_conv_weight_frag": (_I, [_P, _P, _I, _I, _I, _P]),
     "stedm_transpose_f32": (_I, [_P, _P, _I, _I, _P]),
     "stedm_gn_scale_shift": (_I, [_P, _I, _P, _I, _I, _P, _P, _F, _I, _I, _I, _P, _P, _P]),
     "stedm_gn_nslab": (_I, [_I, _I]),
@@ -72,6 +74,7 @@ SIGNATURES = {
     "stedm_graph_end": (_I, [_P, C.POINTER(C.c_void_p)]),
     "stedm_graph_launch": (_I, [_P, _P]),
     "stedm_graph_destroy": (_I, [_P]),
+    "stedm_debug_conv_stamps": (_I, [_P, _I]),
 }
 
 _lib = None

@@ -1,3 +1,19 @@
-// explicit instantiation unit of the v3 DMA convolution (bf16, 1 product); see conv_igemm_dma.inc
-#include "conv_igemm_dma.inc"
-namespace stedm { int conv_dma_pick_bf16_p1(ConvParams& p, hipStream_t st) { return dma_pick<1, __bf16>(p, st); } }
+// explicit instantiation unit of the v3 DMA convolution (bf16, single product); see conv_igemm_dma.inc / conv_igemm_dma9.inc
+#include "conv_igemm_dma9.inc"
+#include "conv_igemm_dma9g.inc"
+namespace stedm {
+int conv_dma_pick_bf16_p1(ConvParams& p, hipStream_t st) {
+  int rc = dma9g_pick<__bf16>(p, st);             // 3x3 with fragment-order weights: weights bypass LDS
+  if (rc >= 0) return rc;
+  rc = dma9_pick<__bf16>(p, st);     // 3x3: one barrier per 16-channel chunk
+  return rc >= 0 ? rc : dma_pick<1, __bf16>(p, st);
+}
+}  // namespace stedm
+
+// diagnostics (timing experiments, STEDM_CONV_DBG & 1024): phase stamps of the last bf16 conv_dma9g launch, 8 per block
+extern "C" int stedm_debug_conv_stamps(unsigned long long* host_out, int nblocks) {
+  if (!host_out || nblocks <= 0 || nblocks > 2048) { stedm::set_error("debug_conv_stamps: bad args"); return 1; }
+  hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_conv_stamps), (size_t)nblocks * 8 * sizeof(unsigned long long));
+  if (e != hipSuccess) { stedm::set_error("debug_conv_stamps: %s", hipGetErrorString(e)); return 2; }
+  return 0;
+}

@@ -1,3 +1,11 @@
-// explicit instantiation unit of the v3 DMA convolution (f16, 1 product); see conv_igemm_dma.inc
-#include "conv_igemm_dma.inc"
-namespace stedm { int conv_dma_pick_f16_p1(ConvParams& p, hipStream_t st) { return dma_pick<1, _Float16>(p, st); } }
+// explicit instantiation unit of the v3 DMA convolution (f16, single product); see conv_igemm_dma.inc / conv_igemm_dma9.inc
+#include "conv_igemm_dma9.inc"
+#include "conv_igemm_dma9g.inc"
+namespace stedm {
+int conv_dma_pick_f16_p1(ConvParams& p, hipStream_t st) {
+  int rc = dma9g_pick<_Float16>(p, st);             // 3x3 with fragment-order weights: weights bypass LDS
+  if (rc >= 0) return rc;
+  rc = dma9_pick<_Float16>(p, st);     // 3x3: one barrier per 16-channel chunk
+  return rc >= 0 ? rc : dma_pick<1, _Float16>(p, st);
+}
+}  // namespace stedm

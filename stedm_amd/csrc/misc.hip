@@ -97,6 +97,37 @@ extern "C" int stedm_pack_conv_weight_up(const float* w, void* w_hi, void* w_lo,
   return 0;
 }
 
+// Fragment-order packing for the register-streamed 3x3 kernel (conv_igemm_dma9g.inc):
+//   out[tn][chunk][tap][q][lane][e] = W[n = tn*128 + (q>>1)*64 + (q&1)*32 + (lane&31)][ci = chunk*16 + (lane>>5)*8 + e][tap]
+// (rows beyond cout are zero). One wave-wide 16-B load = one MFMA B fragment, 1 KiB contiguous.
+template <typename T>
+__global__ void pack_conv_weight_frag_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, long total) {
+  const int nch = cin / 16;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 7);
+    const int lane = (int)((i >> 3) & 63);
+    const int q = (int)((i >> 9) & 3);
+    long r = i >> 11;
+    const int tap = (int)(r % 9); r /= 9;
+    const int chunk = (int)(r % nch);
+    const int tn = (int)(r / nch);
+    const int n = tn * 128 + (q >> 1) * 64 + (q & 1) * 32 + (lane & 31);
+    const int ci = chunk * 16 + (lane >> 5) * 8 + e;
+    out[i] = n < cout ? (T)w[((long)n * cin + ci) * 9 + tap] : (T)0.f;
+  }
+}
+
+extern "C" int stedm_pack_conv_weight_frag(const float* w, void* out, int cout, int cin, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(w && out && cin % 16 == 0, "pack_conv_weight_frag: bad args (cin %% 16)");
+  STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "pack_conv_weight_frag: bad mm_dtype %d", mm_dtype);
+  const long total = (long)((cout + 127) / 128) * (cin / 16) * 9 * 4 * 64 * 8;
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (mm_dtype == STEDM_F16) pack_conv_weight_frag_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(w, (_Float16*)out, cout, cin, total);
+  else pack_conv_weight_frag_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(w, (__bf16*)out, cout, cin, total);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
   __shared__ float tile[32][33];
   const int bx = blockIdx.x * 32, by = blockIdx.y * 32;

@@ -87,6 +87,17 @@ def pack_conv_weight_up(w: torch.Tensor, prec: Precision) -> Tuple[torch.Tensor,
     return hi, lo
 
 
+def pack_conv_weight_frag(w: torch.Tensor, prec: Precision) -> torch.Tensor:
+    """OIHW 3x3 fp32 -> MFMA-fragment-order 16-bit weights (see stedm_pack_conv_weight_frag)."""
+    w = w.detach().contiguous()
+    _chk(w, name="conv weight")
+    cout, cin, ks, _ = w.shape
+    assert ks == 3 and cin % 16 == 0
+    out = torch.empty(((cout + 127) // 128, cin // 16, 9, 4, 64, 8), dtype=torch.int16, device=w.device)
+    check(lib().stedm_pack_conv_weight_frag(w.data_ptr(), out.data_ptr(), cout, cin, prec.mm_dtype, _stream()), "stedm_pack_conv_weight_frag")
+    return out
+
+
 def transpose(w: torch.Tensor) -> torch.Tensor:
     w = w.detach().contiguous()
     _chk(w, name="matrix")
@@ -150,13 +161,14 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
                bias: Optional[torch.Tensor] = None, emb: Optional[torch.Tensor] = None, emb_offset: int = 0,
                emb_bstride: int = 0, res: Optional[torch.Tensor] = None,
                src16: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None, act_out: int = 0,
-               out16: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None) -> torch.Tensor:
+               out16: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None, w_frag: Optional[torch.Tensor] = None) -> torch.Tensor:
     """src1 [B,Hin,Win,c1] NHWC fp32 (fused path) and/or src16 = (hi, lo) 16-bit NHWC planes [B,Hin,Win,Cin] from
     gn_apply16 (DMA path) -> out [B,Hout,Wout,cout] NHWC fp32 (see stedm_conv_igemm)."""
     if out is not None:
         _chk(out, name="out")
     a = ConvArgs()
     a.act_out = act_out
+    a.w_frag = _ptr(w_frag) if prec.npass == 1 else None
     if out16 is not None:
         a.out16_hi = out16[0].data_ptr()
         a.out16_lo = _ptr(out16[1]) if prec.npass == 3 else None

@@ -119,10 +119,10 @@ class AttentionBlock(nn.Module):
 
 
 class _Packed:
-    __slots__ = ("hi", "lo", "bias")
+    __slots__ = ("hi", "lo", "bias", "frag")
 
-    def __init__(self, hi, lo, bias):
-        self.hi, self.lo, self.bias = hi, lo, bias
+    def __init__(self, hi, lo, bias, frag=None):
+        self.hi, self.lo, self.bias, self.frag = hi, lo, bias, frag
 
 
 class UNetModel(nn.Module):
@@ -280,7 +280,10 @@ class UNetModel(nn.Module):
 
         def pack(conv):
             hi, lo = ops.pack_conv_weight(conv.weight.float(), prec)
-            self._packed[id(conv)] = _Packed(hi, lo, None if conv.bias is None else conv.bias.detach().float().contiguous())
+            frag = None
+            if self.conv_path == "dma" and prec.npass == 1 and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.in_channels % 16 == 0:
+                frag = ops.pack_conv_weight_frag(conv.weight.float(), prec)   # register-streamed weights of the 3x3 kernel
+            self._packed[id(conv)] = _Packed(hi, lo, None if conv.bias is None else conv.bias.detach().float().contiguous(), frag)
 
         for m in self.modules():
             if isinstance(m, ResBlock):
@@ -364,7 +367,7 @@ class UNetModel(nn.Module):
         if dma:
             a16 = self._norm16(rb.in_layers[0], 1, x1, x2, x2_bmod)
             ops.conv_igemm(None, pk.hi, pk.lo, h, prec=prec, src16=a16, bias=pk.bias, emb=emb_all, emb_offset=emb_off,
-                           emb_bstride=emb_bstride)
+                           emb_bstride=emb_bstride, w_frag=pk.frag)
         else:
             sc, sh = self._gn(tag + ".gn1", rb.in_layers[0], x1, x2, x2_bmod)
             ops.conv_igemm(x1, pk.hi, pk.lo, h, prec=prec, src2=x2, src2_bmod=x2_bmod, scale=sc, shift=sh, act=1, bias=pk.bias,
@@ -384,7 +387,7 @@ class UNetModel(nn.Module):
         pk2 = self._packed[id(rb.out_layers[3])]
         if dma:
             h16 = self._norm16(rb.out_layers[0], 1, h)
-            ops.conv_igemm(None, pk2.hi, pk2.lo, out, prec=prec, src16=h16, bias=pk2.bias, res=res)
+            ops.conv_igemm(None, pk2.hi, pk2.lo, out, prec=prec, src16=h16, bias=pk2.bias, res=res, w_frag=pk2.frag)
         else:
             sc2, sh2 = self._gn(tag + ".gn2", rb.out_layers[0], h)
             ops.conv_igemm(h, pk2.hi, pk2.lo, out, prec=prec, scale=sc2, shift=sh2, act=1, bias=pk2.bias, res=res)

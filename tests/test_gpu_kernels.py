@@ -285,7 +285,7 @@ def test_gn_stats_apply16(dev, B, H, W, c1, c2, bmod):
     assert rel_err(nchw(_as_float(hi, prec) + _as_float(lo, prec)), xin) < 1e-6
 
 
-def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_emb=True, use_res=True, seed=12):
+def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_emb=True, use_res=True, seed=12, frag=False):
     from stedm_amd import ops
     from stedm_amd._lib import CONV_DOWN, CONV_S1, CONV_UP, CONV_UP_SUBPIXEL
     prec = ops.Precision.parse(prec_name)
@@ -314,7 +314,8 @@ def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_em
     src1 = nhwc(a).to(dev) if mode == "down" else None
     ops.conv_igemm(src1, whi, wlo, out, prec=prec, ks=ks, mode=m, src16=(hi16, lo16), bias=bias.to(dev),
                    emb=None if emb is None else emb.to(dev), emb_offset=8, emb_bstride=0 if emb is None else emb.shape[1],
-                   res=None if res is None else nhwc(res).to(dev))
+                   res=None if res is None else nhwc(res).to(dev),
+                   w_frag=ops.pack_conv_weight_frag(w.to(dev), prec) if frag else None)
     torch.cuda.synchronize()
     err = rel_err(nchw(out), ref)
     assert err < tol, f"{prec_name}: rel err {err:.3e} >= {tol}"
@@ -326,6 +327,30 @@ def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_em
     (1, 64, 64, 32, 32), (64, 8, 8, 128, 128), (8, 32, 32, 64, 128), (1, 128, 128, 32, 32)])
 def test_conv_dma_3x3(dev, prec, tol, B, H, W, cin, cout):
     _conv_dma_case(dev, prec, tol, B, H, W, cin, cout, "s1", 3)
+
+
+@pytest.mark.parametrize("prec,tol", PRECS[1:])
+@pytest.mark.parametrize("B,H,W,cin,cout,emb,res", [
+    (50, 32, 32, 32, 96, True, True), (200, 16, 16, 64, 128, True, False), (801, 8, 8, 32, 32, False, True), (3, 128, 128, 32, 64, True, True),
+    (12, 64, 64, 32, 32, False, False), (64, 32, 32, 64, 160, True, True), (1601, 4, 4, 64, 128, True, True)])
+def test_conv_dma_3x3_frag_weights(dev, prec, tol, B, H, W, cin, cout, emb, res):
+    """256-row tile kernel with register-streamed fragment-order weights (conv_igemm_dma9g.inc); shapes fill >= 192 tiles so it is
+    the kernel the dispatcher picks; ragged sample counts, cout not a multiple of 128, partial last tile."""
+    _conv_dma_case(dev, prec, tol, B, H, W, cin, cout, "s1", 3, use_emb=emb, use_res=res, frag=True)
+
+
+def test_pack_conv_weight_frag_layout(dev):
+    from stedm_amd import ops
+    prec = ops.Precision.parse("f16")
+    cout, cin = 160, 48
+    w = prng.normal(3, "wf.w", (cout, cin, 3, 3))
+    got = ops.pack_conv_weight_frag(w.to(dev), prec).cpu().view(torch.float16).float()      # [tn][chunk][tap][q][lane][8]
+    tn, ch, tap, q, lane, e = torch.meshgrid(*[torch.arange(n) for n in got.shape], indexing="ij")
+    n = tn * 128 + (q // 2) * 64 + (q % 2) * 32 + (lane % 32)
+    ci = ch * 16 + (lane // 32) * 8 + e
+    wp = torch.cat([w, torch.zeros(256 - cout, cin, 3, 3)]).reshape(256, cin, 9)
+    want = wp[n, ci, tap].half().float()
+    assert torch.equal(got, want)
 
 
 @pytest.mark.parametrize("prec,tol", PRECS[:2])

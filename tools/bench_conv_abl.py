@@ -1,6 +1,6 @@
 import os, sys, subprocess
 shapes = "UP 1024|L2 1024->1024 @8 B128|L1 512->512 @16 B128|L0 256"
-for dbg, name in [(0, "full"), (16, "conflict-free A rows"), (19, "conflict-free A rows, no loader work"), (1, "no weight DMA"), (2, "no patch staging"), (3, "no loader work"), (4, "no MFMA"), (8, "no frag reads+MFMA (barriers only)"), (11, "nothing but barriers")]:
+for dbg, name in [(0, "full"), (256, "all blocks on one (cache-hot) tile"), (320, "hot tile, no epilogue"), (2, "no patch DMA"), (1, "no weight DMA")]:
     env = dict(os.environ, STEDM_CONV_DBG=str(dbg), BENCH_FILTER=shapes, BENCH_DMA="1")
     out = subprocess.run([sys.executable, "tools/bench_conv.py", "bf16"], env=env, capture_output=True, text=True).stdout
     print(f"--- dbg={dbg}: {name}")

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Phase timeline of the register-streamed 3x3 conv kernel (run with STEDM_CONV_DBG=1024): per-block stamps of
+entry / tables / first patch / loop end / stores retired, summarised over the grid. Timing experiment only."""
+import os, sys, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("STEDM_CONV_DBG", "1024")
+import numpy as np, torch
+from stedm_amd import ops
+from stedm_amd._lib import lib, check
+
+SHAPES = [("L0 128->128 @32 B64", 64, 32, 32, 128, 128), ("L0 640->128 @32 B128", 128, 32, 32, 640, 128),
+          ("L1 512->512 @16 B128", 128, 16, 16, 512, 512), ("L1 1536->512 @16 B128", 128, 16, 16, 1536, 512),
+          ("L2 2048->1024 @8 B128", 128, 8, 8, 2048, 1024)]
+
+def main():
+    prec = ops.Precision.parse("bf16"); dev = torch.device("cuda:0")
+    for name, B, H, W, cin, cout in SHAPES:
+        x = torch.randn(B, H, W, cin, device=dev)
+        w = torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
+        hi, lo = ops.pack_conv_weight(w, prec); wf = ops.pack_conv_weight_frag(w, prec)
+        h16 = torch.empty(B, H, W, cin, dtype=torch.int16, device=dev)
+        ops.gn_apply16(x, None, h16, None, prec)
+        out = torch.empty(B, H, W, cout, device=dev); bias = torch.randn(cout, device=dev)
+        for _ in range(3):
+            ops.conv_igemm(None, hi, lo, out, prec=prec, src16=(h16, None), bias=bias, w_frag=wf)
+        torch.cuda.synchronize()
+        nb = min(2048, (B * H * W // 256) * ((cout + 127) // 128))
+        buf = np.zeros((nb, 8), dtype=np.uint64)
+        check(lib().stedm_debug_conv_stamps(buf.ctypes.data_as(ctypes.c_void_p), nb), "stamps")
+        t = buf[:, :5].astype(np.int64); t0 = t[:, 0].min()
+        rel = (t - t0) / 100.0   # us
+        d = np.diff(rel, axis=1)
+        print(f"{name}: blocks {nb}  start skew max {rel[:,0].max():.1f} us | tables {d[:,0].mean():.1f}  first-patch {d[:,1].mean():.1f}  "
+              f"loop {d[:,2].mean():.1f} (min {d[:,2].min():.1f} max {d[:,2].max():.1f})  epilogue {d[:,3].mean():.1f} (max {d[:,3].max():.1f}) | "
+              f"last end {rel[:,4].max():.1f} us", flush=True)
+
+if __name__ == "__main__":
+    main()
