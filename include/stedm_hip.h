@@ -77,6 +77,17 @@ int stedm_gn_scale_shift(const float* x1, int c1, const float* x2, int c2, int x
  * (hi, and lo = y - hi when out_lo != NULL) — the concat is materialised in 16-bit, the conv then streams it by
  * LDS-DMA with no per-tile re-normalisation. act: 0 none, 1 SiLU. gamma == NULL: plain conversion (no norm). */
 int stedm_gn_nslab(int C, int HW);
+/* Producer-side statistics (used by UNetModel): chan_stats[B][nslab][C][2] fp32 = per-(sample, 256-pixel slab, channel)
+ * {sum, sum of squares}, nslab = stedm_gn_chan_nslab(HW) = ceil(HW/256). Written by the convolution epilogue
+ * (stedm_conv_args.chan_stats) or by stedm_gn_chan_stats for tensors of other producers. stedm_gn_apply16c folds them into
+ * the group statistics of the virtual concat [x1 | x2] (x2 / cs2 indexed with b % x2_bmod), in a fixed order, and writes
+ * act(GroupNorm(x)) as 16-bit planes; raw_hi/raw_lo (optional) receive the plain 16-bit conversion of [x1 | x2] from the
+ * same read (operand of the ResBlock's 1x1 skip_connection, openaimodel.py:254). */
+int stedm_gn_chan_nslab(int HW);
+int stedm_gn_chan_stats(const float* x, int C, int B, int HW, float* chan_stats, void* stream);
+int stedm_gn_apply16c(const float* x1, int c1, const float* cs1, const float* x2, int c2, const float* cs2, int x2_bmod,
+                      const float* gamma, const float* beta, float eps, int groups, int act, int B, int HW,
+                      void* out_hi, void* out_lo, void* raw_hi, void* raw_lo, int mm_dtype, void* stream);
 int stedm_gn_stats(const float* x1, int c1, const float* x2, int c2, int x2_bmod, int groups, int B, int HW,
                    double* stats, void* stream);
 int stedm_gn_apply16(const float* x1, int c1, const float* x2, int c2, int x2_bmod, const float* gamma,
@@ -114,6 +125,8 @@ typedef struct stedm_conv_args {
   void* out16_hi;
   void* out16_lo;
   const void* w_frag; /* optional: fragment-order weights (stedm_pack_conv_weight_frag) for 3x3, npass 1, DMA path */
+  float* chan_stats;  /* optional: [B][stedm_gn_chan_nslab(Hout*Wout)][cout][2] per-(sample, 256-pixel slab, channel) sum and
+                       * sum of squares of `out` (the next GroupNorm's statistics, see stedm_gn_apply16c); needs out != NULL */
 } stedm_conv_args;
 /* Replaces: GN->SiLU->conv3x3(+bias)(+emb)(+skip) of ResBlock._forward openaimodel.py:268-288,
  * Downsample/Upsample convs (:122-132,:156-173), 1x1 skip_connection (:254), and the 1x1

@@ -34,7 +34,7 @@ class ConvArgs(C.Structure):
         ("cout", C.c_int32), ("npass", C.c_int32), ("mm_dtype", C.c_int32),
         ("src16_hi", C.c_void_p), ("src16_lo", C.c_void_p),
         ("act_out", C.c_int32), ("out16_hi", C.c_void_p), ("out16_lo", C.c_void_p),
-        ("w_frag", C.c_void_p),
+        ("w_frag", C.c_void_p), ("chan_stats", C.c_void_p),
     ]
 
 
@@ -52,6 +52,9 @@ SIGNATURES = {
     "stedm_gn_nslab": (_I, [_I, _I]),
     "stedm_gn_stats": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P]),
     "stedm_gn_apply16": (_I, [_P, _I, _P, _I, _I, _P, _P, _F, _I, _I, _P, _I, _I, _P, _P, _I, _P]),
+    "stedm_gn_chan_nslab": (_I, [_I]),
+    "stedm_gn_chan_stats": (_I, [_P, _I, _I, _I, _P, _P]),
+    "stedm_gn_apply16c": (_I, [_P, _I, _P, _P, _I, _P, _I, _P, _P, _F, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "stedm_conv_igemm": (_I, [C.POINTER(ConvArgs), _P]),
     "stedm_conv_in": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "stedm_conv_out": (_I, [_P, _I, _P, _I, _P, _P, _F, _I, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -312,11 +312,23 @@ bool stedm::conv_geometry(ConvParams& p, int bm) {
   return true;
 }
 
+static int conv_dispatch(ConvParams& p, void* stream);
+
 extern "C" int stedm_conv_igemm(const stedm_conv_args* args, void* stream) {
   STEDM_CHECK_ARG(args, "conv_igemm: null args");
   ConvParams p;
   memset(&p, 0, sizeof(p));
   p.a = *args;
+  const stedm_conv_args& a = p.a;
+  STEDM_CHECK_ARG(!a.chan_stats || a.out, "conv_igemm: chan_stats needs the fp32 output");
+  const int rc = conv_dispatch(p, stream);
+  if (rc != 0 || !a.chan_stats || p.stats_done) return rc;
+  // the kernel that ran has no statistics epilogue: one extra pass over the output
+  const int up = (a.mode == STEDM_CONV_UP || a.mode == STEDM_CONV_UP_SUBPIXEL) ? 4 : 1, down = a.mode == STEDM_CONV_DOWN ? 4 : 1;
+  return stedm_gn_chan_stats(a.out, a.cout, a.B, a.Hin * a.Win * up / down, a.chan_stats, stream);
+}
+
+static int conv_dispatch(ConvParams& p, void* stream) {
   const stedm_conv_args& a = p.a;
   STEDM_CHECK_ARG((a.src1 || a.src16_hi) && a.w_hi && (a.out || a.out16_hi), "conv_igemm: null src/w_hi/out");
   STEDM_CHECK_ARG((!a.act_out && !a.out16_hi) || (a.src16_hi && !a.src1), "conv_igemm: act_out/out16 need the DMA path (src16 only)");

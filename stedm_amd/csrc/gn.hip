@@ -288,3 +288,196 @@ extern "C" int stedm_gn_apply16(const float* x1, int c1, const float* x2, int c2
   STEDM_LAUNCH_CHECK();
   return 0;
 }
+
+// ================================================================================================
+// Producer-side statistics: per-(sample, 256-pixel slab, channel) partial sums
+// ================================================================================================
+// The convolution epilogues (conv_igemm_dma9g.inc) emit chan_stats[B][nslab][C][2] = {sum, sum of squares} of the tensor they
+// write, one slab per 256-pixel M-tile; tensors from other producers get the same partials from gn_chan_stats_kernel. The
+// apply kernel folds them into group statistics in a fixed order (bitwise reproducible), for ANY grouping of the virtual
+// concat [x1 | x2] - the group boundaries of a decoder block straddle the concat seam - so one set of partials serves the
+// next block's GroupNorm, the decoder's concat GroupNorm and nothing has to re-read the fp32 tensor for statistics.
+extern "C" int stedm_gn_chan_nslab(int HW) { return (HW + 255) / 256; }
+
+__global__ void __launch_bounds__(256) gn_chan_stats_kernel(const float* __restrict__ x, int C, int HW, float* __restrict__ cs) {
+  extern __shared__ float cpart[];   // [npl][Q][8]
+  const int b = blockIdx.x, slab = blockIdx.y, nslab = gridDim.y;
+  const int Q = C >> 2, t = threadIdx.x;
+  const float* px = x + (long)b * HW * C;
+  const int px0 = slab * 256, px1 = min(HW, px0 + 256);
+  float* dst = cs + ((long)b * nslab + slab) * C * 2;
+  if (Q <= 256) {
+    const int npl = 256 / Q, tq = t % Q, tp = t / Q;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tp < npl) {
+      for (int pix = px0 + tp; pix < px1; pix += npl) {
+        const float4 v = *reinterpret_cast<const float4*>(px + (long)pix * C + tq * 4);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
+      }
+      float* d = cpart + ((long)tp * Q + tq) * 8;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { d[j] = s[j]; d[4 + j] = q[j]; }
+    }
+    __syncthreads();
+    if (t < Q) {
+      float su[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int l = 0; l < npl; ++l) {   // fixed order
+        const float* d = cpart + ((long)l * Q + t) * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { su[j] += d[j]; sq[j] += d[4 + j]; }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { dst[(t * 4 + j) * 2] = su[j]; dst[(t * 4 + j) * 2 + 1] = sq[j]; }
+    }
+  } else {
+    for (int tq = t; tq < Q; tq += 256) {
+      float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int pix = px0; pix < px1; ++pix) {
+        const float4 v = *reinterpret_cast<const float4*>(px + (long)pix * C + tq * 4);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { dst[(tq * 4 + j) * 2] = s[j]; dst[(tq * 4 + j) * 2 + 1] = q[j]; }
+    }
+  }
+}
+
+extern "C" int stedm_gn_chan_stats(const float* x, int C, int B, int HW, float* chan_stats, void* stream) {
+  STEDM_CHECK_ARG(x && chan_stats && C > 0 && C % 4 == 0 && B > 0 && HW > 0, "gn_chan_stats: bad args (C %% 4)");
+  dim3 grid(B, (HW + 255) / 256);
+  const int Q = C / 4;
+  const size_t lds = Q <= 256 ? (size_t)(256 / Q) * Q * 8 * sizeof(float) : 0;
+  gn_chan_stats_kernel<<<grid, 256, lds, as_stream(stream)>>>(x, C, HW, chan_stats);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+struct GnApplyCArgs {
+  const float* x1;
+  const float* x2;
+  const float* cs1;
+  const float* cs2;
+  int c1, c2, bmod, groups, HW, act, nslab;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  void* out_hi;
+  void* out_lo;
+  void* raw_hi;
+  void* raw_lo;
+};
+
+// y = act(GroupNorm([x1|x2])) from channel partials -> 16-bit planes; optionally also the plain conversion of [x1|x2]
+// (raw planes: the operand of the ResBlock's 1x1 skip convolution) from the same read of the fp32 tensors.
+template <typename T>
+__global__ void __launch_bounds__(256) gn_apply16c_kernel(GnApplyCArgs a, int slab) {
+  typedef T V4 __attribute__((ext_vector_type(4)));
+  __shared__ double dsu[256], dsq[256];
+  __shared__ float lmean[64], lrstd[64];
+  const int b = blockIdx.x, sl = blockIdx.y;
+  const int C = a.c1 + a.c2, Q = C >> 2;
+  const int cpg = C / a.groups;
+  const int b2 = a.bmod > 0 ? b % a.bmod : b;
+  {
+    const int L = 256 / a.groups;                 // lanes per group (groups <= 64)
+    const int g = threadIdx.x / L, l = threadIdx.x % L;
+    double su = 0.0, sq = 0.0;
+    if (g < a.groups) {
+      const int n = cpg * a.nslab;
+      for (int e = l; e < n; e += L) {            // entry = (slab k, channel cc of the group)
+        const int k = e / cpg, c = g * cpg + (e - k * cpg);
+        const float* p = c < a.c1 ? a.cs1 + (((long)b * a.nslab + k) * a.c1 + c) * 2
+                                  : a.cs2 + (((long)b2 * a.nslab + k) * a.c2 + (c - a.c1)) * 2;
+        su += (double)p[0];
+        sq += (double)p[1];
+      }
+    }
+    dsu[threadIdx.x] = su; dsq[threadIdx.x] = sq;
+    __syncthreads();
+    if (g < a.groups && l == 0) {
+      double s = 0.0, q = 0.0;
+      for (int i = 0; i < L; ++i) { s += dsu[threadIdx.x + i]; q += dsq[threadIdx.x + i]; }   // fixed order
+      const double inv_n = 1.0 / ((double)cpg * a.HW);
+      const double mean = s * inv_n;
+      double var = q * inv_n - mean * mean;
+      var = var > 0.0 ? var : 0.0;
+      lmean[g] = (float)mean;
+      lrstd[g] = (float)(1.0 / sqrt(var + (double)a.eps));
+    }
+    __syncthreads();
+  }
+  const float* p1 = a.x1 + (long)b * a.HW * a.c1;
+  const float* p2 = a.x2 ? a.x2 + (long)b2 * a.HW * a.c2 : nullptr;
+  const int px0 = sl * slab, px1 = min(a.HW, px0 + slab);
+  const int total = (px1 - px0) * Q;
+  int pix = px0 + threadIdx.x / Q, q = threadIdx.x % Q;
+  const int dpix = 256 / Q, dq = 256 % Q;
+  V4* oh = reinterpret_cast<V4*>(a.out_hi) + (long)b * a.HW * Q;
+  V4* ol = a.out_lo ? reinterpret_cast<V4*>(a.out_lo) + (long)b * a.HW * Q : nullptr;
+  V4* rh = a.raw_hi ? reinterpret_cast<V4*>(a.raw_hi) + (long)b * a.HW * Q : nullptr;
+  V4* rl = a.raw_lo ? reinterpret_cast<V4*>(a.raw_lo) + (long)b * a.HW * Q : nullptr;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int c = q * 4;
+    float4 v = c < a.c1 ? *reinterpret_cast<const float4*>(p1 + (long)pix * a.c1 + c)
+                        : *reinterpret_cast<const float4*>(p2 + (long)pix * a.c2 + (c - a.c1));
+    const long o = (long)pix * Q + q;
+    if (rh) {
+      V4 hi;
+      hi[0] = (T)v.x; hi[1] = (T)v.y; hi[2] = (T)v.z; hi[3] = (T)v.w;
+      rh[o] = hi;
+      if (rl) {
+        V4 lo;
+        lo[0] = (T)(v.x - (float)hi[0]); lo[1] = (T)(v.y - (float)hi[1]);
+        lo[2] = (T)(v.z - (float)hi[2]); lo[3] = (T)(v.w - (float)hi[3]);
+        rl[o] = lo;
+      }
+    }
+    const float4 gm = *reinterpret_cast<const float4*>(a.gamma + c);
+    const float4 bt = *reinterpret_cast<const float4*>(a.beta + c);
+    if (cpg & 3) {
+      const int g0 = c / cpg, g1 = (c + 1) / cpg, g2 = (c + 2) / cpg, g3 = (c + 3) / cpg;
+      v.x = (v.x - lmean[g0]) * lrstd[g0] * gm.x + bt.x; v.y = (v.y - lmean[g1]) * lrstd[g1] * gm.y + bt.y;
+      v.z = (v.z - lmean[g2]) * lrstd[g2] * gm.z + bt.z; v.w = (v.w - lmean[g3]) * lrstd[g3] * gm.w + bt.w;
+    } else {
+      const int g = c / cpg;
+      const float mf = lmean[g], rstd = lrstd[g];
+      v.x = (v.x - mf) * rstd * gm.x + bt.x; v.y = (v.y - mf) * rstd * gm.y + bt.y;
+      v.z = (v.z - mf) * rstd * gm.z + bt.z; v.w = (v.w - mf) * rstd * gm.w + bt.w;
+    }
+    if (a.act == 1) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+    V4 hi;
+    hi[0] = (T)v.x; hi[1] = (T)v.y; hi[2] = (T)v.z; hi[3] = (T)v.w;
+    oh[o] = hi;
+    if (ol) {
+      V4 lo;
+      lo[0] = (T)(v.x - (float)hi[0]); lo[1] = (T)(v.y - (float)hi[1]);
+      lo[2] = (T)(v.z - (float)hi[2]); lo[3] = (T)(v.w - (float)hi[3]);
+      ol[o] = lo;
+    }
+    pix += dpix; q += dq;
+    if (q >= Q) { q -= Q; ++pix; }
+  }
+}
+
+extern "C" int stedm_gn_apply16c(const float* x1, int c1, const float* cs1, const float* x2, int c2, const float* cs2, int x2_bmod,
+                                 const float* gamma, const float* beta, float eps, int groups, int act, int B, int HW,
+                                 void* out_hi, void* out_lo, void* raw_hi, void* raw_lo, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(x1 && cs1 && out_hi && gamma && beta, "gn_apply16c: null pointer");
+  STEDM_CHECK_ARG((x2 != nullptr) == (c2 > 0) && (x2 == nullptr || cs2 != nullptr), "gn_apply16c: x2/c2/cs2 mismatch");
+  const int C = c1 + c2;
+  STEDM_CHECK_ARG(C % 4 == 0 && c1 % 4 == 0 && C / 4 <= 1024, "gn_apply16c: channels must be multiples of 4, C <= 4096");
+  STEDM_CHECK_ARG(groups > 0 && groups <= 64 && C % groups == 0, "gn_apply16c: need groups <= 64 and C %% groups == 0");
+  STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "gn_apply16c: bad mm_dtype");
+  STEDM_CHECK_ARG(raw_hi || !raw_lo, "gn_apply16c: raw_lo without raw_hi");
+  GnApplyCArgs a{x1, x2, cs1, cs2, c1, c2, x2_bmod, groups, HW, act, (HW + 255) / 256, gamma, beta, eps, out_hi, out_lo, raw_hi, raw_lo};
+  const int slab = gn_slab_pixels(C, HW);
+  dim3 grid(B, (HW + slab - 1) / slab);
+  if (mm_dtype == STEDM_F16)
+    gn_apply16c_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(a, slab);
+  else
+    gn_apply16c_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(a, slab);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}

@@ -154,6 +154,33 @@ def gn_apply16(x1: torch.Tensor, x2: Optional[torch.Tensor], out_hi: torch.Tenso
           "stedm_gn_apply16")
 
 
+def gn_chan_nslab(HW: int) -> int:
+    return (HW + 255) // 256
+
+
+def gn_chan_stats(x: torch.Tensor, out: torch.Tensor) -> None:
+    """Per-(sample, 256-pixel slab, channel) {sum, sumsq} of an NHWC fp32 tensor -> out [B][nslab][C][2] fp32."""
+    _chk(x, name="x")
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    assert out.dtype == torch.float32 and out.numel() >= B * gn_chan_nslab(HW) * C * 2
+    check(lib().stedm_gn_chan_stats(x.data_ptr(), C, B, HW, out.data_ptr(), _stream()), "stedm_gn_chan_stats")
+
+
+def gn_apply16c(x1: torch.Tensor, cs1: torch.Tensor, x2: Optional[torch.Tensor], cs2: Optional[torch.Tensor], out_hi: torch.Tensor,
+                out_lo: Optional[torch.Tensor], prec: Precision, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+                groups: int = 32, act: int = 0, x2_bmod: int = 0, raw: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None) -> None:
+    """act(GroupNorm([x1|x2])) from channel partials -> 16-bit planes (+ optional plain conversion planes `raw`)."""
+    _chk(x1, name="x1")
+    B = x1.shape[0]
+    HW = x1.numel() // (B * x1.shape[-1])
+    c2 = 0 if x2 is None else x2.shape[-1]
+    check(lib().stedm_gn_apply16c(x1.data_ptr(), x1.shape[-1], cs1.data_ptr(), _ptr(x2), c2, _ptr(cs2), x2_bmod, gamma.data_ptr(),
+                                  beta.data_ptr(), float(eps), groups, act, B, HW, out_hi.data_ptr(), _ptr(out_lo),
+                                  None if raw is None else raw[0].data_ptr(), None if raw is None else _ptr(raw[1]),
+                                  prec.mm_dtype, _stream()), "stedm_gn_apply16c")
+
+
 # ------------------------------------------------------------------------------------------- conv
 def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[torch.Tensor], out: torch.Tensor, *, prec: Precision,
                ks: int = 3, mode: int = CONV_S1, src2: Optional[torch.Tensor] = None, src2_bmod: int = 0,
@@ -161,7 +188,8 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
                bias: Optional[torch.Tensor] = None, emb: Optional[torch.Tensor] = None, emb_offset: int = 0,
                emb_bstride: int = 0, res: Optional[torch.Tensor] = None,
                src16: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None, act_out: int = 0,
-               out16: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None, w_frag: Optional[torch.Tensor] = None) -> torch.Tensor:
+               out16: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None, w_frag: Optional[torch.Tensor] = None,
+               chan_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
     """src1 [B,Hin,Win,c1] NHWC fp32 (fused path) and/or src16 = (hi, lo) 16-bit NHWC planes [B,Hin,Win,Cin] from
     gn_apply16 (DMA path) -> out [B,Hout,Wout,cout] NHWC fp32 (see stedm_conv_igemm)."""
     if out is not None:
@@ -169,6 +197,7 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
     a = ConvArgs()
     a.act_out = act_out
     a.w_frag = _ptr(w_frag) if prec.npass == 1 else None
+    a.chan_stats = _ptr(chan_stats)
     if out16 is not None:
         a.out16_hi = out16[0].data_ptr()
         a.out16_lo = _ptr(out16[1]) if prec.npass == 3 else None

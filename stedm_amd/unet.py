@@ -227,6 +227,7 @@ class UNetModel(nn.Module):
         self.conv_path = _os.environ.get("STEDM_CONV_PATH", "dma")
         self._gn_slot = 0
         self._style_cache: Dict[Tuple, torch.Tensor] = {}
+        self._cs: Dict[int, torch.Tensor] = {}
 
     # ------------------------------------------------------------------------------------ engine plumbing
     def convert_to_fp16(self):  # openaimodel.py:745-751 — a no-op in the reference too (openaimodel.py:25-29)
@@ -338,23 +339,41 @@ class UNetModel(nn.Module):
         return sc, sh
 
     # ---- DMA path helpers: 16-bit operand planes -------------------------------------------------------------
-    def _planes(self, B, H, W, C):
-        hi = self._buf(f"a16hi.{B}x{H}x{W}x{C}", (B, H, W, C), torch.int16)
-        lo = self._buf(f"a16lo.{B}x{H}x{W}x{C}", (B, H, W, C), torch.int16) if self.precision.npass == 3 else None
+    def _planes(self, B, H, W, C, kind="a16"):
+        hi = self._buf(f"{kind}hi.{B}x{H}x{W}x{C}", (B, H, W, C), torch.int16)
+        lo = self._buf(f"{kind}lo.{B}x{H}x{W}x{C}", (B, H, W, C), torch.int16) if self.precision.npass == 3 else None
         return hi, lo
 
-    def _norm16(self, norm: Optional[nn.GroupNorm], act: int, x1, x2=None, x2_bmod=0):
-        """act(GroupNorm([x1|x2])) (norm None: plain conversion) written once as 16-bit planes."""
+    # Producer-side GroupNorm statistics: tensors written by a conv epilogue carry per-(sample, slab, channel) partial sums
+    # (stedm_conv_args.chan_stats); tensors from other producers get them lazily from one stedm_gn_chan_stats pass. One set of
+    # partials serves every GroupNorm that reads the tensor (next block, decoder concat with its straddling groups).
+    def _cs_new(self, t: torch.Tensor) -> torch.Tensor:
+        B, C = t.shape[0], t.shape[-1]
+        HW = t.numel() // (B * C)
+        cs = self._buf(f"cs.{t.data_ptr()}", (B, ops.gn_chan_nslab(HW), C, 2))
+        self._cs[t.data_ptr()] = cs
+        return cs
+
+    def _chan_stats(self, t: torch.Tensor) -> torch.Tensor:
+        cs = self._cs.get(t.data_ptr())
+        if cs is None:
+            cs = self._cs_new(t)
+            ops.gn_chan_stats(t, cs)
+        return cs
+
+    def _norm16(self, norm: Optional[nn.GroupNorm], act: int, x1, x2=None, x2_bmod=0, want_raw=False):
+        """act(GroupNorm([x1|x2])) (norm None: plain conversion) written once as 16-bit planes. want_raw: also return the
+        plain conversion of [x1|x2] (operand of the 1x1 skip_connection) produced by the same pass."""
         B, H, W, _ = x1.shape
         C = x1.shape[-1] + (0 if x2 is None else x2.shape[-1])
         hi, lo = self._planes(B, H, W, C)
         if norm is None:
             ops.gn_apply16(x1, x2, hi, lo, self.precision, x2_bmod=x2_bmod)
-        else:
-            stats = self._buf("gn_partials", (B * ops.gn_nslab(C, H * W) * norm.num_groups * 2,), torch.float64)
-            ops.gn_stats(x1, x2, stats, norm.num_groups, x2_bmod)
-            ops.gn_apply16(x1, x2, hi, lo, self.precision, norm.weight, norm.bias, norm.eps, norm.num_groups, act, stats, x2_bmod)
-        return hi, lo
+            return hi, lo
+        raw = self._planes(B, H, W, C, "raw16") if want_raw else None
+        ops.gn_apply16c(x1, self._chan_stats(x1), x2, None if x2 is None else self._chan_stats(x2), hi, lo, self.precision,
+                        norm.weight, norm.bias, norm.eps, norm.num_groups, act, x2_bmod, raw)
+        return ((hi, lo), raw) if want_raw else (hi, lo)
 
     def _res(self, tag: str, rb: ResBlock, x1, x2, emb_all, emb_off, emb_bstride, x2_bmod=0):
         """ResBlock._forward openaimodel.py:268-288 on NHWC tensors; [x1|x2] is the virtual concat input."""
@@ -364,22 +383,25 @@ class UNetModel(nn.Module):
         dma = self.conv_path == "dma"
         pk = self._packed[id(rb.in_layers[2])]
         h = self._buf(f"h.{B}x{H}x{W}x{co}", (B, H, W, co))
+        has_skip = not isinstance(rb.skip_connection, nn.Identity)
         if dma:
-            a16 = self._norm16(rb.in_layers[0], 1, x1, x2, x2_bmod)
+            if has_skip:
+                a16, x16 = self._norm16(rb.in_layers[0], 1, x1, x2, x2_bmod, want_raw=True)
+            else:
+                a16 = self._norm16(rb.in_layers[0], 1, x1, x2, x2_bmod)
             ops.conv_igemm(None, pk.hi, pk.lo, h, prec=prec, src16=a16, bias=pk.bias, emb=emb_all, emb_offset=emb_off,
-                           emb_bstride=emb_bstride, w_frag=pk.frag)
+                           emb_bstride=emb_bstride, w_frag=pk.frag, chan_stats=self._cs_new(h))
         else:
             sc, sh = self._gn(tag + ".gn1", rb.in_layers[0], x1, x2, x2_bmod)
             ops.conv_igemm(x1, pk.hi, pk.lo, h, prec=prec, src2=x2, src2_bmod=x2_bmod, scale=sc, shift=sh, act=1, bias=pk.bias,
                            emb=emb_all, emb_offset=emb_off, emb_bstride=emb_bstride)
         out = self._buf(tag + ".out", (B, H, W, co))
-        if isinstance(rb.skip_connection, nn.Identity):
+        if not has_skip:
             assert x2 is None
             res = x1
         else:
             ps = self._packed[id(rb.skip_connection)]
             if dma:
-                x16 = self._norm16(None, 0, x1, x2, x2_bmod)
                 ops.conv_igemm(None, ps.hi, ps.lo, out, prec=prec, ks=1, src16=x16, bias=ps.bias)
             else:
                 ops.conv_igemm(x1, ps.hi, ps.lo, out, prec=prec, ks=1, src2=x2, src2_bmod=x2_bmod, bias=ps.bias)
@@ -387,7 +409,8 @@ class UNetModel(nn.Module):
         pk2 = self._packed[id(rb.out_layers[3])]
         if dma:
             h16 = self._norm16(rb.out_layers[0], 1, h)
-            ops.conv_igemm(None, pk2.hi, pk2.lo, out, prec=prec, src16=h16, bias=pk2.bias, res=res, w_frag=pk2.frag)
+            ops.conv_igemm(None, pk2.hi, pk2.lo, out, prec=prec, src16=h16, bias=pk2.bias, res=res, w_frag=pk2.frag,
+                           chan_stats=self._cs_new(out))
         else:
             sc2, sh2 = self._gn(tag + ".gn2", rb.out_layers[0], h)
             ops.conv_igemm(h, pk2.hi, pk2.lo, out, prec=prec, scale=sc2, shift=sh2, act=1, bias=pk2.bias, res=res)
@@ -501,6 +524,7 @@ class UNetModel(nn.Module):
 
     def _forward_impl(self, x, c_concat, timesteps, contexts, out, uniform_t=False):
         self._prepare()
+        self._cs = {}
         x = x.float().contiguous()
         B, c1, H, W = x.shape
         nrep = len(contexts)

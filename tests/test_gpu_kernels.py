@@ -285,6 +285,76 @@ def test_gn_stats_apply16(dev, B, H, W, c1, c2, bmod):
     assert rel_err(nchw(_as_float(hi, prec) + _as_float(lo, prec)), xin) < 1e-6
 
 
+@pytest.mark.parametrize("B,H,W,c1,c2,bmod", [(2, 8, 8, 64, 0, 0), (3, 16, 16, 128, 0, 0), (2, 8, 8, 1024, 512, 0), (4, 8, 8, 128, 128, 2),
+                                              (2, 32, 32, 128, 0, 0), (2, 16, 16, 512, 128, 0), (2, 32, 32, 512, 128, 0), (4, 16, 16, 1024, 512, 2),
+                                              (3, 4, 4, 1280, 0, 0), (2, 20, 20, 96, 32, 0)])
+def test_gn_chan_stats_apply16c(dev, B, H, W, c1, c2, bmod):
+    """GroupNorm from per-(sample, slab, channel) partials: group boundaries straddle the concat seam (e.g. 1024+512: cpg 48),
+    ragged last slab (20x20), x2 shared modulo bmod; dual output (normalised + plain conversion planes)."""
+    from stedm_amd import ops
+    prec = ops.Precision.parse("parity")
+    C = c1 + c2
+    x1 = prng.normal(13, "g3.x1", (B, c1, H, W)) * 1.7 + 0.3
+    x2 = prng.normal(13, "g3.x2", (bmod or B, c2, H, W)) * 0.6 - 0.2 if c2 else None
+    g = prng.normal(13, "g3.g", (C,), 0.1, 1.0)
+    b = prng.normal(13, "g3.b", (C,), 0.1)
+    x2f = None if x2 is None else (x2 if not bmod else x2.repeat(B // bmod, 1, 1, 1))
+    xin = x1 if x2 is None else torch.cat([x1, x2f], 1)
+    ref = F.silu(F.group_norm(xin, 32, g, b, 1e-5))
+    d1 = nhwc(x1).to(dev); d2 = None if x2 is None else nhwc(x2).to(dev)
+    ns = ops.gn_chan_nslab(H * W)
+    cs1 = torch.full((B, ns, c1, 2), float("nan"), device=dev)
+    ops.gn_chan_stats(d1, cs1)
+    # partials against a direct per-slab sum
+    flat = d1.view(B, H * W, c1).cpu().double()
+    for k in range(ns):
+        sl = flat[:, k * 256:(k + 1) * 256]
+        assert torch.allclose(cs1[:, k, :, 0].cpu().double(), sl.sum(1), rtol=1e-5, atol=1e-3)
+        assert torch.allclose(cs1[:, k, :, 1].cpu().double(), (sl * sl).sum(1), rtol=1e-5, atol=1e-3)
+    cs2 = None
+    if d2 is not None:
+        cs2 = torch.empty((d2.shape[0], ns, c2, 2), device=dev)
+        ops.gn_chan_stats(d2, cs2)
+    hi = torch.empty((B, H, W, C), dtype=torch.int16, device=dev); lo = torch.empty_like(hi)
+    rhi = torch.empty_like(hi); rlo = torch.empty_like(hi)
+    ops.gn_apply16c(d1, cs1, d2, cs2, hi, lo, prec, g.to(dev), b.to(dev), 1e-5, 32, 1, bmod, raw=(rhi, rlo))
+    assert rel_err(nchw(_as_float(hi, prec) + _as_float(lo, prec)), ref) < 2e-5
+    assert rel_err(nchw(_as_float(rhi, prec) + _as_float(rlo, prec)), xin) < 1e-6
+    # bitwise reproducible
+    hi2 = torch.empty_like(hi); lo2 = torch.empty_like(hi)
+    ops.gn_apply16c(d1, cs1, d2, cs2, hi2, lo2, prec, g.to(dev), b.to(dev), 1e-5, 32, 1, bmod)
+    assert torch.equal(hi, hi2) and torch.equal(lo, lo2)
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16", "parity"])
+@pytest.mark.parametrize("B,H,W,cin,cout", [(64, 32, 32, 32, 128), (200, 16, 16, 64, 96), (801, 8, 8, 32, 160), (2, 8, 8, 64, 64), (3, 32, 32, 64, 64)])
+def test_conv_epilogue_chan_stats(dev, prec, B, H, W, cin, cout):
+    """stedm_conv_args.chan_stats: statistics of the stored output (bias / emb / residual included), from the register-streamed
+    kernel's epilogue (large cases, single product) or the dispatcher's extra pass (small cases, parity mode)."""
+    from stedm_amd import ops
+    pr = ops.Precision.parse(prec)
+    x = torch.randn(B, H, W, cin, device=dev)
+    w = torch.randn(cout, cin, 3, 3, device=dev) / math.sqrt(cin * 9)
+    bias = torch.randn(cout, device=dev); emb = torch.randn(B, cout, device=dev); res = torch.randn(B, H, W, cout, device=dev)
+    hi16 = torch.empty((B, H, W, cin), dtype=torch.int16, device=dev); lo16 = torch.empty_like(hi16)
+    ops.gn_apply16(x, None, hi16, lo16, pr)
+    whi, wlo = ops.pack_conv_weight(w, pr)
+    ns = ops.gn_chan_nslab(H * W)
+    out = torch.empty(B, H, W, cout, device=dev)
+    cs = torch.full((B, ns, cout, 2), float("nan"), device=dev)
+    ops.conv_igemm(None, whi, wlo, out, prec=pr, src16=(hi16, lo16), bias=bias, emb=emb, emb_bstride=cout, res=res,
+                   w_frag=ops.pack_conv_weight_frag(w, pr) if pr.npass == 1 else None, chan_stats=cs)
+    flat = out.view(B, H * W, cout).double()
+    for k in range(ns):
+        sl = flat[:, k * 256:(k + 1) * 256]
+        assert torch.allclose(cs[:, k, :, 0].double(), sl.sum(1), rtol=1e-4, atol=2e-3)
+        assert torch.allclose(cs[:, k, :, 1].double(), (sl * sl).sum(1), rtol=1e-4, atol=2e-3)
+    cs2 = torch.full_like(cs, float("nan"))
+    ops.conv_igemm(None, whi, wlo, out, prec=pr, src16=(hi16, lo16), bias=bias, emb=emb, emb_bstride=cout, res=res,
+                   w_frag=ops.pack_conv_weight_frag(w, pr) if pr.npass == 1 else None, chan_stats=cs2)
+    assert torch.equal(cs, cs2)   # no atomics anywhere: bitwise reproducible
+
+
 def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_emb=True, use_res=True, seed=12, frag=False):
     from stedm_amd import ops
     from stedm_amd._lib import CONV_DOWN, CONV_S1, CONV_UP, CONV_UP_SUBPIXEL
