@@ -54,10 +54,13 @@ int stedm_pack_conv_weight(const float* w_oihw, void* w_hi, void* w_lo, int cout
  * with W_eff[py][px][a][b] = sum of the 3x3 taps that read the same low-res pixel (rows: py=0 -> {0},{1,2}; py=1 -> {0,1},{2}). */
 int stedm_pack_conv_weight_up(const float* w_oihw, void* w_hi, void* w_lo, int cout, int cin, int mm_dtype,
                               void* stream);
-/* OIHW 3x3 fp32 -> MFMA-fragment order [ceil(cout/128)][cin/16][9 taps][4][64 lanes][8] 16-bit (single product): the
- * layout the register-streamed 3x3 kernel reads with one coalesced 16-B load per lane and fragment. Passed to
+/* OIHW 3x3 or 1x1 fp32 -> MFMA-fragment order [ceil(cout/128)][cin/16][ks*ks taps][4][64 lanes][8] 16-bit (single product):
+ * the layout the register-streamed kernels read with one coalesced 16-B load per lane and fragment. Passed to
  * stedm_conv_igemm as w_frag (optional; the kernel falls back to w_hi through LDS when it is NULL). */
-int stedm_pack_conv_weight_frag(const float* w_oihw, void* out, int cout, int cin, int mm_dtype, void* stream);
+int stedm_pack_conv_weight_frag(const float* w_oihw, void* out, int cout, int cin, int ks, int mm_dtype, void* stream);
+/* The same for STEDM_CONV_UP_SUBPIXEL: OIHW 3x3 fp32 -> [4 parities][ceil(cout/128)][cin/16][4 taps][4][64][8] with the
+ * pre-summed taps of stedm_pack_conv_weight_up (single product; cin %% 32 == 0). */
+int stedm_pack_conv_weight_up_frag(const float* w_oihw, void* out, int cout, int cin, int mm_dtype, void* stream);
 /* [rows][cols] fp32 -> [cols][rows] fp32 (Linear weights are consumed K-major). */
 int stedm_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
 

@@ -46,7 +46,8 @@ SIGNATURES = {
     "stedm_device_cus": (_I, []),
     "stedm_pack_conv_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "stedm_pack_conv_weight_up": (_I, [_P, _P, _P, _I, _I, _I, _P]),
-    "stedm_pack_conv_weight_frag": (_I, [_P, _P, _I, _I, _I, _P]),
+    "stedm_pack_conv_weight_frag": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "stedm_pack_conv_weight_up_frag": (_I, [_P, _P, _I, _I, _I, _P]),
     "stedm_transpose_f32": (_I, [_P, _P, _I, _I, _P]),
     "stedm_gn_scale_shift": (_I, [_P, _I, _P, _I, _I, _P, _P, _F, _I, _I, _I, _P, _P, _P]),
     "stedm_gn_nslab": (_I, [_I, _I]),

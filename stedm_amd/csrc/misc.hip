@@ -101,29 +101,68 @@ extern "C" int stedm_pack_conv_weight_up(const float* w, void* w_hi, void* w_lo,
 //   out[tn][chunk][tap][q][lane][e] = W[n = tn*128 + (q>>1)*64 + (q&1)*32 + (lane&31)][ci = chunk*16 + (lane>>5)*8 + e][tap]
 // (rows beyond cout are zero). One wave-wide 16-B load = one MFMA B fragment, 1 KiB contiguous.
 template <typename T>
-__global__ void pack_conv_weight_frag_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, long total) {
+__global__ void pack_conv_weight_frag_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, int taps, long total) {
   const int nch = cin / 16;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int e = (int)(i & 7);
     const int lane = (int)((i >> 3) & 63);
     const int q = (int)((i >> 9) & 3);
     long r = i >> 11;
-    const int tap = (int)(r % 9); r /= 9;
+    const int tap = (int)(r % taps); r /= taps;
     const int chunk = (int)(r % nch);
     const int tn = (int)(r / nch);
     const int n = tn * 128 + (q >> 1) * 64 + (q & 1) * 32 + (lane & 31);
     const int ci = chunk * 16 + (lane >> 5) * 8 + e;
-    out[i] = n < cout ? (T)w[((long)n * cin + ci) * 9 + tap] : (T)0.f;
+    out[i] = n < cout ? (T)w[((long)n * cin + ci) * taps + tap] : (T)0.f;
   }
 }
 
-extern "C" int stedm_pack_conv_weight_frag(const float* w, void* out, int cout, int cin, int mm_dtype, void* stream) {
-  STEDM_CHECK_ARG(w && out && cin % 16 == 0, "pack_conv_weight_frag: bad args (cin %% 16)");
+extern "C" int stedm_pack_conv_weight_frag(const float* w, void* out, int cout, int cin, int ks, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(w && out && cin % 16 == 0 && (ks == 1 || ks == 3), "pack_conv_weight_frag: bad args (cin %% 16, ks 1 or 3)");
+  const int taps = ks * ks;
   STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "pack_conv_weight_frag: bad mm_dtype %d", mm_dtype);
-  const long total = (long)((cout + 127) / 128) * (cin / 16) * 9 * 4 * 64 * 8;
+  const long total = (long)((cout + 127) / 128) * (cin / 16) * taps * 4 * 64 * 8;
   const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  if (mm_dtype == STEDM_F16) pack_conv_weight_frag_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(w, (_Float16*)out, cout, cin, total);
-  else pack_conv_weight_frag_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(w, (__bf16*)out, cout, cin, total);
+  if (mm_dtype == STEDM_F16) pack_conv_weight_frag_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(w, (_Float16*)out, cout, cin, taps, total);
+  else pack_conv_weight_frag_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(w, (__bf16*)out, cout, cin, taps, total);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+// Sub-pixel upsample weights (see pack_conv_weight_up_kernel) in fragment order: [4 parities][tn][cin/16][4 taps][4][64][8]
+template <typename T>
+__global__ void pack_conv_weight_up_frag_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, long per_parity) {
+  const int nch = cin / 16;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < 4 * per_parity; i += (long)gridDim.x * blockDim.x) {
+    const int par = (int)(i / per_parity);
+    const long ii = i - par * per_parity;
+    const int e = (int)(ii & 7);
+    const int lane = (int)((ii >> 3) & 63);
+    const int q = (int)((ii >> 9) & 3);
+    long r = ii >> 11;
+    const int tap = (int)(r & 3); r >>= 2;
+    const int chunk = (int)(r % nch);
+    const int tn = (int)(r / nch);
+    const int n = tn * 128 + (q >> 1) * 64 + (q & 1) * 32 + (lane & 31);
+    const int ci = chunk * 16 + (lane >> 5) * 8 + e;
+    const int py = par >> 1, px = par & 1, a = tap >> 1, b = tap & 1;
+    const int dy0 = py == 0 ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), dy1 = py == 0 ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
+    const int dx0 = px == 0 ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), dx1 = px == 0 ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
+    float v = 0.f;
+    if (n < cout)
+      for (int dy = dy0; dy <= dy1; ++dy)
+        for (int dx = dx0; dx <= dx1; ++dx) v += w[((long)n * cin + ci) * 9 + dy * 3 + dx];
+    out[i] = (T)v;
+  }
+}
+
+extern "C" int stedm_pack_conv_weight_up_frag(const float* w, void* out, int cout, int cin, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(w && out && cin % 32 == 0, "pack_conv_weight_up_frag: bad args (cin %% 32)");
+  STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "pack_conv_weight_up_frag: bad mm_dtype %d", mm_dtype);
+  const long per = (long)((cout + 127) / 128) * (cin / 16) * 4 * 4 * 64 * 8;
+  const int grid = (int)((4 * per + 255) / 256 < 8192 ? (4 * per + 255) / 256 : 8192);
+  if (mm_dtype == STEDM_F16) pack_conv_weight_up_frag_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(w, (_Float16*)out, cout, cin, per);
+  else pack_conv_weight_up_frag_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(w, (__bf16*)out, cout, cin, per);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

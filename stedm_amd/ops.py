@@ -88,13 +88,24 @@ def pack_conv_weight_up(w: torch.Tensor, prec: Precision) -> Tuple[torch.Tensor,
 
 
 def pack_conv_weight_frag(w: torch.Tensor, prec: Precision) -> torch.Tensor:
-    """OIHW 3x3 fp32 -> MFMA-fragment-order 16-bit weights (see stedm_pack_conv_weight_frag)."""
+    """OIHW 3x3 / 1x1 fp32 -> MFMA-fragment-order 16-bit weights (see stedm_pack_conv_weight_frag)."""
     w = w.detach().contiguous()
     _chk(w, name="conv weight")
     cout, cin, ks, _ = w.shape
-    assert ks == 3 and cin % 16 == 0
-    out = torch.empty(((cout + 127) // 128, cin // 16, 9, 4, 64, 8), dtype=torch.int16, device=w.device)
-    check(lib().stedm_pack_conv_weight_frag(w.data_ptr(), out.data_ptr(), cout, cin, prec.mm_dtype, _stream()), "stedm_pack_conv_weight_frag")
+    assert ks in (1, 3) and cin % 16 == 0
+    out = torch.empty(((cout + 127) // 128, cin // 16, ks * ks, 4, 64, 8), dtype=torch.int16, device=w.device)
+    check(lib().stedm_pack_conv_weight_frag(w.data_ptr(), out.data_ptr(), cout, cin, ks, prec.mm_dtype, _stream()), "stedm_pack_conv_weight_frag")
+    return out
+
+
+def pack_conv_weight_up_frag(w: torch.Tensor, prec: Precision) -> torch.Tensor:
+    """OIHW 3x3 fp32 -> fragment-order weights of the sub-pixel upsample form (4 parities x 4 pre-summed taps)."""
+    w = w.detach().contiguous()
+    _chk(w, name="conv weight")
+    cout, cin, ks, _ = w.shape
+    assert ks == 3 and cin % 32 == 0
+    out = torch.empty((4, (cout + 127) // 128, cin // 16, 4, 4, 64, 8), dtype=torch.int16, device=w.device)
+    check(lib().stedm_pack_conv_weight_up_frag(w.data_ptr(), out.data_ptr(), cout, cin, prec.mm_dtype, _stream()), "stedm_pack_conv_weight_up_frag")
     return out
 
 

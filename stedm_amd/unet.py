@@ -282,8 +282,13 @@ class UNetModel(nn.Module):
         def pack(conv):
             hi, lo = ops.pack_conv_weight(conv.weight.float(), prec)
             frag = None
-            if self.conv_path == "dma" and prec.npass == 1 and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.in_channels % 16 == 0:
-                frag = ops.pack_conv_weight_frag(conv.weight.float(), prec)   # register-streamed weights of the 3x3 kernel
+            w4 = conv.weight.float()
+            if w4.dim() == 3:     # Conv1d qkv / proj_out of the AttentionBlock
+                w4 = w4.unsqueeze(-1)
+            k3 = tuple(w4.shape[2:]) == (3, 3) and conv.stride == (1, 1) and conv.in_channels % 16 == 0
+            k1 = tuple(w4.shape[2:]) == (1, 1) and conv.in_channels % 64 == 0
+            if self.conv_path == "dma" and prec.npass == 1 and (k3 or k1):
+                frag = ops.pack_conv_weight_frag(w4, prec)   # register-streamed weights
             self._packed[id(conv)] = _Packed(hi, lo, None if conv.bias is None else conv.bias.detach().float().contiguous(), frag)
 
         for m in self.modules():
@@ -298,7 +303,8 @@ class UNetModel(nn.Module):
                 pack(m.conv)
                 if self.conv_path == "dma":   # sub-pixel form: 4 parity 2x2 convs with pre-summed taps
                     hi, lo = ops.pack_conv_weight_up(m.conv.weight.float(), prec)
-                    self._packed[(id(m.conv), "up")] = _Packed(hi, lo, self._packed[id(m.conv)].bias)
+                    frag = ops.pack_conv_weight_up_frag(m.conv.weight.float(), prec) if prec.npass == 1 and m.conv.in_channels % 32 == 0 else None
+                    self._packed[(id(m.conv), "up")] = _Packed(hi, lo, self._packed[id(m.conv)].bias, frag)
             elif isinstance(m, AttentionBlock):
                 pack(m.qkv)
                 pack(m.proj_out)
@@ -402,7 +408,7 @@ class UNetModel(nn.Module):
         else:
             ps = self._packed[id(rb.skip_connection)]
             if dma:
-                ops.conv_igemm(None, ps.hi, ps.lo, out, prec=prec, ks=1, src16=x16, bias=ps.bias)
+                ops.conv_igemm(None, ps.hi, ps.lo, out, prec=prec, ks=1, src16=x16, bias=ps.bias, w_frag=ps.frag)
             else:
                 ops.conv_igemm(x1, ps.hi, ps.lo, out, prec=prec, ks=1, src2=x2, src2_bmod=x2_bmod, bias=ps.bias)
             res = out
@@ -424,7 +430,7 @@ class UNetModel(nn.Module):
         pq = self._packed[id(ab.qkv)]
         qkv = self._buf(tag + ".qkv", (B, H, W, 3 * Cc))
         if dma:
-            ops.conv_igemm(None, pq.hi, pq.lo, qkv, prec=prec, ks=1, src16=self._norm16(ab.norm, 0, x), bias=pq.bias)
+            ops.conv_igemm(None, pq.hi, pq.lo, qkv, prec=prec, ks=1, src16=self._norm16(ab.norm, 0, x), bias=pq.bias, w_frag=pq.frag)
         else:
             sc, sh = self._gn(tag + ".gn", ab.norm, x)
             ops.conv_igemm(x, pq.hi, pq.lo, qkv, prec=prec, ks=1, scale=sc, shift=sh, act=0, bias=pq.bias)
@@ -433,7 +439,8 @@ class UNetModel(nn.Module):
         pp = self._packed[id(ab.proj_out)]
         out = self._buf(tag + ".out", (B, H, W, Cc))
         if dma:
-            ops.conv_igemm(None, pp.hi, pp.lo, out, prec=prec, ks=1, src16=self._norm16(None, 0, a), bias=pp.bias, res=x)
+            ops.conv_igemm(None, pp.hi, pp.lo, out, prec=prec, ks=1, src16=self._norm16(None, 0, a), bias=pp.bias, res=x, w_frag=pp.frag,
+                           chan_stats=self._cs_new(out))
         else:
             ops.conv_igemm(a, pp.hi, pp.lo, out, prec=prec, ks=1, bias=pp.bias, res=x)
         return out
@@ -465,7 +472,7 @@ class UNetModel(nn.Module):
                 if self.conv_path == "dma":
                     pu = self._packed[(id(layer.conv), "up")]
                     h = ops.conv_igemm(None, pu.hi, pu.lo, out, prec=self.precision, mode=CONV_UP_SUBPIXEL,
-                                       src16=self._norm16(None, 0, h), bias=pu.bias)
+                                       src16=self._norm16(None, 0, h), bias=pu.bias, w_frag=pu.frag)
                 else:
                     h = ops.conv_igemm(h, pk.hi, pk.lo, out, prec=self.precision, mode=CONV_UP, bias=pk.bias)
             else:

@@ -385,7 +385,7 @@ def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_em
     ops.conv_igemm(src1, whi, wlo, out, prec=prec, ks=ks, mode=m, src16=(hi16, lo16), bias=bias.to(dev),
                    emb=None if emb is None else emb.to(dev), emb_offset=8, emb_bstride=0 if emb is None else emb.shape[1],
                    res=None if res is None else nhwc(res).to(dev),
-                   w_frag=ops.pack_conv_weight_frag(w.to(dev), prec) if frag else None)
+                   w_frag=None if not frag else (ops.pack_conv_weight_up_frag(w.to(dev), prec) if mode == "up2" else ops.pack_conv_weight_frag(w.to(dev), prec)))
     torch.cuda.synchronize()
     err = rel_err(nchw(out), ref)
     assert err < tol, f"{prec_name}: rel err {err:.3e} >= {tol}"
@@ -407,6 +407,21 @@ def test_conv_dma_3x3_frag_weights(dev, prec, tol, B, H, W, cin, cout, emb, res)
     """256-row tile kernel with register-streamed fragment-order weights (conv_igemm_dma9g.inc); shapes fill >= 192 tiles so it is
     the kernel the dispatcher picks; ragged sample counts, cout not a multiple of 128, partial last tile."""
     _conv_dma_case(dev, prec, tol, B, H, W, cin, cout, "s1", 3, use_emb=emb, use_res=res, frag=True)
+
+
+@pytest.mark.parametrize("prec,tol", PRECS[1:])
+@pytest.mark.parametrize("B,H,W,cin,cout,res", [(128, 8, 8, 2048, 1024, False), (200, 16, 16, 192, 96, True), (64, 32, 32, 64, 128, False),
+                                                (801, 8, 8, 128, 160, True), (50, 32, 32, 640, 128, True), (13, 64, 64, 64, 32, False)])
+def test_conv_dma_1x1_frag_weights(dev, prec, tol, B, H, W, cin, cout, res):
+    """1x1 convolution as 4 register-streamed 16-channel slices per barrier (conv_rs_kernel<.., 1, 4>)."""
+    _conv_dma_case(dev, prec, tol, B, H, W, cin, cout, "s1", 1, use_emb=False, use_res=res, frag=True)
+
+
+@pytest.mark.parametrize("prec,tol", PRECS[1:])
+@pytest.mark.parametrize("B,H,W,c,cout", [(128, 8, 8, 64, 128), (50, 16, 16, 128, 96), (201, 8, 8, 32, 32), (13, 32, 32, 64, 160), (803, 4, 4, 32, 128)])
+def test_conv_dma_up_subpixel_frag_weights(dev, prec, tol, B, H, W, c, cout):
+    """sub-pixel upsample through the register-streamed kernel (conv_rs_kernel<.., 4, 2>, 4 parities x tiles)."""
+    _conv_dma_case(dev, prec, tol, B, H, W, c, cout, "up2", 3, use_emb=True, use_res=True, frag=True)
 
 
 def test_pack_conv_weight_frag_layout(dev):

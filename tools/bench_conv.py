@@ -48,7 +48,9 @@ def main():
             C = cin
             h16 = torch.empty(B, H, W, C, dtype=torch.int16, device=dev); l16 = torch.empty_like(h16)
             ops.gn_apply16(x1, x2, h16, l16 if prec.npass == 3 else None, prec)
-            wf = ops.pack_conv_weight_frag(w, prec) if (os.environ.get("BENCH_FRAG") and ks == 3 and mode == CONV_S1 and prec.npass == 1) else None
+            wf = None
+            if os.environ.get("BENCH_FRAG") and prec.npass == 1 and mode in (CONV_S1, CONV_UP_SUBPIXEL):
+                wf = ops.pack_conv_weight_up_frag(w, prec) if mode == CONV_UP_SUBPIXEL else ops.pack_conv_weight_frag(w, prec)
             run = lambda: ops.conv_igemm(None, hi, lo, out, prec=prec, ks=ks, mode=mode, src16=(h16, l16), bias=bias, w_frag=wf)
         else:
             run = lambda: ops.conv_igemm(x1, hi, lo, out, prec=prec, ks=ks, mode=mode, src2=x2, scale=sc, shift=sh, act=1 if gn else 0, bias=bias)
