@@ -130,11 +130,22 @@ typedef struct stedm_conv_args {
   const void* w_frag; /* optional: fragment-order weights (stedm_pack_conv_weight_frag) for 3x3, npass 1, DMA path */
   float* chan_stats;  /* optional: [B][stedm_gn_chan_nslab(Hout*Wout)][cout][2] per-(sample, 256-pixel slab, channel) sum and
                        * sum of squares of `out` (the next GroupNorm's statistics, see stedm_gn_apply16c); needs out != NULL */
+  /* Fused skip_connection (optional, 3x3 stride 1, single product, needs w_frag): out = conv3x3(src16) + conv1x1(src16b) +
+   * bias + bias_b — the ResBlock tail `skip_connection(x) + h` (openaimodel.py:254, 288) in one kernel. src16b_hi: raw 16-bit
+   * planes [B][Hin][Win][cb] of the block input (raw output of stedm_gn_apply16c), cb %% 64 == 0; w_frag_b: the 1x1 weights in
+   * fragment order (stedm_pack_conv_weight_frag, ks 1); res must be NULL. stedm_conv_fused_skip_ok() tells whether the
+   * fused kernel covers a given problem; stedm_conv_igemm fails when asked for a fusion it cannot run. */
+  const void* src16b_hi;
+  const void* w_frag_b;
+  const float* bias_b;
+  int32_t cb;
 } stedm_conv_args;
 /* Replaces: GN->SiLU->conv3x3(+bias)(+emb)(+skip) of ResBlock._forward openaimodel.py:268-288,
  * Downsample/Upsample convs (:122-132,:156-173), 1x1 skip_connection (:254), and the 1x1
  * Conv1d qkv / proj_out of AttentionBlock (:326,:334,:343-346). */
 int stedm_conv_igemm(const stedm_conv_args* args, void* stream);
+/* 1 when stedm_conv_igemm would run `args` (with src16b_hi / w_frag_b / cb set) as one fused kernel, else 0. No launch. */
+int stedm_conv_fused_skip_ok(const stedm_conv_args* args);
 
 /* ---- boundary convs (NCHW <-> NHWC) ------------------------------------------------------- */
 /* input_blocks.0: conv3x3(cat([x, c_concat],1)) — DiffusionWrapper hybrid ddpm.py:1414-1417 +

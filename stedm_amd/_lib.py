@@ -35,6 +35,7 @@ class ConvArgs(C.Structure):
         ("src16_hi", C.c_void_p), ("src16_lo", C.c_void_p),
         ("act_out", C.c_int32), ("out16_hi", C.c_void_p), ("out16_lo", C.c_void_p),
         ("w_frag", C.c_void_p), ("chan_stats", C.c_void_p),
+        ("src16b_hi", C.c_void_p), ("w_frag_b", C.c_void_p), ("bias_b", C.c_void_p), ("cb", C.c_int32),
     ]
 
 
@@ -57,6 +58,7 @@ SIGNATURES = {
     "stedm_gn_chan_stats": (_I, [_P, _I, _I, _I, _P, _P]),
     "stedm_gn_apply16c": (_I, [_P, _I, _P, _P, _I, _P, _I, _P, _P, _F, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "stedm_conv_igemm": (_I, [C.POINTER(ConvArgs), _P]),
+    "stedm_conv_fused_skip_ok": (_I, [C.POINTER(ConvArgs)]),
     "stedm_conv_in": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "stedm_conv_out": (_I, [_P, _I, _P, _I, _P, _P, _F, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "stedm_time_embed": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

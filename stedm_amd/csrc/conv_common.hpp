@@ -47,5 +47,5 @@ bool conv_geometry(ConvParams& p, int bm);
 // v2 (warp-specialised) launcher; returns -1 when v2 does not support this problem (caller falls back to v1).
 int conv_launch_ws(ConvParams& p, hipStream_t st);
 // v3 (LDS-DMA operands from 16-bit activation planes); 0 ok, > 0 error (message set).
-int conv_launch_dma(ConvParams& p, hipStream_t st);
+int conv_launch_dma(ConvParams& p, hipStream_t st, bool dry = false);
 }  // namespace stedm

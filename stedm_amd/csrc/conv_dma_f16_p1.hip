@@ -2,9 +2,9 @@
 #include "conv_igemm_dma9.inc"
 #include "conv_igemm_dma9g.inc"
 namespace stedm {
-int conv_dma_pick_f16_p1(ConvParams& p, hipStream_t st) {
-  int rc = dma9g_pick<_Float16>(p, st);             // 3x3 with fragment-order weights: weights bypass LDS
-  if (rc >= 0) return rc;
+int conv_dma_pick_f16_p1(ConvParams& p, hipStream_t st, bool dry) {
+  int rc = dma9g_pick<_Float16>(p, st, dry);        // fragment-order weights: weights bypass LDS
+  if (rc >= 0 || dry || p.a.src16b_hi) return rc;   // a fused skip phase exists in that kernel only
   rc = dma9_pick<_Float16>(p, st);     // 3x3: one barrier per 16-channel chunk
   return rc >= 0 ? rc : dma_pick<1, _Float16>(p, st);
 }

@@ -313,6 +313,16 @@ bool stedm::conv_geometry(ConvParams& p, int bm) {
 }
 
 static int conv_dispatch(ConvParams& p, void* stream);
+static int conv_setup(ConvParams& p);
+
+extern "C" int stedm_conv_fused_skip_ok(const stedm_conv_args* args) {
+  if (!args || !args->src16b_hi || !args->src16_hi) return 0;
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.a = *args;
+  if (conv_setup(p) != 0) return 0;
+  return conv_launch_dma(p, nullptr, /*dry=*/true) == 0 ? 1 : 0;
+}
 
 extern "C" int stedm_conv_igemm(const stedm_conv_args* args, void* stream) {
   STEDM_CHECK_ARG(args, "conv_igemm: null args");
@@ -328,7 +338,8 @@ extern "C" int stedm_conv_igemm(const stedm_conv_args* args, void* stream) {
   return stedm_gn_chan_stats(a.out, a.cout, a.B, a.Hin * a.Win * up / down, a.chan_stats, stream);
 }
 
-static int conv_dispatch(ConvParams& p, void* stream) {
+// validates the arguments and fills the derived sizes of `p`
+static int conv_setup(ConvParams& p) {
   const stedm_conv_args& a = p.a;
   STEDM_CHECK_ARG((a.src1 || a.src16_hi) && a.w_hi && (a.out || a.out16_hi), "conv_igemm: null src/w_hi/out");
   STEDM_CHECK_ARG((!a.act_out && !a.out16_hi) || (a.src16_hi && !a.src1), "conv_igemm: act_out/out16 need the DMA path (src16 only)");
@@ -359,6 +370,15 @@ static int conv_dispatch(ConvParams& p, void* stream) {
   p.M = a.B * p.HWout;
   STEDM_CHECK_ARG(p.Cin % 32 == 0 && (a.c2 == 0 || a.c1 % 32 == 0),
                   "conv_igemm: channel counts must be multiples of 32 (c1=%d c2=%d)", a.c1, a.c2);
+  STEDM_CHECK_ARG(!a.src16b_hi || (a.src16_hi && !a.src1 && a.w_frag && a.w_frag_b && a.ks == 3 && a.mode == STEDM_CONV_S1 && a.npass == 1 && !a.res &&
+                                   a.cb > 0 && a.cb % 64 == 0),
+                  "conv_igemm: the fused skip phase needs the DMA path (src16 only), 3x3 stride 1, single product, w_frag + w_frag_b, cb %% 64 == 0, no res");
+  return 0;
+}
+
+static int conv_dispatch(ConvParams& p, void* stream) {
+  const stedm_conv_args& a = p.a;
+  { const int rc = conv_setup(p); if (rc) return rc; }
   hipStream_t st = as_stream(stream);
   static const int dbg0 = getenv("STEDM_CONV_DBG") ? atoi(getenv("STEDM_CONV_DBG")) : 0;
   p.dbg = dbg0;

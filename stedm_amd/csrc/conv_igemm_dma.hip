@@ -4,14 +4,20 @@
 using namespace stedm;
 
 namespace stedm {
-int conv_dma_pick_f16_p1(ConvParams&, hipStream_t);
+int conv_dma_pick_f16_p1(ConvParams&, hipStream_t, bool dry);
 int conv_dma_pick_f16_p3(ConvParams&, hipStream_t);
-int conv_dma_pick_bf16_p1(ConvParams&, hipStream_t);
+int conv_dma_pick_bf16_p1(ConvParams&, hipStream_t, bool dry);
 int conv_dma_pick_bf16_p3(ConvParams&, hipStream_t);
 }  // namespace stedm
 
-int stedm::conv_launch_dma(ConvParams& p, hipStream_t st) {
+int stedm::conv_launch_dma(ConvParams& p, hipStream_t st, bool dry) {
   const stedm_conv_args& a = p.a;
+  if (a.src16b_hi && a.npass != 1) { set_error("conv_igemm(dma): the fused skip phase is single-product only"); return 1; }
+  if (dry && a.npass != 1) return 1;
+  if (a.src16b_hi && ((long)a.B * a.Hin * a.Win * a.cb >= (1L << 31) || a.cb * 2 + 256 > 16384)) {
+    set_error("conv_igemm(dma): fused skip operand too large (cb=%d)", a.cb);
+    return 1;
+  }
   if ((long)a.B * a.Hin * a.Win * p.Cin >= (1L << 31)) {
     set_error("conv_igemm(dma): activation tensor too large for 32-bit element offsets");
     return 1;
@@ -19,7 +25,9 @@ int stedm::conv_launch_dma(ConvParams& p, hipStream_t st) {
   if (p.Cin * 2 + 256 > 16384) { set_error("conv_igemm(dma): Cin too large for the zero page"); return 1; }
   const bool f16 = a.mm_dtype == STEDM_F16;
   int rc = a.npass == 3 ? (f16 ? conv_dma_pick_f16_p3(p, st) : conv_dma_pick_bf16_p3(p, st))
-                        : (f16 ? conv_dma_pick_f16_p1(p, st) : conv_dma_pick_bf16_p1(p, st));
+                        : (f16 ? conv_dma_pick_f16_p1(p, st, dry) : conv_dma_pick_bf16_p1(p, st, dry));
+  if (dry) return rc < 0 ? 1 : 0;
+  if (rc < 0 && a.src16b_hi) { set_error("conv_igemm(dma): no kernel runs this fused skip problem (see stedm_conv_fused_skip_ok)"); return 1; }
   if (rc < 0) { set_error("conv_igemm(dma): no tile configuration fits (Hin=%d Win=%d mode=%d Cin=%d)", a.Hin, a.Win, a.mode, p.Cin); return 1; }
   return rc;
 }

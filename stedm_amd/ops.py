@@ -200,7 +200,8 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
                emb_bstride: int = 0, res: Optional[torch.Tensor] = None,
                src16: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None, act_out: int = 0,
                out16: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None, w_frag: Optional[torch.Tensor] = None,
-               chan_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+               chan_stats: Optional[torch.Tensor] = None,
+               skip: Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = None, query_fused: bool = False):
     """src1 [B,Hin,Win,c1] NHWC fp32 (fused path) and/or src16 = (hi, lo) 16-bit NHWC planes [B,Hin,Win,Cin] from
     gn_apply16 (DMA path) -> out [B,Hout,Wout,cout] NHWC fp32 (see stedm_conv_igemm)."""
     if out is not None:
@@ -209,6 +210,11 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
     a.act_out = act_out
     a.w_frag = _ptr(w_frag) if prec.npass == 1 else None
     a.chan_stats = _ptr(chan_stats)
+    if skip is not None:   # fused skip_connection: (raw 16-bit planes of the block input, 1x1 weights in fragment order, bias)
+        a.src16b_hi = skip[0].data_ptr()
+        a.cb = skip[0].shape[-1]
+        a.w_frag_b = skip[1].data_ptr()
+        a.bias_b = _ptr(skip[2])
     if out16 is not None:
         a.out16_hi = out16[0].data_ptr()
         a.out16_lo = _ptr(out16[1]) if prec.npass == 3 else None
@@ -242,6 +248,8 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
         assert w_hi.shape == (4 * a.cout, 4, a.c1 + a.c2), (w_hi.shape, a.cout, a.c1, a.c2)
     else:
         assert w_hi.shape == (a.cout, ks * ks, a.c1 + a.c2), (w_hi.shape, a.cout, ks, a.c1, a.c2)
+    if query_fused:     # capability query only: would this (fused) problem run as one kernel?
+        return bool(lib().stedm_conv_fused_skip_ok(C.byref(a)))
     check(lib().stedm_conv_igemm(C.byref(a), _stream()), "stedm_conv_igemm")
     return out
 

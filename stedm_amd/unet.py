@@ -402,17 +402,31 @@ class UNetModel(nn.Module):
             ops.conv_igemm(x1, pk.hi, pk.lo, h, prec=prec, src2=x2, src2_bmod=x2_bmod, scale=sc, shift=sh, act=1, bias=pk.bias,
                            emb=emb_all, emb_offset=emb_off, emb_bstride=emb_bstride)
         out = self._buf(tag + ".out", (B, H, W, co))
+        pk2 = self._packed[id(rb.out_layers[3])]
+        if dma and has_skip:
+            # conv2 + skip_connection(x) in one kernel when the register-streamed kernel covers the problem (asked once per shape)
+            ps = self._packed[id(rb.skip_connection)]
+            h16 = self._norm16(rb.out_layers[0], 1, h)
+            fuse_key = ("fuse", id(rb), B, H, W)
+            fused = self._consts.get(fuse_key)
+            kw = dict(prec=prec, src16=h16, bias=pk2.bias, w_frag=pk2.frag, chan_stats=self._cs_new(out))
+            if fused is None:
+                fused = bool(pk2.frag is not None and ps.frag is not None and
+                             ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias), query_fused=True, **kw))
+                self._consts[fuse_key] = fused
+            if fused:
+                ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias), **kw)
+            else:
+                ops.conv_igemm(None, ps.hi, ps.lo, out, prec=prec, ks=1, src16=x16, bias=ps.bias, w_frag=ps.frag)
+                ops.conv_igemm(None, pk2.hi, pk2.lo, out, res=out, **kw)
+            return out
         if not has_skip:
             assert x2 is None
             res = x1
         else:
             ps = self._packed[id(rb.skip_connection)]
-            if dma:
-                ops.conv_igemm(None, ps.hi, ps.lo, out, prec=prec, ks=1, src16=x16, bias=ps.bias, w_frag=ps.frag)
-            else:
-                ops.conv_igemm(x1, ps.hi, ps.lo, out, prec=prec, ks=1, src2=x2, src2_bmod=x2_bmod, bias=ps.bias)
+            ops.conv_igemm(x1, ps.hi, ps.lo, out, prec=prec, ks=1, src2=x2, src2_bmod=x2_bmod, bias=ps.bias)
             res = out
-        pk2 = self._packed[id(rb.out_layers[3])]
         if dma:
             h16 = self._norm16(rb.out_layers[0], 1, h)
             ops.conv_igemm(None, pk2.hi, pk2.lo, out, prec=prec, src16=h16, bias=pk2.bias, res=res, w_frag=pk2.frag,

@@ -424,6 +424,59 @@ def test_conv_dma_up_subpixel_frag_weights(dev, prec, tol, B, H, W, c, cout):
     _conv_dma_case(dev, prec, tol, B, H, W, c, cout, "up2", 3, use_emb=True, use_res=True, frag=True)
 
 
+@pytest.mark.parametrize("prec,tol", PRECS[1:])
+@pytest.mark.parametrize("B,H,W,cin,cb,cout,emb", [(64, 32, 32, 32, 64, 128, False), (200, 16, 16, 64, 192, 96, True), (801, 8, 8, 32, 128, 160, False),
+                                                   (128, 8, 8, 512, 1024, 768, False), (50, 32, 32, 128, 640, 128, True), (13, 64, 64, 32, 64, 32, False)])
+def test_conv_fused_skip(dev, prec, tol, B, H, W, cin, cb, cout, emb):
+    """conv3x3(h) + conv1x1(x) + both biases in one kernel (ResBlock tail `skip_connection(x) + h`, openaimodel.py:288):
+    the 1x1 runs as a second K-phase of the register-streamed 3x3 kernel; per-channel statistics of the sum come with it."""
+    from stedm_amd import ops
+    pr = ops.Precision.parse(prec)
+    hsrc = F.silu(prng.normal(21, "fs.h", (B, cin, H, W)))
+    x = prng.normal(21, "fs.x", (B, cb, H, W))
+    w3 = prng.normal(21, "fs.w3", (cout, cin, 3, 3), 1.0 / math.sqrt(cin * 9))
+    w1 = prng.normal(21, "fs.w1", (cout, cb, 1, 1), 1.0 / math.sqrt(cb))
+    b3 = prng.normal(21, "fs.b3", (cout,), 0.05); b1 = prng.normal(21, "fs.b1", (cout,), 0.05)
+    ref = F.conv2d(hsrc, w3, b3, padding=1) + F.conv2d(x, w1, b1)
+    e = None
+    if emb:
+        e = prng.normal(21, "fs.e", (B, cout)); ref = ref + e[:, :, None, None]
+    h16 = torch.empty((B, H, W, cin), dtype=torch.int16, device=dev); x16 = torch.empty((B, H, W, cb), dtype=torch.int16, device=dev)
+    ops.gn_apply16(nhwc(hsrc).to(dev), None, h16, None, pr)
+    ops.gn_apply16(nhwc(x).to(dev), None, x16, None, pr)
+    whi, wlo = ops.pack_conv_weight(w3.to(dev), pr)
+    out = torch.full((B, H, W, cout), float("nan"), device=dev)
+    cs = torch.full((B, ops.gn_chan_nslab(H * W), cout, 2), float("nan"), device=dev)
+    kw = dict(prec=pr, src16=(h16, None), bias=b3.to(dev), emb=None if e is None else e.to(dev), emb_bstride=0 if e is None else cout,
+              w_frag=ops.pack_conv_weight_frag(w3.to(dev), pr), chan_stats=cs,
+              skip=(x16, ops.pack_conv_weight_frag(w1.to(dev), pr), b1.to(dev)))
+    assert ops.conv_igemm(None, whi, wlo, out, query_fused=True, **kw)
+    ops.conv_igemm(None, whi, wlo, out, **kw)
+    torch.cuda.synchronize()
+    err = rel_err(nchw(out), ref)
+    assert err < tol, f"{prec}: rel err {err:.3e} >= {tol}"
+    flat = out.view(B, H * W, cout).double()
+    for k in range(cs.shape[1]):
+        sl = flat[:, k * 256:(k + 1) * 256]
+        assert torch.allclose(cs[:, k, :, 0].double(), sl.sum(1), rtol=1e-4, atol=2e-3)
+
+
+def test_conv_fused_skip_rejected_when_unsupported(dev):
+    """a fusion the kernel cannot run is reported by the query and refused by the call (never silently dropped)."""
+    from stedm_amd import ops
+    from stedm_amd._lib import StedmHipError
+    pr = ops.Precision.parse("bf16")
+    B, H, W, cin, cb, cout = 2, 8, 8, 32, 64, 32      # too few tiles for the 256-row kernel
+    h16 = torch.zeros((B, H, W, cin), dtype=torch.int16, device=dev); x16 = torch.zeros((B, H, W, cb), dtype=torch.int16, device=dev)
+    w3 = torch.randn(cout, cin, 3, 3, device=dev); w1 = torch.randn(cout, cb, 1, 1, device=dev)
+    whi, wlo = ops.pack_conv_weight(w3, pr)
+    out = torch.empty(B, H, W, cout, device=dev)
+    kw = dict(prec=pr, src16=(h16, None), w_frag=ops.pack_conv_weight_frag(w3, pr), skip=(x16, ops.pack_conv_weight_frag(w1, pr), None))
+    assert not ops.conv_igemm(None, whi, wlo, out, query_fused=True, **kw)
+    with pytest.raises(StedmHipError):
+        ops.conv_igemm(None, whi, wlo, out, **kw)
+
+
 def test_pack_conv_weight_frag_layout(dev):
     from stedm_amd import ops
     prec = ops.Precision.parse("f16")
