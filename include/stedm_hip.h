@@ -139,6 +139,10 @@ typedef struct stedm_conv_args {
   const void* w_frag_b;
   const float* bias_b;
   int32_t cb;
+  /* Optional workspace (fp32, ws_floats >= 2 * B*Hout*Wout*cout): lets a 3x3 convolution whose grid would leave CUs idle split its
+   * K range over two blocks per tile; the partial tiles are summed in a fixed order by a reduce kernel (bitwise reproducible). */
+  float* ws;
+  int64_t ws_floats;
 } stedm_conv_args;
 /* Replaces: GN->SiLU->conv3x3(+bias)(+emb)(+skip) of ResBlock._forward openaimodel.py:268-288,
  * Downsample/Upsample convs (:122-132,:156-173), 1x1 skip_connection (:254), and the 1x1

@@ -36,6 +36,7 @@ class ConvArgs(C.Structure):
         ("act_out", C.c_int32), ("out16_hi", C.c_void_p), ("out16_lo", C.c_void_p),
         ("w_frag", C.c_void_p), ("chan_stats", C.c_void_p),
         ("src16b_hi", C.c_void_p), ("w_frag_b", C.c_void_p), ("bias_b", C.c_void_p), ("cb", C.c_int32),
+        ("ws", C.c_void_p), ("ws_floats", C.c_int64),
     ]
 
 

@@ -201,7 +201,8 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
                src16: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None, act_out: int = 0,
                out16: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None, w_frag: Optional[torch.Tensor] = None,
                chan_stats: Optional[torch.Tensor] = None,
-               skip: Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = None, query_fused: bool = False):
+               skip: Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = None, query_fused: bool = False,
+               ws: Optional[torch.Tensor] = None):
     """src1 [B,Hin,Win,c1] NHWC fp32 (fused path) and/or src16 = (hi, lo) 16-bit NHWC planes [B,Hin,Win,Cin] from
     gn_apply16 (DMA path) -> out [B,Hout,Wout,cout] NHWC fp32 (see stedm_conv_igemm)."""
     if out is not None:
@@ -210,6 +211,9 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
     a.act_out = act_out
     a.w_frag = _ptr(w_frag) if prec.npass == 1 else None
     a.chan_stats = _ptr(chan_stats)
+    if ws is not None:   # fp32 workspace for the split-K form of small grids
+        a.ws = ws.data_ptr()
+        a.ws_floats = ws.numel()
     if skip is not None:   # fused skip_connection: (raw 16-bit planes of the block input, 1x1 weights in fragment order, bias)
         a.src16b_hi = skip[0].data_ptr()
         a.cb = skip[0].shape[-1]

@@ -395,8 +395,9 @@ class UNetModel(nn.Module):
                 a16, x16 = self._norm16(rb.in_layers[0], 1, x1, x2, x2_bmod, want_raw=True)
             else:
                 a16 = self._norm16(rb.in_layers[0], 1, x1, x2, x2_bmod)
+            ws = self._buf("conv_ws", (2 * B * H * W * co,)) if B * H * W * co <= (1 << 23) else None   # split-K workspace (small grids only)
             ops.conv_igemm(None, pk.hi, pk.lo, h, prec=prec, src16=a16, bias=pk.bias, emb=emb_all, emb_offset=emb_off,
-                           emb_bstride=emb_bstride, w_frag=pk.frag, chan_stats=self._cs_new(h))
+                           emb_bstride=emb_bstride, w_frag=pk.frag, chan_stats=self._cs_new(h), ws=ws)
         else:
             sc, sh = self._gn(tag + ".gn1", rb.in_layers[0], x1, x2, x2_bmod)
             ops.conv_igemm(x1, pk.hi, pk.lo, h, prec=prec, src2=x2, src2_bmod=x2_bmod, scale=sc, shift=sh, act=1, bias=pk.bias,
@@ -430,7 +431,7 @@ class UNetModel(nn.Module):
         if dma:
             h16 = self._norm16(rb.out_layers[0], 1, h)
             ops.conv_igemm(None, pk2.hi, pk2.lo, out, prec=prec, src16=h16, bias=pk2.bias, res=res, w_frag=pk2.frag,
-                           chan_stats=self._cs_new(out))
+                           chan_stats=self._cs_new(out), ws=ws)
         else:
             sc2, sh2 = self._gn(tag + ".gn2", rb.out_layers[0], h)
             ops.conv_igemm(h, pk2.hi, pk2.lo, out, prec=prec, scale=sc2, shift=sh2, act=1, bias=pk2.bias, res=res)

@@ -355,7 +355,7 @@ def test_conv_epilogue_chan_stats(dev, prec, B, H, W, cin, cout):
     assert torch.equal(cs, cs2)   # no atomics anywhere: bitwise reproducible
 
 
-def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_emb=True, use_res=True, seed=12, frag=False):
+def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_emb=True, use_res=True, seed=12, frag=False, ws=False):
     from stedm_amd import ops
     from stedm_amd._lib import CONV_DOWN, CONV_S1, CONV_UP, CONV_UP_SUBPIXEL
     prec = ops.Precision.parse(prec_name)
@@ -385,7 +385,8 @@ def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_em
     ops.conv_igemm(src1, whi, wlo, out, prec=prec, ks=ks, mode=m, src16=(hi16, lo16), bias=bias.to(dev),
                    emb=None if emb is None else emb.to(dev), emb_offset=8, emb_bstride=0 if emb is None else emb.shape[1],
                    res=None if res is None else nhwc(res).to(dev),
-                   w_frag=None if not frag else (ops.pack_conv_weight_up_frag(w.to(dev), prec) if mode == "up2" else ops.pack_conv_weight_frag(w.to(dev), prec)))
+                   w_frag=None if not frag else (ops.pack_conv_weight_up_frag(w.to(dev), prec) if mode == "up2" else ops.pack_conv_weight_frag(w.to(dev), prec)),
+                   ws=torch.empty(2 * out.numel(), device=dev) if ws else None)
     torch.cuda.synchronize()
     err = rel_err(nchw(out), ref)
     assert err < tol, f"{prec_name}: rel err {err:.3e} >= {tol}"
@@ -475,6 +476,29 @@ def test_conv_fused_skip_rejected_when_unsupported(dev):
     assert not ops.conv_igemm(None, whi, wlo, out, query_fused=True, **kw)
     with pytest.raises(StedmHipError):
         ops.conv_igemm(None, whi, wlo, out, **kw)
+
+
+@pytest.mark.parametrize("prec,tol", PRECS[1:])
+@pytest.mark.parametrize("B,H,W,cin,cout,emb,res", [(64, 8, 8, 1024, 1024, True, True), (100, 16, 16, 256, 128, False, True), (30, 32, 32, 256, 96, True, False)])
+def test_conv_dma_3x3_split_k(dev, prec, tol, B, H, W, cin, cout, emb, res):
+    """grids of 96..191 tiles with a workspace: K split over two blocks per tile, partial tiles summed in a fixed order by the
+    reduce kernel, which also applies bias / emb / residual and emits the channel statistics (bitwise reproducible)."""
+    from stedm_amd import ops
+    _conv_dma_case(dev, prec, tol, B, H, W, cin, cout, "s1", 3, use_emb=emb, use_res=res, frag=True, ws=True)
+    pr = ops.Precision.parse(prec)
+    x = torch.randn(B, H, W, cin, device=dev)
+    w = torch.randn(cout, cin, 3, 3, device=dev) / math.sqrt(cin * 9)
+    h16 = torch.empty((B, H, W, cin), dtype=torch.int16, device=dev)
+    ops.gn_apply16(x, None, h16, None, pr)
+    whi, wlo = ops.pack_conv_weight(w, pr); wf = ops.pack_conv_weight_frag(w, pr)
+    outs = []
+    for _ in range(3):
+        out = torch.full((B, H, W, cout), float("nan"), device=dev)
+        cs = torch.full((B, ops.gn_chan_nslab(H * W), cout, 2), float("nan"), device=dev)
+        ops.conv_igemm(None, whi, wlo, out, prec=pr, src16=(h16, None), w_frag=wf, chan_stats=cs, ws=torch.empty(2 * out.numel(), device=dev))
+        outs.append((out, cs))
+    assert all(torch.equal(outs[0][0], o) and torch.equal(outs[0][1], c) for o, c in outs[1:])
+    assert torch.allclose(outs[0][1][:, 0, :, 0].double(), outs[0][0].view(B, H * W, cout)[:, :256].double().sum(1), rtol=1e-4, atol=2e-3)
 
 
 def test_pack_conv_weight_frag_layout(dev):

@@ -51,7 +51,7 @@ def main():
             wf = None
             if os.environ.get("BENCH_FRAG") and prec.npass == 1 and mode in (CONV_S1, CONV_UP_SUBPIXEL):
                 wf = ops.pack_conv_weight_up_frag(w, prec) if mode == CONV_UP_SUBPIXEL else ops.pack_conv_weight_frag(w, prec)
-            run = lambda: ops.conv_igemm(None, hi, lo, out, prec=prec, ks=ks, mode=mode, src16=(h16, l16), bias=bias, w_frag=wf)
+            run = lambda: ops.conv_igemm(None, hi, lo, out, prec=prec, ks=ks, mode=mode, src16=(h16, l16), bias=bias, w_frag=wf, ws=torch.empty(2 * out.numel(), device=dev) if os.environ.get('BENCH_WS') else None)
         else:
             run = lambda: ops.conv_igemm(x1, hi, lo, out, prec=prec, ks=ks, mode=mode, src2=x2, scale=sc, shift=sh, act=1 if gn else 0, bias=bias)
         for _ in range(3): run()
