@@ -410,7 +410,7 @@ class UNetModel(nn.Module):
             h16 = self._norm16(rb.out_layers[0], 1, h)
             fuse_key = ("fuse", id(rb), B, H, W)
             fused = self._consts.get(fuse_key)
-            kw = dict(prec=prec, src16=h16, bias=pk2.bias, w_frag=pk2.frag, chan_stats=self._cs_new(out))
+            kw = dict(prec=prec, src16=h16, bias=pk2.bias, w_frag=pk2.frag, chan_stats=self._cs_new(out), ws=ws)
             if fused is None:
                 fused = bool(pk2.frag is not None and ps.frag is not None and
                              ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias), query_fused=True, **kw))
@@ -588,8 +588,12 @@ class UNetModel(nn.Module):
         h = self._run_block("mid.a", mid[:1], h, None, emb_e, emb_stride, None)
         if nrep > 1:
             h2 = self._buf("mid.rep", (Bd,) + tuple(h.shape[1:]))
+            cs1 = self._cs.get(h.data_ptr())
+            cs2 = self._cs_new(h2) if cs1 is not None else None
             for r in range(nrep):
                 h2[r * B:(r + 1) * B].copy_(h)
+                if cs2 is not None:      # the replicas share the statistics of the shared-encoder tensor
+                    cs2[r * B:(r + 1) * B].copy_(cs1)
             h = h2
         h = self._run_block("mid.b", mid[1:], h, None, emb_d, emb_stride, style_all, li0=1)
         bmod = B if nrep > 1 else 0
