@@ -76,7 +76,9 @@ class ConvTimer:
             r = timer._orig(src1, w_hi, w_lo, out, **kw)
             e1.record()
             M = out.numel() // out.shape[-1]
-            flops = 2.0 * M * out.shape[-1] * w_hi.shape[1] * w_hi.shape[2]
+            flops = 2.0 * M * out.shape[-1] * w_hi.shape[1] * w_hi.shape[2]     # executed MACs (sub-pixel upsample: 4 taps, not 9)
+            if kw.get("skip") is not None:                                       # fused 1x1 skip_connection phase
+                flops += 2.0 * M * out.shape[-1] * kw["skip"][0].shape[-1]
             timer.rec.append((e0, e1, flops))
             return r
 
@@ -230,7 +232,8 @@ def main():
                 traffic = json.load(open(tpath)).get("conv_igemm_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "mfma", "kernel": "conv_dma_kernel (all instantiations; + conv_igemm_kernel for the two stride-2 convs)", "achieved": round(cs["tflops"], 2),
+        roofline = {"bound": "mfma", "kernel": "stedm_conv_igemm launches: conv_rs_kernel (3x3, 3x3+fused 1x1 skip, sub-pixel upsample, 1x1; 48 of 51 per step) "
+                              "+ conv_splitk_reduce / conv_dma9 / conv_igemm_kernel (stride-2) for the rest", "achieved": round(cs["tflops"], 2),
                     "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(cs["tflops"] / PEAK_MFMA_TFLOPS, 4),
                     "traffic": traffic, "launches_per_step": cs["launches"] // 2, "avg_launch_us": round(cs["avg_us"], 2),
                     "algorithmic_gflop_per_launch": round(cs["flops_per_launch"] / 1e9, 3),
