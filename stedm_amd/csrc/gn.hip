@@ -299,57 +299,46 @@ extern "C" int stedm_gn_apply16(const float* x1, int c1, const float* x2, int c2
 // next block's GroupNorm, the decoder's concat GroupNorm and nothing has to re-read the fp32 tensor for statistics.
 extern "C" int stedm_gn_chan_nslab(int HW) { return (HW + 255) / 256; }
 
+// grid (B, slabs of 256 pixels, blocks of 64 channel quads): 256 threads = QB quads x (256 / QB) pixel lanes
 __global__ void __launch_bounds__(256) gn_chan_stats_kernel(const float* __restrict__ x, int C, int HW, float* __restrict__ cs) {
-  extern __shared__ float cpart[];   // [npl][Q][8]
+  __shared__ float cpart[256 * 8];   // [npl][QB][8]
   const int b = blockIdx.x, slab = blockIdx.y, nslab = gridDim.y;
   const int Q = C >> 2, t = threadIdx.x;
-  const float* px = x + (long)b * HW * C;
+  const int qb0 = blockIdx.z * 64, QB = min(64, Q - qb0);
+  const int npl = 256 / QB, tq = t % QB, tp = t / QB;
+  const float* px = x + (long)b * HW * C + (qb0 + tq) * 4;
   const int px0 = slab * 256, px1 = min(HW, px0 + 256);
-  float* dst = cs + ((long)b * nslab + slab) * C * 2;
-  if (Q <= 256) {
-    const int npl = 256 / Q, tq = t % Q, tp = t / Q;
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-    if (tp < npl) {
-      for (int pix = px0 + tp; pix < px1; pix += npl) {
-        const float4 v = *reinterpret_cast<const float4*>(px + (long)pix * C + tq * 4);
-        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-        q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
-      }
-      float* d = cpart + ((long)tp * Q + tq) * 8;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { d[j] = s[j]; d[4 + j] = q[j]; }
+  float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+  if (tp < npl) {
+#pragma unroll 4
+    for (int pix = px0 + tp; pix < px1; pix += npl) {
+      const float4 v = *reinterpret_cast<const float4*>(px + (long)pix * C);
+      s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+      q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
     }
-    __syncthreads();
-    if (t < Q) {
-      float su[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int l = 0; l < npl; ++l) {   // fixed order
-        const float* d = cpart + ((long)l * Q + t) * 8;
+    float* d = cpart + (tp * QB + tq) * 8;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { su[j] += d[j]; sq[j] += d[4 + j]; }
-      }
+    for (int j = 0; j < 4; ++j) { d[j] = s[j]; d[4 + j] = q[j]; }
+  }
+  __syncthreads();
+  if (t < QB) {
+    float su[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < npl; ++l) {   // fixed order
+      const float* d = cpart + (l * QB + t) * 8;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { dst[(t * 4 + j) * 2] = su[j]; dst[(t * 4 + j) * 2 + 1] = sq[j]; }
+      for (int j = 0; j < 4; ++j) { su[j] += d[j]; sq[j] += d[4 + j]; }
     }
-  } else {
-    for (int tq = t; tq < Q; tq += 256) {
-      float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int pix = px0; pix < px1; ++pix) {
-        const float4 v = *reinterpret_cast<const float4*>(px + (long)pix * C + tq * 4);
-        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-        q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
-      }
+    float* dst = cs + (((long)b * nslab + slab) * C + (qb0 + t) * 4) * 2;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { dst[(tq * 4 + j) * 2] = s[j]; dst[(tq * 4 + j) * 2 + 1] = q[j]; }
-    }
+    for (int j = 0; j < 4; ++j) { dst[j * 2] = su[j]; dst[j * 2 + 1] = sq[j]; }
   }
 }
 
 extern "C" int stedm_gn_chan_stats(const float* x, int C, int B, int HW, float* chan_stats, void* stream) {
   STEDM_CHECK_ARG(x && chan_stats && C > 0 && C % 4 == 0 && B > 0 && HW > 0, "gn_chan_stats: bad args (C %% 4)");
-  dim3 grid(B, (HW + 255) / 256);
   const int Q = C / 4;
-  const size_t lds = Q <= 256 ? (size_t)(256 / Q) * Q * 8 * sizeof(float) : 0;
-  gn_chan_stats_kernel<<<grid, 256, lds, as_stream(stream)>>>(x, C, HW, chan_stats);
+  dim3 grid(B, (HW + 255) / 256, (Q + 63) / 64);
+  gn_chan_stats_kernel<<<grid, 256, 0, as_stream(stream)>>>(x, C, HW, chan_stats);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

@@ -243,8 +243,66 @@ __global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ x
   }
 }
 
+// Few-row form (B <= ROWS, N % 4 == 0): the GEMV is a pure weight stream, so the block keeps many 16-B loads in flight -
+// 16 output quads x 16 K-slices, 8 independent loads per thread - and adds the 16 slice partials in a fixed order.
+template <int ROWS>
+__global__ void __launch_bounds__(256) linear_rows_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int B, int K, int N,
+                                                          int act_in, int act_out) {
+  extern __shared__ float lsm[];
+  float* sx = lsm;                         // [ROWS][K]
+  float* part = lsm + ROWS * K;            // [16][ROWS][64]
+  const int q = threadIdx.x & 15, ks = threadIdx.x >> 4;
+  const int n = blockIdx.x * 64 + q * 4;
+  for (int i = threadIdx.x; i < ROWS * K; i += 256) {
+    const int r = i / K, k = i - r * K;
+    float v = r < B ? x[(long)r * K + k] : 0.f;
+    sx[i] = act_in == 1 ? silu_f(v) : (act_in == 2 ? fmaxf(v, 0.f) : v);
+  }
+  __syncthreads();
+  float acc[ROWS][4];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[r][j] = 0.f;
+  if (n < N) {
+    const int per = (K + 15) / 16;
+    const int k0 = ks * per, k1 = min(K, k0 + per);
+#pragma unroll 8
+    for (int k = k0; k < k1; ++k) {
+      const float4 w = *reinterpret_cast<const float4*>(wt + (long)k * N + n);
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        const float xv = sx[r * K + k];
+        acc[r][0] = fmaf(xv, w.x, acc[r][0]); acc[r][1] = fmaf(xv, w.y, acc[r][1]);
+        acc[r][2] = fmaf(xv, w.z, acc[r][2]); acc[r][3] = fmaf(xv, w.w, acc[r][3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[(ks * ROWS + r) * 64 + q * 4 + j] = acc[r][j];
+  __syncthreads();
+  const int nl = threadIdx.x & 63, r = threadIdx.x >> 6;      // 64 outputs x up to 4 rows per pass
+  for (int rr = r; rr < ROWS && rr < B; rr += 4) {
+    const int nn = blockIdx.x * 64 + nl;
+    if (nn < N) {
+      float v = bias ? bias[nn] : 0.f;
+      for (int s2 = 0; s2 < 16; ++s2) v += part[(s2 * ROWS + rr) * 64 + nl];   // fixed order
+      out[(long)rr * N + nn] = act_out == 1 ? silu_f(v) : (act_out == 2 ? fmaxf(v, 0.f) : v);
+    }
+  }
+}
+
 static int launch_linear(const float* x, const float* wt, const float* bias, float* out, int B, int K, int N, int act_in,
                          int act_out, hipStream_t st) {
+  if (N % 4 == 0 && B <= 2 && (size_t)(2 * K + 16 * 2 * 64) * sizeof(float) <= 64 * 1024) {
+    const size_t lds = (size_t)(2 * K + 16 * 2 * 64) * sizeof(float);
+    linear_rows_kernel<2><<<(N + 63) / 64, 256, lds, st>>>(x, wt, bias, out, B, K, N, act_in, act_out);
+    STEDM_LAUNCH_CHECK();
+    return 0;
+  }
   dim3 grid((N + 63) / 64, (B + LIN_ROWS - 1) / LIN_ROWS);
   linear_kernel<<<grid, 256, 0, st>>>(x, wt, bias, out, B, K, N, act_in, act_out);
   STEDM_LAUNCH_CHECK();

@@ -191,12 +191,13 @@ def test_conv_out(dev, B, H, W, c, cout):
 
 
 # ------------------------------------------------------------------------------------------------ embeddings
-@pytest.mark.parametrize("mc", [128, 32])
-def test_time_embed_and_proj(dev, mc):
+@pytest.mark.parametrize("mc,nrow", [(128, 9), (32, 9), (128, 1), (128, 2), (32, 1)])
+def test_time_embed_and_proj(dev, mc, nrow):
+    """nrow <= 2 takes the few-row GEMV kernel (the uniform-timestep sampling path evaluates one row)."""
     from oracle import unet as ou
     from stedm_amd import ops
     ted = mc * 4
-    t = torch.tensor([0, 1, 500, 999, 951, 21, 7, 333, 2], dtype=torch.long)
+    t = torch.tensor([0, 1, 500, 999, 951, 21, 7, 333, 2], dtype=torch.long)[-nrow:]
     B = t.shape[0]
     w0 = prng.normal(5, "te.w0", (ted, mc), 1 / math.sqrt(mc)); b0 = prng.normal(5, "te.b0", (ted,), 0.05)
     w2 = prng.normal(5, "te.w2", (ted, ted), 1 / math.sqrt(ted)); b2 = prng.normal(5, "te.b2", (ted,), 0.05)
