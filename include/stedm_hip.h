@@ -39,6 +39,11 @@ extern "C" {
 #define STEDM_CONV_UP 2   /* nearest x2 then 3x3 pad 1 : Upsample      openaimodel.py:122-132  */
 #define STEDM_CONV_UP_SUBPIXEL 3 /* same operator evaluated as 4 output-parity 2x2 convs on the low-res input with
                                   * pre-summed taps (weights from stedm_pack_conv_weight_up): 4/9 of the MACs; DMA path */
+#define STEDM_CONV_S2D 4  /* Downsample.op (3x3 stride 2 pad 1) on space-to-depth planes: src16 = [B][H/2][W/2][4*cin] from
+                           * stedm_space_to_depth16 (channel block py*2+px holds pixel (2y+py, 2x+px)), evaluated as a stride-1
+                           * conv with 2x2 taps (offsets -1, 0) over 4*cin channels; w_frag from stedm_pack_conv_weight_s2d_frag
+                           * (7 of the 16 (tap, parity) blocks are zero). Register-streamed kernel only (single product): Hin/Win/c1
+                           * describe the planes (H/2, W/2, 4*cin), ks = 3, w_hi may be NULL. */
 
 int stedm_abi_version(void);
 const char* stedm_last_error(void);
@@ -61,6 +66,12 @@ int stedm_pack_conv_weight_frag(const float* w_oihw, void* out, int cout, int ci
 /* The same for STEDM_CONV_UP_SUBPIXEL: OIHW 3x3 fp32 -> [4 parities][ceil(cout/128)][cin/16][4 taps][4][64][8] with the
  * pre-summed taps of stedm_pack_conv_weight_up (single product; cin %% 32 == 0). */
 int stedm_pack_conv_weight_up_frag(const float* w_oihw, void* out, int cout, int cin, int mm_dtype, void* stream);
+/* Operands of STEDM_CONV_S2D. space_to_depth16: NHWC fp32 [B][H][W][C] (H, W even) -> 16-bit planes [B][H/2][W/2][4*C]
+ * (hi, and lo = x - hi when out_lo != NULL). pack_conv_weight_s2d_frag: OIHW 3x3 fp32 -> fragment order
+ * [ceil(cout/128)][4*cin/16][4 taps (a*2+b)][4][64][8] of the equivalent 2x2 conv: tap (a, b) of parity block (py, px) is
+ * W[dy][dx] with dy = {(0,1):0, (1,0):1, (1,1):2}[(a, py)] (none for (0,0)), same for dx. cin %% 4 == 0. */
+int stedm_space_to_depth16(const float* x, int C, int B, int H, int W, void* out_hi, void* out_lo, int mm_dtype, void* stream);
+int stedm_pack_conv_weight_s2d_frag(const float* w_oihw, void* out, int cout, int cin, int mm_dtype, void* stream);
 /* [rows][cols] fp32 -> [cols][rows] fp32 (Linear weights are consumed K-major). */
 int stedm_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
 

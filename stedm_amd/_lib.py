@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libstedm_hip.so")
 
 ABI_VERSION = 1
 F16, BF16 = 0, 1
-CONV_S1, CONV_DOWN, CONV_UP, CONV_UP_SUBPIXEL = 0, 1, 2, 3
+CONV_S1, CONV_DOWN, CONV_UP, CONV_UP_SUBPIXEL, CONV_S2D = 0, 1, 2, 3, 4
 
 
 class StedmHipError(RuntimeError):
@@ -50,6 +50,8 @@ SIGNATURES = {
     "stedm_pack_conv_weight_up": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "stedm_pack_conv_weight_frag": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "stedm_pack_conv_weight_up_frag": (_I, [_P, _P, _I, _I, _I, _P]),
+    "stedm_pack_conv_weight_s2d_frag": (_I, [_P, _P, _I, _I, _I, _P]),
+    "stedm_space_to_depth16": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P]),
     "stedm_transpose_f32": (_I, [_P, _P, _I, _I, _P]),
     "stedm_gn_scale_shift": (_I, [_P, _I, _P, _I, _I, _P, _P, _F, _I, _I, _I, _P, _P, _P]),
     "stedm_gn_nslab": (_I, [_I, _I]),

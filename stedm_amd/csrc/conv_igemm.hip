@@ -304,7 +304,7 @@ bool stedm::conv_geometry(ConvParams& p, int bm) {
     }
     p.whole = 0; p.nsamp = 1; p.trows = bm / p.Wout;
   }
-  if (a.mode == STEDM_CONV_S1 || a.mode == STEDM_CONV_UP_SUBPIXEL) p.PRs = p.trows + 2;
+  if (a.mode == STEDM_CONV_S1 || a.mode == STEDM_CONV_UP_SUBPIXEL || a.mode == STEDM_CONV_S2D) p.PRs = p.trows + 2;
   else if (a.mode == STEDM_CONV_DOWN) p.PRs = 2 * p.trows + 1;
   else p.PRs = (p.trows + 1) / 2 + 2;
   p.PW = a.Win + 2;
@@ -341,12 +341,14 @@ extern "C" int stedm_conv_igemm(const stedm_conv_args* args, void* stream) {
 // validates the arguments and fills the derived sizes of `p`
 static int conv_setup(ConvParams& p) {
   const stedm_conv_args& a = p.a;
-  STEDM_CHECK_ARG((a.src1 || a.src16_hi) && a.w_hi && (a.out || a.out16_hi), "conv_igemm: null src/w_hi/out");
+  STEDM_CHECK_ARG((a.src1 || a.src16_hi) && (a.w_hi || (a.mode == STEDM_CONV_S2D && a.w_frag)) && (a.out || a.out16_hi), "conv_igemm: null src/w_hi/out");
+  STEDM_CHECK_ARG(a.mode != STEDM_CONV_S2D || (a.src16_hi && !a.src1 && a.w_frag && a.ks == 3 && a.npass == 1 && !a.src16b_hi),
+                  "conv_igemm: the space-to-depth form needs src16 planes, w_frag, ks=3, single product");
   STEDM_CHECK_ARG((!a.act_out && !a.out16_hi) || (a.src16_hi && !a.src1), "conv_igemm: act_out/out16 need the DMA path (src16 only)");
   STEDM_CHECK_ARG(!a.src1 || (a.src2 != nullptr) == (a.c2 > 0), "conv_igemm: src2/c2 mismatch");
   STEDM_CHECK_ARG(!a.src16_hi || a.npass == 1 || a.src16_lo, "conv_igemm: npass=3 needs src16_lo");
   STEDM_CHECK_ARG(a.ks == 1 || a.ks == 3, "conv_igemm: ks must be 1 or 3");
-  STEDM_CHECK_ARG(a.mode >= 0 && a.mode <= 3, "conv_igemm: bad mode %d", a.mode);
+  STEDM_CHECK_ARG(a.mode >= 0 && a.mode <= 4, "conv_igemm: bad mode %d", a.mode);
   STEDM_CHECK_ARG(a.mode != STEDM_CONV_UP_SUBPIXEL || (a.src16_hi && !a.src1 && a.ks == 3), "conv_igemm: sub-pixel upsample needs the DMA path (src16) and ks=3");
   STEDM_CHECK_ARG(a.ks == 3 || a.mode == STEDM_CONV_S1, "conv_igemm: 1x1 supports stride 1 only");
   STEDM_CHECK_ARG(a.npass == 1 || a.npass == 3, "conv_igemm: npass must be 1 or 3");
@@ -355,8 +357,8 @@ static int conv_setup(ConvParams& p) {
   STEDM_CHECK_ARG(a.B > 0 && a.Hin > 0 && a.Win > 0 && a.cout > 0, "conv_igemm: bad sizes");
   STEDM_CHECK_ARG(a.mm_dtype == STEDM_F16 || a.mm_dtype == STEDM_BF16, "conv_igemm: bad mm_dtype %d", a.mm_dtype);
   p.Cin = a.c1 + a.c2;
-  p.taps = a.mode == STEDM_CONV_UP_SUBPIXEL ? 4 : a.ks * a.ks;
-  if (a.mode == STEDM_CONV_UP_SUBPIXEL) {
+  p.taps = (a.mode == STEDM_CONV_UP_SUBPIXEL || a.mode == STEDM_CONV_S2D) ? 4 : a.ks * a.ks;
+  if (a.mode == STEDM_CONV_UP_SUBPIXEL || a.mode == STEDM_CONV_S2D) {
     p.Hout = a.Hin; p.Wout = a.Win;     // tiles are cut on the LOW-RES grid; each tile is computed for the 4 output parities
   } else if (a.mode == STEDM_CONV_DOWN) {
     STEDM_CHECK_ARG(a.Hin % 2 == 0 && a.Win % 2 == 0, "conv_igemm: stride-2 needs even Hin/Win");

@@ -167,6 +167,75 @@ extern "C" int stedm_pack_conv_weight_up_frag(const float* w, void* out, int cou
   return 0;
 }
 
+// STEDM_CONV_S2D weights: the stride-2 3x3 as a 2x2 conv over the 4 parity blocks of the space-to-depth planes, fragment order
+template <typename T>
+__global__ void pack_conv_weight_s2d_frag_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, long total) {
+  const int nch = 4 * cin / 16;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 7);
+    const int lane = (int)((i >> 3) & 63);
+    const int q = (int)((i >> 9) & 3);
+    long r = i >> 11;
+    const int tap = (int)(r & 3); r >>= 2;
+    const int chunk = (int)(r % nch);
+    const int tn = (int)(r / nch);
+    const int n = tn * 128 + (q >> 1) * 64 + (q & 1) * 32 + (lane & 31);
+    const int cc = chunk * 16 + (lane >> 5) * 8 + e;          // channel of the planes: parity block * cin + c
+    const int par = cc / cin, c = cc - par * cin;
+    const int py = par >> 1, px = par & 1, a = tap >> 1, b = tap & 1;
+    const int dy = a == 0 ? (py == 1 ? 0 : -1) : (py == 0 ? 1 : 2);
+    const int dx = b == 0 ? (px == 1 ? 0 : -1) : (px == 0 ? 1 : 2);
+    out[i] = (n < cout && dy >= 0 && dx >= 0) ? (T)w[((long)n * cin + c) * 9 + dy * 3 + dx] : (T)0.f;
+  }
+}
+
+extern "C" int stedm_pack_conv_weight_s2d_frag(const float* w, void* out, int cout, int cin, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(w && out && cin % 8 == 0, "pack_conv_weight_s2d_frag: bad args (cin %% 8)");
+  STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "pack_conv_weight_s2d_frag: bad mm_dtype %d", mm_dtype);
+  const long total = (long)((cout + 127) / 128) * (4 * cin / 16) * 4 * 4 * 64 * 8;
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (mm_dtype == STEDM_F16) pack_conv_weight_s2d_frag_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(w, (_Float16*)out, cout, cin, total);
+  else pack_conv_weight_s2d_frag_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(w, (__bf16*)out, cout, cin, total);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+// NHWC fp32 -> space-to-depth 16-bit planes [B][H/2][W/2][4C]; thread = one channel quad of one input pixel
+template <typename T>
+__global__ void __launch_bounds__(256) space_to_depth16_kernel(const float* __restrict__ x, T* __restrict__ hi, T* __restrict__ lo, int C, int H, int W,
+                                                               long total_q) {
+  typedef T V4 __attribute__((ext_vector_type(4)));
+  const int Q = C >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total_q; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % Q);
+    long pix = i / Q;
+    const int xx = (int)(pix % W); pix /= W;
+    const int yy = (int)(pix % H);
+    const long b = pix / H;
+    const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+    const long o = ((((b * (H >> 1) + (yy >> 1)) * (W >> 1) + (xx >> 1)) * 4 + ((yy & 1) * 2 + (xx & 1))) * (long)C >> 2) + q;
+    V4 h4;
+    h4[0] = (T)v.x; h4[1] = (T)v.y; h4[2] = (T)v.z; h4[3] = (T)v.w;
+    reinterpret_cast<V4*>(hi)[o] = h4;
+    if (lo) {
+      V4 l4;
+      l4[0] = (T)(v.x - (float)h4[0]); l4[1] = (T)(v.y - (float)h4[1]); l4[2] = (T)(v.z - (float)h4[2]); l4[3] = (T)(v.w - (float)h4[3]);
+      reinterpret_cast<V4*>(lo)[o] = l4;
+    }
+  }
+}
+
+extern "C" int stedm_space_to_depth16(const float* x, int C, int B, int H, int W, void* out_hi, void* out_lo, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(x && out_hi && C > 0 && C % 4 == 0 && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "space_to_depth16: bad args (C %% 4, even H/W)");
+  STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "space_to_depth16: bad mm_dtype %d", mm_dtype);
+  const long total_q = (long)B * H * W * (C / 4);
+  const int grid = (int)((total_q + 255) / 256 < 16384 ? (total_q + 255) / 256 : 16384);
+  if (mm_dtype == STEDM_F16) space_to_depth16_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(x, (_Float16*)out_hi, (_Float16*)out_lo, C, H, W, total_q);
+  else space_to_depth16_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(x, (__bf16*)out_hi, (__bf16*)out_lo, C, H, W, total_q);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
   __shared__ float tile[32][33];
   const int bx = blockIdx.x * 32, by = blockIdx.y * 32;

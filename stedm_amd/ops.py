@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import BF16, CONV_DOWN, CONV_S1, CONV_UP, CONV_UP_SUBPIXEL, F16, ConvArgs, check, lib
+from ._lib import BF16, CONV_DOWN, CONV_S1, CONV_S2D, CONV_UP, CONV_UP_SUBPIXEL, F16, ConvArgs, check, lib
 
 
 @dataclass(frozen=True)
@@ -107,6 +107,25 @@ def pack_conv_weight_up_frag(w: torch.Tensor, prec: Precision) -> torch.Tensor:
     out = torch.empty((4, (cout + 127) // 128, cin // 16, 4, 4, 64, 8), dtype=torch.int16, device=w.device)
     check(lib().stedm_pack_conv_weight_up_frag(w.data_ptr(), out.data_ptr(), cout, cin, prec.mm_dtype, _stream()), "stedm_pack_conv_weight_up_frag")
     return out
+
+
+def pack_conv_weight_s2d_frag(w: torch.Tensor, prec: Precision) -> torch.Tensor:
+    """OIHW 3x3 fp32 (stride-2 Downsample.op) -> fragment-order weights of the equivalent 2x2 conv over space-to-depth planes."""
+    w = w.detach().contiguous()
+    _chk(w, name="conv weight")
+    cout, cin, ks, _ = w.shape
+    assert ks == 3 and cin % 8 == 0
+    out = torch.empty(((cout + 127) // 128, 4 * cin // 16, 4, 4, 64, 8), dtype=torch.int16, device=w.device)
+    check(lib().stedm_pack_conv_weight_s2d_frag(w.data_ptr(), out.data_ptr(), cout, cin, prec.mm_dtype, _stream()), "stedm_pack_conv_weight_s2d_frag")
+    return out
+
+
+def space_to_depth16(x: torch.Tensor, out_hi: torch.Tensor, out_lo: Optional[torch.Tensor], prec: Precision) -> None:
+    """NHWC fp32 [B,H,W,C] -> 16-bit planes [B,H/2,W/2,4C] (channel block py*2+px = pixel (2y+py, 2x+px))."""
+    _chk(x, name="x")
+    B, H, W, C = x.shape
+    assert tuple(out_hi.shape) == (B, H // 2, W // 2, 4 * C) and out_hi.dtype == torch.int16
+    check(lib().stedm_space_to_depth16(x.data_ptr(), C, B, H, W, out_hi.data_ptr(), _ptr(out_lo), prec.mm_dtype, _stream()), "stedm_space_to_depth16")
 
 
 def transpose(w: torch.Tensor) -> torch.Tensor:
@@ -240,7 +259,7 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
     a.B, a.Hin, a.Win = B, Hin, Win
     a.mode, a.ks = mode, ks
     a.scale, a.shift, a.act = _ptr(scale), _ptr(shift), act
-    a.w_hi, a.w_lo = w_hi.data_ptr(), (_ptr(w_lo) if prec.npass == 3 else None)
+    a.w_hi, a.w_lo = _ptr(w_hi), (_ptr(w_lo) if prec.npass == 3 else None)
     a.bias = _ptr(bias)
     a.emb = None if emb is None else emb.data_ptr() + 4 * emb_offset
     a.emb_bstride = emb_bstride
@@ -250,6 +269,8 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
     a.npass, a.mm_dtype = prec.npass, prec.mm_dtype
     if mode == CONV_UP_SUBPIXEL:
         assert w_hi.shape == (4 * a.cout, 4, a.c1 + a.c2), (w_hi.shape, a.cout, a.c1, a.c2)
+    elif mode == CONV_S2D:
+        assert w_hi is None and w_frag is not None and src1 is None, "the space-to-depth form runs on the register-streamed kernel only"
     else:
         assert w_hi.shape == (a.cout, ks * ks, a.c1 + a.c2), (w_hi.shape, a.cout, ks, a.c1, a.c2)
     if query_fused:     # capability query only: would this (fused) problem run as one kernel?

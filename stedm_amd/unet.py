@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._lib import CONV_DOWN, CONV_S1, CONV_UP, CONV_UP_SUBPIXEL, StedmHipError
+from ._lib import CONV_S2D, CONV_DOWN, CONV_S1, CONV_UP, CONV_UP_SUBPIXEL, StedmHipError
 from .ops import Precision
 
 
@@ -299,6 +299,10 @@ class UNetModel(nn.Module):
                     pack(m.skip_connection)
             elif isinstance(m, Downsample):
                 pack(m.op)
+                if self.conv_path == "dma" and prec.npass == 1 and m.op.in_channels % 8 == 0:
+                    # stride-2 conv as a stride-1 2x2 conv over space-to-depth planes (register-streamed kernel)
+                    self._packed[(id(m.op), "s2d")] = _Packed(None, None, self._packed[id(m.op)].bias,
+                                                              ops.pack_conv_weight_s2d_frag(m.op.weight.float(), prec))
             elif isinstance(m, Upsample):
                 pack(m.conv)
                 if self.conv_path == "dma":   # sub-pixel form: 4 parity 2x2 convs with pre-summed taps
@@ -478,8 +482,17 @@ class UNetModel(nn.Module):
                 pk = self._packed[id(layer.op)]
                 B, H, W, _ = h.shape
                 out = self._buf(ltag + ".out", (B, H // 2, W // 2, layer.out_channels))
-                # stride-2 patches do not fit the DMA kernel's LDS budget: fused fp32-source kernel
-                h = ops.conv_igemm(h, pk.hi, pk.lo, out, prec=self.precision, mode=CONV_DOWN, bias=pk.bias)
+                ps2 = self._packed.get((id(layer.op), "s2d"))
+                if ps2 is not None and H % 2 == 0 and W % 2 == 0 and (H // 2) * (W // 2) >= 16:
+                    C = h.shape[-1]
+                    planes = self._buf(f"s2d16.{B}x{H}x{W}x{C}", (B, H // 2, W // 2, 4 * C), torch.int16)
+                    ops.space_to_depth16(h, planes, None, self.precision)
+                    ws = self._buf("conv_ws", (2 * out.numel(),))
+                    h = ops.conv_igemm(None, None, None, out, prec=self.precision, mode=CONV_S2D, src16=(planes, None), bias=ps2.bias,
+                                       w_frag=ps2.frag, chan_stats=self._cs_new(out), ws=ws)
+                else:
+                    # fused fp32-source kernel (parity mode / odd sizes)
+                    h = ops.conv_igemm(h, pk.hi, pk.lo, out, prec=self.precision, mode=CONV_DOWN, bias=pk.bias)
             elif isinstance(layer, Upsample):
                 pk = self._packed[id(layer.conv)]
                 B, H, W, _ = h.shape

@@ -502,6 +502,36 @@ def test_conv_dma_3x3_split_k(dev, prec, tol, B, H, W, cin, cout, emb, res):
     assert torch.allclose(outs[0][1][:, 0, :, 0].double(), outs[0][0].view(B, H * W, cout)[:, :256].double().sum(1), rtol=1e-4, atol=2e-3)
 
 
+@pytest.mark.parametrize("prec,tol", PRECS[1:])
+@pytest.mark.parametrize("B,H,W,cin,cout,ws", [(64, 32, 32, 128, 128, True), (64, 16, 16, 512, 512, True), (3, 8, 8, 32, 32, False), (5, 16, 16, 64, 96, True),
+                                                (2, 64, 64, 32, 160, False), (9, 8, 8, 64, 64, True)])
+def test_conv_s2d_downsample(dev, prec, tol, B, H, W, cin, cout, ws):
+    """Downsample.op (3x3 stride 2 pad 1, openaimodel.py:156-173) as a 2x2 stride-1 conv over space-to-depth planes on the
+    register-streamed kernel; with a workspace the small grids split K. Statistics of the output come from the epilogue / reduce."""
+    from stedm_amd import ops
+    from stedm_amd._lib import CONV_S2D
+    pr = ops.Precision.parse(prec)
+    x = prng.normal(31, "sd.x", (B, cin, H, W))
+    w = prng.normal(31, "sd.w", (cout, cin, 3, 3), 1.0 / math.sqrt(cin * 9))
+    bias = prng.normal(31, "sd.b", (cout,), 0.05)
+    ref = F.conv2d(x, w, bias, stride=2, padding=1)
+    planes = torch.empty((B, H // 2, W // 2, 4 * cin), dtype=torch.int16, device=dev)
+    ops.space_to_depth16(nhwc(x).to(dev), planes, None, pr)
+    # the planes hold pixel (2y+py, 2x+px) in channel block py*2+px
+    got = _as_float(planes, pr).view(B, H // 2, W // 2, 2, 2, cin).permute(0, 5, 1, 3, 2, 4).reshape(B, cin, H, W).cpu()
+    assert rel_err(got, x) < (2e-2 if prec == "bf16" else 2e-3)   # 16-bit rounding of values up to ~4 sigma
+    out = torch.full((B, H // 2, W // 2, cout), float("nan"), device=dev)
+    cs = torch.full((B, ops.gn_chan_nslab(H * W // 4), cout, 2), float("nan"), device=dev)
+    ops.conv_igemm(None, None, None, out, prec=pr, mode=CONV_S2D, src16=(planes, None), bias=bias.to(dev),
+                   w_frag=ops.pack_conv_weight_s2d_frag(w.to(dev), pr), chan_stats=cs, ws=torch.empty(2 * out.numel(), device=dev) if ws else None)
+    torch.cuda.synchronize()
+    err = rel_err(nchw(out), ref)
+    assert err < tol, f"{prec}: rel err {err:.3e} >= {tol}"
+    flat = out.view(B, -1, cout).double()
+    for k in range(cs.shape[1]):
+        assert torch.allclose(cs[:, k, :, 0].double(), flat[:, k * 256:(k + 1) * 256].sum(1), rtol=1e-4, atol=2e-3)
+
+
 def test_pack_conv_weight_frag_layout(dev):
     from stedm_amd import ops
     prec = ops.Precision.parse("f16")
