@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(256) conv_in_kernel(const float* __restrict__ 
 // Fast path (256 % cout == 0, cin <= 8): a thread owns one output channel and keeps its 9*cin weights in registers;
 // a block covers 8 image rows, the haloed input patch sits in LDS padded to 8 floats per position (two 16-B
 // broadcast reads per tap).
-constexpr int CI_ROWS = 8;
+constexpr int CI_ROWS = 2;   // small row blocks: 4+ waves per SIMD hide the LDS latency of the broadcast reads
 __global__ void __launch_bounds__(256) conv_in_fast_kernel(const float* __restrict__ x1, int c1, const float* __restrict__ x2,
                                                            int c2, int bmod, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ out, int H, int W,

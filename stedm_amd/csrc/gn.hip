@@ -1,6 +1,8 @@
 // GroupNorm statistics -> per-(sample, channel) scale/shift, over the virtual concat [x1 | x2].
 // One block per (sample, group): two passes over its cpg x HW slice (second pass hits L1/L2),
 // so the variance is the centred, biased form nn.GroupNorm computes (util.py:214-216).
+#include <stdlib.h>
+
 #include "common.hpp"
 using namespace stedm;
 
@@ -401,52 +403,70 @@ __global__ void __launch_bounds__(256) gn_apply16c_kernel(GnApplyCArgs a, int sl
   const float* p2 = a.x2 ? a.x2 + (long)b2 * a.HW * a.c2 : nullptr;
   const int px0 = sl * slab, px1 = min(a.HW, px0 + slab);
   const int total = (px1 - px0) * Q;
-  int pix = px0 + threadIdx.x / Q, q = threadIdx.x % Q;
-  const int dpix = 256 / Q, dq = 256 % Q;
   V4* oh = reinterpret_cast<V4*>(a.out_hi) + (long)b * a.HW * Q;
   V4* ol = a.out_lo ? reinterpret_cast<V4*>(a.out_lo) + (long)b * a.HW * Q : nullptr;
   V4* rh = a.raw_hi ? reinterpret_cast<V4*>(a.raw_hi) + (long)b * a.HW * Q : nullptr;
   V4* rl = a.raw_lo ? reinterpret_cast<V4*>(a.raw_lo) + (long)b * a.HW * Q : nullptr;
-  for (int i = threadIdx.x; i < total; i += 256) {
-    const int c = q * 4;
-    float4 v = c < a.c1 ? *reinterpret_cast<const float4*>(p1 + (long)pix * a.c1 + c)
-                        : *reinterpret_cast<const float4*>(p2 + (long)pix * a.c2 + (c - a.c1));
-    const long o = (long)pix * Q + q;
-    if (rh) {
-      V4 hi;
-      hi[0] = (T)v.x; hi[1] = (T)v.y; hi[2] = (T)v.z; hi[3] = (T)v.w;
-      rh[o] = hi;
-      if (rl) {
-        V4 lo;
-        lo[0] = (T)(v.x - (float)hi[0]); lo[1] = (T)(v.y - (float)hi[1]);
-        lo[2] = (T)(v.z - (float)hi[2]); lo[3] = (T)(v.w - (float)hi[3]);
-        rl[o] = lo;
+  // U independent cursors per thread (elements tid + k*256, advancing by U*256): the pass is a pure stream, its speed is the
+  // number of 16-B loads in flight
+  constexpr int U = 4;
+  int pixs[U], qs[U];
+#pragma unroll
+  for (int k = 0; k < U; ++k) { const int e = threadIdx.x + k * 256; pixs[k] = px0 + e / Q; qs[k] = e % Q; }
+  const int dpix = (256 * U) / Q, dq = (256 * U) % Q;
+  for (int i = threadIdx.x; i < total; i += 256 * U) {
+    float4 v[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      if (i + k * 256 < total) {
+        const int c = qs[k] * 4;
+        v[k] = c < a.c1 ? *reinterpret_cast<const float4*>(p1 + (long)pixs[k] * a.c1 + c)
+                        : *reinterpret_cast<const float4*>(p2 + (long)pixs[k] * a.c2 + (c - a.c1));
       }
     }
-    const float4 gm = *reinterpret_cast<const float4*>(a.gamma + c);
-    const float4 bt = *reinterpret_cast<const float4*>(a.beta + c);
-    if (cpg & 3) {
-      const int g0 = c / cpg, g1 = (c + 1) / cpg, g2 = (c + 2) / cpg, g3 = (c + 3) / cpg;
-      v.x = (v.x - lmean[g0]) * lrstd[g0] * gm.x + bt.x; v.y = (v.y - lmean[g1]) * lrstd[g1] * gm.y + bt.y;
-      v.z = (v.z - lmean[g2]) * lrstd[g2] * gm.z + bt.z; v.w = (v.w - lmean[g3]) * lrstd[g3] * gm.w + bt.w;
-    } else {
-      const int g = c / cpg;
-      const float mf = lmean[g], rstd = lrstd[g];
-      v.x = (v.x - mf) * rstd * gm.x + bt.x; v.y = (v.y - mf) * rstd * gm.y + bt.y;
-      v.z = (v.z - mf) * rstd * gm.z + bt.z; v.w = (v.w - mf) * rstd * gm.w + bt.w;
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      if (i + k * 256 < total) {
+        const int c = qs[k] * 4;
+        float4 w = v[k];
+        const long o = (long)pixs[k] * Q + qs[k];
+        if (rh) {
+          V4 hi;
+          hi[0] = (T)w.x; hi[1] = (T)w.y; hi[2] = (T)w.z; hi[3] = (T)w.w;
+          rh[o] = hi;
+          if (rl) {
+            V4 lo;
+            lo[0] = (T)(w.x - (float)hi[0]); lo[1] = (T)(w.y - (float)hi[1]);
+            lo[2] = (T)(w.z - (float)hi[2]); lo[3] = (T)(w.w - (float)hi[3]);
+            rl[o] = lo;
+          }
+        }
+        const float4 gm = *reinterpret_cast<const float4*>(a.gamma + c);
+        const float4 bt = *reinterpret_cast<const float4*>(a.beta + c);
+        if (cpg & 3) {
+          const int g0 = c / cpg, g1 = (c + 1) / cpg, g2 = (c + 2) / cpg, g3 = (c + 3) / cpg;
+          w.x = (w.x - lmean[g0]) * lrstd[g0] * gm.x + bt.x; w.y = (w.y - lmean[g1]) * lrstd[g1] * gm.y + bt.y;
+          w.z = (w.z - lmean[g2]) * lrstd[g2] * gm.z + bt.z; w.w = (w.w - lmean[g3]) * lrstd[g3] * gm.w + bt.w;
+        } else {
+          const int g = c / cpg;
+          const float mf = lmean[g], rstd = lrstd[g];
+          w.x = (w.x - mf) * rstd * gm.x + bt.x; w.y = (w.y - mf) * rstd * gm.y + bt.y;
+          w.z = (w.z - mf) * rstd * gm.z + bt.z; w.w = (w.w - mf) * rstd * gm.w + bt.w;
+        }
+        if (a.act == 1) { w.x = silu_f(w.x); w.y = silu_f(w.y); w.z = silu_f(w.z); w.w = silu_f(w.w); }
+        V4 hi;
+        hi[0] = (T)w.x; hi[1] = (T)w.y; hi[2] = (T)w.z; hi[3] = (T)w.w;
+        oh[o] = hi;
+        if (ol) {
+          V4 lo;
+          lo[0] = (T)(w.x - (float)hi[0]); lo[1] = (T)(w.y - (float)hi[1]);
+          lo[2] = (T)(w.z - (float)hi[2]); lo[3] = (T)(w.w - (float)hi[3]);
+          ol[o] = lo;
+        }
+      }
+      pixs[k] += dpix; qs[k] += dq;
+      if (qs[k] >= Q) { qs[k] -= Q; ++pixs[k]; }
     }
-    if (a.act == 1) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
-    V4 hi;
-    hi[0] = (T)v.x; hi[1] = (T)v.y; hi[2] = (T)v.z; hi[3] = (T)v.w;
-    oh[o] = hi;
-    if (ol) {
-      V4 lo;
-      lo[0] = (T)(v.x - (float)hi[0]); lo[1] = (T)(v.y - (float)hi[1]);
-      lo[2] = (T)(v.z - (float)hi[2]); lo[3] = (T)(v.w - (float)hi[3]);
-      ol[o] = lo;
-    }
-    pix += dpix; q += dq;
-    if (q >= Q) { q -= Q; ++pix; }
   }
 }
 
@@ -461,7 +481,10 @@ extern "C" int stedm_gn_apply16c(const float* x1, int c1, const float* cs1, cons
   STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "gn_apply16c: bad mm_dtype");
   STEDM_CHECK_ARG(raw_hi || !raw_lo, "gn_apply16c: raw_lo without raw_hi");
   GnApplyCArgs a{x1, x2, cs1, cs2, c1, c2, x2_bmod, groups, HW, act, (HW + 255) / 256, gamma, beta, eps, out_hi, out_lo, raw_hi, raw_lo};
-  const int slab = gn_slab_pixels(C, HW);
+  static const int slab_kb = getenv("STEDM_GN_SLAB_KB") ? atoi(getenv("STEDM_GN_SLAB_KB")) : 32;
+  int slab = (slab_kb * 256 + C - 1) / C;   // pixels per block: slab_kb KiB of fp32 input
+  if (slab < 1) slab = 1;
+  if (slab > HW) slab = HW;
   dim3 grid(B, (HW + slab - 1) / slab);
   if (mm_dtype == STEDM_F16)
     gn_apply16c_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(a, slab);
