@@ -257,8 +257,15 @@ def main():
             "roofline": roofline,
         }
         if not args.no_parity_leg and world == 1:
-            # fp32-parity mode (fp16 x3 split products) throughput next to the fast mode, same workload
             del sg, smp
+            if args.precision != "f16":
+                # fp16 single product: the same kernels and speed class as bf16 with 8x smaller operand rounding
+                ld.model.diffusion_model.set_precision("f16")
+                dtf, _ = run_steps(ld, xT, cond, unc, 2, max(4, args.steps // 2), 1)
+                out["f16_mode"] = {"dtype": "f16", "value": round(max(4, args.steps // 2) / dtf, 3), "unit": "steps/s",
+                                   "note": "fp16 single product; NS32 U-Net output vs the reference golden: rel-L2 7e-4 (bf16: 6e-3), "
+                                           "tests/test_gpu_unet.py::test_unet_fast_modes_reported"}
+            # fp32-parity mode (fp16 x3 split products) throughput next to the fast mode, same workload
             ld.model.diffusion_model.set_precision("parity")
             dtp, _ = run_steps(ld, xT, cond, unc, 2, max(4, args.steps // 2), 1)
             out["parity_mode"] = {"dtype": "f16x3", "value": round(max(4, args.steps // 2) / dtp, 3), "unit": "steps/s",

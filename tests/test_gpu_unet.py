@@ -172,3 +172,37 @@ def test_unet_with_spatial_transformer_vs_oracle(dev):
     bad = UNetModel(**dict(kw, context_dim=64)).eval().to(dev)
     with pytest.raises(RuntimeError):
         bad(x.to(dev), t.to(dev), context=ctx.to(dev))
+
+
+def test_unet_bench_config_single_product_vs_parity(dev, golden):
+    """BASELINE metric configuration (NS32, batch 64, CFG pass = 128 decoder rows): at this size the single-product modes run the
+    register-streamed kernels (3x3, fused skip_connection, split-K, sub-pixel upsample, space-to-depth downsample, producer-side
+    GroupNorm statistics), which the batch-2 golden cases are too small to select. Checked against the parity mode (itself pinned
+    to the reference at 1e-3 above; batch 64 runs the same parity kernels), plus two size-independent properties: rows of the
+    batch are independent (a permuted batch gives the permuted output, bitwise) and the pass is bitwise reproducible."""
+    B = 64
+    m = build(NS32, 0, dev, "parity")
+    x = prng.normal(3, "bc.x", (B, 4, 32, 32)).to(dev)
+    cc = prng.normal(3, "bc.cc", (B, 3, 32, 32)).to(dev)
+    ctx_c = prng.normal(3, "bc.ctx", (B, 512)).to(dev)
+    ctx_u = prng.normal(3, "bc.ctxu", (B, 512)).to(dev)
+    t = torch.full((B,), 951, dtype=torch.long, device=dev)
+    ec, eu = m.forward_cfg(x, cc, t, ctx_c, ctx_u, uniform_t=True)
+    ref = torch.cat([ec, eu]).double().cpu()
+    # the first two rows of the conditional half against the reference golden inputs is covered above; here: internal consistency
+    for precision, tol_l2, tol_max in (("f16", 2e-3, 1e-2), ("bf16", 1.5e-2, 8e-2)):
+        m.set_precision(precision)
+        fc, fu = m.forward_cfg(x, cc, t, ctx_c, ctx_u, uniform_t=True)
+        got = torch.cat([fc, fu]).double().cpu()
+        l2 = float((got - ref).norm() / ref.norm())
+        mx = float((got - ref).abs().max() / ref.std())
+        print(f"[ns32 B=64 cfg {precision}] vs parity mode: rel-L2 {l2:.3e}, max/std {mx:.3e}")
+        assert l2 < tol_l2 and mx < tol_max
+        fc2, fu2 = m.forward_cfg(x, cc, t, ctx_c, ctx_u, uniform_t=True)
+        assert torch.equal(fc, fc2) and torch.equal(fu, fu2)            # reproducible bits
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).to(dev)
+        pc, pu = m.forward_cfg(x[perm].contiguous(), cc[perm].contiguous(), t, ctx_c[perm].contiguous(), ctx_u[perm].contiguous(), uniform_t=True)
+        assert torch.equal(pc, fc[perm]) and torch.equal(pu, fu[perm])  # rows are independent
+    # two sequential single forwards (the reference's ddim.py:177-178 form) equal the shared-encoder pass in the fast mode too
+    y1 = m.forward_parts(x, cc, t, ctx_c, uniform_t=True)
+    assert float((y1.double().cpu() - fc.double().cpu()).abs().max() / ref.std()) < 8e-2
