@@ -294,7 +294,7 @@ extern "C" int stedm_gn_apply16(const float* x1, int c1, const float* x2, int c2
 // ================================================================================================
 // Producer-side statistics: per-(sample, 256-pixel slab, channel) partial sums
 // ================================================================================================
-// The convolution epilogues (conv_igemm_dma9g.inc) emit chan_stats[B][nslab][C][2] = {sum, sum of squares} of the tensor they
+// The convolution epilogues (conv_rs.inc) emit chan_stats[B][nslab][C][2] = {sum, sum of squares} of the tensor they
 // write, one slab per 256-pixel M-tile; tensors from other producers get the same partials from gn_chan_stats_kernel. The
 // apply kernel folds them into group statistics in a fixed order (bitwise reproducible), for ANY grouping of the virtual
 // concat [x1 | x2] - the group boundaries of a decoder block straddle the concat seam - so one set of partials serves the

@@ -97,7 +97,7 @@ extern "C" int stedm_pack_conv_weight_up(const float* w, void* w_hi, void* w_lo,
   return 0;
 }
 
-// Fragment-order packing for the register-streamed 3x3 kernel (conv_igemm_dma9g.inc):
+// Fragment-order packing for the register-streamed 3x3 kernel (conv_rs.inc):
 //   out[tn][chunk][tap][q][lane][e] = W[n = tn*128 + (q>>1)*64 + (q&1)*32 + (lane&31)][ci = chunk*16 + (lane>>5)*8 + e][tap]
 // (rows beyond cout are zero). One wave-wide 16-B load = one MFMA B fragment, 1 KiB contiguous.
 template <typename T>

@@ -539,12 +539,13 @@ class UNetModel(nn.Module):
 
     def _style_proj(self, contexts, B, ted):
         """emb_layers of the ResBlockStyle applied to the style vector(s) (openaimodel.py:277 with emb = context). The
-        style vectors do not change during a sampling run: cached per (storage, version) of the context tensors."""
+        style vectors do not change during a sampling run: cached per (storage, version) of the context tensors. An entry keeps
+        its context tensors alive, so a freed tensor's address cannot come back under a stale entry."""
         c = self._consts
         key = tuple((cx.data_ptr(), cx._version, tuple(cx.shape)) for cx in contexts) + (self._pack_key is not None and id(c["style_wt"]),)
         hit = self._style_cache.get(key)
         if hit is not None:
-            return hit
+            return hit[0]
         nrep = len(contexts)
         if nrep == 1:
             ctx_all = contexts[0].float().contiguous()
@@ -554,7 +555,7 @@ class UNetModel(nn.Module):
                                  torch.empty((B * nrep, c["style_wt"].shape[1]), dtype=torch.float32, device=ctx_all.device))
         if len(self._style_cache) > 8:
             self._style_cache.clear()
-        self._style_cache[key] = style_all
+        self._style_cache[key] = (style_all, tuple(contexts))
         return style_all
 
     def _forward_impl(self, x, c_concat, timesteps, contexts, out, uniform_t=False):

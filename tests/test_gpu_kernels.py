@@ -406,7 +406,7 @@ def test_conv_dma_3x3(dev, prec, tol, B, H, W, cin, cout):
     (50, 32, 32, 32, 96, True, True), (200, 16, 16, 64, 128, True, False), (801, 8, 8, 32, 32, False, True), (3, 128, 128, 32, 64, True, True),
     (12, 64, 64, 32, 32, False, False), (64, 32, 32, 64, 160, True, True), (1601, 4, 4, 64, 128, True, True)])
 def test_conv_dma_3x3_frag_weights(dev, prec, tol, B, H, W, cin, cout, emb, res):
-    """256-row tile kernel with register-streamed fragment-order weights (conv_igemm_dma9g.inc); shapes fill >= 192 tiles so it is
+    """256-row tile kernel with register-streamed fragment-order weights (conv_rs.inc); shapes fill >= 192 tiles so it is
     the kernel the dispatcher picks; ragged sample counts, cout not a multiple of 128, partial last tile."""
     _conv_dma_case(dev, prec, tol, B, H, W, cin, cout, "s1", 3, use_emb=emb, use_res=res, frag=True)
 

@@ -206,3 +206,16 @@ def test_unet_bench_config_single_product_vs_parity(dev, golden):
     # two sequential single forwards (the reference's ddim.py:177-178 form) equal the shared-encoder pass in the fast mode too
     y1 = m.forward_parts(x, cc, t, ctx_c, uniform_t=True)
     assert float((y1.double().cpu() - fc.double().cpu()).abs().max() / ref.std()) < 8e-2
+
+
+def test_style_projection_cache_is_not_fooled_by_address_reuse(dev):
+    """Two forwards with different temporaries as context (the second may be allocated at the first one's address)."""
+    m = build(TINY, 6, dev)
+    x = prng.normal(6, "sc.x", (2, 7, 16, 16)).to(dev)
+    t = torch.tensor([501, 501], dtype=torch.long, device=dev)
+    ca = prng.normal(6, "sc.a", (2, 128)); cb = prng.normal(6, "sc.b", (2, 128))
+    ya = m(x, t, context=ca.to(dev)).clone()
+    yb = m(x, t, context=cb.to(dev)).clone()
+    keep = cb.to(dev)
+    yb2 = m(x, t, context=keep)
+    assert torch.equal(yb, yb2) and not torch.equal(ya, yb)
