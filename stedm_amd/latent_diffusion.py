@@ -53,7 +53,8 @@ class DiffusionWrapper(nn.Module):
         return self.diffusion_model.forward_parts(x, xc, t, cc, out=out, uniform_t=uniform_t)   # cat folded into the first conv
 
     def _same_tensor(self, a, b) -> bool:
-        """Content equality of two conditioning tensors, decided once per (storage, version) pair (no per-step sync)."""
+        """Content equality of two conditioning tensors, decided once per (storage, version) pair (no per-step sync). An entry
+        keeps both tensors alive, so a freed tensor's address cannot reappear under a stale verdict."""
         if a is b or (a.shape == b.shape and a.data_ptr() == b.data_ptr()):
             return True
         if a.shape != b.shape:
@@ -63,8 +64,8 @@ class DiffusionWrapper(nn.Module):
         if key not in cache:
             if len(cache) > 64:
                 cache.clear()
-            cache[key] = bool(torch.equal(a, b))
-        return cache[key]
+            cache[key] = (bool(torch.equal(a, b)), a, b)
+        return cache[key][0]
 
     @torch.no_grad()
     def forward_cfg(self, x, t, cond: dict, uncond: dict, out=None, uniform_t=False):
