@@ -159,3 +159,45 @@ def test_predict_step_surface_end_to_end(dev):
     err = rel(got, ref)
     print(f"[predict_step surface] rel err vs oracle pipeline: {err:.3e}")
     assert err < 1e-3
+
+
+def test_bench_step_graph_replay_equals_eager_and_tracks_parity_mode(dev):
+    """The exact step bench.py times (NS32, 64 latents, DDIM-50 + CFG 1.5, bf16 single product, hipGraph replay): replayed steps
+    give the bits of eager steps, and three denoising steps stay within the single-product budget of the parity mode."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_model, synth_inputs
+    from stedm_amd.ddim import DDIMSampler, StepGraph
+    B, nsteps = 64, 3
+    xT, cond, unc = synth_inputs(dev, B, 0, 1)
+    finals = {}
+    for precision in ("bf16", "parity"):
+        ld = build_model(dev, precision)
+        smp = DDIMSampler(ld, use_graph=True)
+        smp.make_schedule(50, ddim_eta=0.0, verbose=False)
+        n = smp.ddim_timesteps.shape[0]
+        img_e = xT.clone()
+        sg = StepGraph(smp, img_e, cond, unc, 1.5)
+        sg.reset(n - 1)
+        for _ in range(nsteps):
+            sg.step_eager()
+        torch.cuda.synchronize()
+        finals[precision] = img_e.clone()
+        if precision == "bf16":
+            img_g = xT.clone()
+            sg2 = StepGraph(smp, img_g, cond, unc, 1.5)
+            sg2.reset(n - 1)
+            sg2.step_eager()
+            with sg2.stream_ctx():
+                sg2.capture()
+                for _ in range(nsteps - 1):
+                    sg2.replay()
+                torch.cuda.current_stream().synchronize()
+            sg2.join()
+            torch.cuda.synchronize()
+            assert torch.equal(img_g, img_e)
+        del ld, smp, sg
+    a, b = finals["bf16"].double().cpu(), finals["parity"].double().cpu()
+    l2 = float((a - b).norm() / b.norm())
+    print(f"[bench step x{nsteps}] bf16 vs parity mode latents: rel-L2 {l2:.3e}")
+    assert l2 < 5e-3
