@@ -168,10 +168,12 @@ int stedm_conv_fused_skip_ok(const stedm_conv_args* args);
  * w OIHW fp32 [cout][c1+c2][3][3]; out NHWC [B][H][W][cout]. Exact fp32 FMA. */
 int stedm_conv_in(const float* x1, int c1, const float* x2, int c2, int x2_bmod, const float* w_oihw,
                   const float* bias, float* out, int B, int H, int W, int cout, void* stream);
-/* out: GN->SiLU->conv3x3 to out_channels openaimodel.py:729-733, 806. src NHWC [B][H][W][c]; GroupNorm statistics as
- * the slab partials of stedm_gn_stats (stats[B][nslab][groups][2]); w OIHW fp32 [cout][c][3][3]; out NCHW. */
-int stedm_conv_out(const float* src, int c, const double* stats, int nslab, const float* gamma, const float* beta,
-                   float eps, int groups, const float* w_oihw, const float* bias, float* out, int B, int H, int W,
+/* out: GN->SiLU->conv3x3 to out_channels openaimodel.py:729-733, 806. src NHWC [B][H][W][c] (c %% 16 == 0); GroupNorm statistics
+ * from the producer-side channel partials chan_stats[B][ceil(H*W/256)][c][2] (stedm_conv_args.chan_stats / stedm_gn_chan_stats);
+ * w HWIO fp32 [3][3][c][cp], cp = 4 (cout <= 4) or 8, zero-padded (the OIHW weight permuted once by the host); c %% 32 == 0;
+ * out NCHW. Exact fp32 FMA. */
+int stedm_conv_out(const float* src, int c, const float* chan_stats, const float* gamma, const float* beta,
+                   float eps, int groups, const float* w_hwio, const float* bias, float* out, int B, int H, int W,
                    int cout, void* stream);
 
 /* ---- embedding path ---------------------------------------------------------------------- */

@@ -114,36 +114,40 @@ extern "C" int stedm_conv_in(const float* x1, int c1, const float* x2, int c2, i
   return 0;
 }
 
-// conv_out: block = (sample, 4 rows x 32 columns of output pixels). GroupNorm mean/rstd are reduced from the stats
-// partials of stedm_gn_stats in the block prologue (fixed order). Channels are walked in chunks of 32: the haloed,
-// normalised + activated patch chunk [6][34][32(+1 pad)] and the weight chunk [9][32][cout<=8 as 2 float4] sit in
-// LDS; a thread owns one pixel and half of the chunk's channels for all output channels; halves meet in LDS.
+// conv_out: block = (sample, 4 rows x 32 columns of output pixels). GroupNorm mean/rstd are folded from the producer-side channel
+// partials (chan_stats[B][ceil(HW/256)][c][2], fixed order) in the block prologue. Channels are walked in chunks of 32: the haloed,
+// normalised + activated patch chunk [6][34][32(+4 pad)] sits in LDS; a thread owns one pixel and half of the chunk's channels
+// for all output channels, reads 4 channels per 16-B LDS load, and takes the weights through the scalar cache (HWIO layout
+// [3][3][c][4 or 8], zero-padded: the index is wave-uniform and contiguous per tap and channel quad, so they arrive in SGPRs by wide scalar loads
+// and feed the FMAs directly); the two halves meet in LDS.
 constexpr int CO_MAXOUT = 8;
 constexpr int CO_TR = 4, CO_TC = 32, CO_CH = 32;
-__global__ void __launch_bounds__(256) conv_out_kernel(const float* __restrict__ src, int c, const double* __restrict__ stats,
-                                                       int nslab, const float* __restrict__ gamma, const float* __restrict__ beta,
+template <int COUTP>
+__global__ void __launch_bounds__(256) conv_out_kernel(const float* __restrict__ src, int c, const float* __restrict__ cs,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float eps, int groups, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ out, int H, int W,
                                                        int cout, int tr, int tc) {
   extern __shared__ __attribute__((aligned(16))) float smo[];
-  constexpr int PR = CO_TR + 2, PC = CO_TC + 2, PST = CO_CH + 1;
+  constexpr int PR = CO_TR + 2, PC = CO_TC + 2, PST = CO_CH + 4;
   float* sscale = smo;                       // [c]
   float* sshift = sscale + c;                // [c]
   float* sx = sshift + c;                    // [PR][PC][PST]
-  float* sw = sx + PR * PC * PST;            // [9][CO_CH][8]
-  float* sred = sw + 9 * CO_CH * 8;          // [128][8]
+  float* sred = sx + PR * PC * PST;          // [128][COUTP]
   const int tiles = tr * tc;
   const int b = blockIdx.x / tiles, t = blockIdx.x % tiles;
   const int y0 = (t / tc) * CO_TR, x0 = (t % tc) * CO_TC;
   const int cpg = c / groups;
-  const int HW = H * W;
+  const int HW = H * W, nslab = (HW + 255) / 256;
   for (int ch = threadIdx.x; ch < c; ch += 256) {
     const int g = ch / cpg;
     double su = 0.0, sq = 0.0;
-    for (int k = 0; k < nslab; ++k) {
-      su += stats[(((long)b * nslab + k) * groups + g) * 2];
-      sq += stats[(((long)b * nslab + k) * groups + g) * 2 + 1];
-    }
+    for (int k = 0; k < nslab; ++k)          // fixed order: slab, then channel of the group
+      for (int cc = g * cpg; cc < (g + 1) * cpg; ++cc) {
+        const float* p = cs + (((long)b * nslab + k) * c + cc) * 2;
+        su += (double)p[0];
+        sq += (double)p[1];
+      }
     const double inv_n = 1.0 / ((double)cpg * HW);
     const double mean = su * inv_n;
     double var = sq * inv_n - mean * mean;
@@ -153,11 +157,12 @@ __global__ void __launch_bounds__(256) conv_out_kernel(const float* __restrict__
     sscale[ch] = gm;
     sshift[ch] = beta[ch] - (float)mean * gm;
   }
-  const int pix = threadIdx.x & 127, half = threadIdx.x >> 7;
+  const int pix = threadIdx.x & 127;
+  const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);   // wave-uniform: keeps the weight index scalar
   const int yl = pix / CO_TC, xl = pix % CO_TC;
-  float acc[CO_MAXOUT];
+  float acc[COUTP];
 #pragma unroll
-  for (int o = 0; o < CO_MAXOUT; ++o) acc[o] = 0.f;
+  for (int o = 0; o < COUTP; ++o) acc[o] = 0.f;
   for (int c0 = 0; c0 < c; c0 += CO_CH) {
     __syncthreads();
     for (int i = threadIdx.x; i < PR * PC * (CO_CH / 4); i += 256) {
@@ -172,55 +177,56 @@ __global__ void __launch_bounds__(256) conv_out_kernel(const float* __restrict__
         v.x = silu_f(fmaf(v.x, sscale[cc], sshift[cc])); v.y = silu_f(fmaf(v.y, sscale[cc + 1], sshift[cc + 1]));
         v.z = silu_f(fmaf(v.z, sscale[cc + 2], sshift[cc + 2])); v.w = silu_f(fmaf(v.w, sscale[cc + 3], sshift[cc + 3]));
       }
-      float* d = sx + (pr * PC + pc) * PST + q * 4;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-    for (int i = threadIdx.x; i < 9 * CO_CH * 8; i += 256) {
-      const int o = i & 7, ci = (i >> 3) % CO_CH, tap = i / (8 * CO_CH);
-      sw[i] = (o < cout && c0 + ci < c) ? w[((long)o * c + c0 + ci) * 9 + tap] : 0.f;
+      *reinterpret_cast<float4*>(sx + (pr * PC + pc) * PST + q * 4) = v;
     }
     __syncthreads();
+    const int cb = c0 + half * (CO_CH / 2);          // first channel of this half (uniform)
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int dy = tap / 3, dx = tap % 3;
       const float* px = sx + ((yl + dy) * PC + xl + dx) * PST + half * (CO_CH / 2);
-      const float4* pw = reinterpret_cast<const float4*>(sw + (tap * CO_CH + half * (CO_CH / 2)) * 8);
-#pragma unroll 4
-      for (int ci = 0; ci < CO_CH / 2; ++ci) {
-        const float v = px[ci];
-        const float4 wa = pw[ci * 2], wb = pw[ci * 2 + 1];
-        acc[0] = fmaf(v, wa.x, acc[0]); acc[1] = fmaf(v, wa.y, acc[1]); acc[2] = fmaf(v, wa.z, acc[2]); acc[3] = fmaf(v, wa.w, acc[3]);
-        acc[4] = fmaf(v, wb.x, acc[4]); acc[5] = fmaf(v, wb.y, acc[5]); acc[6] = fmaf(v, wb.z, acc[6]); acc[7] = fmaf(v, wb.w, acc[7]);
+#pragma unroll
+      for (int ci = 0; ci < CO_CH / 2; ci += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(px + ci);
+        const float* wp = w + ((long)tap * c + cb + ci) * COUTP;     // [tap][ci][COUTP], zero-padded: 4 * COUTP contiguous floats
+#pragma unroll
+        for (int o = 0; o < COUTP; ++o) {
+          acc[o] = fmaf(v.x, wp[o], acc[o]); acc[o] = fmaf(v.y, wp[COUTP + o], acc[o]);
+          acc[o] = fmaf(v.z, wp[2 * COUTP + o], acc[o]); acc[o] = fmaf(v.w, wp[3 * COUTP + o], acc[o]);
+        }
       }
     }
   }
   __syncthreads();
   if (half == 1) {
 #pragma unroll
-    for (int o = 0; o < CO_MAXOUT; ++o) sred[pix * 8 + o] = acc[o];
+    for (int o = 0; o < COUTP; ++o) sred[pix * COUTP + o] = acc[o];
   }
   __syncthreads();
   if (half == 0) {
     const int y = y0 + yl, x = x0 + xl;
     if (y < H && x < W) {
 #pragma unroll
-      for (int o = 0; o < CO_MAXOUT; ++o)
-        if (o < cout) out[(((long)b * cout + o) * H + y) * W + x] = acc[o] + sred[pix * 8 + o] + (bias ? bias[o] : 0.f);
+      for (int o = 0; o < COUTP; ++o)
+        if (o < cout) out[(((long)b * cout + o) * H + y) * W + x] = acc[o] + sred[pix * COUTP + o] + (bias ? bias[o] : 0.f);
     }
   }
 }
 
-extern "C" int stedm_conv_out(const float* src, int c, const double* stats, int nslab, const float* gamma, const float* beta,
+extern "C" int stedm_conv_out(const float* src, int c, const float* chan_stats, const float* gamma, const float* beta,
                               float eps, int groups, const float* w, const float* bias, float* out, int B, int H, int W,
                               int cout, void* stream) {
-  STEDM_CHECK_ARG(src && stats && gamma && beta && w && out, "conv_out: null pointer");
-  STEDM_CHECK_ARG(c % 4 == 0 && cout >= 1 && cout <= CO_MAXOUT && groups > 0 && c % groups == 0,
-                  "conv_out: need c %% 4 == 0, c %% groups == 0 and cout <= %d (c=%d cout=%d)", CO_MAXOUT, c, cout);
-  const size_t lds = ((size_t)2 * c + (size_t)(CO_TR + 2) * (CO_TC + 2) * (CO_CH + 1) + 9 * CO_CH * 8 + 128 * 8) * sizeof(float);
+  STEDM_CHECK_ARG(src && chan_stats && gamma && beta && w && out, "conv_out: null pointer");
+  STEDM_CHECK_ARG(c % 32 == 0 && cout >= 1 && cout <= CO_MAXOUT && groups > 0 && c % groups == 0,
+                  "conv_out: need c %% 32 == 0, c %% groups == 0 and cout <= %d (c=%d cout=%d)", CO_MAXOUT, c, cout);
+  const int coutp = cout <= 4 ? 4 : 8;
+  const size_t lds = ((size_t)2 * c + (size_t)(CO_TR + 2) * (CO_TC + 2) * (CO_CH + 4) + 128 * coutp) * sizeof(float);
   STEDM_CHECK_ARG(lds <= 64 * 1024, "conv_out: needs %zu B LDS", lds);
   const int tr = (H + CO_TR - 1) / CO_TR, tc = (W + CO_TC - 1) / CO_TC;
-  conv_out_kernel<<<B * tr * tc, 256, lds, as_stream(stream)>>>(src, c, stats, nslab, gamma, beta, eps, groups, w, bias, out, H, W,
-                                                             cout, tr, tc);
+  if (coutp == 4)
+    conv_out_kernel<4><<<B * tr * tc, 256, lds, as_stream(stream)>>>(src, c, chan_stats, gamma, beta, eps, groups, w, bias, out, H, W, cout, tr, tc);
+  else
+    conv_out_kernel<8><<<B * tr * tc, 256, lds, as_stream(stream)>>>(src, c, chan_stats, gamma, beta, eps, groups, w, bias, out, H, W, cout, tr, tc);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

@@ -292,17 +292,30 @@ def conv_in(x1: torch.Tensor, x2: Optional[torch.Tensor], w: torch.Tensor, bias:
     return out
 
 
+def conv_out_weight(w_oihw: torch.Tensor) -> torch.Tensor:
+    """OIHW [cout,c,3,3] -> the layout stedm_conv_out reads: HWIO [3,3,c,cp] zero-padded to cp = 4 or 8 output channels."""
+    cout, c = w_oihw.shape[:2]
+    cp = 4 if cout <= 4 else 8
+    w = torch.zeros((3, 3, c, cp), dtype=torch.float32, device=w_oihw.device)
+    w[..., :cout] = w_oihw.detach().float().permute(2, 3, 1, 0)
+    return w.contiguous()
+
+
 def conv_out(src: torch.Tensor, norm_weight: torch.Tensor, norm_bias: torch.Tensor, eps: float, groups: int, w: torch.Tensor,
-             bias: Optional[torch.Tensor], out: torch.Tensor, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """src [B,H,W,c] NHWC -> out [B,cout,H,W] NCHW with GroupNorm + SiLU fused into the patch load (statistics from
-    gn_stats; computed here when `stats` is None)."""
+             bias: Optional[torch.Tensor], out: torch.Tensor, chan_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """src [B,H,W,c] NHWC -> out [B,cout,H,W] NCHW with GroupNorm + SiLU fused into the patch load (statistics from the
+    producer-side channel partials; computed here by one stedm_gn_chan_stats pass when `chan_stats` is None). `w` is the OIHW
+    weight [cout,c,3,3] or, to skip the per-call permute, the tensor from conv_out_weight()."""
     _chk(src, name="src")
     B, H, W, c = src.shape
-    nslab = gn_nslab(c, H * W)
-    if stats is None:
-        stats = torch.empty((B * nslab * groups * 2,), dtype=torch.float64, device=src.device)
-    gn_stats(src, None, stats, groups)
-    check(lib().stedm_conv_out(src.data_ptr(), c, stats.data_ptr(), nslab, norm_weight.data_ptr(), norm_bias.data_ptr(), float(eps),
+    cout = out.shape[1]
+    if w.dim() == 4 and tuple(w.shape[:3]) != (3, 3, c):      # OIHW
+        w = conv_out_weight(w)
+    assert tuple(w.shape) == (3, 3, c, 4 if cout <= 4 else 8)
+    if chan_stats is None:
+        chan_stats = torch.empty((B, gn_chan_nslab(H * W), c, 2), dtype=torch.float32, device=src.device)
+        gn_chan_stats(src, chan_stats)
+    check(lib().stedm_conv_out(src.data_ptr(), c, chan_stats.data_ptr(), norm_weight.data_ptr(), norm_bias.data_ptr(), float(eps),
                                groups, w.data_ptr(), _ptr(bias), out.data_ptr(), B, H, W, out.shape[1], _stream()), "stedm_conv_out")
     return out
 

@@ -335,6 +335,7 @@ class UNetModel(nn.Module):
         self._emb_off = {id(rb): o for rb, o in self._emb_layout}
         self._emb_ntot = off
         srb = self.middle_block[1].block
+        c["out_w_hwio"] = ops.conv_out_weight(self.out[2].weight)   # conv_out reads [3][3][c][4|8]
         c["style_wt"] = ops.transpose(srb.emb_layers[1].weight.float())
         c["style_b"] = srb.emb_layers[1].bias.detach().float().contiguous()
         self._pack_key = key
@@ -616,6 +617,6 @@ class UNetModel(nn.Module):
         if out is None:
             out = torch.empty((Bd, self.out_channels, H, W), dtype=torch.float32, device=x.device)
         gn = self.out[0]
-        stats = self._buf("gn_partials_out", (Bd * ops.gn_nslab(h.shape[-1], H * W) * gn.num_groups * 2,), torch.float64)
-        ops.conv_out(h, gn.weight, gn.bias, gn.eps, gn.num_groups, self.out[2].weight, self.out[2].bias, out, stats)
+        cs = self._chan_stats(h) if self.conv_path == "dma" else None     # left by the last ResBlock's conv epilogue
+        ops.conv_out(h, gn.weight, gn.bias, gn.eps, gn.num_groups, c["out_w_hwio"], self.out[2].bias, out, cs)
         return out
