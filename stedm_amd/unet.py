@@ -228,6 +228,7 @@ class UNetModel(nn.Module):
         self._gn_slot = 0
         self._style_cache: Dict[Tuple, torch.Tensor] = {}
         self._cs: Dict[int, torch.Tensor] = {}
+        self._raw16: Dict[int, Tuple] = {}
 
     # ------------------------------------------------------------------------------------ engine plumbing
     def convert_to_fp16(self):  # openaimodel.py:745-751 — a no-op in the reference too (openaimodel.py:25-29)
@@ -386,7 +387,7 @@ class UNetModel(nn.Module):
                         norm.weight, norm.bias, norm.eps, norm.num_groups, act, x2_bmod, raw)
         return ((hi, lo), raw) if want_raw else (hi, lo)
 
-    def _res(self, tag: str, rb: ResBlock, x1, x2, emb_all, emb_off, emb_bstride, x2_bmod=0):
+    def _res(self, tag: str, rb: ResBlock, x1, x2, emb_all, emb_off, emb_bstride, x2_bmod=0, want16=False):
         """ResBlock._forward openaimodel.py:268-288 on NHWC tensors; [x1|x2] is the virtual concat input."""
         prec = self.precision
         B, H, W, _ = x1.shape
@@ -409,13 +410,17 @@ class UNetModel(nn.Module):
                            emb=emb_all, emb_offset=emb_off, emb_bstride=emb_bstride)
         out = self._buf(tag + ".out", (B, H, W, co))
         pk2 = self._packed[id(rb.out_layers[3])]
+        o16 = None
+        if dma and want16:     # the consumer (Upsample) reads plain 16-bit planes: the conv epilogue writes them, no conversion pass
+            o16 = self._planes(B, H, W, co, "up16")
+            self._raw16[out.data_ptr()] = o16
         if dma and has_skip:
             # conv2 + skip_connection(x) in one kernel when the register-streamed kernel covers the problem (asked once per shape)
             ps = self._packed[id(rb.skip_connection)]
             h16 = self._norm16(rb.out_layers[0], 1, h)
             fuse_key = ("fuse", id(rb), B, H, W)
             fused = self._consts.get(fuse_key)
-            kw = dict(prec=prec, src16=h16, bias=pk2.bias, w_frag=pk2.frag, chan_stats=self._cs_new(out), ws=ws)
+            kw = dict(prec=prec, src16=h16, bias=pk2.bias, w_frag=pk2.frag, chan_stats=self._cs_new(out), ws=ws, out16=o16)
             if fused is None:
                 fused = bool(pk2.frag is not None and ps.frag is not None and
                              ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias), query_fused=True, **kw))
@@ -436,7 +441,7 @@ class UNetModel(nn.Module):
         if dma:
             h16 = self._norm16(rb.out_layers[0], 1, h)
             ops.conv_igemm(None, pk2.hi, pk2.lo, out, prec=prec, src16=h16, bias=pk2.bias, res=res, w_frag=pk2.frag,
-                           chan_stats=self._cs_new(out), ws=ws)
+                           chan_stats=self._cs_new(out), ws=ws, out16=o16)
         else:
             sc2, sh2 = self._gn(tag + ".gn2", rb.out_layers[0], h)
             ops.conv_igemm(h, pk2.hi, pk2.lo, out, prec=prec, scale=sc2, shift=sh2, act=1, bias=pk2.bias, res=res)
@@ -467,10 +472,13 @@ class UNetModel(nn.Module):
 
     def _run_block(self, tag: str, blk, h, skip, emb_all, emb_bstride, style_all, skip_bmod=0, li0=0):
         """TimestepEmbedSequential.forward openaimodel.py:93-101 (+ the th.cat of :800 folded into the first layer)."""
-        for li, layer in enumerate(blk, start=li0):
+        layers = list(blk)
+        for li, layer in enumerate(layers, start=li0):
             ltag = f"{tag}.{li}"
+            nxt = layers[li - li0 + 1] if li - li0 + 1 < len(layers) else None
             if isinstance(layer, ResBlock):
-                h = self._res(ltag, layer, h, skip, emb_all, self._emb_off[id(layer)], emb_bstride, x2_bmod=skip_bmod)
+                h = self._res(ltag, layer, h, skip, emb_all, self._emb_off[id(layer)], emb_bstride, x2_bmod=skip_bmod,
+                              want16=isinstance(nxt, Upsample))
                 skip = None
             elif isinstance(layer, ResBlockStyle):
                 h = self._res(ltag, layer.block, h, None, style_all, 0, style_all.shape[1])
@@ -500,8 +508,9 @@ class UNetModel(nn.Module):
                 out = self._buf(ltag + ".out", (B, H * 2, W * 2, layer.out_channels))
                 if self.conv_path == "dma":
                     pu = self._packed[(id(layer.conv), "up")]
+                    src16 = self._raw16.get(h.data_ptr()) or self._norm16(None, 0, h)
                     h = ops.conv_igemm(None, pu.hi, pu.lo, out, prec=self.precision, mode=CONV_UP_SUBPIXEL,
-                                       src16=self._norm16(None, 0, h), bias=pu.bias, w_frag=pu.frag)
+                                       src16=src16, bias=pu.bias, w_frag=pu.frag)
                 else:
                     h = ops.conv_igemm(h, pk.hi, pk.lo, out, prec=self.precision, mode=CONV_UP, bias=pk.bias)
             else:
@@ -562,6 +571,7 @@ class UNetModel(nn.Module):
     def _forward_impl(self, x, c_concat, timesteps, contexts, out, uniform_t=False):
         self._prepare()
         self._cs = {}
+        self._raw16 = {}
         x = x.float().contiguous()
         B, c1, H, W = x.shape
         nrep = len(contexts)
