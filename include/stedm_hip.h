@@ -98,8 +98,11 @@ int stedm_gn_nslab(int C, int HW);
  * act(GroupNorm(x)) as 16-bit planes; raw_hi/raw_lo (optional) receive the plain 16-bit conversion of [x1 | x2] from the
  * same read (operand of the ResBlock's 1x1 skip_connection, openaimodel.py:254). */
 int stedm_gn_chan_nslab(int HW);
-int stedm_gn_chan_stats(const float* x, int C, int B, int HW, float* chan_stats, void* stream);
-int stedm_gn_apply16c(const float* x1, int c1, const float* cs1, const float* x2, int c2, const float* cs2, int x2_bmod,
+/* nslab: slot count of chan_stats; 0 or stedm_gn_chan_nslab(HW): runs of 256 pixels, otherwise nslab runs of ceil(HW/nslab). */
+int stedm_gn_chan_stats(const float* x, int C, int B, int HW, int nslab, float* chan_stats, void* stream);
+/* nslab1 / nslab2: slot counts of cs1 / cs2. ANY partition of a sample's pixels into slots serves (the consumer adds all slots):
+ * 256-pixel runs (3x3 / 1x1 epilogues), (tile, output parity) pairs (sub-pixel upsample), row pairs (stedm_conv_in). */
+int stedm_gn_apply16c(const float* x1, int c1, const float* cs1, int nslab1, const float* x2, int c2, const float* cs2, int nslab2, int x2_bmod,
                       const float* gamma, const float* beta, float eps, int groups, int act, int B, int HW,
                       void* out_hi, void* out_lo, void* raw_hi, void* raw_lo, int mm_dtype, void* stream);
 int stedm_gn_stats(const float* x1, int c1, const float* x2, int c2, int x2_bmod, int groups, int B, int HW,
@@ -139,8 +142,10 @@ typedef struct stedm_conv_args {
   void* out16_hi;
   void* out16_lo;
   const void* w_frag; /* optional: fragment-order weights (stedm_pack_conv_weight_frag) for 3x3, npass 1, DMA path */
-  float* chan_stats;  /* optional: [B][stedm_gn_chan_nslab(Hout*Wout)][cout][2] per-(sample, 256-pixel slab, channel) sum and
-                       * sum of squares of `out` (the next GroupNorm's statistics, see stedm_gn_apply16c); needs out != NULL */
+  float* chan_stats;  /* optional: [B][chan_nslab][cout][2] per-(sample, slot, channel) sum and sum of squares of `out` (the next
+                       * GroupNorm's statistics, see stedm_gn_apply16c); needs out != NULL. chan_nslab = 0 means
+                       * stedm_gn_chan_nslab(Hout*Wout) slots of 256 pixels; STEDM_CONV_UP_SUBPIXEL fills 4 * ceil(Hin*Win/256) slots
+                       * (tile x output parity) from its epilogue when chan_nslab says so; any other count is filled by an extra pass */
   /* Fused skip_connection (optional, 3x3 stride 1, single product, needs w_frag): out = conv3x3(src16) + conv1x1(src16b) +
    * bias + bias_b — the ResBlock tail `skip_connection(x) + h` (openaimodel.py:254, 288) in one kernel. src16b_hi: raw 16-bit
    * planes [B][Hin][Win][cb] of the block input (raw output of stedm_gn_apply16c), cb %% 64 == 0; w_frag_b: the 1x1 weights in
@@ -154,6 +159,7 @@ typedef struct stedm_conv_args {
    * K range over two blocks per tile; the partial tiles are summed in a fixed order by a reduce kernel (bitwise reproducible). */
   float* ws;
   int64_t ws_floats;
+  int32_t chan_nslab; /* slot count of chan_stats (see there) */
 } stedm_conv_args;
 /* Replaces: GN->SiLU->conv3x3(+bias)(+emb)(+skip) of ResBlock._forward openaimodel.py:268-288,
  * Downsample/Upsample convs (:122-132,:156-173), 1x1 skip_connection (:254), and the 1x1
@@ -167,12 +173,14 @@ int stedm_conv_fused_skip_ok(const stedm_conv_args* args);
  * openaimodel.py:542. x1 NCHW [B][c1][H][W], x2 NCHW [B or bmod][c2][H][W] (may be NULL);
  * w OIHW fp32 [cout][c1+c2][3][3]; out NHWC [B][H][W][cout]. Exact fp32 FMA. */
 int stedm_conv_in(const float* x1, int c1, const float* x2, int c2, int x2_bmod, const float* w_oihw,
-                  const float* bias, float* out, int B, int H, int W, int cout, void* stream);
+                  const float* bias, float* out, int B, int H, int W, int cout, float* chan_stats, void* stream);
+/* chan_stats (optional, fast path only: c1+c2 <= 8, 256 %% cout == 0, H even): [B][H/2][cout][2] channel partials of `out`, one slot
+ * per pair of image rows; returns 3 without writing when the fast path does not apply (the caller then uses stedm_gn_chan_stats). */
 /* out: GN->SiLU->conv3x3 to out_channels openaimodel.py:729-733, 806. src NHWC [B][H][W][c] (c %% 16 == 0); GroupNorm statistics
- * from the producer-side channel partials chan_stats[B][ceil(H*W/256)][c][2] (stedm_conv_args.chan_stats / stedm_gn_chan_stats);
+ * from the producer-side channel partials chan_stats[B][nslab][c][2] (stedm_conv_args.chan_stats / stedm_gn_chan_stats);
  * w HWIO fp32 [3][3][c][cp], cp = 4 (cout <= 4) or 8, zero-padded (the OIHW weight permuted once by the host); c %% 32 == 0;
  * out NCHW. Exact fp32 FMA. */
-int stedm_conv_out(const float* src, int c, const float* chan_stats, const float* gamma, const float* beta,
+int stedm_conv_out(const float* src, int c, const float* chan_stats, int nslab, const float* gamma, const float* beta,
                    float eps, int groups, const float* w_hwio, const float* bias, float* out, int B, int H, int W,
                    int cout, void* stream);
 

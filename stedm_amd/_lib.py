@@ -36,7 +36,7 @@ class ConvArgs(C.Structure):
         ("act_out", C.c_int32), ("out16_hi", C.c_void_p), ("out16_lo", C.c_void_p),
         ("w_frag", C.c_void_p), ("chan_stats", C.c_void_p),
         ("src16b_hi", C.c_void_p), ("w_frag_b", C.c_void_p), ("bias_b", C.c_void_p), ("cb", C.c_int32),
-        ("ws", C.c_void_p), ("ws_floats", C.c_int64),
+        ("ws", C.c_void_p), ("ws_floats", C.c_int64), ("chan_nslab", C.c_int32),
     ]
 
 
@@ -58,12 +58,12 @@ SIGNATURES = {
     "stedm_gn_stats": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P]),
     "stedm_gn_apply16": (_I, [_P, _I, _P, _I, _I, _P, _P, _F, _I, _I, _P, _I, _I, _P, _P, _I, _P]),
     "stedm_gn_chan_nslab": (_I, [_I]),
-    "stedm_gn_chan_stats": (_I, [_P, _I, _I, _I, _P, _P]),
-    "stedm_gn_apply16c": (_I, [_P, _I, _P, _P, _I, _P, _I, _P, _P, _F, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
+    "stedm_gn_chan_stats": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "stedm_gn_apply16c": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _F, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "stedm_conv_igemm": (_I, [C.POINTER(ConvArgs), _P]),
     "stedm_conv_fused_skip_ok": (_I, [C.POINTER(ConvArgs)]),
-    "stedm_conv_in": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "stedm_conv_out": (_I, [_P, _I, _P, _P, _P, _F, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "stedm_conv_in": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "stedm_conv_out": (_I, [_P, _I, _P, _I, _P, _P, _F, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "stedm_time_embed": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "stedm_emb_proj": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "stedm_linear": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

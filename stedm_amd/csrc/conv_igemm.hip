@@ -335,7 +335,7 @@ extern "C" int stedm_conv_igemm(const stedm_conv_args* args, void* stream) {
   if (rc != 0 || !a.chan_stats || p.stats_done) return rc;
   // the kernel that ran has no statistics epilogue: one extra pass over the output
   const int up = (a.mode == STEDM_CONV_UP || a.mode == STEDM_CONV_UP_SUBPIXEL) ? 4 : 1, down = a.mode == STEDM_CONV_DOWN ? 4 : 1;
-  return stedm_gn_chan_stats(a.out, a.cout, a.B, a.Hin * a.Win * up / down, a.chan_stats, stream);
+  return stedm_gn_chan_stats(a.out, a.cout, a.B, a.Hin * a.Win * up / down, a.chan_nslab, a.chan_stats, stream);
 }
 
 // validates the arguments and fills the derived sizes of `p`

@@ -53,8 +53,8 @@ constexpr int CI_ROWS = 2;   // small row blocks: 4+ waves per SIMD hide the LDS
 __global__ void __launch_bounds__(256) conv_in_fast_kernel(const float* __restrict__ x1, int c1, const float* __restrict__ x2,
                                                            int c2, int bmod, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ out, int H, int W,
-                                                           int cout, int rblocks) {
-  extern __shared__ __attribute__((aligned(16))) float smi[];   // [CI_ROWS+2][W+2][8]
+                                                           int cout, int rblocks, float* __restrict__ cs) {
+  extern __shared__ __attribute__((aligned(16))) float smi[];   // [CI_ROWS+2][W+2][8], then [256][2] statistics partials
   const int cin = c1 + c2;
   const int PW = W + 2;
   const int b = blockIdx.x / rblocks, y0 = (blockIdx.x % rblocks) * CI_ROWS;
@@ -78,6 +78,7 @@ __global__ void __launch_bounds__(256) conv_in_fast_kernel(const float* __restri
   const float bv = bias ? bias[co] : 0.f;
   __syncthreads();
   const int rows = min(CI_ROWS, H - y0);
+  float ssum = 0.f, ssq = 0.f;
   for (int pix = pl; pix < rows * W; pix += npl) {
     const int yl = pix / W, x = pix - yl * W;
     float acc = bv;
@@ -90,23 +91,36 @@ __global__ void __launch_bounds__(256) conv_in_fast_kernel(const float* __restri
       acc = fmaf(v.x, wr[tap][4], acc); acc = fmaf(v.y, wr[tap][5], acc); acc = fmaf(v.z, wr[tap][6], acc); acc = fmaf(v.w, wr[tap][7], acc);
     }
     out[(((long)b * H + y0 + yl) * W + x) * cout + co] = acc;
+    ssum += acc; ssq += acc * acc;
+  }
+  if (cs) {   // per-(sample, row block, channel) partials: the pixel lanes of a channel meet in LDS, fixed order
+    float* sp = smi + (CI_ROWS + 2) * PW * 8;
+    sp[threadIdx.x * 2] = ssum; sp[threadIdx.x * 2 + 1] = ssq;
+    __syncthreads();
+    if (threadIdx.x < cout) {
+      float su = 0.f, sq = 0.f;
+      for (int l = 0; l < npl; ++l) { su += sp[(l * cout + threadIdx.x) * 2]; sq += sp[(l * cout + threadIdx.x) * 2 + 1]; }
+      float* d = cs + (((long)b * rblocks + blockIdx.x % rblocks) * cout + threadIdx.x) * 2;
+      d[0] = su; d[1] = sq;
+    }
   }
 }
 
 extern "C" int stedm_conv_in(const float* x1, int c1, const float* x2, int c2, int x2_bmod, const float* w,
-                             const float* bias, float* out, int B, int H, int W, int cout, void* stream) {
+                             const float* bias, float* out, int B, int H, int W, int cout, float* chan_stats, void* stream) {
   STEDM_CHECK_ARG(x1 && w && out, "conv_in: null pointer");
   STEDM_CHECK_ARG((x2 != nullptr) == (c2 > 0), "conv_in: x2/c2 mismatch");
   const int cin = c1 + c2;
   if (cin <= 8 && cout <= 256 && 256 % cout == 0) {
-    const size_t ldsf = (size_t)(CI_ROWS + 2) * (W + 2) * 8 * sizeof(float);
-    if (ldsf <= 64 * 1024) {
+    const size_t ldsf = ((size_t)(CI_ROWS + 2) * (W + 2) * 8 + 512) * sizeof(float);
+    if (ldsf <= 64 * 1024 && (!chan_stats || H % CI_ROWS == 0)) {
       const int rblocks = (H + CI_ROWS - 1) / CI_ROWS;
-      conv_in_fast_kernel<<<B * rblocks, 256, ldsf, as_stream(stream)>>>(x1, c1, x2, c2, x2_bmod, w, bias, out, H, W, cout, rblocks);
+      conv_in_fast_kernel<<<B * rblocks, 256, ldsf, as_stream(stream)>>>(x1, c1, x2, c2, x2_bmod, w, bias, out, H, W, cout, rblocks, chan_stats);
       STEDM_LAUNCH_CHECK();
       return 0;
     }
   }
+  if (chan_stats) return 3;   // no statistics epilogue on the generic path: nothing was launched
   const size_t lds = ((size_t)3 * (W + 2) * cin + (size_t)9 * cin * cout) * sizeof(float);
   STEDM_CHECK_ARG(lds <= 64 * 1024, "conv_in: cin=%d cout=%d W=%d needs %zu B LDS (> 64 KiB)", cin, cout, W, lds);
   conv_in_kernel<<<B * H, 256, lds, as_stream(stream)>>>(x1, c1, x2, c2, x2_bmod, w, bias, out, H, W, cout);
@@ -123,7 +137,7 @@ extern "C" int stedm_conv_in(const float* x1, int c1, const float* x2, int c2, i
 constexpr int CO_MAXOUT = 8;
 constexpr int CO_TR = 4, CO_TC = 32, CO_CH = 32;
 template <int COUTP>
-__global__ void __launch_bounds__(256) conv_out_kernel(const float* __restrict__ src, int c, const float* __restrict__ cs,
+__global__ void __launch_bounds__(256) conv_out_kernel(const float* __restrict__ src, int c, const float* __restrict__ cs, int nslab,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float eps, int groups, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ out, int H, int W,
@@ -138,7 +152,7 @@ __global__ void __launch_bounds__(256) conv_out_kernel(const float* __restrict__
   const int b = blockIdx.x / tiles, t = blockIdx.x % tiles;
   const int y0 = (t / tc) * CO_TR, x0 = (t % tc) * CO_TC;
   const int cpg = c / groups;
-  const int HW = H * W, nslab = (HW + 255) / 256;
+  const int HW = H * W;
   for (int ch = threadIdx.x; ch < c; ch += 256) {
     const int g = ch / cpg;
     double su = 0.0, sq = 0.0;
@@ -213,10 +227,10 @@ __global__ void __launch_bounds__(256) conv_out_kernel(const float* __restrict__
   }
 }
 
-extern "C" int stedm_conv_out(const float* src, int c, const float* chan_stats, const float* gamma, const float* beta,
+extern "C" int stedm_conv_out(const float* src, int c, const float* chan_stats, int nslab, const float* gamma, const float* beta,
                               float eps, int groups, const float* w, const float* bias, float* out, int B, int H, int W,
                               int cout, void* stream) {
-  STEDM_CHECK_ARG(src && chan_stats && gamma && beta && w && out, "conv_out: null pointer");
+  STEDM_CHECK_ARG(src && chan_stats && gamma && beta && w && out && nslab > 0, "conv_out: null pointer / nslab");
   STEDM_CHECK_ARG(c % 32 == 0 && cout >= 1 && cout <= CO_MAXOUT && groups > 0 && c % groups == 0,
                   "conv_out: need c %% 32 == 0, c %% groups == 0 and cout <= %d (c=%d cout=%d)", CO_MAXOUT, c, cout);
   const int coutp = cout <= 4 ? 4 : 8;
@@ -224,9 +238,9 @@ extern "C" int stedm_conv_out(const float* src, int c, const float* chan_stats, 
   STEDM_CHECK_ARG(lds <= 64 * 1024, "conv_out: needs %zu B LDS", lds);
   const int tr = (H + CO_TR - 1) / CO_TR, tc = (W + CO_TC - 1) / CO_TC;
   if (coutp == 4)
-    conv_out_kernel<4><<<B * tr * tc, 256, lds, as_stream(stream)>>>(src, c, chan_stats, gamma, beta, eps, groups, w, bias, out, H, W, cout, tr, tc);
+    conv_out_kernel<4><<<B * tr * tc, 256, lds, as_stream(stream)>>>(src, c, chan_stats, nslab, gamma, beta, eps, groups, w, bias, out, H, W, cout, tr, tc);
   else
-    conv_out_kernel<8><<<B * tr * tc, 256, lds, as_stream(stream)>>>(src, c, chan_stats, gamma, beta, eps, groups, w, bias, out, H, W, cout, tr, tc);
+    conv_out_kernel<8><<<B * tr * tc, 256, lds, as_stream(stream)>>>(src, c, chan_stats, nslab, gamma, beta, eps, groups, w, bias, out, H, W, cout, tr, tc);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

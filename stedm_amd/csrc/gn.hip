@@ -302,14 +302,14 @@ extern "C" int stedm_gn_apply16(const float* x1, int c1, const float* x2, int c2
 extern "C" int stedm_gn_chan_nslab(int HW) { return (HW + 255) / 256; }
 
 // grid (B, slabs of 256 pixels, blocks of 64 channel quads): 256 threads = QB quads x (256 / QB) pixel lanes
-__global__ void __launch_bounds__(256) gn_chan_stats_kernel(const float* __restrict__ x, int C, int HW, float* __restrict__ cs) {
+__global__ void __launch_bounds__(256) gn_chan_stats_kernel(const float* __restrict__ x, int C, int HW, int slab_px, float* __restrict__ cs) {
   __shared__ float cpart[256 * 8];   // [npl][QB][8]
   const int b = blockIdx.x, slab = blockIdx.y, nslab = gridDim.y;
   const int Q = C >> 2, t = threadIdx.x;
   const int qb0 = blockIdx.z * 64, QB = min(64, Q - qb0);
   const int npl = 256 / QB, tq = t % QB, tp = t / QB;
   const float* px = x + (long)b * HW * C + (qb0 + tq) * 4;
-  const int px0 = slab * 256, px1 = min(HW, px0 + 256);
+  const int px0 = min(HW, slab * slab_px), px1 = min(HW, px0 + slab_px);   // trailing slots of an over-allocated partition stay 0
   float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
   if (tp < npl) {
 #pragma unroll 4
@@ -336,11 +336,13 @@ __global__ void __launch_bounds__(256) gn_chan_stats_kernel(const float* __restr
   }
 }
 
-extern "C" int stedm_gn_chan_stats(const float* x, int C, int B, int HW, float* chan_stats, void* stream) {
-  STEDM_CHECK_ARG(x && chan_stats && C > 0 && C % 4 == 0 && B > 0 && HW > 0, "gn_chan_stats: bad args (C %% 4)");
+extern "C" int stedm_gn_chan_stats(const float* x, int C, int B, int HW, int nslab, float* chan_stats, void* stream) {
+  STEDM_CHECK_ARG(x && chan_stats && C > 0 && C % 4 == 0 && B > 0 && HW > 0 && nslab >= 0, "gn_chan_stats: bad args (C %% 4)");
   const int Q = C / 4;
-  dim3 grid(B, (HW + 255) / 256, (Q + 63) / 64);
-  gn_chan_stats_kernel<<<grid, 256, 0, as_stream(stream)>>>(x, C, HW, chan_stats);
+  if (nslab == 0) nslab = (HW + 255) / 256;
+  const int slab_px = nslab == (HW + 255) / 256 ? 256 : (HW + nslab - 1) / nslab;   // the default partition is 256-pixel runs
+  dim3 grid(B, nslab, (Q + 63) / 64);
+  gn_chan_stats_kernel<<<grid, 256, 0, as_stream(stream)>>>(x, C, HW, slab_px, chan_stats);
   STEDM_LAUNCH_CHECK();
   return 0;
 }
@@ -350,7 +352,7 @@ struct GnApplyCArgs {
   const float* x2;
   const float* cs1;
   const float* cs2;
-  int c1, c2, bmod, groups, HW, act, nslab;
+  int c1, c2, bmod, groups, HW, act, nslab1, nslab2;
   const float* gamma;
   const float* beta;
   float eps;
@@ -376,13 +378,15 @@ __global__ void __launch_bounds__(256) gn_apply16c_kernel(GnApplyCArgs a, int sl
     const int g = threadIdx.x / L, l = threadIdx.x % L;
     double su = 0.0, sq = 0.0;
     if (g < a.groups) {
-      const int n = cpg * a.nslab;
-      for (int e = l; e < n; e += L) {            // entry = (slab k, channel cc of the group)
+      const int nmax = a.nslab1 > a.nslab2 ? a.nslab1 : a.nslab2;
+      const int n = cpg * nmax;
+      for (int e = l; e < n; e += L) {            // entry = (slab k, channel cc of the group); tensors may be partitioned differently
         const int k = e / cpg, c = g * cpg + (e - k * cpg);
-        const float* p = c < a.c1 ? a.cs1 + (((long)b * a.nslab + k) * a.c1 + c) * 2
-                                  : a.cs2 + (((long)b2 * a.nslab + k) * a.c2 + (c - a.c1)) * 2;
-        su += (double)p[0];
-        sq += (double)p[1];
+        if (c < a.c1) {
+          if (k < a.nslab1) { const float* p = a.cs1 + (((long)b * a.nslab1 + k) * a.c1 + c) * 2; su += (double)p[0]; sq += (double)p[1]; }
+        } else if (k < a.nslab2) {
+          const float* p = a.cs2 + (((long)b2 * a.nslab2 + k) * a.c2 + (c - a.c1)) * 2; su += (double)p[0]; sq += (double)p[1];
+        }
       }
     }
     dsu[threadIdx.x] = su; dsq[threadIdx.x] = sq;
@@ -470,7 +474,7 @@ __global__ void __launch_bounds__(256) gn_apply16c_kernel(GnApplyCArgs a, int sl
   }
 }
 
-extern "C" int stedm_gn_apply16c(const float* x1, int c1, const float* cs1, const float* x2, int c2, const float* cs2, int x2_bmod,
+extern "C" int stedm_gn_apply16c(const float* x1, int c1, const float* cs1, int nslab1, const float* x2, int c2, const float* cs2, int nslab2, int x2_bmod,
                                  const float* gamma, const float* beta, float eps, int groups, int act, int B, int HW,
                                  void* out_hi, void* out_lo, void* raw_hi, void* raw_lo, int mm_dtype, void* stream) {
   STEDM_CHECK_ARG(x1 && cs1 && out_hi && gamma && beta, "gn_apply16c: null pointer");
@@ -480,7 +484,8 @@ extern "C" int stedm_gn_apply16c(const float* x1, int c1, const float* cs1, cons
   STEDM_CHECK_ARG(groups > 0 && groups <= 64 && C % groups == 0, "gn_apply16c: need groups <= 64 and C %% groups == 0");
   STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "gn_apply16c: bad mm_dtype");
   STEDM_CHECK_ARG(raw_hi || !raw_lo, "gn_apply16c: raw_lo without raw_hi");
-  GnApplyCArgs a{x1, x2, cs1, cs2, c1, c2, x2_bmod, groups, HW, act, (HW + 255) / 256, gamma, beta, eps, out_hi, out_lo, raw_hi, raw_lo};
+  STEDM_CHECK_ARG(nslab1 > 0 && (x2 == nullptr || nslab2 > 0), "gn_apply16c: nslab1 / nslab2 must be the slot counts of cs1 / cs2");
+  GnApplyCArgs a{x1, x2, cs1, cs2, c1, c2, x2_bmod, groups, HW, act, nslab1, x2 ? nslab2 : 0, gamma, beta, eps, out_hi, out_lo, raw_hi, raw_lo};
   static const int slab_kb = getenv("STEDM_GN_SLAB_KB") ? atoi(getenv("STEDM_GN_SLAB_KB")) : 32;
   int slab = (slab_kb * 256 + C - 1) / C;   // pixels per block: slab_kb KiB of fp32 input
   if (slab < 1) slab = 1;

@@ -189,12 +189,13 @@ def gn_chan_nslab(HW: int) -> int:
 
 
 def gn_chan_stats(x: torch.Tensor, out: torch.Tensor) -> None:
-    """Per-(sample, 256-pixel slab, channel) {sum, sumsq} of an NHWC fp32 tensor -> out [B][nslab][C][2] fp32."""
+    """Per-(sample, slot, channel) {sum, sumsq} of an NHWC fp32 tensor -> out [B][nslab][C][2] fp32 (any nslab: the sample's
+    pixels are cut into nslab runs)."""
     _chk(x, name="x")
     B, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * C)
-    assert out.dtype == torch.float32 and out.numel() >= B * gn_chan_nslab(HW) * C * 2
-    check(lib().stedm_gn_chan_stats(x.data_ptr(), C, B, HW, out.data_ptr(), _stream()), "stedm_gn_chan_stats")
+    assert out.dtype == torch.float32 and out.dim() == 4 and out.shape[0] == B and tuple(out.shape[2:]) == (C, 2)
+    check(lib().stedm_gn_chan_stats(x.data_ptr(), C, B, HW, out.shape[1], out.data_ptr(), _stream()), "stedm_gn_chan_stats")
 
 
 def gn_apply16c(x1: torch.Tensor, cs1: torch.Tensor, x2: Optional[torch.Tensor], cs2: Optional[torch.Tensor], out_hi: torch.Tensor,
@@ -205,7 +206,8 @@ def gn_apply16c(x1: torch.Tensor, cs1: torch.Tensor, x2: Optional[torch.Tensor],
     B = x1.shape[0]
     HW = x1.numel() // (B * x1.shape[-1])
     c2 = 0 if x2 is None else x2.shape[-1]
-    check(lib().stedm_gn_apply16c(x1.data_ptr(), x1.shape[-1], cs1.data_ptr(), _ptr(x2), c2, _ptr(cs2), x2_bmod, gamma.data_ptr(),
+    check(lib().stedm_gn_apply16c(x1.data_ptr(), x1.shape[-1], cs1.data_ptr(), cs1.shape[1], _ptr(x2), c2, _ptr(cs2),
+                                  0 if cs2 is None else cs2.shape[1], x2_bmod, gamma.data_ptr(),
                                   beta.data_ptr(), float(eps), groups, act, B, HW, out_hi.data_ptr(), _ptr(out_lo),
                                   None if raw is None else raw[0].data_ptr(), None if raw is None else _ptr(raw[1]),
                                   prec.mm_dtype, _stream()), "stedm_gn_apply16c")
@@ -230,6 +232,7 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
     a.act_out = act_out
     a.w_frag = _ptr(w_frag) if prec.npass == 1 else None
     a.chan_stats = _ptr(chan_stats)
+    a.chan_nslab = 0 if chan_stats is None else chan_stats.shape[1]
     if ws is not None:   # fp32 workspace for the split-K form of small grids
         a.ws = ws.data_ptr()
         a.ws_floats = ws.numel()
@@ -280,16 +283,25 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
 
 
 def conv_in(x1: torch.Tensor, x2: Optional[torch.Tensor], w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor,
-            x2_bmod: int = 0) -> torch.Tensor:
-    """x1 [B,c1,H,W] NCHW (+ x2 [B,c2,H,W]) -> out [B,H,W,cout] NHWC."""
+            x2_bmod: int = 0, chan_stats: Optional[torch.Tensor] = None) -> bool:
+    """x1 [B,c1,H,W] NCHW (+ x2 [B,c2,H,W]) -> out [B,H,W,cout] NHWC. chan_stats [B, H/2, cout, 2] (optional): channel partials of
+    `out` per pair of image rows; returns whether they were written (False: the shape took the generic path, which has no
+    statistics epilogue, and the caller computes them with gn_chan_stats)."""
     _chk(x1, name="x1")
     B, c1, H, W = x1.shape
     c2 = 0 if x2 is None else x2.shape[1]
     if x2 is not None:
         _chk(x2, name="x2")
-    check(lib().stedm_conv_in(x1.data_ptr(), c1, _ptr(x2), c2, x2_bmod, w.data_ptr(), _ptr(bias), out.data_ptr(), B, H, W,
-                              out.shape[-1], _stream()), "stedm_conv_in")
-    return out
+    args = (x1.data_ptr(), c1, _ptr(x2), c2, x2_bmod, w.data_ptr(), _ptr(bias), out.data_ptr(), B, H, W, out.shape[-1])
+    if chan_stats is not None and H % 2 == 0:
+        assert tuple(chan_stats.shape) == (B, H // 2, out.shape[-1], 2) and chan_stats.dtype == torch.float32
+        rc = lib().stedm_conv_in(*args, chan_stats.data_ptr(), _stream())
+        if rc == 0:
+            return True
+        if rc != 3:
+            check(rc, "stedm_conv_in")
+    check(lib().stedm_conv_in(*args, None, _stream()), "stedm_conv_in")
+    return False
 
 
 def conv_out_weight(w_oihw: torch.Tensor) -> torch.Tensor:
@@ -315,7 +327,7 @@ def conv_out(src: torch.Tensor, norm_weight: torch.Tensor, norm_bias: torch.Tens
     if chan_stats is None:
         chan_stats = torch.empty((B, gn_chan_nslab(H * W), c, 2), dtype=torch.float32, device=src.device)
         gn_chan_stats(src, chan_stats)
-    check(lib().stedm_conv_out(src.data_ptr(), c, chan_stats.data_ptr(), norm_weight.data_ptr(), norm_bias.data_ptr(), float(eps),
+    check(lib().stedm_conv_out(src.data_ptr(), c, chan_stats.data_ptr(), chan_stats.shape[1], norm_weight.data_ptr(), norm_bias.data_ptr(), float(eps),
                                groups, w.data_ptr(), _ptr(bias), out.data_ptr(), B, H, W, out.shape[1], _stream()), "stedm_conv_out")
     return out
 

@@ -359,10 +359,11 @@ class UNetModel(nn.Module):
     # Producer-side GroupNorm statistics: tensors written by a conv epilogue carry per-(sample, slab, channel) partial sums
     # (stedm_conv_args.chan_stats); tensors from other producers get them lazily from one stedm_gn_chan_stats pass. One set of
     # partials serves every GroupNorm that reads the tensor (next block, decoder concat with its straddling groups).
-    def _cs_new(self, t: torch.Tensor) -> torch.Tensor:
+    def _cs_new(self, t: torch.Tensor, nslab: Optional[int] = None) -> torch.Tensor:
+        """statistics buffer of tensor `t` ([B][nslab][C][2]; any partition of a sample's pixels into nslab slots serves)"""
         B, C = t.shape[0], t.shape[-1]
         HW = t.numel() // (B * C)
-        cs = self._buf(f"cs.{t.data_ptr()}", (B, ops.gn_chan_nslab(HW), C, 2))
+        cs = self._buf(f"cs.{t.data_ptr()}", (B, nslab or ops.gn_chan_nslab(HW), C, 2))
         self._cs[t.data_ptr()] = cs
         return cs
 
@@ -509,8 +510,9 @@ class UNetModel(nn.Module):
                 if self.conv_path == "dma":
                     pu = self._packed[(id(layer.conv), "up")]
                     src16 = self._raw16.get(h.data_ptr()) or self._norm16(None, 0, h)
+                    # statistics slots of the sub-pixel form: (256-pixel run of the low-res grid) x (output parity)
                     h = ops.conv_igemm(None, pu.hi, pu.lo, out, prec=self.precision, mode=CONV_UP_SUBPIXEL,
-                                       src16=src16, bias=pu.bias, w_frag=pu.frag)
+                                       src16=src16, bias=pu.bias, w_frag=pu.frag, chan_stats=self._cs_new(out, 4 * ops.gn_chan_nslab(H * W)))
                 else:
                     h = ops.conv_igemm(h, pk.hi, pk.lo, out, prec=self.precision, mode=CONV_UP, bias=pk.bias)
             else:
@@ -603,7 +605,13 @@ class UNetModel(nn.Module):
         style_all = self._style_proj(contexts, B, ted)
 
         conv0 = self.input_blocks[0][0]
-        h = ops.conv_in(x, c_concat, conv0.weight, conv0.bias, self._buf("in0.out", (B, H, W, self.model_channels)))
+        h = self._buf("in0.out", (B, H, W, self.model_channels))
+        if self.conv_path == "dma" and H % 2 == 0:
+            cs0 = self._cs_new(h, H // 2)                     # one slot per pair of image rows, from the kernel's epilogue
+            if not ops.conv_in(x, c_concat, conv0.weight, conv0.bias, h, chan_stats=cs0):
+                del self._cs[h.data_ptr()]                    # generic path: statistics on first use
+        else:
+            ops.conv_in(x, c_concat, conv0.weight, conv0.bias, h)
         hs = [h]
         for i, blk in enumerate(self.input_blocks[1:], start=1):
             h = self._run_block(f"in{i}", blk, h, None, emb_e, emb_stride, None)

@@ -532,6 +532,59 @@ def test_conv_s2d_downsample(dev, prec, tol, B, H, W, cin, cout, ws):
         assert torch.allclose(cs[:, k, :, 0].double(), flat[:, k * 256:(k + 1) * 256].sum(1), rtol=1e-4, atol=2e-3)
 
 
+def test_chan_stats_any_partition(dev):
+    """The statistics slots may cut a sample's pixels any way (256-pixel runs, row pairs from conv_in, run x parity from the
+    sub-pixel upsample): producers with different partitions feed one GroupNorm over their concat."""
+    from stedm_amd import ops
+    prec = ops.Precision.parse("parity")
+    B, H, W, c1, c2 = 3, 16, 16, 64, 32
+    x1 = prng.normal(41, "ap.x1", (B, c1, H, W)) * 1.3 + 0.2
+    x2 = prng.normal(41, "ap.x2", (B, c2, H, W)) * 0.7 - 0.1
+    g = prng.normal(41, "ap.g", (c1 + c2,), 0.1, 1.0); b = prng.normal(41, "ap.b", (c1 + c2,), 0.1)
+    ref = F.silu(F.group_norm(torch.cat([x1, x2], 1), 32, g, b, 1e-5))
+    d1, d2 = nhwc(x1).to(dev), nhwc(x2).to(dev)
+    cs1 = torch.empty((B, 5, c1, 2), device=dev); cs2 = torch.empty((B, 8, c2, 2), device=dev)     # 5 runs of 52 px; 8 runs of 32 px
+    ops.gn_chan_stats(d1, cs1); ops.gn_chan_stats(d2, cs2)
+    assert torch.allclose(cs1.sum(1)[..., 0].cpu(), x1.sum((2, 3)), rtol=1e-5, atol=1e-3)
+    hi = torch.empty((B, H, W, c1 + c2), dtype=torch.int16, device=dev); lo = torch.empty_like(hi)
+    ops.gn_apply16c(d1, cs1, d2, cs2, hi, lo, prec, g.to(dev), b.to(dev), 1e-5, 32, 1)
+    assert rel_err(nchw(_as_float(hi, prec) + _as_float(lo, prec)), ref) < 2e-5
+
+
+@pytest.mark.parametrize("B,H,W,c1,c2,cout", [(4, 32, 32, 4, 3, 128), (2, 16, 16, 7, 0, 32), (3, 8, 8, 4, 3, 64)])
+def test_conv_in_epilogue_chan_stats(dev, B, H, W, c1, c2, cout):
+    from stedm_amd import ops
+    x1 = torch.randn(B, c1, H, W, device=dev); x2 = torch.randn(B, c2, H, W, device=dev) if c2 else None
+    w = torch.randn(cout, c1 + c2, 3, 3, device=dev) * 0.2; bias = torch.randn(cout, device=dev)
+    out = torch.empty(B, H, W, cout, device=dev)
+    cs = torch.full((B, H // 2, cout, 2), float("nan"), device=dev)
+    assert ops.conv_in(x1, x2, w, bias, out, chan_stats=cs)
+    ref = F.conv2d(x1 if x2 is None else torch.cat([x1, x2], 1), w, bias, padding=1)
+    assert rel_err(nchw(out), ref.cpu()) < 2e-5
+    rows = out.view(B, H // 2, 2 * W, cout).double()
+    assert torch.allclose(cs[..., 0].double(), rows.sum(2), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(cs[..., 1].double(), (rows * rows).sum(2), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+@pytest.mark.parametrize("B,H,W,c,cout", [(128, 8, 8, 64, 128), (50, 16, 16, 128, 96), (13, 32, 32, 64, 160)])
+def test_conv_up_subpixel_epilogue_chan_stats(dev, prec, B, H, W, c, cout):
+    """statistics of the upsampled tensor in 4 * ceil(H*W/256) slots per sample (low-res run x output parity)."""
+    from stedm_amd import ops
+    from stedm_amd._lib import CONV_UP_SUBPIXEL
+    pr = ops.Precision.parse(prec)
+    x = torch.randn(B, H, W, c, device=dev); w = torch.randn(cout, c, 3, 3, device=dev) / math.sqrt(c * 9)
+    h16 = torch.empty((B, H, W, c), dtype=torch.int16, device=dev)
+    ops.gn_apply16(x, None, h16, None, pr)
+    whi, wlo = ops.pack_conv_weight_up(w, pr)
+    out = torch.empty(B, 2 * H, 2 * W, cout, device=dev)
+    cs = torch.full((B, 4 * ops.gn_chan_nslab(H * W), cout, 2), float("nan"), device=dev)
+    ops.conv_igemm(None, whi, wlo, out, prec=pr, mode=CONV_UP_SUBPIXEL, src16=(h16, None), w_frag=ops.pack_conv_weight_up_frag(w, pr), chan_stats=cs)
+    flat = out.view(B, -1, cout).double()
+    assert torch.allclose(cs.sum(1)[..., 0].double(), flat.sum(1), rtol=1e-4, atol=5e-3)
+    assert torch.allclose(cs.sum(1)[..., 1].double(), (flat * flat).sum(1), rtol=1e-4, atol=5e-3)
+
+
 def test_pack_conv_weight_frag_layout(dev):
     from stedm_amd import ops
     prec = ops.Precision.parse("f16")
