@@ -205,6 +205,10 @@ int stedm_linear(const float* x, const float* wt, const float* bias, float* out,
 /* openaimodel.py:378-394. qkv [B][T][heads*3*ch] with channel = h*3*ch + {q:0,k:ch,v:2ch} + c;
  * out [B][T][heads*ch]; scale ch^-1/4 on q and k, softmax in fp32. */
 int stedm_attn_legacy(const float* qkv, float* out, int B, int T, int heads, int ch, void* stream);
+/* The same for T == 64 tokens and ch in {32, 64, 128} on MFMA (single-product modes): q, k, v and the softmax weights are rounded
+ * to the 16-bit operand type, logits / softmax / normalisation stay fp32; writes the 16-bit operand plane [B][64][heads*ch] that
+ * proj_out's 1x1 reads (no fp32 intermediate). */
+int stedm_attn_legacy16(const float* qkv, void* out16, int B, int T, int heads, int ch, int mm_dtype, void* stream);
 
 /* ---- DDIM update with rescaled classifier-free guidance ----------------------------------- */
 /* ddim.py:179-184 (CFG + std rescale over dims (C,H), unbiased) and :195-210 (x0 / dir / noise).

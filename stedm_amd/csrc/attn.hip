@@ -167,3 +167,136 @@ extern "C" int stedm_attn_legacy(const float* qkv, float* out, int B, int T, int
   STEDM_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// T = 64 tokens (the 8x8 middle block), single-product modes: the whole attention of one (sample, head) on one wave's MFMAs.
+//   S^T = K Q^T (keys on the rows: the softmax over keys of a query is a reduction over the lane's own registers plus one
+//   cross-half exchange), P = exp(scale^2 S^T - max) stays in the accumulators and is the B operand of O^T = V^T P as it lies:
+//   k-slot j of k-step (it, u) of lane half h is key (j&3) + 8(2u + (j>>2)) + 4h + 32 it, and V^T is gathered in that order.
+// Operands are rounded to the 16-bit MFMA type (as every other contraction of these modes), logits / softmax / normalisation fp32.
+// Output: the 16-bit operand plane [B][64][heads*ch] of proj_out (no fp32 round trip, no conversion pass).
+// ------------------------------------------------------------------------------------------------
+#include "conv_common.hpp"
+
+template <typename T, int CH>
+__global__ void __launch_bounds__(256) attn64_mfma_kernel(const float* __restrict__ qkv, T* __restrict__ out, int nprob, int heads, float scale2) {
+  using V8 = typename MM<T>::V8;
+  typedef T V4T __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int prob = blockIdx.x * 4 + wave;
+  if (prob >= nprob) return;
+  const int b = prob / heads, hd = prob % heads;
+  const int C3 = heads * 3 * CH, C = heads * CH;
+  const float* base = qkv + (long)b * 64 * C3 + hd * 3 * CH;
+  const int r = lane & 31, h = lane >> 5;
+
+  auto frag8 = [&](const float* p) {   // 8 consecutive floats -> one MFMA fragment
+    const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
+    V8 f;
+    f[0] = (T)x.x; f[1] = (T)x.y; f[2] = (T)x.z; f[3] = (T)x.w; f[4] = (T)y.x; f[5] = (T)y.y; f[6] = (T)y.z; f[7] = (T)y.w;
+    return f;
+  };
+
+  f32x16 st[2][2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[it][jt][e] = 0.f;
+#pragma unroll
+  for (int s = 0; s < CH / 16; ++s) {
+    V8 ka[2], qb[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) ka[it] = frag8(base + (long)(32 * it + r) * C3 + CH + 16 * s + 8 * h);
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) qb[jt] = frag8(base + (long)(32 * jt + r) * C3 + 16 * s + 8 * h);
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) st[it][jt] = MM<T>::mfma(ka[it], qb[jt], st[it][jt]);
+  }
+  // softmax over the keys of query column 32 jt + r: 32 values in this lane, 32 in lane ^ 32
+  float inv[2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) m = fmaxf(m, st[it][jt][e]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = __expf((st[it][jt][e] - m) * scale2);
+        st[it][jt][e] = pv;
+        sum += pv;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    inv[jt] = 1.0f / sum;
+  }
+  // O^T[d][q] = sum_k V[k][d] P[k][q]
+  f32x16 ot[CH / 32][2];
+#pragma unroll
+  for (int dt = 0; dt < CH / 32; ++dt)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ot[dt][jt][e] = 0.f;
+#pragma unroll
+  for (int it = 0; it < 2; ++it)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      V8 pb[2];
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pb[jt][j] = (T)st[it][jt][8 * u + j];
+#pragma unroll
+      for (int dt = 0; dt < CH / 32; ++dt) {
+        V8 va;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int key = (j & 3) + 8 * (2 * u + (j >> 2)) + 4 * h + 32 * it;
+          va[j] = (T)base[(long)key * C3 + 2 * CH + 32 * dt + r];
+        }
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) ot[dt][jt] = MM<T>::mfma(va, pb[jt], ot[dt][jt]);
+      }
+    }
+  // lane (column q = 32 jt + r) holds channels d = 32 dt + (e&3) + 8(e>>2) + 4h: 4 consecutive channels per e-quad -> 8-B stores
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    T* orow = out + ((long)b * 64 + 32 * jt + r) * C + hd * CH;
+#pragma unroll
+    for (int dt = 0; dt < CH / 32; ++dt)
+#pragma unroll
+      for (int eq = 0; eq < 4; ++eq) {
+        V4T v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (T)(ot[dt][jt][eq * 4 + k] * inv[jt]);
+        *reinterpret_cast<V4T*>(orow + 32 * dt + 8 * eq + 4 * h) = v;
+      }
+  }
+}
+
+extern "C" int stedm_attn_legacy16(const float* qkv, void* out16, int B, int T, int heads, int ch, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(qkv && out16 && B > 0 && heads > 0, "attn_legacy16: bad args");
+  STEDM_CHECK_ARG(T == 64 && (ch == 128 || ch == 64 || ch == 32), "attn_legacy16: covers T == 64 and ch in {32, 64, 128} (T=%d ch=%d)", T, ch);
+  STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "attn_legacy16: bad mm_dtype");
+  const int nprob = B * heads, grid = (nprob + 3) / 4;
+  const float scale2 = 1.0f / sqrtf((float)ch);
+  hipStream_t st = as_stream(stream);
+#define LAUNCH_ATTN(TT, CHH) attn64_mfma_kernel<TT, CHH><<<grid, 256, 0, st>>>(qkv, (TT*)out16, nprob, heads, scale2)
+  if (mm_dtype == STEDM_F16) {
+    if (ch == 128) LAUNCH_ATTN(_Float16, 128); else if (ch == 64) LAUNCH_ATTN(_Float16, 64); else LAUNCH_ATTN(_Float16, 32);
+  } else {
+    if (ch == 128) LAUNCH_ATTN(__bf16, 128); else if (ch == 64) LAUNCH_ATTN(__bf16, 64); else LAUNCH_ATTN(__bf16, 32);
+  }
+#undef LAUNCH_ATTN
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}

@@ -431,6 +431,16 @@ def attn_legacy(qkv: torch.Tensor, out: torch.Tensor, heads: int) -> torch.Tenso
     return out
 
 
+def attn_legacy16(qkv: torch.Tensor, out16: torch.Tensor, heads: int, prec: Precision) -> torch.Tensor:
+    """qkv [B,64,heads*3*ch] fp32 -> out16 [B,64,heads*ch] 16-bit operand plane (MFMA form, single-product modes)."""
+    _chk(qkv, name="qkv")
+    B, T, C3 = qkv.shape
+    ch = C3 // (3 * heads)
+    assert out16.dtype == torch.int16 and out16.numel() == B * T * heads * ch
+    check(lib().stedm_attn_legacy16(qkv.data_ptr(), out16.data_ptr(), B, T, heads, ch, prec.mm_dtype, _stream()), "stedm_attn_legacy16")
+    return out16
+
+
 # ------------------------------------------------------------------------------------------- DDIM
 def ddim_step(x: torch.Tensor, e_c: torch.Tensor, e_u: Optional[torch.Tensor], coefs: torch.Tensor, x_prev: torch.Tensor,
               pred_x0: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,

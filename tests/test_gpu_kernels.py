@@ -227,6 +227,22 @@ def test_attn_legacy(dev, B, T, heads, ch):
     assert rel_err(out.permute(0, 2, 1), ref) < 5e-5
 
 
+@pytest.mark.parametrize("prec,tol", [("f16", 1e-2), ("bf16", 6e-2)])
+@pytest.mark.parametrize("B,heads,ch", [(2, 8, 128), (3, 4, 64), (5, 2, 32), (130, 8, 128)])
+def test_attn_legacy16_mfma(dev, prec, tol, B, heads, ch):
+    """64-token attention on MFMA with 16-bit operands (single-product modes) against the fp32 oracle; output is the 16-bit plane."""
+    from oracle import unet as ou
+    from stedm_amd import ops
+    pr = ops.Precision.parse(prec)
+    T = 64
+    qkv = prng.normal(7, "a16.qkv", (B, heads * 3 * ch, T)) * 1.5
+    ref = ou.qkv_attention_legacy(qkv, heads)                       # [B, C, T]
+    out = torch.empty((B, T, heads * ch), dtype=torch.int16, device=dev)
+    ops.attn_legacy16(qkv.permute(0, 2, 1).contiguous().to(dev), out, heads, pr)
+    got = _as_float(out, pr).permute(0, 2, 1)
+    assert rel_err(got, ref) < tol
+
+
 # ------------------------------------------------------------------------------------------------ DDIM
 @pytest.mark.parametrize("B,C,H,W,cfg,eta", [(2, 4, 32, 32, True, 0.0), (3, 3, 16, 16, True, 1.0), (2, 4, 8, 8, False, 1.0),
                                              (1, 3, 128, 128, True, 0.0), (2, 4, 12, 24, True, 0.5)])
