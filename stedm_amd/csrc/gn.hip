@@ -373,6 +373,34 @@ __global__ void __launch_bounds__(256) gn_apply16c_kernel(GnApplyCArgs a, int sl
   const int C = a.c1 + a.c2, Q = C >> 2;
   const int cpg = C / a.groups;
   const int b2 = a.bmod > 0 ? b % a.bmod : b;
+  const float* p1 = a.x1 + (long)b * a.HW * a.c1;
+  const float* p2 = a.x2 ? a.x2 + (long)b2 * a.HW * a.c2 : nullptr;
+  const int px0 = sl * slab, px1 = min(a.HW, px0 + slab);
+  const int total = (px1 - px0) * Q;
+  V4* oh = reinterpret_cast<V4*>(a.out_hi) + (long)b * a.HW * Q;
+  V4* ol = a.out_lo ? reinterpret_cast<V4*>(a.out_lo) + (long)b * a.HW * Q : nullptr;
+  V4* rh = a.raw_hi ? reinterpret_cast<V4*>(a.raw_hi) + (long)b * a.HW * Q : nullptr;
+  V4* rl = a.raw_lo ? reinterpret_cast<V4*>(a.raw_lo) + (long)b * a.HW * Q : nullptr;
+  // U independent cursors per thread (elements tid + k*256, advancing by U*256): the pass is a pure stream, its speed is the
+  // number of 16-B loads in flight
+  constexpr int U = 4;
+  int pixs[U], qs[U];
+#pragma unroll
+  for (int k = 0; k < U; ++k) { const int e = threadIdx.x + k * 256; pixs[k] = px0 + e / Q; qs[k] = e % Q; }
+  const int dpix = (256 * U) / Q, dq = (256 * U) % Q;
+  // the first batch of loads is issued before the statistics prologue: its latency hides behind the partial-sum reduction
+  float4 v[U];
+  auto load_batch = [&](int i) {
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      if (i + k * 256 < total) {
+        const int c = qs[k] * 4;
+        v[k] = c < a.c1 ? *reinterpret_cast<const float4*>(p1 + (long)pixs[k] * a.c1 + c)
+                        : *reinterpret_cast<const float4*>(p2 + (long)pixs[k] * a.c2 + (c - a.c1));
+      }
+    }
+  };
+  load_batch(threadIdx.x);
   {
     const int L = 256 / a.groups;                 // lanes per group (groups <= 64)
     const int g = threadIdx.x / L, l = threadIdx.x % L;
@@ -403,31 +431,8 @@ __global__ void __launch_bounds__(256) gn_apply16c_kernel(GnApplyCArgs a, int sl
     }
     __syncthreads();
   }
-  const float* p1 = a.x1 + (long)b * a.HW * a.c1;
-  const float* p2 = a.x2 ? a.x2 + (long)b2 * a.HW * a.c2 : nullptr;
-  const int px0 = sl * slab, px1 = min(a.HW, px0 + slab);
-  const int total = (px1 - px0) * Q;
-  V4* oh = reinterpret_cast<V4*>(a.out_hi) + (long)b * a.HW * Q;
-  V4* ol = a.out_lo ? reinterpret_cast<V4*>(a.out_lo) + (long)b * a.HW * Q : nullptr;
-  V4* rh = a.raw_hi ? reinterpret_cast<V4*>(a.raw_hi) + (long)b * a.HW * Q : nullptr;
-  V4* rl = a.raw_lo ? reinterpret_cast<V4*>(a.raw_lo) + (long)b * a.HW * Q : nullptr;
-  // U independent cursors per thread (elements tid + k*256, advancing by U*256): the pass is a pure stream, its speed is the
-  // number of 16-B loads in flight
-  constexpr int U = 4;
-  int pixs[U], qs[U];
-#pragma unroll
-  for (int k = 0; k < U; ++k) { const int e = threadIdx.x + k * 256; pixs[k] = px0 + e / Q; qs[k] = e % Q; }
-  const int dpix = (256 * U) / Q, dq = (256 * U) % Q;
   for (int i = threadIdx.x; i < total; i += 256 * U) {
-    float4 v[U];
-#pragma unroll
-    for (int k = 0; k < U; ++k) {
-      if (i + k * 256 < total) {
-        const int c = qs[k] * 4;
-        v[k] = c < a.c1 ? *reinterpret_cast<const float4*>(p1 + (long)pixs[k] * a.c1 + c)
-                        : *reinterpret_cast<const float4*>(p2 + (long)pixs[k] * a.c2 + (c - a.c1));
-      }
-    }
+    if (i != (int)threadIdx.x) load_batch(i);
 #pragma unroll
     for (int k = 0; k < U; ++k) {
       if (i + k * 256 < total) {
