@@ -232,15 +232,23 @@ int stedm_step_set_t(const int64_t* ts_table, const int32_t* step_idx, int64_t* 
 int stedm_svit_patch_embed(const float* img, int B, int ns, int H, int W, int patch, const float* ln_w,
                            const float* ln_b, float eps, const float* wt, const float* bias, const float* pos,
                            const float* cls, float* x, int dim, void* stream);
+/* The same embedding in three steps, so that its Linear runs on MFMA: (1) patch gather + LayerNorm -> 16-bit operand planes
+ * [B*ntok][patch_dim]; (2) stedm_conv_igemm (1x1) with the Linear's weight and bias -> tok [B*ntok][dim] fp32; (3) tok_place:
+ * x[:,2+t] = tok[t] + pos[2+t], x[:,0] = cls + pos[0], x[:,1] = pos[1]. */
+int stedm_svit_patch_ln16(const float* img, int B, int ns, int H, int W, int patch, const float* ln_w, const float* ln_b,
+                          float eps, void* out_hi, void* out_lo, int mm_dtype, void* stream);
+int stedm_svit_tok_place(const float* tok, const float* pos, const float* cls, float* x, int B, int ntok, int dim, void* stream);
 /* PreNorm LayerNorm vit_set.py:14-20 -> 16-bit operand planes [rows][dim] for the MFMA GEMMs (out_lo may be NULL). */
 int stedm_ln_apply16(const float* x, const float* gamma, const float* beta, float eps, void* out_hi, void* out_lo,
                      long rows, int dim, int mm_dtype, void* stream);
 /* to_qkv output [B][T][3*heads*64] ('(h d)' per chunk, vit_set.py:53-54) -> q/k [B*heads][Tp][64] (q scaled by
- * qscale = exp(temperature), vit_set.py:56; rows >= T zero) and V^T [B*heads][64][Tp]; Tp multiple of 128. */
+ * qscale = exp(temperature) * log2(e): stedm_lsa_flash works in the log2 domain, vit_set.py:56; rows >= T zero) and
+ * V^T [B*heads][64][Tp]; Tp multiple of 128. */
 int stedm_qkv_pack(const float* qkv, float qscale, void* q_hi, void* q_lo, void* k_hi, void* k_lo, void* vt_hi,
                    void* vt_lo, int B, int T, int Tp, int heads, int mm_dtype, void* stream);
 /* LSA attention vit_set.py:56-66: softmax over keys of q.k with the DIAGONAL masked to -FLT_MAX, times v; flash-style
- * on MFMA (head dim 64). out planes [B][T][heads*64] ('b h n d -> b n (h d)'). */
+ * on MFMA (head dim 64). q.k must be log2(e) times the reference's logits (see stedm_qkv_pack): p = exp2(s - max).
+ * out planes [B][T][heads*64] ('b h n d -> b n (h d)'). */
 int stedm_lsa_flash(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi,
                     const void* vt_lo, void* out_hi, void* out_lo, int B, int T, int Tp, int heads, int npass,
                     int mm_dtype, void* stream);

@@ -104,6 +104,90 @@ extern "C" int stedm_svit_patch_embed(const float* img, int B, int ns, int H, in
   return 0;
 }
 
+// MFMA form of the patch embedding: (1) gather + LayerNorm of the patch features -> 16-bit operand planes [B*ntok][pd],
+// (2) the Linear as a 1x1 GEMM (stedm_conv_igemm), (3) + pos_embedding, placed at token 2.., cls / zero time token written.
+template <typename T>
+__global__ void __launch_bounds__(256) svit_patch_ln16_kernel(PatchArgs a, T* __restrict__ hi, T* __restrict__ lo) {
+  extern __shared__ float sf[];   // [tg][pd]
+  const int pw = a.W / a.p, ph = a.H / a.p;
+  const int C = 3 * a.ns, pd = a.p * a.p * C;
+  const int groups_per_row = pw / a.tg;
+  const int b = blockIdx.x / (ph * groups_per_row);
+  const int rem = blockIdx.x % (ph * groups_per_row);
+  const int hp = rem / groups_per_row, w0 = (rem % groups_per_row) * a.tg;
+  const int ntok = ph * pw;
+  const int run = a.tg * a.p * 3;
+  for (int i = threadIdx.x; i < a.ns * a.p * run; i += 256) {
+    const int e = i % run;
+    const int p1 = (i / run) % a.p;
+    const int s = i / (run * a.p);
+    const int px = e / 3, c = e - px * 3;
+    const int t = px / a.p, p2 = px - t * a.p;
+    const float v = a.img[((((long)b * a.ns + s) * a.H + hp * a.p + p1) * a.W + w0 * a.p) * 3 + e];
+    sf[t * pd + (p1 * a.p + p2) * C + c * a.ns + s] = v;   // stacked channel = c*ns + s (vit_set.py:105-106)
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int t = wave; t < a.tg; t += 4) {
+    float s1 = 0.f;
+    for (int k = lane; k < pd; k += 64) s1 += sf[t * pd + k];
+    const float mean = wave_sum(s1) / pd;
+    float s2 = 0.f;
+    for (int k = lane; k < pd; k += 64) { const float d = sf[t * pd + k] - mean; s2 += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(s2) / pd + a.eps);
+    const long row = (long)b * ntok + hp * pw + w0 + t;
+    for (int k = lane; k < pd; k += 64) {
+      const float v = (sf[t * pd + k] - mean) * rstd * a.ln_w[k] + a.ln_b[k];
+      const T h = (T)v;
+      hi[row * pd + k] = h;
+      if (lo) lo[row * pd + k] = (T)(v - (float)h);
+    }
+  }
+}
+
+extern "C" int stedm_svit_patch_ln16(const float* img, int B, int ns, int H, int W, int patch, const float* ln_w, const float* ln_b,
+                                     float eps, void* out_hi, void* out_lo, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(img && ln_w && ln_b && out_hi, "svit_patch_ln16: null pointer");
+  STEDM_CHECK_ARG(H % patch == 0 && W % patch == 0, "svit_patch_ln16: image not divisible by patch");
+  STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "svit_patch_ln16: bad mm_dtype");
+  const int pd = patch * patch * 3 * ns, pw = W / patch;
+  int tg = 8;     // tokens per block: keeps several blocks per CU
+  while (tg > 1 && ((size_t)tg * pd * 4 > 48 * 1024 || pw % tg != 0)) tg >>= 1;
+  STEDM_CHECK_ARG(pw % tg == 0 && (size_t)tg * pd * 4 <= 64 * 1024, "svit_patch_ln16: patch_dim %d too large", pd);
+  PatchArgs a{img, ln_w, ln_b, nullptr, nullptr, nullptr, nullptr, nullptr, ns, H, W, patch, 0, tg, eps};
+  const size_t lds = (size_t)tg * pd * sizeof(float);
+  const int grid = B * (H / patch) * (pw / tg);
+  if (mm_dtype == STEDM_F16) svit_patch_ln16_kernel<_Float16><<<grid, 256, lds, as_stream(stream)>>>(a, (_Float16*)out_hi, (_Float16*)out_lo);
+  else svit_patch_ln16_kernel<__bf16><<<grid, 256, lds, as_stream(stream)>>>(a, (__bf16*)out_hi, (__bf16*)out_lo);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void __launch_bounds__(256) svit_tok_place_kernel(const float* __restrict__ tok, const float* __restrict__ pos,
+                                                             const float* __restrict__ cls, float* __restrict__ x, int ntok, int dim4, long total4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const int n4 = (int)(i % dim4);
+    const long row = i / dim4;                  // over B * (ntok + 2)
+    const int t = (int)(row % (ntok + 2));
+    const long b = row / (ntok + 2);
+    const float4 p = reinterpret_cast<const float4*>(pos)[(long)t * dim4 + n4];
+    float4 v;
+    if (t >= 2) v = reinterpret_cast<const float4*>(tok)[(b * ntok + t - 2) * dim4 + n4];
+    else if (t == 0) v = reinterpret_cast<const float4*>(cls)[n4];
+    else v = make_float4(0.f, 0.f, 0.f, 0.f);    // zero time token (t_emb = None, vit_set.py:177-178)
+    reinterpret_cast<float4*>(x)[i] = make_float4(v.x + p.x, v.y + p.y, v.z + p.z, v.w + p.w);
+  }
+}
+
+extern "C" int stedm_svit_tok_place(const float* tok, const float* pos, const float* cls, float* x, int B, int ntok, int dim, void* stream) {
+  STEDM_CHECK_ARG(tok && pos && cls && x && B > 0 && ntok > 0 && dim > 0 && dim % 4 == 0, "svit_tok_place: bad args (dim %% 4)");
+  const long total4 = (long)B * (ntok + 2) * (dim / 4);
+  const int grid = (int)((total4 + 255) / 256 < 16384 ? (total4 + 255) / 256 : 16384);
+  svit_tok_place_kernel<<<grid, 256, 0, as_stream(stream)>>>(tok, pos, cls, x, ntok, dim / 4, total4);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ LayerNorm -> 16-bit
 template <typename T>
 __global__ void __launch_bounds__(256) ln_apply16_kernel(const float* __restrict__ x, const float* __restrict__ g,
@@ -271,38 +355,50 @@ __global__ void __launch_bounds__(256, 2) lsa_flash_kernel(FlashArgs a) {
         s[sub] = MM<T>::mfma(kf, qf[0][ks], s[sub]);
       }
     }
-    // ---- mask (diagonal: a token never attends to itself, vit_set.py:58-60; padding keys) + online softmax
-    float mx = -INFINITY;
+    // ---- mask (diagonal: a token never attends to itself, vit_set.py:58-60; padding keys) + online softmax. The logits arrive in
+    // the log2 domain (qkv_pack folds log2(e) into q), so the exponential is the hardware exp2; the masks only touch the one tile
+    // that holds this wave's own keys and the tiles past T (wave-uniform branches); the running output is rescaled only when some
+    // lane's maximum actually moved.
+    if ((q0 >> 6) == kt) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (kt * 64 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h == qidx) s[sub][e] = -FLT_MAX;
+    }
+    if (kt * 64 + 64 > a.T) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (kt * 64 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= a.T) s[sub][e] = -INFINITY;
+    }
+    float mx = s[0][0];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int key = kt * 64 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        float v = s[sub][e];
-        if (key == qidx) v = -FLT_MAX;
-        if (key >= a.T) v = -INFINITY;
-        s[sub][e] = v;
-        mx = fmaxf(mx, v);
-      }
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[sub][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float rs = 0.f;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float pv = __expf(s[sub][e] - m_new);
+        const float pv = __builtin_amdgcn_exp2f(s[sub][e] - m_new);
         s[sub][e] = pv;
         rs += pv;
       }
     rs += __shfl_xor(rs, 32, 64);
     l_run = l_run * alpha + rs;
     m_run = m_new;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+      for (int d = 0; d < 2; ++d)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+    }
     // ---- O^T += V^T P^T
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
@@ -391,15 +487,39 @@ __global__ void __launch_bounds__(256) svit_head_kernel(const float* __restrict_
   __shared__ float red[4];
   const int b = blockIdx.x;
   const float* px = x + (long)b * Tn * dim;
-  for (int n = threadIdx.x; n < dim; n += 256) {
-    float s = 0.f;
-    if (pool == 1) s = px[n];
-    else {
-      for (int t = 0; t < Tn; ++t) s += px[(long)t * dim + n];
-      if (pool == 0) s /= (float)Tn;
+  if (pool != 1 && (dim & 3) == 0 && dim <= 1024) {
+    // token pooling: 256 threads = Q channel quads x (256 / Q) token lanes, 16-B loads; the lanes meet in LDS in a fixed order
+    float* spart = sp + dim;                      // [lanes][dim]
+    const int Q = dim >> 2, lanes = 256 / Q;
+    const int q = threadIdx.x % Q, tl = threadIdx.x / Q;
+    if (tl < lanes) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+      for (int t = tl; t < Tn; t += lanes) {
+        const float4 v = *reinterpret_cast<const float4*>(px + (long)t * dim + q * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      *reinterpret_cast<float4*>(spart + (long)tl * dim + q * 4) = acc;
     }
-    if (c_old) s += c_old[(long)b * dim + n];
-    sp[n] = s;
+    __syncthreads();
+    for (int n = threadIdx.x; n < dim; n += 256) {
+      float s = 0.f;
+      for (int l = 0; l < lanes; ++l) s += spart[(long)l * dim + n];
+      if (pool == 0) s /= (float)Tn;
+      if (c_old) s += c_old[(long)b * dim + n];
+      sp[n] = s;
+    }
+  } else {
+    for (int n = threadIdx.x; n < dim; n += 256) {
+      float s = 0.f;
+      if (pool == 1) s = px[n];
+      else {
+        for (int t = 0; t < Tn; ++t) s += px[(long)t * dim + n];
+        if (pool == 0) s /= (float)Tn;
+      }
+      if (c_old) s += c_old[(long)b * dim + n];
+      sp[n] = s;
+    }
   }
   __syncthreads();
   float s1 = 0.f;
@@ -423,7 +543,8 @@ extern "C" int stedm_svit_head(const float* x, int B, int T, int dim, int pool, 
                                void* stream) {
   STEDM_CHECK_ARG(x && ln_w && ln_b && wt && bias && out, "svit_head: null pointer");
   STEDM_CHECK_ARG(pool >= 0 && pool <= 2, "svit_head: pool must be 0 (mean), 1 (cls) or 2 (sum)");
-  svit_head_kernel<<<B, 256, dim * sizeof(float), as_stream(stream)>>>(x, T, dim, pool, c_old, ln_w, ln_b, eps, wt, bias, out, ncls);
+  const int lanes = (dim % 4 == 0 && dim <= 1024) ? 256 / (dim / 4) : 0;
+  svit_head_kernel<<<B, 256, (size_t)(1 + lanes) * dim * sizeof(float), as_stream(stream)>>>(x, T, dim, pool, c_old, ln_w, ln_b, eps, wt, bias, out, ncls);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

@@ -375,6 +375,21 @@ def svit_patch_embed(img, ln_w, ln_b, eps, wt, bias, pos, cls, x, patch: int):
     return x
 
 
+def svit_patch_ln16(img, ln_w, ln_b, eps, hi, lo, patch: int, prec: Precision):
+    """patch gather + LayerNorm of SPT -> 16-bit operand planes [B*ntok, patch_dim] (the Linear then runs as a GEMM)."""
+    _chk(img, name="style images")
+    B, ns, H, W, C3 = img.shape
+    assert C3 == 3
+    check(lib().stedm_svit_patch_ln16(img.data_ptr(), B, ns, H, W, patch, ln_w.data_ptr(), ln_b.data_ptr(), float(eps), hi.data_ptr(), _ptr(lo),
+                                      prec.mm_dtype, _stream()), "stedm_svit_patch_ln16")
+
+
+def svit_tok_place(tok, pos, cls, x):
+    """x[:, 2+t] = tok[t] + pos[2+t]; x[:, 0] = cls + pos[0]; x[:, 1] = pos[1]."""
+    B, T, dim = x.shape
+    check(lib().stedm_svit_tok_place(tok.data_ptr(), pos.data_ptr(), cls.data_ptr(), x.data_ptr(), B, T - 2, dim, _stream()), "stedm_svit_tok_place")
+
+
 def ln_apply16(x, gamma, beta, eps, hi, lo, prec: Precision):
     _chk(x, name="x")
     rows = x.numel() // x.shape[-1]

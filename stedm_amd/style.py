@@ -127,13 +127,20 @@ class sViT(nn.Module):
         P = {}
         prec = self.precision
         tp = self.to_patch_embedding.to_patch_tokens
-        P["pe_wt"] = ops.transpose(tp[2].weight.float())
+        def pack(w):   # Linear [N][K] -> packed 1x1 conv operands (+ fragment order for the register-streamed kernel)
+            w4 = w.float().unsqueeze(-1).unsqueeze(-1)
+            hi, lo = ops.pack_conv_weight(w4, prec)
+            frag = ops.pack_conv_weight_frag(w4, prec) if prec.npass == 1 and w4.shape[1] % 64 == 0 else None
+            return hi, lo, frag
+
+        P["pe"] = pack(tp[2].weight)
         for l, (attn, ff) in enumerate(self.transformer.layers):
-            P[f"qkv{l}"] = ops.pack_conv_weight(attn.fn.to_qkv.weight.float().unsqueeze(-1), prec)
-            P[f"out{l}"] = ops.pack_conv_weight(attn.fn.to_out[0].weight.float().unsqueeze(-1), prec)
-            P[f"ff1{l}"] = ops.pack_conv_weight(ff.fn.net[0].weight.float().unsqueeze(-1), prec)
-            P[f"ff2{l}"] = ops.pack_conv_weight(ff.fn.net[3].weight.float().unsqueeze(-1), prec)
-            P[f"tau{l}"] = float(attn.fn.temperature.detach().exp().item())
+            P[f"qkv{l}"] = pack(attn.fn.to_qkv.weight)
+            P[f"out{l}"] = pack(attn.fn.to_out[0].weight)
+            P[f"ff1{l}"] = pack(ff.fn.net[0].weight)
+            P[f"ff2{l}"] = pack(ff.fn.net[3].weight)
+            # logits scale exp(temperature) (vit_set.py:56) times log2(e): lsa_flash exponentiates with the hardware exp2
+            P[f"tau{l}"] = float(attn.fn.temperature.detach().exp().item()) * 1.4426950408889634
         P["head_wt"] = ops.transpose(self.mlp_head[1].weight.float())
         self._packed = P
         self._pack_key = key
@@ -143,7 +150,7 @@ class sViT(nn.Module):
         K = a16[0].shape[-1]
         v = lambda t: None if t is None else t.view(1, 1, M, -1)
         ops.conv_igemm(None, w[0], w[1], v(out), prec=self.precision, ks=1, src16=(v(a16[0]), v(a16[1])), bias=bias, res=v(res),
-                       act_out=act_out, out16=None if out16 is None else (v(out16[0]), v(out16[1])))
+                       act_out=act_out, out16=None if out16 is None else (v(out16[0]), v(out16[1])), w_frag=w[2])
 
     @torch.no_grad()
     def forward(self, img, t_emb=None, c_old=None):
@@ -165,10 +172,15 @@ class sViT(nn.Module):
         M = B * T
         tp = self.to_patch_embedding.to_patch_tokens
         x = self._buf("x", (B, T, dim))
-        ops.svit_patch_embed(img, tp[1].weight, tp[1].bias, tp[1].eps, P["pe_wt"], tp[2].bias, self.pos_embedding, self.cls_token, x,
-                             self.patch_size)
         i16 = torch.int16
         lo_ok = prec.npass == 3
+        # SPT: gather + LayerNorm -> 16-bit planes, Linear on MFMA, + pos_embedding / cls / zero time token
+        pd = tp[2].in_features
+        pe16 = (self._buf("pe.hi", (B * n, pd), i16), self._buf("pe.lo", (B * n, pd), i16) if lo_ok else None)
+        ops.svit_patch_ln16(img, tp[1].weight, tp[1].bias, tp[1].eps, pe16[0], pe16[1], self.patch_size, prec)
+        tok = self._buf("pe.tok", (B * n, dim))
+        self._gemm(pe16, P["pe"], B * n, dim, bias=tp[2].bias, out=tok)
+        ops.svit_tok_place(tok, self.pos_embedding, self.cls_token, x)
         ln = (self._buf("ln.hi", (M, dim), i16), self._buf("ln.lo", (M, dim), i16) if lo_ok else None)
         qkv = self._buf("qkv", (M, 3 * heads * 64))
         mk = lambda nm, shp: (self._buf(nm + ".hi", shp, i16, zero=True), self._buf(nm + ".lo", shp, i16, zero=True) if lo_ok else None)

@@ -94,7 +94,7 @@ def test_lsa_flash_vs_oracle(dev, B, T, heads):
     i16 = torch.int16
     mk = lambda shp: (torch.zeros(shp, dtype=i16, device=dev), torch.zeros(shp, dtype=i16, device=dev))
     qd, kd, vd = mk((B * heads, Tp, 64)), mk((B * heads, Tp, 64)), mk((B * heads, 64, Tp))
-    ops.qkv_pack(qkv.to(dev).contiguous(), tau, qd, kd, vd, B, T, Tp, heads, prec)
+    ops.qkv_pack(qkv.to(dev).contiguous(), tau * math.log2(math.e), qd, kd, vd, B, T, Tp, heads, prec)   # lsa_flash works in log2
     od = mk((B, T, heads * 64))
     ops.lsa_flash(qd, kd, vd, od, B, T, Tp, heads, prec)
     got = od[0].view(torch.float16).float() + od[1].view(torch.float16).float()
