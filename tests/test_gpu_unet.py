@@ -174,13 +174,14 @@ def test_unet_with_spatial_transformer_vs_oracle(dev):
         bad(x.to(dev), t.to(dev), context=ctx.to(dev))
 
 
-def test_unet_bench_config_single_product_vs_parity(dev, golden):
+@pytest.mark.parametrize("B", [64, 50])
+def test_unet_bench_config_single_product_vs_parity(dev, golden, B):
     """BASELINE metric configuration (NS32, batch 64, CFG pass = 128 decoder rows): at this size the single-product modes run the
     register-streamed kernels (3x3, fused skip_connection, split-K, sub-pixel upsample, space-to-depth downsample, producer-side
     GroupNorm statistics), which the batch-2 golden cases are too small to select. Checked against the parity mode (itself pinned
     to the reference at 1e-3 above; batch 64 runs the same parity kernels), plus two size-independent properties: rows of the
-    batch are independent (a permuted batch gives the permuted output, bitwise) and the pass is bitwise reproducible."""
-    B = 64
+    batch are independent (a permuted batch gives the permuted output, bitwise) and the pass is bitwise reproducible.
+    B = 50 leaves ragged tiles everywhere (50 and 100 samples do not fill the 4-sample whole-image tiles of the 8x8 level)."""
     m = build(NS32, 0, dev, "parity")
     x = prng.normal(3, "bc.x", (B, 4, 32, 32)).to(dev)
     cc = prng.normal(3, "bc.cc", (B, 3, 32, 32)).to(dev)
@@ -196,7 +197,7 @@ def test_unet_bench_config_single_product_vs_parity(dev, golden):
         got = torch.cat([fc, fu]).double().cpu()
         l2 = float((got - ref).norm() / ref.norm())
         mx = float((got - ref).abs().max() / ref.std())
-        print(f"[ns32 B=64 cfg {precision}] vs parity mode: rel-L2 {l2:.3e}, max/std {mx:.3e}")
+        print(f"[ns32 B={B} cfg {precision}] vs parity mode: rel-L2 {l2:.3e}, max/std {mx:.3e}")
         assert l2 < tol_l2 and mx < tol_max
         fc2, fu2 = m.forward_cfg(x, cc, t, ctx_c, ctx_u, uniform_t=True)
         assert torch.equal(fc, fc2) and torch.equal(fu, fu2)            # reproducible bits
