@@ -75,6 +75,8 @@ class ConvTimer:
             e0.record()
             r = timer._orig(src1, w_hi, w_lo, out, **kw)
             e1.record()
+            if out is None:    # 16-bit-plane output only (qkv of the attention block)
+                out = kw["out16"][0]
             M = out.numel() // out.shape[-1]
             if w_hi is None:   # space-to-depth Downsample: 9 taps x cin of the stride-2 conv (the 2x2 x 4cin form executes 16/9 of that)
                 flops = 2.0 * M * out.shape[-1] * 9 * kw["src16"][0].shape[-1] / 4

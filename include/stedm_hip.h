@@ -207,8 +207,9 @@ int stedm_linear(const float* x, const float* wt, const float* bias, float* out,
 int stedm_attn_legacy(const float* qkv, float* out, int B, int T, int heads, int ch, void* stream);
 /* The same for T == 64 tokens and ch in {32, 64, 128} on MFMA (single-product modes): q, k, v and the softmax weights are rounded
  * to the 16-bit operand type, logits / softmax / normalisation stay fp32; writes the 16-bit operand plane [B][64][heads*ch] that
- * proj_out's 1x1 reads (no fp32 intermediate). */
-int stedm_attn_legacy16(const float* qkv, void* out16, int B, int T, int heads, int ch, int mm_dtype, void* stream);
+ * proj_out's 1x1 reads (no fp32 intermediate). qkv_is16: qkv is itself the 16-bit plane written by the qkv convolution's epilogue
+ * (stedm_conv_args.out16_hi) instead of fp32 - the same rounding, half the bytes. */
+int stedm_attn_legacy16(const void* qkv, int qkv_is16, void* out16, int B, int T, int heads, int ch, int mm_dtype, void* stream);
 
 /* ---- DDIM update with rescaled classifier-free guidance ----------------------------------- */
 /* ddim.py:179-184 (CFG + std rescale over dims (C,H), unbiased) and :195-210 (x0 / dir / noise).

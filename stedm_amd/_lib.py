@@ -68,7 +68,7 @@ SIGNATURES = {
     "stedm_emb_proj": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "stedm_linear": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "stedm_attn_legacy": (_I, [_P, _P, _I, _I, _I, _I, _P]),
-    "stedm_attn_legacy16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "stedm_attn_legacy16": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "stedm_ddim_step": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _I, _I, _I, _I, _P]),
     "stedm_step_advance": (_I, [_P, _I, _P]),
     "stedm_step_set_t": (_I, [_P, _P, _P, _I, _P]),

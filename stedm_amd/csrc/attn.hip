@@ -178,8 +178,9 @@ extern "C" int stedm_attn_legacy(const float* qkv, float* out, int B, int T, int
 // ------------------------------------------------------------------------------------------------
 #include "conv_common.hpp"
 
-template <typename T, int CH>
-__global__ void __launch_bounds__(256) attn64_mfma_kernel(const float* __restrict__ qkv, T* __restrict__ out, int nprob, int heads, float scale2) {
+// IN16: qkv arrives as the 16-bit plane the qkv convolution's epilogue wrote (same rounding as converting here, half the bytes).
+template <typename T, int CH, bool IN16>
+__global__ void __launch_bounds__(256) attn64_mfma_kernel(const void* __restrict__ qkv_, T* __restrict__ out, int nprob, int heads, float scale2) {
   using V8 = typename MM<T>::V8;
   typedef T V4T __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -187,11 +188,14 @@ __global__ void __launch_bounds__(256) attn64_mfma_kernel(const float* __restric
   if (prob >= nprob) return;
   const int b = prob / heads, hd = prob % heads;
   const int C3 = heads * 3 * CH, C = heads * CH;
-  const float* base = qkv + (long)b * 64 * C3 + hd * 3 * CH;
+  const long boff = (long)b * 64 * C3 + hd * 3 * CH;
+  const float* base = reinterpret_cast<const float*>(qkv_) + boff;
+  const T* base16 = reinterpret_cast<const T*>(qkv_) + boff;
   const int r = lane & 31, h = lane >> 5;
 
-  auto frag8 = [&](const float* p) {   // 8 consecutive floats -> one MFMA fragment
-    const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
+  auto frag8 = [&](long off) {   // 8 consecutive elements at element offset `off` -> one MFMA fragment
+    if (IN16) return *reinterpret_cast<const V8*>(base16 + off);
+    const float4 x = *reinterpret_cast<const float4*>(base + off), y = *reinterpret_cast<const float4*>(base + off + 4);
     V8 f;
     f[0] = (T)x.x; f[1] = (T)x.y; f[2] = (T)x.z; f[3] = (T)x.w; f[4] = (T)y.x; f[5] = (T)y.y; f[6] = (T)y.z; f[7] = (T)y.w;
     return f;
@@ -208,9 +212,9 @@ __global__ void __launch_bounds__(256) attn64_mfma_kernel(const float* __restric
   for (int s = 0; s < CH / 16; ++s) {
     V8 ka[2], qb[2];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) ka[it] = frag8(base + (long)(32 * it + r) * C3 + CH + 16 * s + 8 * h);
+    for (int it = 0; it < 2; ++it) ka[it] = frag8((long)(32 * it + r) * C3 + CH + 16 * s + 8 * h);
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt) qb[jt] = frag8(base + (long)(32 * jt + r) * C3 + 16 * s + 8 * h);
+    for (int jt = 0; jt < 2; ++jt) qb[jt] = frag8((long)(32 * jt + r) * C3 + 16 * s + 8 * h);
 #pragma unroll
     for (int it = 0; it < 2; ++it)
 #pragma unroll
@@ -261,7 +265,8 @@ __global__ void __launch_bounds__(256) attn64_mfma_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int key = (j & 3) + 8 * (2 * u + (j >> 2)) + 4 * h + 32 * it;
-          va[j] = (T)base[(long)key * C3 + 2 * CH + 32 * dt + r];
+          const long vo = (long)key * C3 + 2 * CH + 32 * dt + r;
+          va[j] = IN16 ? base16[vo] : (T)base[vo];
         }
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) ot[dt][jt] = MM<T>::mfma(va, pb[jt], ot[dt][jt]);
@@ -283,18 +288,22 @@ __global__ void __launch_bounds__(256) attn64_mfma_kernel(const float* __restric
   }
 }
 
-extern "C" int stedm_attn_legacy16(const float* qkv, void* out16, int B, int T, int heads, int ch, int mm_dtype, void* stream) {
+extern "C" int stedm_attn_legacy16(const void* qkv, int qkv_is16, void* out16, int B, int T, int heads, int ch, int mm_dtype, void* stream) {
   STEDM_CHECK_ARG(qkv && out16 && B > 0 && heads > 0, "attn_legacy16: bad args");
   STEDM_CHECK_ARG(T == 64 && (ch == 128 || ch == 64 || ch == 32), "attn_legacy16: covers T == 64 and ch in {32, 64, 128} (T=%d ch=%d)", T, ch);
   STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "attn_legacy16: bad mm_dtype");
   const int nprob = B * heads, grid = (nprob + 3) / 4;
   const float scale2 = 1.0f / sqrtf((float)ch);
   hipStream_t st = as_stream(stream);
-#define LAUNCH_ATTN(TT, CHH) attn64_mfma_kernel<TT, CHH><<<grid, 256, 0, st>>>(qkv, (TT*)out16, nprob, heads, scale2)
+#define LAUNCH_ATTN(TT, CHH)                                                                                         \
+  {                                                                                                                 \
+    if (qkv_is16) attn64_mfma_kernel<TT, CHH, true><<<grid, 256, 0, st>>>(qkv, (TT*)out16, nprob, heads, scale2);    \
+    else attn64_mfma_kernel<TT, CHH, false><<<grid, 256, 0, st>>>(qkv, (TT*)out16, nprob, heads, scale2);           \
+  }
   if (mm_dtype == STEDM_F16) {
-    if (ch == 128) LAUNCH_ATTN(_Float16, 128); else if (ch == 64) LAUNCH_ATTN(_Float16, 64); else LAUNCH_ATTN(_Float16, 32);
+    if (ch == 128) LAUNCH_ATTN(_Float16, 128) else if (ch == 64) LAUNCH_ATTN(_Float16, 64) else LAUNCH_ATTN(_Float16, 32)
   } else {
-    if (ch == 128) LAUNCH_ATTN(__bf16, 128); else if (ch == 64) LAUNCH_ATTN(__bf16, 64); else LAUNCH_ATTN(__bf16, 32);
+    if (ch == 128) LAUNCH_ATTN(__bf16, 128) else if (ch == 64) LAUNCH_ATTN(__bf16, 64) else LAUNCH_ATTN(__bf16, 32)
   }
 #undef LAUNCH_ATTN
   STEDM_LAUNCH_CHECK();

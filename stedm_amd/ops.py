@@ -447,12 +447,14 @@ def attn_legacy(qkv: torch.Tensor, out: torch.Tensor, heads: int) -> torch.Tenso
 
 
 def attn_legacy16(qkv: torch.Tensor, out16: torch.Tensor, heads: int, prec: Precision) -> torch.Tensor:
-    """qkv [B,64,heads*3*ch] fp32 -> out16 [B,64,heads*ch] 16-bit operand plane (MFMA form, single-product modes)."""
-    _chk(qkv, name="qkv")
+    """qkv [B,64,heads*3*ch] (fp32, or the int16 plane a conv epilogue wrote) -> out16 [B,64,heads*ch] 16-bit operand plane
+    (MFMA form, single-product modes)."""
+    is16 = qkv.dtype == torch.int16
+    _chk(qkv, torch.int16 if is16 else torch.float32, name="qkv")
     B, T, C3 = qkv.shape
     ch = C3 // (3 * heads)
     assert out16.dtype == torch.int16 and out16.numel() == B * T * heads * ch
-    check(lib().stedm_attn_legacy16(qkv.data_ptr(), out16.data_ptr(), B, T, heads, ch, prec.mm_dtype, _stream()), "stedm_attn_legacy16")
+    check(lib().stedm_attn_legacy16(qkv.data_ptr(), 1 if is16 else 0, out16.data_ptr(), B, T, heads, ch, prec.mm_dtype, _stream()), "stedm_attn_legacy16")
     return out16
 
 

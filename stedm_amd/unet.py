@@ -454,22 +454,26 @@ class UNetModel(nn.Module):
         B, H, W, Cc = x.shape
         dma = self.conv_path == "dma"
         pq = self._packed[id(ab.qkv)]
+        pp = self._packed[id(ab.proj_out)]
+        out = self._buf(tag + ".out", (B, H, W, Cc))
+        ch = Cc // ab.num_heads
+        if dma and prec.npass == 1 and H * W == 64 and ch in (32, 64, 128):
+            # 64 tokens: the qkv conv writes its result as a 16-bit plane, the whole attention of a (sample, head) runs on one wave's
+            # MFMAs and is written as proj_out's 16-bit operand plane (same operand rounding as everywhere in these modes)
+            qkv16 = self._planes(B, H, W, 3 * Cc, "qkv16")
+            ops.conv_igemm(None, pq.hi, pq.lo, None, prec=prec, ks=1, src16=self._norm16(ab.norm, 0, x), bias=pq.bias, w_frag=pq.frag,
+                           out16=qkv16)
+            a16 = self._planes(B, H, W, Cc, "attn16")
+            ops.attn_legacy16(qkv16[0].view(B, H * W, 3 * Cc), a16[0], ab.num_heads, prec)
+            ops.conv_igemm(None, pp.hi, pp.lo, out, prec=prec, ks=1, src16=a16, bias=pp.bias, res=x, w_frag=pp.frag,
+                           chan_stats=self._cs_new(out))
+            return out
         qkv = self._buf(tag + ".qkv", (B, H, W, 3 * Cc))
         if dma:
             ops.conv_igemm(None, pq.hi, pq.lo, qkv, prec=prec, ks=1, src16=self._norm16(ab.norm, 0, x), bias=pq.bias, w_frag=pq.frag)
         else:
             sc, sh = self._gn(tag + ".gn", ab.norm, x)
             ops.conv_igemm(x, pq.hi, pq.lo, qkv, prec=prec, ks=1, scale=sc, shift=sh, act=0, bias=pq.bias)
-        pp = self._packed[id(ab.proj_out)]
-        out = self._buf(tag + ".out", (B, H, W, Cc))
-        ch = Cc // ab.num_heads
-        if dma and prec.npass == 1 and H * W == 64 and ch in (32, 64, 128):
-            # 64 tokens: the whole attention of a (sample, head) on one wave's MFMAs, written as proj_out's 16-bit operand plane
-            a16 = self._planes(B, H, W, Cc, "attn16")
-            ops.attn_legacy16(qkv.view(B, H * W, 3 * Cc), a16[0], ab.num_heads, prec)
-            ops.conv_igemm(None, pp.hi, pp.lo, out, prec=prec, ks=1, src16=a16, bias=pp.bias, res=x, w_frag=pp.frag,
-                           chan_stats=self._cs_new(out))
-            return out
         a = self._buf(tag + ".a", (B, H, W, Cc))
         ops.attn_legacy(qkv.view(B, H * W, 3 * Cc), a.view(B, H * W, Cc), ab.num_heads)
         if dma:

@@ -238,9 +238,16 @@ def test_attn_legacy16_mfma(dev, prec, tol, B, heads, ch):
     qkv = prng.normal(7, "a16.qkv", (B, heads * 3 * ch, T)) * 1.5
     ref = ou.qkv_attention_legacy(qkv, heads)                       # [B, C, T]
     out = torch.empty((B, T, heads * ch), dtype=torch.int16, device=dev)
-    ops.attn_legacy16(qkv.permute(0, 2, 1).contiguous().to(dev), out, heads, pr)
+    qd = qkv.permute(0, 2, 1).contiguous().to(dev)
+    ops.attn_legacy16(qd, out, heads, pr)
     got = _as_float(out, pr).permute(0, 2, 1)
     assert rel_err(got, ref) < tol
+    # the same from a 16-bit qkv plane (what the qkv conv's epilogue writes): identical operand rounding, identical bits
+    q16 = torch.empty(qd.shape, dtype=torch.int16, device=dev)
+    ops.gn_apply16(qd.view(B, 1, T, -1), None, q16.view(B, 1, T, -1), None, pr)
+    out2 = torch.empty_like(out)
+    ops.attn_legacy16(q16, out2, heads, pr)
+    assert torch.equal(out, out2)
 
 
 # ------------------------------------------------------------------------------------------------ DDIM
