@@ -220,3 +220,24 @@ def test_style_projection_cache_is_not_fooled_by_address_reuse(dev):
     keep = cb.to(dev)
     yb2 = m(x, t, context=keep)
     assert torch.equal(yb, yb2) and not torch.equal(ya, yb)
+
+
+def test_unet_64x64_latents_single_product_vs_parity(dev):
+    """BASELINE config 5 geometry (64x64x4 latents: NS32 widths at twice the resolution, levels 64/32/16, 256 tokens in the middle
+    attention -> fp32 attention kernel): the register-streamed kernels on 64-wide rows against the parity mode."""
+    B = 16
+    m = build(NS32, 0, dev, "parity")
+    x = prng.normal(5, "n64.x", (B, 4, 64, 64)).to(dev)
+    cc = prng.normal(5, "n64.cc", (B, 3, 64, 64)).to(dev)
+    ctx_c = prng.normal(5, "n64.ctx", (B, 512)).to(dev)
+    ctx_u = prng.normal(5, "n64.ctxu", (B, 512)).to(dev)
+    t = torch.full((B,), 501, dtype=torch.long, device=dev)
+    ec, eu = m.forward_cfg(x, cc, t, ctx_c, ctx_u, uniform_t=True)
+    ref = torch.cat([ec, eu]).double().cpu()
+    for precision, tol in (("f16", 2e-3), ("bf16", 1.5e-2)):
+        m.set_precision(precision)
+        fc, fu = m.forward_cfg(x, cc, t, ctx_c, ctx_u, uniform_t=True)
+        got = torch.cat([fc, fu]).double().cpu()
+        l2 = float((got - ref).norm() / ref.norm())
+        print(f"[ns32 widths @64x64 B={B} cfg {precision}] vs parity mode: rel-L2 {l2:.3e}")
+        assert l2 < tol
