@@ -155,8 +155,9 @@ typedef struct stedm_conv_args {
   const void* w_frag_b;
   const float* bias_b;
   int32_t cb;
-  /* Optional workspace (fp32, ws_floats >= 2 * B*Hout*Wout*cout): lets a 3x3 convolution whose grid would leave CUs idle split its
-   * K range over two blocks per tile; the partial tiles are summed in a fixed order by a reduce kernel (bitwise reproducible). */
+  /* Optional workspace (fp32): lets a 3x3 convolution whose grid would leave CUs idle split its K range over k = 2, 4, 8 or 16
+   * blocks per tile (the largest k with ws_floats >= k * B*Hout*Wout*cout that is needed); the partial tiles are summed in a fixed
+   * order by a reduce kernel (bitwise reproducible). */
   float* ws;
   int64_t ws_floats;
   int32_t chan_nslab; /* slot count of chan_stats (see there) */

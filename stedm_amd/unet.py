@@ -402,7 +402,9 @@ class UNetModel(nn.Module):
                 a16, x16 = self._norm16(rb.in_layers[0], 1, x1, x2, x2_bmod, want_raw=True)
             else:
                 a16 = self._norm16(rb.in_layers[0], 1, x1, x2, x2_bmod)
-            ws = self._buf("conv_ws", (2 * B * H * W * co,)) if B * H * W * co <= (1 << 23) else None   # split-K workspace (small grids only)
+            # split-K workspace (small grids only): room for up to 16 partial tiles when the tensor is small, 2 otherwise
+            nel = B * H * W * co
+            ws = self._buf("conv_ws", ((16 if nel <= (1 << 20) else (4 if nel <= (1 << 22) else 2)) * nel,)) if nel <= (1 << 23) else None
             ops.conv_igemm(None, pk.hi, pk.lo, h, prec=prec, src16=a16, bias=pk.bias, emb=emb_all, emb_offset=emb_off,
                            emb_bstride=emb_bstride, w_frag=pk.frag, chan_stats=self._cs_new(h), ws=ws)
         else:
@@ -509,7 +511,7 @@ class UNetModel(nn.Module):
                     C = h.shape[-1]
                     planes = self._buf(f"s2d16.{B}x{H}x{W}x{C}", (B, H // 2, W // 2, 4 * C), torch.int16)
                     ops.space_to_depth16(h, planes, None, self.precision)
-                    ws = self._buf("conv_ws", (2 * out.numel(),))
+                    ws = self._buf("conv_ws", ((16 if out.numel() <= (1 << 20) else 2) * out.numel(),))
                     h = ops.conv_igemm(None, None, None, out, prec=self.precision, mode=CONV_S2D, src16=(planes, None), bias=ps2.bias,
                                        w_frag=ps2.frag, chan_stats=self._cs_new(out), ws=ws)
                 else:

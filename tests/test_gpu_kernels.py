@@ -410,7 +410,7 @@ def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_em
                    emb=None if emb is None else emb.to(dev), emb_offset=8, emb_bstride=0 if emb is None else emb.shape[1],
                    res=None if res is None else nhwc(res).to(dev),
                    w_frag=None if not frag else (ops.pack_conv_weight_up_frag(w.to(dev), prec) if mode == "up2" else ops.pack_conv_weight_frag(w.to(dev), prec)),
-                   ws=torch.empty(2 * out.numel(), device=dev) if ws else None)
+                   ws=torch.empty(16 * out.numel(), device=dev) if ws else None)
     torch.cuda.synchronize()
     err = rel_err(nchw(out), ref)
     assert err < tol, f"{prec_name}: rel err {err:.3e} >= {tol}"
@@ -503,10 +503,13 @@ def test_conv_fused_skip_rejected_when_unsupported(dev):
 
 
 @pytest.mark.parametrize("prec,tol", PRECS[1:])
-@pytest.mark.parametrize("B,H,W,cin,cout,emb,res", [(64, 8, 8, 1024, 1024, True, True), (100, 16, 16, 256, 128, False, True), (30, 32, 32, 256, 96, True, False)])
+@pytest.mark.parametrize("B,H,W,cin,cout,emb,res", [(64, 8, 8, 1024, 1024, True, True), (100, 16, 16, 256, 128, False, True), (30, 32, 32, 256, 96, True, False),
+                                                    (4, 8, 8, 1024, 1024, True, True), (2, 16, 16, 512, 512, False, True), (1, 32, 32, 256, 128, True, False),
+                                                    (3, 8, 8, 512, 160, True, True)])
 def test_conv_dma_3x3_split_k(dev, prec, tol, B, H, W, cin, cout, emb, res):
-    """grids of 96..191 tiles with a workspace: K split over two blocks per tile, partial tiles summed in a fixed order by the
-    reduce kernel, which also applies bias / emb / residual and emits the channel statistics (bitwise reproducible)."""
+    """grids that leave CUs idle, with a workspace: K split over 2..16 blocks per tile (the small cases: 16 ways), partial tiles
+    summed in a fixed order by the reduce kernel, which also applies bias / emb / residual and emits the channel statistics
+    (bitwise reproducible)."""
     from stedm_amd import ops
     _conv_dma_case(dev, prec, tol, B, H, W, cin, cout, "s1", 3, use_emb=emb, use_res=res, frag=True, ws=True)
     pr = ops.Precision.parse(prec)
@@ -519,7 +522,7 @@ def test_conv_dma_3x3_split_k(dev, prec, tol, B, H, W, cin, cout, emb, res):
     for _ in range(3):
         out = torch.full((B, H, W, cout), float("nan"), device=dev)
         cs = torch.full((B, ops.gn_chan_nslab(H * W), cout, 2), float("nan"), device=dev)
-        ops.conv_igemm(None, whi, wlo, out, prec=pr, src16=(h16, None), w_frag=wf, chan_stats=cs, ws=torch.empty(2 * out.numel(), device=dev))
+        ops.conv_igemm(None, whi, wlo, out, prec=pr, src16=(h16, None), w_frag=wf, chan_stats=cs, ws=torch.empty(16 * out.numel(), device=dev))
         outs.append((out, cs))
     assert all(torch.equal(outs[0][0], o) and torch.equal(outs[0][1], c) for o, c in outs[1:])
     assert torch.allclose(outs[0][1][:, 0, :, 0].double(), outs[0][0].view(B, H * W, cout)[:, :256].double().sum(1), rtol=1e-4, atol=2e-3)
