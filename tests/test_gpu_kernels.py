@@ -525,6 +525,12 @@ def test_conv_dma_3x3_split_k(dev, prec, tol, B, H, W, cin, cout, emb, res):
         ops.conv_igemm(None, whi, wlo, out, prec=pr, src16=(h16, None), w_frag=wf, chan_stats=cs, ws=torch.empty(16 * out.numel(), device=dev))
         outs.append((out, cs))
     assert all(torch.equal(outs[0][0], o) and torch.equal(outs[0][1], c) for o, c in outs[1:])
+    # 16-bit side output (operand planes of an Upsample consumer) comes out of the reduce kernel
+    o16 = torch.zeros((B, H, W, cout), dtype=torch.int16, device=dev)
+    out2 = torch.empty_like(outs[0][0])
+    ops.conv_igemm(None, whi, wlo, out2, prec=pr, src16=(h16, None), w_frag=wf, ws=torch.empty(16 * out2.numel(), device=dev), out16=(o16, None))
+    assert torch.equal(out2, outs[0][0])
+    assert torch.equal(_as_float(o16, pr), out2.to(torch.float16 if prec == "f16" else torch.bfloat16).float())
     assert torch.allclose(outs[0][1][:, 0, :, 0].double(), outs[0][0].view(B, H * W, cout)[:, :256].double().sum(1), rtol=1e-4, atol=2e-3)
 
 
