@@ -431,7 +431,7 @@ class UNetModel(nn.Module):
             if fused:
                 ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias), **kw)
             else:
-                ops.conv_igemm(None, ps.hi, ps.lo, out, prec=prec, ks=1, src16=x16, bias=ps.bias, w_frag=ps.frag)
+                ops.conv_igemm(None, ps.hi, ps.lo, out, prec=prec, ks=1, src16=x16, bias=ps.bias, w_frag=ps.frag, ws=ws)
                 ops.conv_igemm(None, pk2.hi, pk2.lo, out, res=out, **kw)
             return out
         if not has_skip:

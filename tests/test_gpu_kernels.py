@@ -443,6 +443,13 @@ def test_conv_dma_1x1_frag_weights(dev, prec, tol, B, H, W, cin, cout, res):
 
 
 @pytest.mark.parametrize("prec,tol", PRECS[1:])
+@pytest.mark.parametrize("B,H,W,cin,cout,res", [(2, 8, 8, 2048, 1024, False), (1, 16, 16, 1536, 512, True), (4, 8, 8, 1024, 3072, False), (3, 32, 32, 640, 128, True)])
+def test_conv_dma_1x1_split_k(dev, prec, tol, B, H, W, cin, cout, res):
+    """small-batch 1x1 (skip_connection, qkv): K split over several blocks per tile with the workspace."""
+    _conv_dma_case(dev, prec, tol, B, H, W, cin, cout, "s1", 1, use_emb=False, use_res=res, frag=True, ws=True)
+
+
+@pytest.mark.parametrize("prec,tol", PRECS[1:])
 @pytest.mark.parametrize("B,H,W,c,cout", [(128, 8, 8, 64, 128), (50, 16, 16, 128, 96), (201, 8, 8, 32, 32), (13, 32, 32, 64, 160), (803, 4, 4, 32, 128)])
 def test_conv_dma_up_subpixel_frag_weights(dev, prec, tol, B, H, W, c, cout):
     """sub-pixel upsample through the register-streamed kernel (conv_rs_kernel<.., 4, 2>, 4 parities x tiles)."""
