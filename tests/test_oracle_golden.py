@@ -4,6 +4,7 @@ outputs exact; fp32 outputs 1e-5 relative to the tensor's std (different op orde
 import types
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import ddim as oddim
@@ -201,3 +202,31 @@ def test_f10_ddim(golden):
     xp, x0 = oddim.ddim_update(xT, e, *ds.scalars(10), noise=torch.from_numpy(fx["step_noise"]))
     close(xp, fx["step_xprev"], 1e-5)
     close(x0, fx["step_x0"], 1e-5)
+
+
+@pytest.mark.parametrize("tag,B,hw,seed,cfg", [
+    ("tiny", 2, 16, 6, dict(image_size=16, in_channels=7, model_channels=32, out_channels=4, channel_mult=(1, 2, 4), num_heads=4)),
+    ("ns32", 2, 32, 0, {})])
+def test_f14_gradients(golden, tag, B, hw, seed, cfg):
+    """Reverse-mode gradients of the oracle (autograd over the functional restatement) against the reference's own
+    UNetModel forward + L1 + backward (make_golden_grads.py): loss, dL/dx, dL/dcontext, every parameter's grad norm + samples."""
+    from oracle import train as otrain
+    from tests.golden.make_golden_grads import pick_index
+    fx = golden(f"f14_grads_{tag}")
+    cfg = ounet.UNetConfig(**cfg)
+    plan = ounet.build_plan(cfg)
+    P = prng.fill_state_dict(plan.shapes, seed)
+    x = prng.normal(seed, f"unet.{tag}.x", (B, cfg.in_channels, hw, hw))
+    ctx = prng.normal(seed, f"unet.{tag}.ctx", (B, cfg.model_channels * 4))
+    target = prng.normal(seed, f"unet.{tag}.target", (B, cfg.out_channels, hw, hw))
+    loss, grads, dx, dctx, _ = otrain.unet_loss_and_grads(P, cfg, x, torch.from_numpy(fx["t"]), ctx, target)
+    assert abs(loss - float(fx["loss"])) < 1e-5 * float(fx["loss"])
+    check_summary(dx, fx, "dx", 2e-4, tag)
+    close(dctx, fx["dctx"], 2e-4)
+    assert set(grads) == {k[2:-5] for k in fx.files if k.startswith("g.") and k.endswith(".norm")}
+    for name, g in grads.items():
+        n = float(fx[f"g.{name}.norm"])
+        a = g.double().reshape(-1)
+        assert abs(float(a.norm()) - n) <= 2e-4 * n + 1e-12, name
+        pick = a[torch.from_numpy(pick_index(a.numel()))].numpy()
+        assert np.abs(pick - fx[f"g.{name}.pick"]).max() <= 2e-4 * n / np.sqrt(a.numel()) * 30 + 1e-9, name
