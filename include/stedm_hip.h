@@ -266,6 +266,52 @@ int stedm_agg_reduce(const float* feats, float* out, int B, int n, int F, int mo
 int stedm_spatial_rescale(const float* x, const float* w, float* out, int B, int cin, int cout, int H, int W,
                           int n_stages, void* stream);
 
+/* ---- training step: backward of the U-Net, loss, optimizer -------------------------------------
+ * Replaces torch.autograd over UNetModel.forward (openaimodel.py:761-806) inside LatentDiffusion.p_losses (ddpm.py:1015-1048),
+ * torch.optim.AdamW (ldm_diffusion.py:224-234) and LitEma.forward (ema.py:25-44). The convolution contractions of the backward
+ * (dgrad, wgrad) run on stedm_conv_igemm itself: dgrad with the flipped/transposed filter, wgrad as the GEMM
+ * dW[(tap,ci)][co] = sum_p col[(tap,ci)][p] * dYt[co][p] over the planes stedm_im2col_t16 writes. */
+/* chan partials (stedm_gn_chan_stats / conv epilogues) of the virtual concat [x1|x2] -> mean_rstd [B][groups][2]. */
+int stedm_gn_fold(const float* cs1, int nslab1, int c1, const float* cs2, int nslab2, int c2, int groups, int B, int HW,
+                  float eps, float* mean_rstd, void* stream);
+/* Backward of act(GroupNorm32([x1|x2])) (util.py:199-216; act 1 = SiLU): dA [B][HW][C] -> dx (+ add, the block's residual
+ * branch) into dx1 [B][HW][c1] / dx2 [B][HW][c2] (accN: accumulate), optional 16-bit planes of dx, dgamma/dbeta (acc_param).
+ * ws: stedm_gn_bwd_ws_floats(B, HW, C, groups) floats. */
+int stedm_gn_bwd(const float* x1, int c1, const float* x2, int c2, const float* mean_rstd, const float* gamma,
+                 const float* beta, int groups, int act, const float* dA, const float* add, int B, int HW, float* ws,
+                 float* dx1, int acc1, float* dx2, int acc2, void* dx16_hi, void* dx16_lo, int mm_dtype, float* dgamma,
+                 float* dbeta, int acc_param, void* stream);
+long stedm_gn_bwd_ws_floats(int B, int HW, int C, int groups);
+/* 16-bit NHWC planes [B][Hs][Ws][C] -> transposed im2col [(tap*C + c)][Ppad] over the conv's output grid (mode 0 stride 1,
+ * 1 nearest-2x upsample + conv (openaimodel.py:129-131), 2 stride 2 pad 1 (:164-166)); pixels >= P are zero. */
+int stedm_im2col_t16(const void* src16, void* dst16, int B, int Hs, int Ws, int C, int ks, int mode, long Ppad, void* stream);
+/* GEMM result dw [taps][cin_ld][cout_ld] -> OIHW gradient [cout][cin][taps] (accumulate: +=). */
+int stedm_wgrad_to_oihw(const float* dw, float* grad, int cout, int cin, int taps, int cin_ld, int cout_ld, int accumulate,
+                        void* stream);
+/* chan partials cs [B][nslab][C][2] -> per-sample channel sums per_sample[b*ld + c] (NULL: skip) and their batch total
+ * total[c] (bias gradients; the per-sample sums are the gradient of the emb_layers output, openaimodel.py:277-280). */
+int stedm_chan_sum_fold(const float* cs, int B, int nslab, int C, float* per_sample, long ld, float* total, int accumulate,
+                        void* stream);
+/* backward of F.interpolate(scale 2, nearest): out [B][H][W][C] (+)= 2x2 block sums of in [B][2H][2W][C]. */
+int stedm_sum2x2(const float* in, float* out, int B, int H, int W, int C, int accumulate, void* stream);
+/* in [B][Ho][Wo][C] fp32 -> 16-bit planes [B][2Ho][2Wo][C], value at even positions, zero elsewhere (stride-2 dgrad). */
+int stedm_zero_insert16(const float* in, void* hi, void* lo, int B, int Ho, int Wo, int C, int mm_dtype, void* stream);
+/* backward of QKVAttentionLegacy (openaimodel.py:378-394): qkv, d_qkv [B][T][heads*3*ch]; d_out [B][T][heads*ch]. */
+int stedm_attn_legacy_bwd(const float* qkv, const float* d_out, float* d_qkv, int B, int T, int heads, int ch, void* stream);
+/* C = alpha op(A) op(B) + beta C (fp32; the embedding Linears' backward: rows = batch). */
+int stedm_gemm_f32(const float* A, long lda, int trans_a, const float* B, long ldb, int trans_b, float* C, long ldc, int M,
+                   int N, int K, float alpha, float beta, void* stream);
+/* mode 0: out = silu(x); mode 1: out = dy * silu'(x). */
+int stedm_silu(const float* x, const float* dy, float* out, long n, int mode, void* stream);
+/* loss = mean|target - pred| (ddpm.py:282-295 'l1' + :1030-1040), d_pred = grad_scale * sign(pred - target) / n (NULL: skip).
+ * ws: 1024 doubles. */
+int stedm_l1_loss(const float* pred, const float* target, long n, float grad_scale, float* d_pred, double* ws, float* loss,
+                  void* stream);
+/* AdamW + EMA over many tensors: table [ntensors] of {float* p, const float* g, float* m, float* v, float* ema|NULL, long n};
+ * block i updates elements [chunk_off[i], chunk_off[i] + 4096) of tensor chunk_tensor[i]. step counts from 1. */
+int stedm_adamw_ema(const void* table, const int* chunk_tensor, const long* chunk_off, int nchunks, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int step, float ema_decay, float grad_scale, void* stream);
+
 /* ---- HIP graph capture helpers (plumbing for the sampling loop) ---------------------------- */
 int stedm_graph_begin(void* stream);
 int stedm_graph_end(void* stream, void** graph_exec_out);

@@ -1,0 +1,564 @@
+// Backward-pass kernels of the training step (p_losses ddpm.py:1015-1048 under autograd, i.e. the reverse
+// of UNetModel.forward openaimodel.py:761-806). The two heavy contractions of every convolution's backward run on the forward's
+// own MFMA convolution kernels: dgrad = the same convolution with the flipped / transposed filter; wgrad = one GEMM
+// dW[(tap, ci)][co] = sum_p col[(tap, ci)][p] * dY^T[co][p] over "transposed im2col" planes written here. Everything else
+// (GroupNorm+SiLU backward, attention backward, reductions, loss, optimizer) is HBM-bound fp32 work in this file.
+// No atomics: every reduction has a fixed order, gradients are bitwise reproducible.
+#include "common.hpp"
+
+using namespace stedm;
+
+namespace {
+
+__device__ __forceinline__ float silu_grad(float y) {
+  const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+  return s * (1.0f + y * (1.0f - s));
+}
+
+// ------------------------------------------------------------------------------------------------ GroupNorm statistics
+// chan partials of the (virtual concat) input -> mr[B][groups][2] = {mean, rstd}
+__global__ void __launch_bounds__(256) gn_fold_kernel(const float* __restrict__ cs1, int nslab1, int c1, const float* __restrict__ cs2, int nslab2,
+                                                      int c2, int groups, int HW, float eps, float* __restrict__ mr) {
+  __shared__ double dsu[256], dsq[256];
+  const int b = blockIdx.x, C = c1 + c2, cpg = C / groups;
+  const int L = 256 / groups, g = threadIdx.x / L, l = threadIdx.x % L;
+  double su = 0.0, sq = 0.0;
+  if (g < groups) {
+    const int nmax = nslab1 > nslab2 ? nslab1 : nslab2;
+    for (int e = l; e < cpg * nmax; e += L) {
+      const int k = e / cpg, c = g * cpg + (e - k * cpg);
+      if (c < c1) {
+        if (k < nslab1) { const float* p = cs1 + (((long)b * nslab1 + k) * c1 + c) * 2; su += (double)p[0]; sq += (double)p[1]; }
+      } else if (k < nslab2) {
+        const float* p = cs2 + (((long)b * nslab2 + k) * c2 + (c - c1)) * 2; su += (double)p[0]; sq += (double)p[1];
+      }
+    }
+  }
+  dsu[threadIdx.x] = su; dsq[threadIdx.x] = sq;
+  __syncthreads();
+  if (threadIdx.x < groups) {
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < L; ++i) { s += dsu[threadIdx.x * L + i]; q += dsq[threadIdx.x * L + i]; }
+    const double n = (double)cpg * HW, mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mr[((long)b * groups + threadIdx.x) * 2] = (float)mean;
+    mr[((long)b * groups + threadIdx.x) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+struct GnBwdArgs {
+  const float* x1; const float* x2; int c1, c2;
+  const float* mr; const float* gamma; const float* beta; const float* dA;   // dA: [B][HW][C] gradient w.r.t. act(GN(x))
+  int groups, HW, act;
+  float* part;        // [B][nslab][C][2] {sum dy, sum dy*xhat}
+  const float* gm;    // [B][groups][2]   {mean_g(gamma*dy), mean_g(gamma*dy*xhat)}
+  const float* add;   // optional [B][HW][C] added to dx (the residual / skip branch of the block)
+  float* dx1; float* dx2; int acc1, acc2;
+  void* o_hi; void* o_lo;   // optional 16-bit planes of dx (operand of the producer convolution's dgrad / wgrad)
+};
+
+// grid (B, 256-pixel slabs, blocks of 64 channel quads)
+__global__ void __launch_bounds__(256) gn_bwd_stats_kernel(GnBwdArgs a) {
+  __shared__ float cpart[256 * 8];
+  const int b = blockIdx.x, slab = blockIdx.y, nslab = gridDim.y;
+  const int C = a.c1 + a.c2, Q = C >> 2, t = threadIdx.x, cpg = C / a.groups;
+  const int qb0 = blockIdx.z * 64, QB = min(64, Q - qb0);
+  const int npl = 256 / QB, tq = t % QB, tp = t / QB;
+  const int c = (qb0 + tq) * 4;
+  const int px0 = min(a.HW, slab * 256), px1 = min(a.HW, px0 + 256);
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (tp < npl) {
+    float mean[4], rstd[4], ga[4], be[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int g = (c + j) / cpg;
+      mean[j] = a.mr[((long)b * a.groups + g) * 2]; rstd[j] = a.mr[((long)b * a.groups + g) * 2 + 1];
+      ga[j] = a.gamma[c + j]; be[j] = a.beta[c + j];
+    }
+    const float* px = c < a.c1 ? a.x1 + (long)b * a.HW * a.c1 + c : a.x2 + (long)b * a.HW * a.c2 + (c - a.c1);
+    const int ldx = c < a.c1 ? a.c1 : a.c2;
+    const float* pd = a.dA + (long)b * a.HW * C + c;
+    for (int pix = px0 + tp; pix < px1; pix += npl) {
+      const float4 xv = *reinterpret_cast<const float4*>(px + (long)pix * ldx);
+      const float4 dv = *reinterpret_cast<const float4*>(pd + (long)pix * C);
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float xh = (xs[j] - mean[j]) * rstd[j];
+        const float dy = a.act ? ds[j] * silu_grad(xh * ga[j] + be[j]) : ds[j];
+        s1[j] += dy; s2[j] += dy * xh;
+      }
+    }
+    float* d = cpart + (tp * QB + tq) * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { d[j] = s1[j]; d[4 + j] = s2[j]; }
+  }
+  __syncthreads();
+  if (t < QB) {
+    float u[4] = {0.f, 0.f, 0.f, 0.f}, w[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < npl; ++l) {
+      const float* d = cpart + (l * QB + t) * 8;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { u[j] += d[j]; w[j] += d[4 + j]; }
+    }
+    float* dst = a.part + (((long)b * nslab + slab) * C + (qb0 + t) * 4) * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dst[j * 2] = u[j]; dst[j * 2 + 1] = w[j]; }
+  }
+}
+
+// grid B: slab partials -> bc[B][C][2] (per-sample channel sums) and gm[B][groups][2]
+__global__ void __launch_bounds__(256) gn_bwd_fold_kernel(const float* __restrict__ part, int nslab, int C, int groups, int HW,
+                                                          const float* __restrict__ gamma, float* __restrict__ bc, float* __restrict__ gm) {
+  extern __shared__ float sm[];   // [C][2] gamma-weighted sums
+  const int b = blockIdx.x, cpg = C / groups;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float u = 0.f, w = 0.f;
+    for (int k = 0; k < nslab; ++k) { const float* p = part + (((long)b * nslab + k) * C + c) * 2; u += p[0]; w += p[1]; }
+    bc[((long)b * C + c) * 2] = u; bc[((long)b * C + c) * 2 + 1] = w;
+    sm[c * 2] = u * gamma[c]; sm[c * 2 + 1] = w * gamma[c];
+  }
+  __syncthreads();
+  if (threadIdx.x < groups) {
+    double u = 0.0, w = 0.0;
+    for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c) { u += (double)sm[c * 2]; w += (double)sm[c * 2 + 1]; }
+    const double n = (double)cpg * HW;
+    gm[((long)b * groups + threadIdx.x) * 2] = (float)(u / n);
+    gm[((long)b * groups + threadIdx.x) * 2 + 1] = (float)(w / n);
+  }
+}
+
+// dgamma[c] (+)= sum_b bc[b][c][1]; dbeta[c] (+)= sum_b bc[b][c][0]
+__global__ void gn_bwd_param_kernel(const float* __restrict__ bc, int B, int C, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float u = 0.f, w = 0.f;
+  for (int b = 0; b < B; ++b) { u += bc[((long)b * C + c) * 2]; w += bc[((long)b * C + c) * 2 + 1]; }
+  dgamma[c] = (accumulate ? dgamma[c] : 0.f) + w;
+  dbeta[c] = (accumulate ? dbeta[c] : 0.f) + u;
+}
+
+// dx = rstd * (gamma*dy - m1 - xhat*m2) (+ add); grid (B, ceil(HW*Q / 1024)), one float4 per thread x 4
+template <typename T>
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(GnBwdArgs a) {
+  typedef T V4 __attribute__((ext_vector_type(4)));
+  const int b = blockIdx.x, C = a.c1 + a.c2, Q = C >> 2, cpg = C / a.groups;
+  const long total = (long)a.HW * Q;
+  for (int k = 0; k < 4; ++k) {
+    const long e = ((long)blockIdx.y * 4 + k) * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int pix = (int)(e / Q), c = (int)(e % Q) * 4;
+    const bool first = c < a.c1;
+    const float4 xv = first ? *reinterpret_cast<const float4*>(a.x1 + ((long)b * a.HW + pix) * a.c1 + c)
+                            : *reinterpret_cast<const float4*>(a.x2 + ((long)b * a.HW + pix) * a.c2 + (c - a.c1));
+    const long o = ((long)b * a.HW + pix) * C + c;
+    const float4 dv = *reinterpret_cast<const float4*>(a.dA + o);
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int g = (c + j) / cpg;
+      const float mean = a.mr[((long)b * a.groups + g) * 2], rstd = a.mr[((long)b * a.groups + g) * 2 + 1];
+      const float m1 = a.gm[((long)b * a.groups + g) * 2], m2 = a.gm[((long)b * a.groups + g) * 2 + 1];
+      const float ga = a.gamma[c + j];
+      const float xh = (xs[j] - mean) * rstd;
+      const float dy = a.act ? ds[j] * silu_grad(xh * ga + a.beta[c + j]) : ds[j];
+      r[j] = rstd * (ga * dy - m1 - xh * m2);
+    }
+    if (a.add) {
+      const float4 av = *reinterpret_cast<const float4*>(a.add + o);
+      r[0] += av.x; r[1] += av.y; r[2] += av.z; r[3] += av.w;
+    }
+    float* dst = first ? a.dx1 + ((long)b * a.HW + pix) * a.c1 + c : a.dx2 + ((long)b * a.HW + pix) * a.c2 + (c - a.c1);
+    if (first ? a.acc1 : a.acc2) {
+      const float4 old = *reinterpret_cast<const float4*>(dst);
+      r[0] += old.x; r[1] += old.y; r[2] += old.z; r[3] += old.w;
+    }
+    *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1], r[2], r[3]);
+    if (a.o_hi) {
+      V4 hi;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hi[j] = (T)r[j];
+      reinterpret_cast<V4*>(a.o_hi)[o >> 2] = hi;
+      if (a.o_lo) {
+        V4 lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lo[j] = (T)(r[j] - (float)hi[j]);
+        reinterpret_cast<V4*>(a.o_lo)[o >> 2] = lo;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ transposed im2col (16-bit)
+// src [B][Hs][Ws][C] 16-bit NHWC -> dst [(tap*C + c)][Ppad], p = (b*Ho + y)*Wo + x over the OUTPUT grid of the convolution;
+// mode 0: stride 1 (Ho = Hs); 1: nearest-2x upsample then conv (Ho = 2Hs); 2: stride 2 (Ho = Hs/2). ks 1 or 3 (pad ks/2).
+// grid (Ppad/64, ceil(C/64), taps), 256 threads: a 64-pixel x 64-channel tile goes through LDS.
+__global__ void __launch_bounds__(256) im2col_t16_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int B, int Hs, int Ws, int C, int Ho,
+                                                         int Wo, int ks, int mode, long P, long Ppad) {
+  __shared__ uint16_t tile[64][72];
+  const int tap = blockIdx.z, ky = tap / ks - ks / 2, kx = tap % ks - ks / 2;
+  const long p0 = (long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int e = threadIdx.x + it * 256, pl = e >> 3, cq = (e & 7) * 8;
+    const long p = p0 + pl;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (p < P && c0 + cq < C) {
+      const int x = (int)(p % Wo), y = (int)((p / Wo) % Ho), b = (int)(p / ((long)Wo * Ho));
+      int sy, sx; bool ok;
+      if (mode == 1) { const int uy = y + ky, ux = x + kx; ok = uy >= 0 && uy < Ho && ux >= 0 && ux < Wo; sy = uy >> 1; sx = ux >> 1; }
+      else if (mode == 2) { sy = 2 * y + ky; sx = 2 * x + kx; ok = sy >= 0 && sy < Hs && sx >= 0 && sx < Ws; }
+      else { sy = y + ky; sx = x + kx; ok = sy >= 0 && sy < Hs && sx >= 0 && sx < Ws; }
+      if (ok) v = *reinterpret_cast<const uint4*>(src + (((long)b * Hs + sy) * Ws + sx) * C + c0 + cq);
+    }
+    *reinterpret_cast<uint4*>(&tile[pl][cq]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int e = threadIdx.x + it * 256, cl = e >> 3, pq = (e & 7) * 8;
+    if (c0 + cl >= C) continue;
+    uint16_t r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = tile[pq + j][cl];
+    uint4 v;
+    v.x = r[0] | ((uint32_t)r[1] << 16); v.y = r[2] | ((uint32_t)r[3] << 16);
+    v.z = r[4] | ((uint32_t)r[5] << 16); v.w = r[6] | ((uint32_t)r[7] << 16);
+    *reinterpret_cast<uint4*>(dst + ((long)tap * C + c0 + cl) * Ppad + p0 + pq) = v;
+  }
+}
+
+// dw [taps][cin_ld][cout_ld] fp32 (GEMM result) -> grad OIHW [cout][cin][taps] (+= when accumulate)
+__global__ void wgrad_to_oihw_kernel(const float* __restrict__ dw, float* __restrict__ grad, int cout, int cin, int taps, int cin_ld, int cout_ld,
+                                     int accumulate, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int tap = (int)(i % taps), ci = (int)((i / taps) % cin), co = (int)(i / ((long)taps * cin));
+  const float v = dw[((long)tap * cin_ld + ci) * cout_ld + co];
+  grad[i] = (accumulate ? grad[i] : 0.f) + v;
+}
+
+// cs [B][nslab][C][2] (sums in [..][0]) -> per_sample[b*ld + c] (optional) and total[c] (+= when accumulate; optional)
+__global__ void chan_sum_fold_kernel(const float* __restrict__ cs, int B, int nslab, int C, float* __restrict__ per_sample, long ld, float* __restrict__ total,
+                                     int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float tot = 0.f;
+  for (int b = 0; b < B; ++b) {
+    float u = 0.f;
+    for (int k = 0; k < nslab; ++k) u += cs[(((long)b * nslab + k) * C + c) * 2];
+    if (per_sample) per_sample[(long)b * ld + c] = u;
+    tot += u;
+  }
+  if (total) total[c] = (accumulate ? total[c] : 0.f) + tot;
+}
+
+// ------------------------------------------------------------------------------------------------ resampling
+// out[b][y][x][c] (+)= sum of the 2x2 block of in [B][2H][2W][C]  (backward of the nearest-neighbour 2x upsample)
+__global__ void sum2x2_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, int Q, int accumulate, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int q = (int)(i % Q), x = (int)((i / Q) % W), y = (int)((i / ((long)Q * W)) % H), b = (int)(i / ((long)Q * W * H));
+  const float4* p = reinterpret_cast<const float4*>(in) + (((long)b * 2 * H + 2 * y) * 2 * W + 2 * x) * Q + q;
+  const float4 a0 = p[0], a1 = p[Q], a2 = p[(long)2 * W * Q], a3 = p[(long)2 * W * Q + Q];
+  float4 r = make_float4(a0.x + a1.x + a2.x + a3.x, a0.y + a1.y + a2.y + a3.y, a0.z + a1.z + a2.z + a3.z, a0.w + a1.w + a2.w + a3.w);
+  float4* o = reinterpret_cast<float4*>(out) + i;
+  if (accumulate) { const float4 v = *o; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+  *o = r;
+}
+
+// 16-bit planes [B][2Ho][2Wo][C]: value of in[b][y/2][x/2][c] at even (y, x), zero elsewhere (dgrad of a stride-2 convolution
+// is the stride-1 convolution of this zero-inserted gradient with the flipped filter)
+template <typename T>
+__global__ void zero_insert16_kernel(const float* __restrict__ in, T* __restrict__ hi, T* __restrict__ lo, int Ho, int Wo, int Q, long total) {
+  typedef T V4 __attribute__((ext_vector_type(4)));
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over the [B][2Ho][2Wo][Q] output
+  if (i >= total) return;
+  const int q = (int)(i % Q), x = (int)((i / Q) % (2 * Wo)), y = (int)((i / ((long)Q * 2 * Wo)) % (2 * Ho)), b = (int)(i / ((long)Q * 4 * Wo * Ho));
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!(x & 1) && !(y & 1)) v = reinterpret_cast<const float4*>(in)[(((long)b * Ho + (y >> 1)) * Wo + (x >> 1)) * Q + q];
+  V4 h; h[0] = (T)v.x; h[1] = (T)v.y; h[2] = (T)v.z; h[3] = (T)v.w;
+  reinterpret_cast<V4*>(hi)[i] = h;
+  if (lo) {
+    V4 l; l[0] = (T)(v.x - (float)h[0]); l[1] = (T)(v.y - (float)h[1]); l[2] = (T)(v.z - (float)h[2]); l[3] = (T)(v.w - (float)h[3]);
+    reinterpret_cast<V4*>(lo)[i] = l;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ attention backward
+// QKVAttentionLegacy (openaimodel.py:378-394) reversed; one block per (sample, head); P and dS live in LDS ([T][T] fp32 each).
+__global__ void __launch_bounds__(256) attn_legacy_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, float* __restrict__ dqkv, int T,
+                                                              int heads, int ch) {
+  extern __shared__ float sm[];
+  float* P = sm;
+  float* dS = sm + (long)T * T;
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+  const long ld = (long)heads * 3 * ch, ldo = (long)heads * ch;
+  const float* q = qkv + (long)b * T * ld + (long)h * 3 * ch;
+  const float* k = q + ch;
+  const float* v = q + 2 * ch;
+  const float* go = dO + (long)b * T * ldo + (long)h * ch;
+  float* dq = dqkv + (long)b * T * ld + (long)h * 3 * ch;
+  float* dk = dq + ch;
+  float* dv = dq + 2 * ch;
+  const float s2 = 1.0f / sqrtf((float)ch);   // (ch^-1/4)^2: the scale sits on both q and k
+  for (int e = threadIdx.x; e < T * T; e += 256) {
+    const int i = e / T, j = e % T;
+    float acc = 0.f, accp = 0.f;
+    for (int c = 0; c < ch; c += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(q + i * ld + c), bb = *reinterpret_cast<const float4*>(k + j * ld + c);
+      acc += a.x * bb.x + a.y * bb.y + a.z * bb.z + a.w * bb.w;
+      const float4 g = *reinterpret_cast<const float4*>(go + i * ldo + c), vv = *reinterpret_cast<const float4*>(v + j * ld + c);
+      accp += g.x * vv.x + g.y * vv.y + g.z * vv.z + g.w * vv.w;
+    }
+    P[e] = acc * s2; dS[e] = accp;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < T; i += 256) {   // softmax row i, then dS = P * (dP - sum_j P*dP)
+    float m = -INFINITY;
+    for (int j = 0; j < T; ++j) m = fmaxf(m, P[i * T + j]);
+    float s = 0.f;
+    for (int j = 0; j < T; ++j) { const float e = __expf(P[i * T + j] - m); P[i * T + j] = e; s += e; }
+    const float inv = 1.0f / s;
+    float delta = 0.f;
+    for (int j = 0; j < T; ++j) { const float p = P[i * T + j] * inv; P[i * T + j] = p; delta += p * dS[i * T + j]; }
+    for (int j = 0; j < T; ++j) dS[i * T + j] = P[i * T + j] * (dS[i * T + j] - delta);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < T * ch; e += 256) {
+    const int r = e / ch, c = e % ch;
+    float av = 0.f, aq = 0.f, ak = 0.f;
+    for (int j = 0; j < T; ++j) {
+      av += P[j * T + r] * go[j * ldo + c];       // dV[r] = sum_i P[i][r] dO[i]
+      aq += dS[r * T + j] * k[j * ld + c];        // dQ[r] = s2 sum_j dS[r][j] K[j]
+      ak += dS[j * T + r] * q[j * ld + c];        // dK[r] = s2 sum_i dS[i][r] Q[i]
+    }
+    dv[r * ld + c] = av; dq[r * ld + c] = aq * s2; dk[r * ld + c] = ak * s2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ small fp32 GEMM
+// C[M][N] = alpha * op(A) op(B) + beta * C; op(A)[m][k] = ta ? A[k*lda + m] : A[m*lda + k]; op(B)[k][n] = tb ? B[n*ldb + k] : B[k*ldb + n]
+__global__ void __launch_bounds__(256) gemm_f32_kernel(const float* __restrict__ A, long lda, int ta, const float* __restrict__ Bm, long ldb, int tb,
+                                                       float* __restrict__ Cm, long ldc, int M, int N, int K, float alpha, float beta) {
+  __shared__ float sa[32][33], sb[32][33];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 16 x 16 threads, 2 x 2 outputs each
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    for (int e = threadIdx.x; e < 1024; e += 256) {
+      const int r = e >> 5, cidx = e & 31;
+      {  // sa[m][k]
+        const int m = ta ? m0 + cidx : m0 + r, kk = ta ? k0 + r : k0 + cidx;
+        const float val = (m < M && kk < K) ? (ta ? A[(long)kk * lda + m] : A[(long)m * lda + kk]) : 0.f;
+        if (ta) sa[cidx][r] = val; else sa[r][cidx] = val;
+      }
+      {  // sb[k][n]
+        const int kk = tb ? k0 + cidx : k0 + r, n = tb ? n0 + r : n0 + cidx;
+        const float val = (kk < K && n < N) ? (tb ? Bm[(long)n * ldb + kk] : Bm[(long)kk * ldb + n]) : 0.f;
+        if (tb) sb[cidx][r] = val; else sb[r][cidx] = val;
+      }
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int kk = 0; kk < 32; ++kk) {
+      const float a0 = sa[ty * 2][kk], a1 = sa[ty * 2 + 1][kk], b0 = sb[kk][tx * 2], b1 = sb[kk][tx * 2 + 1];
+      acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + ty * 2 + i, n = n0 + tx * 2 + j;
+      if (m < M && n < N) Cm[(long)m * ldc + n] = alpha * acc[i][j] + (beta != 0.f ? beta * Cm[(long)m * ldc + n] : 0.f);
+    }
+}
+
+// mode 0: out = silu(x); mode 1: out = dy * silu'(x)
+__global__ void silu_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ out, long n, int mode) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = mode == 0 ? silu_f(x[i]) : dy[i] * silu_grad(x[i]);
+}
+
+// ------------------------------------------------------------------------------------------------ loss
+// L1 (ddpm.py:282-295, 1030-1040): loss = mean |target - pred|; dpred = sign(pred - target) * scale / n
+__global__ void __launch_bounds__(256) l1_partial_kernel(const float* __restrict__ pred, const float* __restrict__ target, float* __restrict__ dpred, long n,
+                                                         float gscale, double* __restrict__ part) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float d = pred[i] - target[i];
+    s += (double)fabsf(d);
+    if (dpred) dpred[i] = d > 0.f ? gscale : (d < 0.f ? -gscale : 0.f);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ void l1_final_kernel(const double* __restrict__ part, int nb, double inv_n, float* __restrict__ loss) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < nb; ++i) s += part[i];
+    *loss = (float)(s * inv_n);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ optimizer
+// AdamW (torch.optim.AdamW semantics) + LitEma (ema.py:25-44) over many tensors in one launch. table[t] = {p, g, m, v, ema, n};
+// chunk_tensor[blockIdx.x] / chunk_off[blockIdx.x] map a block to 4096 elements of one tensor.
+struct OptTensor { float* p; const float* g; float* m; float* v; float* ema; long n; };
+__global__ void __launch_bounds__(256) adamw_ema_kernel(const OptTensor* __restrict__ table, const int* __restrict__ chunk_tensor,
+                                                        const long* __restrict__ chunk_off, float lr, float beta1, float beta2, float eps, float wd, float bc1,
+                                                        float bc2_sqrt, float ema_decay, float grad_scale) {
+  const OptTensor t = table[chunk_tensor[blockIdx.x]];
+  const long o0 = chunk_off[blockIdx.x];
+  for (int k = 0; k < 16; ++k) {
+    const long i = o0 + k * 256 + threadIdx.x;
+    if (i >= t.n) return;
+    const float g = t.g[i] * grad_scale;
+    float p = t.p[i] * (1.0f - lr * wd);
+    const float m = beta1 * t.m[i] + (1.0f - beta1) * g;
+    const float v = beta2 * t.v[i] + (1.0f - beta2) * g * g;
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p -= (lr / bc1) * (m / denom);
+    t.p[i] = p; t.m[i] = m; t.v[i] = v;
+    if (t.ema) { const float s = t.ema[i]; t.ema[i] = s - (1.0f - ema_decay) * (s - p); }
+  }
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" int stedm_gn_fold(const float* cs1, int nslab1, int c1, const float* cs2, int nslab2, int c2, int groups, int B, int HW, float eps, float* mean_rstd,
+                             void* stream) {
+  STEDM_CHECK_ARG(cs1 && mean_rstd && groups > 0 && groups <= 64 && (c1 + c2) % groups == 0 && (cs2 != nullptr) == (c2 > 0), "gn_fold: bad args");
+  gn_fold_kernel<<<B, 256, 0, as_stream(stream)>>>(cs1, nslab1, c1, cs2, nslab2, c2, groups, HW, eps, mean_rstd);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int stedm_gn_bwd(const float* x1, int c1, const float* x2, int c2, const float* mean_rstd, const float* gamma, const float* beta, int groups, int act,
+                            const float* dA, const float* add, int B, int HW, float* ws, float* dx1, int acc1, float* dx2, int acc2, void* dx16_hi,
+                            void* dx16_lo, int mm_dtype, float* dgamma, float* dbeta, int acc_param, void* stream) {
+  const int C = c1 + c2;
+  STEDM_CHECK_ARG(x1 && mean_rstd && gamma && beta && dA && ws && dx1 && dgamma && dbeta, "gn_bwd: null pointer");
+  STEDM_CHECK_ARG((x2 != nullptr) == (c2 > 0) && (c2 == 0 || dx2), "gn_bwd: x2/c2/dx2 mismatch");
+  STEDM_CHECK_ARG(C % 4 == 0 && c1 % 4 == 0 && groups > 0 && groups <= 64 && C % groups == 0 && C * 8 <= 65536, "gn_bwd: channel constraints");
+  STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "gn_bwd: bad mm_dtype");
+  const int nslab = (HW + 255) / 256, Q = C / 4;
+  // workspace: part [B][nslab][C][2] | bc [B][C][2] | gm [B][groups][2]
+  float* part = ws;
+  float* bc = part + (long)B * nslab * C * 2;
+  float* gm = bc + (long)B * C * 2;
+  GnBwdArgs a{x1, x2, c1, c2, mean_rstd, gamma, beta, dA, groups, HW, act, part, gm, add, dx1, dx2, acc1, acc2, dx16_hi, dx16_lo};
+  hipStream_t st = as_stream(stream);
+  gn_bwd_stats_kernel<<<dim3(B, nslab, (Q + 63) / 64), 256, 0, st>>>(a);
+  gn_bwd_fold_kernel<<<B, 256, (size_t)C * 8, st>>>(part, nslab, C, groups, HW, gamma, bc, gm);
+  gn_bwd_param_kernel<<<(C + 255) / 256, 256, 0, st>>>(bc, B, C, dgamma, dbeta, acc_param);
+  const dim3 grid(B, (unsigned)(((long)HW * Q + 1023) / 1024));
+  if (mm_dtype == STEDM_F16) gn_bwd_apply_kernel<_Float16><<<grid, 256, 0, st>>>(a);
+  else gn_bwd_apply_kernel<__bf16><<<grid, 256, 0, st>>>(a);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" long stedm_gn_bwd_ws_floats(int B, int HW, int C, int groups) {
+  return (long)B * ((HW + 255) / 256) * C * 2 + (long)B * C * 2 + (long)B * groups * 2;
+}
+
+extern "C" int stedm_im2col_t16(const void* src16, void* dst16, int B, int Hs, int Ws, int C, int ks, int mode, long Ppad, void* stream) {
+  STEDM_CHECK_ARG(src16 && dst16 && C % 8 == 0 && (ks == 1 || ks == 3) && mode >= 0 && mode <= 2 && Ppad % 64 == 0, "im2col_t16: bad args");
+  const int Ho = mode == 1 ? 2 * Hs : (mode == 2 ? Hs / 2 : Hs), Wo = mode == 1 ? 2 * Ws : (mode == 2 ? Ws / 2 : Ws);
+  const long P = (long)B * Ho * Wo;
+  STEDM_CHECK_ARG(Ppad >= P, "im2col_t16: Ppad < P");
+  dim3 grid((unsigned)(Ppad / 64), (C + 63) / 64, ks * ks);
+  im2col_t16_kernel<<<grid, 256, 0, as_stream(stream)>>>((const uint16_t*)src16, (uint16_t*)dst16, B, Hs, Ws, C, Ho, Wo, ks, mode, P, Ppad);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int stedm_wgrad_to_oihw(const float* dw, float* grad, int cout, int cin, int taps, int cin_ld, int cout_ld, int accumulate, void* stream) {
+  STEDM_CHECK_ARG(dw && grad && cin_ld >= cin && cout_ld >= cout, "wgrad_to_oihw: bad args");
+  const long total = (long)cout * cin * taps;
+  wgrad_to_oihw_kernel<<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(dw, grad, cout, cin, taps, cin_ld, cout_ld, accumulate, total);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int stedm_chan_sum_fold(const float* cs, int B, int nslab, int C, float* per_sample, long ld, float* total, int accumulate, void* stream) {
+  STEDM_CHECK_ARG(cs && (per_sample || total), "chan_sum_fold: bad args");
+  chan_sum_fold_kernel<<<(C + 255) / 256, 256, 0, as_stream(stream)>>>(cs, B, nslab, C, per_sample, ld, total, accumulate);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int stedm_sum2x2(const float* in, float* out, int B, int H, int W, int C, int accumulate, void* stream) {
+  STEDM_CHECK_ARG(in && out && C % 4 == 0, "sum2x2: bad args");
+  const long total = (long)B * H * W * (C / 4);
+  sum2x2_kernel<<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(in, out, H, W, C / 4, accumulate, total);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int stedm_zero_insert16(const float* in, void* hi, void* lo, int B, int Ho, int Wo, int C, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(in && hi && C % 4 == 0 && (mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16), "zero_insert16: bad args");
+  const long total = (long)B * 4 * Ho * Wo * (C / 4);
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  if (mm_dtype == STEDM_F16) zero_insert16_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(in, (_Float16*)hi, (_Float16*)lo, Ho, Wo, C / 4, total);
+  else zero_insert16_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(in, (__bf16*)hi, (__bf16*)lo, Ho, Wo, C / 4, total);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int stedm_attn_legacy_bwd(const float* qkv, const float* d_out, float* d_qkv, int B, int T, int heads, int ch, void* stream) {
+  STEDM_CHECK_ARG(qkv && d_out && d_qkv && ch % 4 == 0, "attn_legacy_bwd: bad args");
+  const size_t lds = (size_t)T * T * 8;
+  STEDM_CHECK_ARG(lds <= 160 * 1024 - 1024, "attn_legacy_bwd: T = %d tokens exceed the LDS-resident form (T <= 140)", T);
+  static bool attr = false;
+  if (!attr) { STEDM_HIP_TRY(hipFuncSetAttribute((const void*)attn_legacy_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)); attr = true; }
+  attn_legacy_bwd_kernel<<<B * heads, 256, lds, as_stream(stream)>>>(qkv, d_out, d_qkv, T, heads, ch);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int stedm_gemm_f32(const float* A, long lda, int trans_a, const float* Bm, long ldb, int trans_b, float* Cm, long ldc, int M, int N, int K, float alpha,
+                              float beta, void* stream) {
+  STEDM_CHECK_ARG(A && Bm && Cm && M > 0 && N > 0 && K > 0, "gemm_f32: bad args");
+  gemm_f32_kernel<<<dim3((N + 31) / 32, (M + 31) / 32), 256, 0, as_stream(stream)>>>(A, lda, trans_a, Bm, ldb, trans_b, Cm, ldc, M, N, K, alpha, beta);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int stedm_silu(const float* x, const float* dy, float* out, long n, int mode, void* stream) {
+  STEDM_CHECK_ARG(x && out && (mode == 0 || dy), "silu: bad args");
+  silu_kernel<<<(unsigned)((n + 255) / 256), 256, 0, as_stream(stream)>>>(x, dy, out, n, mode);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int stedm_l1_loss(const float* pred, const float* target, long n, float grad_scale, float* d_pred, double* ws, float* loss, void* stream) {
+  STEDM_CHECK_ARG(pred && target && ws && loss && n > 0, "l1_loss: bad args");
+  const int nb = (int)((n + 256 * 16 - 1) / (256 * 16) < 1024 ? (n + 256 * 16 - 1) / (256 * 16) : 1024);
+  l1_partial_kernel<<<nb, 256, 0, as_stream(stream)>>>(pred, target, d_pred, n, grad_scale / (float)n, ws);
+  l1_final_kernel<<<1, 64, 0, as_stream(stream)>>>(ws, nb, 1.0 / (double)n, loss);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int stedm_adamw_ema(const void* table, const int* chunk_tensor, const long* chunk_off, int nchunks, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int step, float ema_decay, float grad_scale, void* stream) {
+  STEDM_CHECK_ARG(table && chunk_tensor && chunk_off && nchunks > 0 && step >= 1, "adamw_ema: bad args");
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+  adamw_ema_kernel<<<nchunks, 256, 0, as_stream(stream)>>>((const OptTensor*)table, chunk_tensor, chunk_off, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2),
+                                                          ema_decay, grad_scale);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}

@@ -482,6 +482,105 @@ def step_set_t(ts_table: torch.Tensor, step_idx: torch.Tensor, t_buf: torch.Tens
           "stedm_step_set_t")
 
 
+
+# ------------------------------------------------------------------------------------------- training step (backward)
+def gn_fold(cs1: torch.Tensor, cs2: Optional[torch.Tensor], groups: int, HW: int, eps: float, out: torch.Tensor) -> torch.Tensor:
+    """chan partials of [x1|x2] -> out [B][groups][2] = {mean, rstd}."""
+    B, c1 = cs1.shape[0], cs1.shape[2]
+    c2 = 0 if cs2 is None else cs2.shape[2]
+    assert tuple(out.shape) == (B, groups, 2)
+    check(lib().stedm_gn_fold(cs1.data_ptr(), cs1.shape[1], c1, _ptr(cs2), 0 if cs2 is None else cs2.shape[1], c2, groups, B, HW, float(eps),
+                              out.data_ptr(), _stream()), "stedm_gn_fold")
+    return out
+
+
+def gn_bwd_ws_floats(B: int, HW: int, C: int, groups: int) -> int:
+    return lib().stedm_gn_bwd_ws_floats(B, HW, C, groups)
+
+
+def gn_bwd(x1, x2, mean_rstd, gamma, beta, groups: int, act: int, dA, add, ws, dx1, acc1: bool, dx2, acc2: bool, dx16, prec: Precision,
+           dgamma, dbeta, acc_param: bool) -> None:
+    """Backward of act(GroupNorm([x1|x2])): see stedm_gn_bwd."""
+    _chk(x1, name="x1"); _chk(dA, name="dA")
+    B, c1 = x1.shape[0], x1.shape[-1]
+    HW = x1.numel() // (B * c1)
+    c2 = 0 if x2 is None else x2.shape[-1]
+    assert dA.numel() == B * HW * (c1 + c2) and ws.numel() >= gn_bwd_ws_floats(B, HW, c1 + c2, groups)
+    check(lib().stedm_gn_bwd(x1.data_ptr(), c1, _ptr(x2), c2, mean_rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), groups, act, dA.data_ptr(),
+                             _ptr(add), B, HW, ws.data_ptr(), dx1.data_ptr(), int(acc1), _ptr(dx2), int(acc2),
+                             None if dx16 is None else dx16[0].data_ptr(), None if dx16 is None else _ptr(dx16[1]), prec.mm_dtype,
+                             dgamma.data_ptr(), dbeta.data_ptr(), int(acc_param), _stream()), "stedm_gn_bwd")
+
+
+def im2col_t16(src16: torch.Tensor, dst16: torch.Tensor, ks: int, mode: int) -> None:
+    """16-bit NHWC plane [B,Hs,Ws,C] -> [(tap*C + c)][Ppad] (dst16 [ks*ks*C, Ppad])."""
+    B, Hs, Ws, Cc = src16.shape
+    assert src16.dtype == torch.int16 and dst16.dtype == torch.int16 and dst16.shape[0] == ks * ks * Cc
+    check(lib().stedm_im2col_t16(src16.data_ptr(), dst16.data_ptr(), B, Hs, Ws, Cc, ks, mode, dst16.shape[1], _stream()), "stedm_im2col_t16")
+
+
+def wgrad_to_oihw(dw: torch.Tensor, grad: torch.Tensor, cin_ld: int, cout_ld: int, accumulate: bool) -> None:
+    cout, cin = grad.shape[0], grad.shape[1]
+    taps = grad.numel() // (cout * cin)
+    _chk(grad, name="grad")
+    check(lib().stedm_wgrad_to_oihw(dw.data_ptr(), grad.data_ptr(), cout, cin, taps, cin_ld, cout_ld, int(accumulate), _stream()), "stedm_wgrad_to_oihw")
+
+
+def chan_sum_fold(cs: torch.Tensor, per_sample: Optional[torch.Tensor], ld: int, total: Optional[torch.Tensor], accumulate: bool) -> None:
+    B, nslab, Cc, _ = cs.shape
+    check(lib().stedm_chan_sum_fold(cs.data_ptr(), B, nslab, Cc, _ptr(per_sample), ld, _ptr(total), int(accumulate), _stream()), "stedm_chan_sum_fold")
+
+
+def sum2x2(x: torch.Tensor, out: torch.Tensor, accumulate: bool) -> None:
+    B, H, W, Cc = out.shape
+    assert tuple(x.shape) == (B, 2 * H, 2 * W, Cc)
+    check(lib().stedm_sum2x2(x.data_ptr(), out.data_ptr(), B, H, W, Cc, int(accumulate), _stream()), "stedm_sum2x2")
+
+
+def zero_insert16(x: torch.Tensor, hi: torch.Tensor, lo: Optional[torch.Tensor], prec: Precision) -> None:
+    B, Ho, Wo, Cc = x.shape
+    assert tuple(hi.shape) == (B, 2 * Ho, 2 * Wo, Cc)
+    check(lib().stedm_zero_insert16(x.data_ptr(), hi.data_ptr(), _ptr(lo), B, Ho, Wo, Cc, prec.mm_dtype, _stream()), "stedm_zero_insert16")
+
+
+def attn_legacy_bwd(qkv: torch.Tensor, d_out: torch.Tensor, d_qkv: torch.Tensor, heads: int) -> None:
+    B, T, C3 = qkv.shape
+    check(lib().stedm_attn_legacy_bwd(qkv.data_ptr(), d_out.data_ptr(), d_qkv.data_ptr(), B, T, heads, C3 // (3 * heads), _stream()),
+          "stedm_attn_legacy_bwd")
+
+
+def gemm_f32(A: torch.Tensor, ta: bool, Bm: torch.Tensor, tb: bool, Cm: torch.Tensor, alpha: float = 1.0, beta: float = 0.0) -> torch.Tensor:
+    """Cm = alpha * op(A) @ op(Bm) + beta * Cm on 2-D fp32 tensors (rows may be strided views: last stride must be 1)."""
+    for t in (A, Bm, Cm):
+        assert t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.is_cuda
+    M, N = Cm.shape
+    K = A.shape[0] if ta else A.shape[1]
+    assert (A.shape[1] if ta else A.shape[0]) == M and (Bm.shape[0] if tb else Bm.shape[1]) == N and (Bm.shape[1] if tb else Bm.shape[0]) == K
+    check(lib().stedm_gemm_f32(A.data_ptr(), A.stride(0), int(ta), Bm.data_ptr(), Bm.stride(0), int(tb), Cm.data_ptr(), Cm.stride(0), M, N, K,
+                               float(alpha), float(beta), _stream()), "stedm_gemm_f32")
+    return Cm
+
+
+def silu(x: torch.Tensor, out: torch.Tensor, dy: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dy None: out = silu(x); else out = dy * silu'(x)."""
+    _chk(x, name="x")
+    check(lib().stedm_silu(x.data_ptr(), _ptr(dy), out.data_ptr(), x.numel(), 0 if dy is None else 1, _stream()), "stedm_silu")
+    return out
+
+
+def l1_loss(pred: torch.Tensor, target: torch.Tensor, d_pred: Optional[torch.Tensor], ws: torch.Tensor, loss: torch.Tensor, grad_scale: float = 1.0):
+    _chk(pred, name="pred"); _chk(target, name="target")
+    assert ws.dtype == torch.float64 and ws.numel() >= 1024 and pred.numel() == target.numel()
+    check(lib().stedm_l1_loss(pred.data_ptr(), target.data_ptr(), pred.numel(), float(grad_scale), _ptr(d_pred), ws.data_ptr(), loss.data_ptr(), _stream()),
+          "stedm_l1_loss")
+    return loss
+
+
+def adamw_ema(table: torch.Tensor, chunk_tensor: torch.Tensor, chunk_off: torch.Tensor, lr: float, beta1: float, beta2: float, eps: float,
+              weight_decay: float, step: int, ema_decay: float, grad_scale: float = 1.0) -> None:
+    check(lib().stedm_adamw_ema(table.data_ptr(), chunk_tensor.data_ptr(), chunk_off.data_ptr(), chunk_tensor.numel(), float(lr), float(beta1),
+                                float(beta2), float(eps), float(weight_decay), int(step), float(ema_decay), float(grad_scale), _stream()), "stedm_adamw_ema")
+
 # ------------------------------------------------------------------------------------------- graphs
 class Graph:
     """hipGraph captured on the current torch stream (all buffers must be allocated beforehand)."""

@@ -1,0 +1,452 @@
+"""Training step of the U-Net on the HIP path: forward (the inference kernels, every block's intermediates kept), L1 loss,
+hand-scheduled backward, AdamW + EMA.
+
+Mirrors what autograd does for the reference in `LatentDiffusion.p_losses` / `training_step` (ddpm.py:1015-1048, 345-358) with
+`torch.optim.AdamW` (modules/ldm_diffusion.py:224-234) and `LitEma` (ldm/modules/ema.py:25-44); SURVEY §8 row A15.
+
+The backward is a reverse walk over the tape `UNetModel._forward_impl` records in training mode:
+  * convolution dgrad  = the forward's MFMA convolution kernel with the flipped / transposed filter (stride-2: over the
+    zero-inserted gradient; nearest-2x upsample: at the high resolution, then 2x2 sums);
+  * convolution wgrad  = one GEMM dW[(tap,ci)][co] = sum_p col[(tap,ci)][p] dY^T[co][p] on the same kernels, over transposed
+    im2col planes (stedm_im2col_t16); K = B*H*W is split over blocks by the register-streamed kernel's split-K;
+  * GroupNorm+SiLU, attention, embeddings, reductions: fp32 kernels of csrc/bwd.hip;
+  * 16-bit operands of the backward contractions are bf16 (fp32 exponent range: no loss scaling), single product or
+    hi/lo 3-product following the forward's mode; activations are recomputed from the saved fp32 tensors, not stored.
+Gradients are bitwise reproducible (no atomics)."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import BF16
+from .ops import Precision
+from .unet import AttentionBlock, Downsample, ResBlock, UNetModel, Upsample
+
+
+def _r64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+class UNetTrainer:
+    """forward / backward / optimizer step for one `UNetModel` (parameters stay the module's own `nn.Parameter`s, gradients
+    land in their `.grad`, so DDP-style all-reduce and checkpointing see the usual tensors)."""
+
+    def __init__(self, unet: UNetModel, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 ema_decay: Optional[float] = 0.9999):
+        self.m = unet
+        self.lr, self.betas, self.eps, self.wd = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.ema_decay = ema_decay
+        self.step_count = 0
+        self.ema_updates = 0
+        self._grads_ready = False
+        self._dpacks: Dict[int, tuple] = {}
+        self._opt = None
+        self.G: Dict[int, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------------------------------------ helpers
+    @property
+    def bprec(self) -> Precision:
+        return Precision(BF16, self.m.precision.npass)
+
+    def _buf(self, name, shape, dtype=torch.float32):
+        return self.m._buf("bw." + name, shape, dtype)
+
+    def _planes(self, kind: str, shape) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        hi = self._buf(f"{kind}.hi.{tuple(shape)}", shape, torch.int16)
+        lo = self._buf(f"{kind}.lo.{tuple(shape)}", shape, torch.int16) if self.bprec.npass == 3 else None
+        return hi, lo
+
+    def _cast16(self, x1, x2=None, kind="c16"):
+        """plain conversion of [x1|x2] (NHWC fp32) to the backward's 16-bit operand planes"""
+        shape = tuple(x1.shape[:-1]) + (x1.shape[-1] + (0 if x2 is None else x2.shape[-1]),)
+        hi, lo = self._planes(kind, shape)
+        ops.gn_apply16(x1, x2, hi, lo, self.bprec)
+        return hi, lo
+
+    def _norm16(self, norm: nn.GroupNorm, act: int, x1, x2=None):
+        m = self.m
+        shape = tuple(x1.shape[:-1]) + (x1.shape[-1] + (0 if x2 is None else x2.shape[-1]),)
+        hi, lo = self._planes("a16", shape)
+        ops.gn_apply16c(x1, m._chan_stats(x1), x2, None if x2 is None else m._chan_stats(x2), hi, lo, self.bprec, norm.weight, norm.bias,
+                        norm.eps, norm.num_groups, act)
+        return hi, lo
+
+    def _grad_of(self, t: torch.Tensor) -> Tuple[torch.Tensor, bool]:
+        """(gradient buffer of activation `t`, whether it already holds a contribution)"""
+        key = t.data_ptr()
+        g = self.G.get(key)
+        if g is not None:
+            return g, True
+        g = self._buf(f"g.{key}", tuple(t.shape))
+        self.G[key] = g
+        return g, False
+
+    def _param_grad(self, p: nn.Parameter) -> torch.Tensor:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p, dtype=torch.float32)
+        return p.grad
+
+    def _w4(self, conv) -> torch.Tensor:
+        w = conv.weight.detach().float()
+        return w.unsqueeze(-1) if w.dim() == 3 else w
+
+    def _dpack(self, conv, pad_cin: int = 0, pad_cout: int = 0):
+        """weights of the dgrad convolution: filter flipped and transposed (layout shuffle), packed like forward weights"""
+        key = id(conv)
+        hit = self._dpacks.get(key)
+        if hit is not None:
+            return hit
+        bp = self.bprec
+        w = self._w4(conv)
+        wt = w.flip(2, 3).transpose(0, 1).contiguous()       # [cin_fwd][cout_fwd][k][k]: maps dY (cout_fwd channels) -> dX
+        if pad_cin or pad_cout:
+            full = torch.zeros((pad_cout or wt.shape[0], pad_cin or wt.shape[1]) + tuple(wt.shape[2:]), dtype=torch.float32, device=wt.device)
+            full[:wt.shape[0], :wt.shape[1]] = wt
+            wt = full
+        ks = wt.shape[-1]
+        hi, lo = ops.pack_conv_weight(wt, bp)
+        frag = None
+        if self.m.conv_path == "dma" and bp.npass == 1 and ((ks == 3 and wt.shape[1] % 16 == 0) or (ks == 1 and wt.shape[1] % 64 == 0)):
+            frag = ops.pack_conv_weight_frag(wt, bp)
+        self._dpacks[key] = (hi, lo, frag, ks)
+        return self._dpacks[key]
+
+    def _ws(self, nel: int) -> Optional[torch.Tensor]:
+        if nel > (1 << 23):
+            return None
+        return self.m._buf("conv_ws", ((16 if nel <= (1 << 20) else (4 if nel <= (1 << 22) else 2)) * nel,))
+
+    def _dgrad(self, conv, dy16, out: torch.Tensor, accumulate: bool = False, pad_cin: int = 0, pad_cout: int = 0) -> torch.Tensor:
+        """out (+)= conv(dy16, flipped filter); dy16 planes are at the resolution of `out`"""
+        hi, lo, frag, ks = self._dpack(conv, pad_cin, pad_cout)
+        ops.conv_igemm(None, hi, lo, out, prec=self.bprec, ks=ks, src16=dy16, w_frag=frag, res=out if accumulate else None, ws=self._ws(out.numel()))
+        return out
+
+    def _wgrad(self, src16, dy16, dy_f32: Optional[torch.Tensor], wparam: nn.Parameter, ks: int, mode: int) -> None:
+        """wparam.grad = sum_p src[p + tap] (x) dy[p] (see module docstring); src16 / dy16 are (hi, lo) NHWC planes"""
+        bp = self.bprec
+        B, Hs, Ws, Cs = src16[0].shape
+        Bo, Ho, Wo, co = dy16[0].shape
+        P = Bo * Ho * Wo
+        Ppad = _r64(P)
+        taps = ks * ks
+        col = self._planes("col", (taps * Cs, Ppad))
+        dyt = self._planes("dyt", (co, Ppad))
+        for i in range(bp.npass == 3 and 2 or 1):
+            ops.im2col_t16(src16[i], col[i], ks, mode)
+            ops.im2col_t16(dy16[i], dyt[i], 1, 0)
+        frag = None
+        if self.m.conv_path == "dma" and bp.npass == 1 and P == Ppad and dy_f32 is not None and dy_f32.numel() == P * co:
+            # register-streamed kernel (splits K = B*H*W over blocks): dY^T in MFMA-fragment order
+            frag = ops.pack_conv_weight_frag(ops.transpose(dy_f32.view(P, co)).view(co, P, 1, 1), bp)
+        dw = self._buf("dw", (taps, Cs, 1, co))
+        ops.conv_igemm(None, dyt[0].view(co, 1, Ppad), None if dyt[1] is None else dyt[1].view(co, 1, Ppad), dw, prec=bp, ks=1,
+                       src16=(col[0].view(taps, Cs, 1, Ppad), None if col[1] is None else col[1].view(taps, Cs, 1, Ppad)), w_frag=frag,
+                       ws=self._ws(dw.numel()))
+        ops.wgrad_to_oihw(dw, self._param_grad(wparam), Cs, co, False)
+
+    def _bias_grad(self, dy: torch.Tensor, bias: Optional[nn.Parameter], per_sample: Optional[torch.Tensor] = None, ld: int = 0) -> None:
+        """bias.grad = sum over (batch, pixels) of dy [B,H,W,C]; per_sample[b*ld + c] = sum over pixels (optional)"""
+        B, Cc = dy.shape[0], dy.shape[-1]
+        cs = self._buf(f"cs.{B}x{Cc}x{dy.numel() // (B * Cc)}", (B, ops.gn_chan_nslab(dy.numel() // (B * Cc)), Cc, 2))
+        ops.gn_chan_stats(dy, cs)
+        ops.chan_sum_fold(cs, per_sample, ld, None if bias is None else self._param_grad(bias), False)
+
+    def _gn_bwd(self, norm: nn.GroupNorm, act: int, x1, x2, dA, add, dx16=None):
+        m = self.m
+        B, c1 = x1.shape[0], x1.shape[-1]
+        c2 = 0 if x2 is None else x2.shape[-1]
+        HW = x1.numel() // (B * c1)
+        G = norm.num_groups
+        mr = self._buf(f"mr.{B}x{G}", (B, G, 2))
+        ops.gn_fold(m._chan_stats(x1), None if x2 is None else m._chan_stats(x2), G, HW, norm.eps, mr)
+        ws = self._buf("gnws", (ops.gn_bwd_ws_floats(B, HW, c1 + c2, G),))
+        g1, a1 = self._grad_of(x1)
+        g2, a2 = self._grad_of(x2) if x2 is not None else (None, False)
+        ops.gn_bwd(x1, x2, mr, norm.weight, norm.bias, G, act, dA, add, ws, g1, a1, g2, a2, dx16, self.bprec, self._param_grad(norm.weight),
+                   self._param_grad(norm.bias), False)
+
+    # ------------------------------------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, c_concat: Optional[torch.Tensor], t: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
+        """eps prediction [B,out,H,W] (NCHW), keeping what the backward needs."""
+        m = self.m
+        m._tape = []
+        try:
+            out = m._forward_impl(x, c_concat, t, [context], None, uniform_t=False)
+        except Exception:
+            m._tape = None
+            raise
+        self.tape = m._tape
+        self.tape_emb = m._tape_emb
+        m._tape = None
+        return out
+
+    # ------------------------------------------------------------------------------------------------ backward
+    @torch.no_grad()
+    def backward(self, d_eps: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """d_eps [B,out,H,W] = dL/d(eps prediction). Fills `.grad` of every parameter; returns (dL/dx [B,in,H,W] over the
+        concatenated [x | c_concat] input, dL/dcontext [B, 4*model_channels])."""
+        m = self.m
+        self.G = {}
+        self._dpacks = {}
+        B = d_eps.shape[0]
+        ted = m.model_channels * 4
+        self.dE = self._buf("dE", (B, m._emb_ntot))
+        self.dEs = None
+        dx_in = None
+        for rec in reversed(self.tape):
+            kind = rec[0]
+            if kind == "conv_out":
+                self._conv_out_bwd(rec[1], d_eps.float().contiguous())
+            elif kind == "res":
+                self._res_bwd(*rec[1:])
+            elif kind == "attn":
+                self._attn_bwd(*rec[1:])
+            elif kind == "up":
+                self._up_bwd(*rec[1:])
+            elif kind == "down":
+                self._down_bwd(*rec[1:])
+            elif kind == "conv_in":
+                dx_in = self._conv_in_bwd(*rec[1:])
+            else:
+                raise RuntimeError(kind)
+        dctx = self._emb_bwd(B, ted)
+        self._grads_ready = True
+        return dx_in, dctx
+
+    def _conv_out_bwd(self, h, d_eps):
+        m = self.m
+        gn, conv = m.out[0], m.out[2]
+        B, H, W, Cc = h.shape
+        co = conv.out_channels
+        cp = 32
+        dy = self._buf("out.dy", (B, H, W, cp))
+        dy.zero_()
+        dy[..., :co].copy_(d_eps.permute(0, 2, 3, 1))            # layout shuffle NCHW -> NHWC (padded to 32 channels)
+        dy16 = self._cast16(dy, kind="dy")
+        a16 = self._norm16(gn, 1, h)
+        self._wgrad(a16, dy16, dy, conv.weight, 3, 0)
+        tot = self._buf("out.db", (cp,))
+        cs = self._buf("out.cs", (B, ops.gn_chan_nslab(H * W), cp, 2))
+        ops.gn_chan_stats(dy, cs)
+        ops.chan_sum_fold(cs, None, 0, tot, False)
+        self._param_grad(conv.bias).copy_(tot[:co])
+        dA = self._buf(f"dA.{B}x{H}x{W}x{Cc}", (B, H, W, Cc))
+        self._dgrad(conv, dy16, dA, pad_cin=cp)
+        self._gn_bwd(gn, 1, h, None, dA, None)
+
+    def _conv_in_bwd(self, x, c_concat, h0):
+        m = self.m
+        conv = m.input_blocks[0][0]
+        B, H, W, co = h0.shape
+        cin = conv.in_channels
+        cp = 32
+        g, have = self._grad_of(h0)
+        assert have
+        dy16 = self._cast16(g, kind="dy")
+        xin = self._buf("in.x", (B, H, W, cp))
+        xin.zero_()
+        xin[..., :x.shape[1]].copy_(x.permute(0, 2, 3, 1))
+        if c_concat is not None:
+            xin[..., x.shape[1]:cin].copy_(c_concat.permute(0, 2, 3, 1))
+        x16 = self._cast16(xin, kind="x16")
+        self._wgrad(x16, dy16, g, conv.weight, 3, 0)
+        self._bias_grad(g, conv.bias)
+        dxp = self._buf("in.dx", (B, H, W, cp))
+        self._dgrad(conv, dy16, dxp, pad_cout=cp)
+        return dxp[..., :cin].permute(0, 3, 1, 2).contiguous()
+
+    def _res_bwd(self, rb: ResBlock, x1, x2, h, out, emb_off):
+        B, H, W, co = out.shape
+        cin = x1.shape[-1] + (0 if x2 is None else x2.shape[-1])
+        conv1, conv2 = rb.in_layers[2], rb.out_layers[3]
+        dout, have = self._grad_of(out)
+        assert have, "no gradient reached this block's output"
+        dout16 = self._cast16(dout, kind="dy")
+        has_skip = not isinstance(rb.skip_connection, nn.Identity)
+        self._bias_grad(dout, conv2.bias)
+        if has_skip:
+            sk = rb.skip_connection
+            self._param_grad(sk.bias).copy_(conv2.bias.grad)             # same sums: both biases add onto `out`
+            x16 = self._cast16(x1, x2, kind="x16")
+            self._wgrad(x16, dout16, dout, sk.weight, 1, 0)
+            add = self._buf(f"add.{B}x{H}x{W}x{cin}", (B, H, W, cin))
+            self._dgrad(sk, dout16, add)
+        else:
+            add = dout
+        # conv2 and its GroupNorm + SiLU
+        h16 = self._norm16(rb.out_layers[0], 1, h)
+        self._wgrad(h16, dout16, dout, conv2.weight, 3, 0)
+        dA2 = self._buf(f"dA.{B}x{H}x{W}x{co}", (B, H, W, co))
+        self._dgrad(conv2, dout16, dA2)
+        dh16 = self._planes("dh16", (B, H, W, co))
+        self._gn_bwd(rb.out_layers[0], 1, h, None, dA2, None, dx16=dh16)
+        dh = self.G[h.data_ptr()]
+        # the embedding enters between conv1 and the second GroupNorm (openaimodel.py:276-287): its gradient is the per-sample
+        # channel sum of dh, conv1's bias gradient the batch total
+        if emb_off is None:
+            self.dEs = self._buf("dEs", (B, co))
+            self._bias_grad(dh, conv1.bias, self.dEs, co)
+        else:
+            self._bias_grad(dh, conv1.bias, self.dE[:, emb_off:], self.dE.shape[1])
+        self._param_grad(rb.emb_layers[1].bias).copy_(conv1.bias.grad)    # same sums: both biases add onto h
+        # conv1 and the first GroupNorm + SiLU over the (virtual concat) input
+        a16 = self._norm16(rb.in_layers[0], 1, x1, x2)
+        self._wgrad(a16, dh16, dh, conv1.weight, 3, 0)
+        dA1 = self._buf(f"dA1.{B}x{H}x{W}x{cin}", (B, H, W, cin))
+        self._dgrad(conv1, dh16, dA1)
+        self._gn_bwd(rb.in_layers[0], 1, x1, x2, dA1, add)
+
+    def _attn_bwd(self, ab: AttentionBlock, x, qkv, a, out):
+        B, H, W, Cc = x.shape
+        T = H * W
+        dout, have = self._grad_of(out)
+        assert have
+        dout16 = self._cast16(dout, kind="dy")
+        self._bias_grad(dout, ab.proj_out.bias)
+        a16 = self._cast16(a, kind="x16")
+        self._wgrad(a16, dout16, dout, ab.proj_out.weight, 1, 0)
+        da = self._buf(f"attn.da.{B}x{T}x{Cc}", (B, H, W, Cc))
+        self._dgrad(ab.proj_out, dout16, da)
+        dqkv = self._buf(f"attn.dqkv.{B}x{T}x{Cc}", (B, H, W, 3 * Cc))
+        ops.attn_legacy_bwd(qkv.view(B, T, 3 * Cc), da.view(B, T, Cc), dqkv.view(B, T, 3 * Cc), ab.num_heads)
+        dqkv16 = self._cast16(dqkv, kind="dy3")
+        self._bias_grad(dqkv, ab.qkv.bias)
+        n16 = self._norm16(ab.norm, 0, x)
+        self._wgrad(n16, dqkv16, dqkv, ab.qkv.weight, 1, 0)
+        dn = self._buf(f"attn.dn.{B}x{T}x{Cc}", (B, H, W, Cc))
+        self._dgrad(ab.qkv, dqkv16, dn)
+        self._gn_bwd(ab.norm, 0, x, None, dn, dout)
+
+    def _up_bwd(self, layer: Upsample, hin, out):
+        B, H, W, Cc = hin.shape
+        dout, have = self._grad_of(out)
+        assert have
+        dout16 = self._cast16(dout, kind="dy")
+        self._bias_grad(dout, layer.conv.bias)
+        src16 = self._cast16(hin, kind="x16")
+        self._wgrad(src16, dout16, dout, layer.conv.weight, 3, 1)
+        tmp = self._buf(f"up.t.{B}x{H}x{W}x{Cc}", (B, 2 * H, 2 * W, Cc))
+        self._dgrad(layer.conv, dout16, tmp)
+        g, acc = self._grad_of(hin)
+        ops.sum2x2(tmp, g, acc)
+
+    def _down_bwd(self, layer: Downsample, hin, out):
+        B, H, W, Cc = hin.shape
+        co = out.shape[-1]
+        dout, have = self._grad_of(out)
+        assert have
+        dout16 = self._cast16(dout, kind="dy")
+        self._bias_grad(dout, layer.op.bias)
+        src16 = self._cast16(hin, kind="x16")
+        self._wgrad(src16, dout16, dout, layer.op.weight, 3, 2)
+        z16 = self._planes("z16", (B, H, W, co))
+        ops.zero_insert16(dout, z16[0], z16[1], self.bprec)
+        g, acc = self._grad_of(hin)
+        self._dgrad(layer.op, z16, g, accumulate=acc)
+
+    def _colsum(self, mat: torch.Tensor, dst: torch.Tensor) -> None:
+        """dst[n] = sum_b mat[b][n]"""
+        B, N = mat.shape
+        cs = self._buf(f"colsum.{B}x{N}", (1, ops.gn_chan_nslab(B), N, 2))
+        ops.gn_chan_stats(mat.view(1, B, 1, N), cs)
+        ops.chan_sum_fold(cs, None, 0, dst, False)
+
+    def _emb_bwd(self, B: int, ted: int) -> torch.Tensor:
+        """backward of the embedding paths: emb_layers of every ResBlock (one concatenated Linear, openaimodel.py:231-237),
+        time_embed (:529-534; the sinusoid has no parameters), and the style block's emb_layers on the context vector."""
+        m = self.m
+        c = m._consts
+        timesteps, emb, ctx = self.tape_emb
+        mc = m.model_channels
+        # ---- ResBlock emb_layers: E = silu(emb) @ Wcat^T + b
+        S = ops.silu(emb, self._buf("emb.S", (B, ted)))
+        dW = self._buf("emb.dWcat", (m._emb_ntot, ted))
+        ops.gemm_f32(self.dE, True, S, False, dW)
+        for rb, off in m._emb_layout:
+            lin = rb.emb_layers[1]
+            lin.weight.grad = dW[off:off + rb.out_channels]      # row block of the concatenated gradient (no copy)
+        dS = self._buf("emb.dS", (B, ted))
+        ops.gemm_f32(self.dE, False, c["emb_wt"], True, dS)
+        demb = ops.silu(emb, self._buf("emb.demb", (B, ted)), dy=dS)
+        # ---- time_embed: emb = silu(te @ W0^T + b0) @ W2^T + b2
+        l0, l2 = m.time_embed[0], m.time_embed[2]
+        te = m._buf("emb_ws", (B * (mc + ted),))[:B * mc].view(B, mc)
+        u = ops.linear(te, c["te_w0t"], c["te_b0"], self._buf("emb.u", (B, ted)))
+        h1 = ops.silu(u, self._buf("emb.h1", (B, ted)))
+        ops.gemm_f32(demb, True, h1, False, self._param_grad(l2.weight))
+        self._colsum(demb, self._param_grad(l2.bias))
+        dh1 = ops.gemm_f32(demb, False, l2.weight.detach(), False, self._buf("emb.dh1", (B, ted)))
+        du = ops.silu(u, self._buf("emb.du", (B, ted)), dy=dh1)
+        ops.gemm_f32(du, True, te, False, self._param_grad(l0.weight))
+        self._colsum(du, self._param_grad(l0.bias))
+        # ---- style block: Es = silu(ctx) @ Ws^T + bs  (ResBlockStyle: emb = context, openaimodel.py:291-297)
+        srb = m.middle_block[1].block
+        lin = srb.emb_layers[1]
+        ctx = ctx.float().contiguous()
+        Sc = ops.silu(ctx, self._buf("emb.Sc", (B, ted)))
+        ops.gemm_f32(self.dEs, True, Sc, False, self._param_grad(lin.weight))
+        dSc = ops.gemm_f32(self.dEs, False, lin.weight.detach(), False, self._buf("emb.dSc", (B, ted)))
+        return ops.silu(ctx, torch.empty_like(ctx), dy=dSc)
+
+    # ------------------------------------------------------------------------------------------------ loss + optimizer
+    @torch.no_grad()
+    def loss_and_backward(self, x, c_concat, t, context, target) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """L1 loss of ddpm.py:1030-1040 on the eps prediction, then the full backward. -> (loss [1] device tensor, dx, dcontext)"""
+        pred = self.forward(x, c_concat, t, context)
+        loss = self._buf("loss", (1,))
+        dpred = self._buf(f"dpred.{tuple(pred.shape)}", tuple(pred.shape))
+        ops.l1_loss(pred, target.float().contiguous(), dpred, self._buf("loss.ws", (1024,), torch.float64), loss)
+        dx, dctx = self.backward(dpred)
+        return loss, dx, dctx
+
+    def _build_opt(self):
+        import ctypes as C
+        import numpy as np
+        params = [p for p in self.m.parameters()]
+        dev = params[0].device
+        st = {"m": [torch.zeros_like(p, dtype=torch.float32) for p in params], "v": [torch.zeros_like(p, dtype=torch.float32) for p in params],
+              "ema": [p.detach().clone() for p in params] if self.ema_decay is not None else None, "params": params}
+        tab = np.zeros((len(params), 6), dtype=np.int64)
+        ct, co = [], []
+        for i, p in enumerate(params):
+            assert p.is_contiguous() and p.grad is not None and p.grad.is_contiguous(), "run backward() before the first optimizer step"
+            tab[i] = (p.data_ptr(), p.grad.data_ptr(), st["m"][i].data_ptr(), st["v"][i].data_ptr(),
+                      st["ema"][i].data_ptr() if st["ema"] is not None else 0, p.numel())
+            for o in range(0, p.numel(), 4096):
+                ct.append(i); co.append(o)
+        st["table"] = torch.from_numpy(tab).to(dev)
+        st["ct"] = torch.tensor(ct, dtype=torch.int32, device=dev)
+        st["co"] = torch.tensor(co, dtype=torch.int64, device=dev)
+        st["gptrs"] = [p.grad.data_ptr() for p in params]
+        self._opt = st
+
+    @torch.no_grad()
+    def optimizer_step(self) -> None:
+        """AdamW over every parameter + EMA shadow update (ema.py:25-44: decay = min(decay, (1+n)/(10+n)))."""
+        assert self._grads_ready, "optimizer_step() needs gradients from backward()"
+        if self._opt is None:
+            self._build_opt()
+        st = self._opt
+        assert st["gptrs"] == [p.grad.data_ptr() for p in st["params"]], "gradient tensors moved since the optimizer table was built"
+        self.step_count += 1
+        decay = 0.0
+        if self.ema_decay is not None:
+            self.ema_updates += 1
+            decay = min(self.ema_decay, (1 + self.ema_updates) / (10 + self.ema_updates))
+        ops.adamw_ema(st["table"], st["ct"], st["co"], self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, decay)
+        self.m.invalidate()      # parameters changed through raw pointers: repack on the next forward
+        self._grads_ready = False
+
+    def ema_parameters(self) -> Optional[List[torch.Tensor]]:
+        return None if self._opt is None else self._opt["ema"]
+
+    @torch.no_grad()
+    def train_step(self, x, c_concat, t, context, target) -> torch.Tensor:
+        loss, _, _ = self.loss_and_backward(x, c_concat, t, context, target)
+        self.optimizer_step()
+        return loss

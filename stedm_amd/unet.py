@@ -229,6 +229,7 @@ class UNetModel(nn.Module):
         self._style_cache: Dict[Tuple, torch.Tensor] = {}
         self._cs: Dict[int, torch.Tensor] = {}
         self._raw16: Dict[int, Tuple] = {}
+        self._tape: Optional[list] = None     # training forward (stedm_amd/train.py): one record per layer for the backward pass
 
     # ------------------------------------------------------------------------------------ engine plumbing
     def convert_to_fp16(self):  # openaimodel.py:745-751 — a no-op in the reference too (openaimodel.py:25-29)
@@ -395,7 +396,9 @@ class UNetModel(nn.Module):
         co = rb.out_channels
         dma = self.conv_path == "dma"
         pk = self._packed[id(rb.in_layers[2])]
-        h = self._buf(f"h.{B}x{H}x{W}x{co}", (B, H, W, co))
+        # training keeps every block's intermediate (the backward pass reads it); inference shares one buffer per shape
+        h = self._buf(tag + ".h" if self._tape is not None else f"h.{B}x{H}x{W}x{co}", (B, H, W, co))
+        self._last_h = h
         has_skip = not isinstance(rb.skip_connection, nn.Identity)
         if dma:
             if has_skip:
@@ -459,7 +462,7 @@ class UNetModel(nn.Module):
         pp = self._packed[id(ab.proj_out)]
         out = self._buf(tag + ".out", (B, H, W, Cc))
         ch = Cc // ab.num_heads
-        if dma and prec.npass == 1 and H * W == 64 and ch in (32, 64, 128):
+        if dma and prec.npass == 1 and H * W == 64 and ch in (32, 64, 128) and self._tape is None:
             # 64 tokens: the qkv conv writes its result as a 16-bit plane, the whole attention of a (sample, head) runs on one wave's
             # MFMAs and is written as proj_out's 16-bit operand plane (same operand rounding as everywhere in these modes)
             qkv16 = self._planes(B, H, W, 3 * Cc, "qkv16")
@@ -478,6 +481,8 @@ class UNetModel(nn.Module):
             ops.conv_igemm(x, pq.hi, pq.lo, qkv, prec=prec, ks=1, scale=sc, shift=sh, act=0, bias=pq.bias)
         a = self._buf(tag + ".a", (B, H, W, Cc))
         ops.attn_legacy(qkv.view(B, H * W, 3 * Cc), a.view(B, H * W, Cc), ab.num_heads)
+        if self._tape is not None:
+            self._tape.append(("attn", ab, x, qkv, a, out))
         if dma:
             ops.conv_igemm(None, pp.hi, pp.lo, out, prec=prec, ks=1, src16=self._norm16(None, 0, a), bias=pp.bias, res=x, w_frag=pp.frag,
                            chan_stats=self._cs_new(out))
@@ -492,20 +497,30 @@ class UNetModel(nn.Module):
             ltag = f"{tag}.{li}"
             nxt = layers[li - li0 + 1] if li - li0 + 1 < len(layers) else None
             if isinstance(layer, ResBlock):
+                x1 = h
                 h = self._res(ltag, layer, h, skip, emb_all, self._emb_off[id(layer)], emb_bstride, x2_bmod=skip_bmod,
                               want16=isinstance(nxt, Upsample))
+                if self._tape is not None:
+                    self._tape.append(("res", layer, x1, skip, self._last_h, h, self._emb_off[id(layer)]))
                 skip = None
             elif isinstance(layer, ResBlockStyle):
+                x1 = h
                 h = self._res(ltag, layer.block, h, None, style_all, 0, style_all.shape[1])
+                if self._tape is not None:
+                    self._tape.append(("res", layer.block, x1, None, self._last_h, h, None))
             elif isinstance(layer, AttentionBlock):
                 h = self._attn(ltag, layer, h)
             elif type(layer).__name__ == "SpatialTransformer":
+                if self._tape is not None:
+                    raise NotImplementedError("training backward of the SpatialTransformer is not built (the shipped configs do not use it)")
                 # routed without context, exactly like the reference (openaimodel.py:99-100)
                 h = layer.run(h, self._packed[id(layer)], self.precision, self._buf)
             elif isinstance(layer, Downsample):
                 pk = self._packed[id(layer.op)]
                 B, H, W, _ = h.shape
                 out = self._buf(ltag + ".out", (B, H // 2, W // 2, layer.out_channels))
+                if self._tape is not None:
+                    self._tape.append(("down", layer, h, out))
                 ps2 = self._packed.get((id(layer.op), "s2d"))
                 if ps2 is not None and H % 2 == 0 and W % 2 == 0 and (H // 2) * (W // 2) >= 16:
                     C = h.shape[-1]
@@ -521,6 +536,8 @@ class UNetModel(nn.Module):
                 pk = self._packed[id(layer.conv)]
                 B, H, W, _ = h.shape
                 out = self._buf(ltag + ".out", (B, H * 2, W * 2, layer.out_channels))
+                if self._tape is not None:
+                    self._tape.append(("up", layer, h, out))
                 if self.conv_path == "dma":
                     pu = self._packed[(id(layer.conv), "up")]
                     src16 = self._raw16.get(h.data_ptr()) or self._norm16(None, 0, h)
@@ -626,6 +643,9 @@ class UNetModel(nn.Module):
                 del self._cs[h.data_ptr()]                    # generic path: statistics on first use
         else:
             ops.conv_in(x, c_concat, conv0.weight, conv0.bias, h)
+        if self._tape is not None:
+            self._tape.append(("conv_in", x, c_concat, h))
+            self._tape_emb = (timesteps, emb, contexts[0])
         hs = [h]
         for i, blk in enumerate(self.input_blocks[1:], start=1):
             h = self._run_block(f"in{i}", blk, h, None, emb_e, emb_stride, None)
@@ -651,4 +671,6 @@ class UNetModel(nn.Module):
         gn = self.out[0]
         cs = self._chan_stats(h) if self.conv_path == "dma" else None     # left by the last ResBlock's conv epilogue
         ops.conv_out(h, gn.weight, gn.bias, gn.eps, gn.num_groups, c["out_w_hwio"], self.out[2].bias, out, cs)
+        if self._tape is not None:
+            self._tape.append(("conv_out", h, out))
         return out

@@ -1,0 +1,144 @@
+"""GPU tier, training step: the hand-scheduled HIP backward against the REFERENCE's own gradients
+(tests/golden/f14_grads_*.npz: reference UNetModel forward + L1 + autograd backward) and against the oracle restatement.
+Tolerance: 1e-3 relative (per-tensor L2 norm; sampled entries relative to the tensor's RMS) in parity mode."""
+import numpy as np
+import pytest
+import torch
+
+from stedm_amd.utils import prng
+from tests.golden.make_golden_grads import pick_index
+from tests.golden.summary import check_summary
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(image_size=16, in_channels=7, model_channels=32, out_channels=4, num_res_blocks=2,
+            attention_resolutions=[32, 16, 8], channel_mult=[1, 2, 4], num_heads=4)
+NS32 = dict(image_size=32, in_channels=7, model_channels=128, out_channels=4, num_res_blocks=2,
+            attention_resolutions=[32, 16, 8], channel_mult=[1, 4, 8], num_heads=8)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def build(cfg, seed, dev, precision="parity"):
+    from stedm_amd.unet import UNetModel
+    m = UNetModel(precision=precision, **cfg).eval()
+    prng.fill_module_(m, seed=seed)
+    return m.to(dev)
+
+
+def _inputs(tag, cfg, B, hw, seed, dev):
+    x = prng.normal(seed, f"unet.{tag}.x", (B, cfg["in_channels"], hw, hw)).to(dev)
+    ctx = prng.normal(seed, f"unet.{tag}.ctx", (B, cfg["model_channels"] * 4)).to(dev)
+    target = prng.normal(seed, f"unet.{tag}.target", (B, cfg["out_channels"], hw, hw)).to(dev)
+    return x, ctx, target
+
+
+def _check_grads(m, fx, tol, what):
+    worst = (0.0, "")
+    nmax = max(float(fx[f"g.{name}.norm"]) for name, _ in m.named_parameters())
+    for name, p in m.named_parameters():
+        assert p.grad is not None, f"{name}: no gradient"
+        n = float(fx[f"g.{name}.norm"])
+        a = p.grad.double().reshape(-1).cpu()
+        if n < 1e-6 * nmax:
+            # mathematically zero gradient (a per-channel bias in front of a GroupNorm with one channel per group): both sides hold
+            # rounding noise only
+            assert float(a.norm()) < 1e-5 * nmax, f"{what} {name}: expected a vanishing gradient"
+            continue
+        en = abs(float(a.norm()) - n) / (n + 1e-30)
+        rms = n / np.sqrt(a.numel())
+        ep = float(np.abs(a[torch.from_numpy(pick_index(a.numel()))].numpy() - fx[f"g.{name}.pick"]).max()) / (rms + 1e-30)
+        worst = max(worst, (en, name + " (norm)"), (ep / 30, name + " (samples)"))
+        assert en <= tol, f"{what} {name}: grad norm off by {en:.2e}"
+        assert ep <= 30 * tol, f"{what} {name}: sampled grad entries off by {ep:.2e} of the tensor's rms"
+    return worst
+
+
+@pytest.mark.parametrize("tag,cfg,B,hw,seed", [("tiny", TINY, 2, 16, 6), ("ns32", NS32, 2, 32, 0)])
+def test_unet_backward_vs_reference_golden(dev, golden, tag, cfg, B, hw, seed):
+    from stedm_amd.train import UNetTrainer
+    fx = golden(f"f14_grads_{tag}")
+    m = build(cfg, seed, dev)
+    tr = UNetTrainer(m)
+    x, ctx, target = _inputs(tag, cfg, B, hw, seed, dev)
+    t = torch.from_numpy(fx["t"]).to(dev)
+    loss, dx, dctx = tr.loss_and_backward(x[:, :4].contiguous(), x[:, 4:].contiguous(), t, ctx, target)
+    assert abs(float(loss) - float(fx["loss"])) < 1e-4 * float(fx["loss"])
+    err_c = float((dctx.double().cpu() - torch.from_numpy(fx["dctx"]).double()).norm() / torch.from_numpy(fx["dctx"]).double().norm())
+    check_summary(dx, fx, "dx", 2e-3, tag)
+    worst = _check_grads(m, fx, 1e-3, tag)
+    print(f"[{tag}] loss {float(loss):.6f}  dctx rel-L2 {err_c:.2e}  worst param grad {worst[0]:.2e} at {worst[1]}")
+    assert err_c < 1e-3
+
+
+def test_unet_backward_is_bitwise_reproducible(dev):
+    from stedm_amd.train import UNetTrainer
+    m = build(TINY, 6, dev)
+    tr = UNetTrainer(m)
+    x, ctx, target = _inputs("tiny", TINY, 2, 16, 6, dev)
+    t = torch.tensor([951, 21], device=dev)
+    tr.loss_and_backward(x[:, :4].contiguous(), x[:, 4:].contiguous(), t, ctx, target)
+    g1 = [p.grad.clone() for p in m.parameters()]
+    tr.loss_and_backward(x[:, :4].contiguous(), x[:, 4:].contiguous(), t, ctx, target)
+    assert all(torch.equal(a, p.grad) for a, p in zip(g1, m.parameters()))
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16", 6e-2), ("f16", 3e-2)])
+def test_unet_backward_single_product_modes(dev, golden, precision, tol):
+    """single-product forward (bf16 / f16 operands) + bf16 single-product backward: reported against the reference gradients"""
+    from stedm_amd.train import UNetTrainer
+    fx = golden("f14_grads_tiny")
+    m = build(TINY, 6, dev, precision)
+    tr = UNetTrainer(m)
+    x, ctx, target = _inputs("tiny", TINY, 2, 16, 6, dev)
+    t = torch.from_numpy(fx["t"]).to(dev)
+    loss, dx, dctx = tr.loss_and_backward(x[:, :4].contiguous(), x[:, 4:].contiguous(), t, ctx, target)
+    errs = []
+    for name, p in m.named_parameters():
+        n = float(fx[f"g.{name}.norm"])
+        errs.append(abs(float(p.grad.double().norm()) - n) / n)
+    print(f"[{precision}] loss {float(loss):.5f} (ref {float(fx['loss']):.5f}); grad-norm error median {np.median(errs):.2e} max {max(errs):.2e}")
+    assert abs(float(loss) - float(fx["loss"])) < 2e-2 * float(fx["loss"])
+    assert np.median(errs) < tol
+
+
+def test_adamw_ema_step_vs_oracle(dev):
+    """fused multi-tensor AdamW + EMA kernel against the oracle's restatement of torch.optim.AdamW / LitEma (two steps)."""
+    from oracle import train as otrain
+    from stedm_amd.train import UNetTrainer
+    m = build(TINY, 6, dev)
+    tr = UNetTrainer(m, lr=1e-3, weight_decay=0.01, ema_decay=0.9999)
+    params = list(m.parameters())
+    ref_p = [p.detach().cpu().clone() for p in params]
+    ref_m = [torch.zeros_like(p) for p in ref_p]
+    ref_v = [torch.zeros_like(p) for p in ref_p]
+    ref_e = [p.clone() for p in ref_p]
+    for step in (1, 2):
+        for i, p in enumerate(params):
+            p.grad = prng.normal(step, f"g{i}", tuple(p.shape)).to(dev) * 0.01 if p.grad is None else p.grad.copy_(prng.normal(step, f"g{i}", tuple(p.shape)) * 0.01)
+        tr._grads_ready = True
+        tr.optimizer_step()
+        d = otrain.ema_decay(step)
+        for i in range(len(params)):
+            otrain.adamw_step(ref_p[i], prng.normal(step, f"g{i}", tuple(ref_p[i].shape)) * 0.01, ref_m[i], ref_v[i], step, 1e-3, weight_decay=0.01)
+            otrain.ema_update(ref_e[i], ref_p[i], d)
+    for i, p in enumerate(params):
+        assert torch.allclose(p.detach().cpu(), ref_p[i], rtol=2e-6, atol=2e-7), i
+        assert torch.allclose(tr.ema_parameters()[i].cpu(), ref_e[i], rtol=2e-6, atol=2e-7), i
+
+
+def test_train_steps_reduce_the_loss(dev):
+    """a few optimizer steps on a fixed batch: the loss goes down and the packed weights follow the updated parameters"""
+    from stedm_amd.train import UNetTrainer
+    m = build(TINY, 6, dev, "bf16")
+    tr = UNetTrainer(m, lr=2e-4, weight_decay=0.0)
+    x, ctx, target = _inputs("tiny", TINY, 2, 16, 6, dev)
+    t = torch.tensor([951, 21], device=dev)
+    losses = [float(tr.train_step(x[:, :4].contiguous(), x[:, 4:].contiguous(), t, ctx, target)) for _ in range(6)]
+    print("losses", ["%.4f" % v for v in losses])
+    assert losses[-1] < losses[0] - 0.01
