@@ -242,18 +242,23 @@ __global__ void wgrad_to_oihw_kernel(const float* __restrict__ dw, float* __rest
 }
 
 // cs [B][nslab][C][2] (sums in [..][0]) -> per_sample[b*ld + c] (optional) and total[c] (+= when accumulate; optional)
-__global__ void chan_sum_fold_kernel(const float* __restrict__ cs, int B, int nslab, int C, float* __restrict__ per_sample, long ld, float* __restrict__ total,
-                                     int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// grid ceil(C/64); 256 threads = 64 channels x 4 sample lanes (fixed-order fold of the 4 lanes through LDS)
+__global__ void __launch_bounds__(256) chan_sum_fold_kernel(const float* __restrict__ cs, int B, int nslab, int C, float* __restrict__ per_sample, long ld,
+                                                            float* __restrict__ total, int accumulate) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
   float tot = 0.f;
-  for (int b = 0; b < B; ++b) {
-    float u = 0.f;
-    for (int k = 0; k < nslab; ++k) u += cs[(((long)b * nslab + k) * C + c) * 2];
-    if (per_sample) per_sample[(long)b * ld + c] = u;
-    tot += u;
+  if (c < C) {
+    for (int b = bl; b < B; b += 4) {
+      float u = 0.f;
+      for (int k = 0; k < nslab; ++k) u += cs[(((long)b * nslab + k) * C + c) * 2];
+      if (per_sample) per_sample[(long)b * ld + c] = u;
+      tot += u;
+    }
   }
-  if (total) total[c] = (accumulate ? total[c] : 0.f) + tot;
+  red[bl][cl] = tot;
+  __syncthreads();
+  if (bl == 0 && c < C && total) total[c] = (accumulate ? total[c] : 0.f) + ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
 }
 
 // ------------------------------------------------------------------------------------------------ resampling
@@ -494,7 +499,7 @@ extern "C" int stedm_wgrad_to_oihw(const float* dw, float* grad, int cout, int c
 
 extern "C" int stedm_chan_sum_fold(const float* cs, int B, int nslab, int C, float* per_sample, long ld, float* total, int accumulate, void* stream) {
   STEDM_CHECK_ARG(cs && (per_sample || total), "chan_sum_fold: bad args");
-  chan_sum_fold_kernel<<<(C + 255) / 256, 256, 0, as_stream(stream)>>>(cs, B, nslab, C, per_sample, ld, total, accumulate);
+  chan_sum_fold_kernel<<<(C + 63) / 64, 256, 0, as_stream(stream)>>>(cs, B, nslab, C, per_sample, ld, total, accumulate);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

@@ -42,6 +42,10 @@ struct MM<__bf16> {
 };
 
 
+// zero page read by halo / padding / overhang lanes of the LDS-DMA loaders: must cover one pixel row of channels (2*Cin bytes) plus a
+// chunk; 132 KB admits Cin up to 65536 (the wgrad GEMMs of the training step have K = B*H*W "channels")
+#define STEDM_ZERO_PAGE_BYTES 135168
+
 namespace stedm {
 // Fills the tile geometry of `p` for an M-tile of `bm` output pixels. Returns false (with the error set) when the
 // spatial shape cannot be tiled that way.

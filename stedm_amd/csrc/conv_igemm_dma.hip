@@ -14,7 +14,7 @@ int stedm::conv_launch_dma(ConvParams& p, hipStream_t st, bool dry) {
   const stedm_conv_args& a = p.a;
   if (a.src16b_hi && a.npass != 1) { set_error("conv_igemm(dma): the fused skip phase is single-product only"); return 1; }
   if (dry && a.npass != 1) return 1;
-  if (a.src16b_hi && ((long)a.B * a.Hin * a.Win * a.cb >= (1L << 31) || a.cb * 2 + 256 > 16384)) {
+  if (a.src16b_hi && ((long)a.B * a.Hin * a.Win * a.cb >= (1L << 31) || a.cb * 2 + 256 > STEDM_ZERO_PAGE_BYTES)) {
     set_error("conv_igemm(dma): fused skip operand too large (cb=%d)", a.cb);
     return 1;
   }
@@ -22,7 +22,7 @@ int stedm::conv_launch_dma(ConvParams& p, hipStream_t st, bool dry) {
     set_error("conv_igemm(dma): activation tensor too large for 32-bit element offsets");
     return 1;
   }
-  if (p.Cin * 2 + 256 > 16384) { set_error("conv_igemm(dma): Cin too large for the zero page"); return 1; }
+  if (p.Cin * 2 + 256 > STEDM_ZERO_PAGE_BYTES) { set_error("conv_igemm(dma): Cin too large for the zero page"); return 1; }
   const bool f16 = a.mm_dtype == STEDM_F16;
   int rc = a.npass == 3 ? (f16 ? conv_dma_pick_f16_p3(p, st) : conv_dma_pick_bf16_p3(p, st))
                         : (f16 ? conv_dma_pick_f16_p1(p, st, dry) : conv_dma_pick_bf16_p1(p, st, dry));

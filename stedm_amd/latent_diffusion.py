@@ -179,6 +179,42 @@ class LatentDiffusion(nn.Module):
         loss = loss_simple.mean()
         return loss, {"val/loss_simple": loss, "val/loss": loss}
 
+    # ------------------------------------------------------------------------------------------ training step (U-Net parameters)
+    def configure_trainer(self, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                          ema_decay: Optional[float] = 0.9999):
+        """AdamW over the U-Net's parameters (modules/ldm_diffusion.py:224-234 builds `torch.optim.AdamW(self._model.model.parameters()
+        ...)`) + the EMA shadow of ddpm.py:369-371 / ema.py:25-44, as one fused kernel (stedm_amd/train.py)."""
+        from .train import UNetTrainer
+        self._trainer = UNetTrainer(self.model.diffusion_model, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, ema_decay=ema_decay)
+        return self._trainer
+
+    @torch.no_grad()
+    def p_losses_backward(self, x_start, cond, t, noise=None):
+        """p_losses (ddpm.py:1015-1048) followed by the backward pass autograd runs for the reference in training_step
+        (ddpm.py:345-358): loss_type l1, eps-parameterisation, logvar == 0. Fills `.grad` of the U-Net's parameters and returns
+        (loss, loss_dict, dL/dx_noisy over [x | c_concat], dL/dc_crossattn). The cond-stage modules are not trained here."""
+        if self.loss_type != 'l1':
+            raise NotImplementedError("the training step is built for loss_type 'l1' (conf/diffusion/ldm_based.yaml)")
+        tr = getattr(self, "_trainer", None) or self.configure_trainer()
+        noise = torch.randn_like(x_start) if noise is None else noise
+        x_noisy = self.q_sample(x_start, t, noise)
+        cd = self._as_cond_dict(cond)
+        cc, ca = cd["c_concat"], cd["c_crossattn"]
+        xc = cc[0] if len(cc) == 1 else torch.cat(cc, 1)
+        ctx = ca[0] if len(ca) == 1 else torch.cat(ca, 1)
+        loss, dx, dctx = tr.loss_and_backward(x_noisy, xc, t, ctx, noise)
+        return loss, {"train/loss_simple": loss, "train/loss": loss}, dx, dctx
+
+    @torch.no_grad()
+    def training_step_hip(self, x_start, cond, t=None, noise=None):
+        """One optimisation step on a prepared batch (latents + conditioning as `get_input` returns them): t ~ U{0..T-1}
+        (ddpm.py:878), p_losses + backward, AdamW + EMA. Returns the loss (device tensor)."""
+        if t is None:
+            t = torch.randint(0, self.num_timesteps, (x_start.shape[0],), device=x_start.device).long()
+        loss, _, _, _ = self.p_losses_backward(x_start, cond, t, noise)
+        self._trainer.optimizer_step()
+        return loss
+
     # ------------------------------------------------------------------------------------------ sampling
     @torch.no_grad()
     def sample_log(self, cond, batch_size, ddim, ddim_steps, **kwargs):

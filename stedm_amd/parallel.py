@@ -40,3 +40,20 @@ def all_gather_samples(local: torch.Tensor, global_batch: int, group=None) -> to
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad, group=group)
     return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
+
+
+def all_reduce_buckets(flat: torch.Tensor, bucket_elems: int, group=None) -> int:
+    """In-place SUM all-reduce of a flat gradient arena in buckets of `bucket_elems` elements (views, no copies); returns the
+    world size (1 when torch.distributed is not initialised: nothing to do)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    world = dist.get_world_size(group)
+    if world == 1:
+        return 1
+    assert flat.dim() == 1 and flat.is_contiguous() and bucket_elems > 0
+    works = [dist.all_reduce(flat[o:o + bucket_elems], op=dist.ReduceOp.SUM, group=group, async_op=True)
+             for o in range(0, flat.numel(), bucket_elems)]
+    for w in works:
+        w.wait()
+    return world

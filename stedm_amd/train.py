@@ -84,9 +84,27 @@ class UNetTrainer:
         self.G[key] = g
         return g, False
 
+    def _alloc_grads(self) -> None:
+        """Every parameter's `.grad` is a view into one flat fp32 arena (bucketed all-reduce and the optimizer kernel walk it without
+        copies); the emb_layers weights come first, in the order of the concatenated embedding Linear, so that its weight
+        gradient is written by one GEMM straight into place."""
+        m = self.m
+        emb_w = [rb.emb_layers[1].weight for rb, _ in m._emb_layout]
+        seen = {id(p) for p in emb_w}
+        order = emb_w + [p for p in m.parameters() if id(p) not in seen]
+        total = sum(p.numel() for p in order)
+        self.grad_arena = torch.zeros((total,), dtype=torch.float32, device=order[0].device)
+        off = 0
+        for p in order:
+            p.grad = self.grad_arena[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        ted = m.model_channels * 4
+        self._dWcat = self.grad_arena[:m._emb_ntot * ted].view(m._emb_ntot, ted)
+        self._arena_params = order
+
     def _param_grad(self, p: nn.Parameter) -> torch.Tensor:
-        if p.grad is None:
-            p.grad = torch.zeros_like(p, dtype=torch.float32)
+        if p.grad is None or getattr(self, "grad_arena", None) is None:
+            self._alloc_grads()
         return p.grad
 
     def _w4(self, conv) -> torch.Tensor:
@@ -365,11 +383,8 @@ class UNetTrainer:
         mc = m.model_channels
         # ---- ResBlock emb_layers: E = silu(emb) @ Wcat^T + b
         S = ops.silu(emb, self._buf("emb.S", (B, ted)))
-        dW = self._buf("emb.dWcat", (m._emb_ntot, ted))
-        ops.gemm_f32(self.dE, True, S, False, dW)
-        for rb, off in m._emb_layout:
-            lin = rb.emb_layers[1]
-            lin.weight.grad = dW[off:off + rb.out_channels]      # row block of the concatenated gradient (no copy)
+        self._param_grad(m._emb_layout[0][0].emb_layers[1].weight)
+        ops.gemm_f32(self.dE, True, S, False, self._dWcat)       # the emb_layers weight gradients are row blocks of this matrix
         dS = self._buf("emb.dS", (B, ted))
         ops.gemm_f32(self.dE, False, c["emb_wt"], True, dS)
         demb = ops.silu(emb, self._buf("emb.demb", (B, ted)), dy=dS)
@@ -407,7 +422,7 @@ class UNetTrainer:
     def _build_opt(self):
         import ctypes as C
         import numpy as np
-        params = [p for p in self.m.parameters()]
+        params = list(self._arena_params)
         dev = params[0].device
         st = {"m": [torch.zeros_like(p, dtype=torch.float32) for p in params], "v": [torch.zeros_like(p, dtype=torch.float32) for p in params],
               "ema": [p.detach().clone() for p in params] if self.ema_decay is not None else None, "params": params}
@@ -426,6 +441,16 @@ class UNetTrainer:
         self._opt = st
 
     @torch.no_grad()
+    def all_reduce_grads(self, group=None, bucket_mb: int = 256) -> int:
+        """Data-parallel training (train_diff.py runs Lightning DDP): sum the gradient arena over the ranks in a few large buckets
+        (xGMI rings are per-link bound: few, large collectives); the 1/world average is folded into the optimizer kernel.
+        Returns the world size."""
+        from .parallel import all_reduce_buckets
+        world = all_reduce_buckets(self.grad_arena, bucket_mb * (1 << 20) // 4, group)
+        self._grad_scale = 1.0 / world
+        return world
+
+    @torch.no_grad()
     def optimizer_step(self) -> None:
         """AdamW over every parameter + EMA shadow update (ema.py:25-44: decay = min(decay, (1+n)/(10+n)))."""
         assert self._grads_ready, "optimizer_step() needs gradients from backward()"
@@ -438,7 +463,8 @@ class UNetTrainer:
         if self.ema_decay is not None:
             self.ema_updates += 1
             decay = min(self.ema_decay, (1 + self.ema_updates) / (10 + self.ema_updates))
-        ops.adamw_ema(st["table"], st["ct"], st["co"], self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, decay)
+        ops.adamw_ema(st["table"], st["ct"], st["co"], self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, decay,
+                      grad_scale=getattr(self, "_grad_scale", 1.0))
         self.m.invalidate()      # parameters changed through raw pointers: repack on the next forward
         self._grads_ready = False
 
@@ -446,7 +472,10 @@ class UNetTrainer:
         return None if self._opt is None else self._opt["ema"]
 
     @torch.no_grad()
-    def train_step(self, x, c_concat, t, context, target) -> torch.Tensor:
+    def train_step(self, x, c_concat, t, context, target, group=None) -> torch.Tensor:
+        import torch.distributed as dist
         loss, _, _ = self.loss_and_backward(x, c_concat, t, context, target)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            self.all_reduce_grads(group)
         self.optimizer_step()
         return loss

@@ -56,3 +56,36 @@ def test_two_rank_gloo_matches_single_process():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert torch.equal(got, ref)   # bit-identical: sharding does not change any sample
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(10_000, generator=g)
+    w = par.all_reduce_buckets(flat, 3_000)          # 4 buckets, the last one short
+    if rank == 0:
+        q.put((w, flat.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_buckets_sum():
+    """training path: the gradient arena is summed over ranks bucket by bucket, in place (the 1/world average is applied by the
+    optimizer kernel)"""
+    ref = sum(torch.randn(10_000, generator=torch.Generator().manual_seed(100 + r)) for r in range(2))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    world, got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert world == 2
+    assert torch.allclose(torch.from_numpy(got), ref, rtol=0, atol=1e-6)
+    assert par.all_reduce_buckets(torch.ones(8), 4) == 1     # not initialised: identity

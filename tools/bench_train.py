@@ -1,0 +1,47 @@
+"""Training-step timing (BASELINE config 2: 32x32x4 latents, batch 64, bf16): forward + L1 + backward + AdamW/EMA."""
+import argparse, sys, time
+import torch
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stedm_amd.utils import prng
+from stedm_amd.unet import UNetModel
+from stedm_amd.train import UNetTrainer
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=64)
+ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--warmup", type=int, default=2)
+ap.add_argument("--precision", default="bf16")
+ap.add_argument("--parts", action="store_true")
+a = ap.parse_args()
+NS32 = dict(image_size=32, in_channels=7, model_channels=128, out_channels=4, num_res_blocks=2, attention_resolutions=[32, 16, 8], channel_mult=[1, 4, 8], num_heads=8)
+dev = torch.device("cuda:0")
+m = UNetModel(precision=a.precision, **NS32).eval(); prng.fill_module_(m, seed=0); m = m.to(dev)
+tr = UNetTrainer(m, lr=1e-5)
+B = a.batch
+g = torch.Generator(device="cpu").manual_seed(1)
+x = torch.randn(B, 4, 32, 32, generator=g).to(dev); cc = torch.randn(B, 3, 32, 32, generator=g).to(dev)
+ctx = torch.randn(B, 512, generator=g).to(dev); tgt = torch.randn(B, 4, 32, 32, generator=g).to(dev)
+t = torch.randint(0, 1000, (B,), generator=g).to(dev)
+for _ in range(a.warmup):
+    loss = tr.train_step(x, cc, t, ctx, tgt)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(a.steps):
+    loss = tr.train_step(x, cc, t, ctx, tgt)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.steps
+print(f"train step B={B} {a.precision}: {dt * 1e3:.2f} ms  ({1 / dt:.2f} steps/s, {B / dt:.0f} samples/s)  loss {float(loss):.4f}")
+if a.parts:
+    def tm(f, n=3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n): f()
+        torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+    print("forward   %.2f ms" % tm(lambda: tr.forward(x, cc, t, ctx)))
+    dp = torch.randn(B, 4, 32, 32, device=dev) * 1e-5
+    print("backward  %.2f ms" % tm(lambda: tr.backward(dp)))
+    tr._grads_ready = True
+    def opt():
+        tr._grads_ready = True; tr.optimizer_step()
+    print("optimizer %.2f ms" % tm(opt))
+    print("repack    %.2f ms" % tm(lambda: (m.invalidate(), m._prepare())))

@@ -1,5 +1,6 @@
 import sys, numpy as np, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stedm_amd.utils import prng
 from stedm_amd.unet import UNetModel
 from stedm_amd.train import UNetTrainer
