@@ -271,6 +271,10 @@ int stedm_spatial_rescale(const float* x, const float* w, float* out, int B, int
  * torch.optim.AdamW (ldm_diffusion.py:224-234) and LitEma.forward (ema.py:25-44). The convolution contractions of the backward
  * (dgrad, wgrad) run on stedm_conv_igemm itself: dgrad with the flipped/transposed filter, wgrad as the GEMM
  * dW[(tap,ci)][co] = sum_p col[(tap,ci)][p] * dYt[co][p] over the planes stedm_im2col_t16 writes. */
+/* The packs of stedm_pack_conv_weight / _frag from a strided source: element (n, ci, tap) = w[n*sn + ci*sc + (flip ? taps-1-tap : tap)]
+ * (dgrad filter = flipped + transposed OIHW parameter; dY^T of the wgrad GEMM from the NHWC gradient). NULL outputs are skipped. */
+int stedm_pack_conv_weight_strided(const float* w, long sn, long sc, int flip, void* w_hi, void* w_lo, void* w_frag, int cout,
+                                   int cin, int ks, int mm_dtype, void* stream);
 /* chan partials (stedm_gn_chan_stats / conv epilogues) of the virtual concat [x1|x2] -> mean_rstd [B][groups][2]. */
 int stedm_gn_fold(const float* cs1, int nslab1, int c1, const float* cs2, int nslab2, int c2, int groups, int B, int HW,
                   float eps, float* mean_rstd, void* stream);
@@ -298,9 +302,10 @@ int stedm_sum2x2(const float* in, float* out, int B, int H, int W, int C, int ac
 int stedm_zero_insert16(const float* in, void* hi, void* lo, int B, int Ho, int Wo, int C, int mm_dtype, void* stream);
 /* backward of QKVAttentionLegacy (openaimodel.py:378-394): qkv, d_qkv [B][T][heads*3*ch]; d_out [B][T][heads*ch]. */
 int stedm_attn_legacy_bwd(const float* qkv, const float* d_out, float* d_qkv, int B, int T, int heads, int ch, void* stream);
-/* C = alpha op(A) op(B) + beta C (fp32; the embedding Linears' backward: rows = batch). */
+/* C = alpha op(A) op(B) + beta C (fp32; the embedding Linears' backward: rows = batch). ws (optional, ws_floats floats): partial
+ * sums of the split-K form taken when the output is small and K long (fixed-order reduce). */
 int stedm_gemm_f32(const float* A, long lda, int trans_a, const float* B, long ldb, int trans_b, float* C, long ldc, int M,
-                   int N, int K, float alpha, float beta, void* stream);
+                   int N, int K, float alpha, float beta, float* ws, long ws_floats, void* stream);
 /* mode 0: out = silu(x); mode 1: out = dy * silu'(x). */
 int stedm_silu(const float* x, const float* dy, float* out, long n, int mode, void* stream);
 /* loss = mean|target - pred| (ddpm.py:282-295 'l1' + :1030-1040), d_pred = grad_scale * sign(pred - target) / n (NULL: skip).

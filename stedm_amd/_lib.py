@@ -82,6 +82,7 @@ SIGNATURES = {
     "stedm_geglu16": (_I, [_P, _P, _P, C.c_long, _I, _I, _P]),
     "stedm_agg_reduce": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "stedm_spatial_rescale": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "stedm_pack_conv_weight_strided": (_I, [_P, C.c_long, C.c_long, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "stedm_gn_fold": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P]),
     "stedm_gn_bwd": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P]),
     "stedm_gn_bwd_ws_floats": (C.c_long, [_I, _I, _I, _I]),
@@ -91,7 +92,7 @@ SIGNATURES = {
     "stedm_sum2x2": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "stedm_zero_insert16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "stedm_attn_legacy_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
-    "stedm_gemm_f32": (_I, [_P, C.c_long, _I, _P, C.c_long, _I, _P, C.c_long, _I, _I, _I, _F, _F, _P]),
+    "stedm_gemm_f32": (_I, [_P, C.c_long, _I, _P, C.c_long, _I, _P, C.c_long, _I, _I, _I, _F, _F, _P, C.c_long, _P]),
     "stedm_silu": (_I, [_P, _P, _P, C.c_long, _I, _P]),
     "stedm_l1_loss": (_I, [_P, _P, C.c_long, _F, _P, _P, _P, _P]),
     "stedm_adamw_ema": (_I, [_P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _F, _F, _P]),

@@ -129,14 +129,20 @@ __global__ void __launch_bounds__(256) gn_bwd_fold_kernel(const float* __restric
   }
 }
 
-// dgamma[c] (+)= sum_b bc[b][c][1]; dbeta[c] (+)= sum_b bc[b][c][0]
-__global__ void gn_bwd_param_kernel(const float* __restrict__ bc, int B, int C, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// dgamma[c] (+)= sum_b bc[b][c][1]; dbeta[c] (+)= sum_b bc[b][c][0]; grid ceil(C/64), 256 threads = 64 channels x 4 sample lanes
+__global__ void __launch_bounds__(256) gn_bwd_param_kernel(const float* __restrict__ bc, int B, int C, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           int accumulate) {
+  __shared__ float red[4][64][2];
+  const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
   float u = 0.f, w = 0.f;
-  for (int b = 0; b < B; ++b) { u += bc[((long)b * C + c) * 2]; w += bc[((long)b * C + c) * 2 + 1]; }
-  dgamma[c] = (accumulate ? dgamma[c] : 0.f) + w;
-  dbeta[c] = (accumulate ? dbeta[c] : 0.f) + u;
+  if (c < C)
+    for (int b = bl; b < B; b += 4) { u += bc[((long)b * C + c) * 2]; w += bc[((long)b * C + c) * 2 + 1]; }
+  red[bl][cl][0] = u; red[bl][cl][1] = w;
+  __syncthreads();
+  if (bl == 0 && c < C) {
+    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + ((red[0][cl][0] + red[1][cl][0]) + (red[2][cl][0] + red[3][cl][0]));
+    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + ((red[0][cl][1] + red[1][cl][1]) + (red[2][cl][1] + red[3][cl][1]));
+  }
 }
 
 // dx = rstd * (gamma*dy - m1 - xhat*m2) (+ add); grid (B, ceil(HW*Q / 1024)), one float4 per thread x 4
@@ -348,12 +354,15 @@ __global__ void __launch_bounds__(256) attn_legacy_bwd_kernel(const float* __res
 // ------------------------------------------------------------------------------------------------ small fp32 GEMM
 // C[M][N] = alpha * op(A) op(B) + beta * C; op(A)[m][k] = ta ? A[k*lda + m] : A[m*lda + k]; op(B)[k][n] = tb ? B[n*ldb + k] : B[k*ldb + n]
 __global__ void __launch_bounds__(256) gemm_f32_kernel(const float* __restrict__ A, long lda, int ta, const float* __restrict__ Bm, long ldb, int tb,
-                                                       float* __restrict__ Cm, long ldc, int M, int N, int K, float alpha, float beta) {
+                                                       float* __restrict__ Cm, long ldc, int M, int N, int K, float alpha, float beta, int kchunk,
+                                                       float* __restrict__ part) {
   __shared__ float sa[32][33], sb[32][33];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 16 x 16 threads, 2 x 2 outputs each
   const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
   float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-  for (int k0 = 0; k0 < K; k0 += 32) {
+  const int kbeg = blockIdx.z * kchunk;                     // split-K: slice z accumulates K range [kbeg, kend) into part[z]
+  if (gridDim.z > 1) K = min(K, kbeg + kchunk);
+  for (int k0 = kbeg; k0 < K; k0 += 32) {
     for (int e = threadIdx.x; e < 1024; e += 256) {
       const int r = e >> 5, cidx = e & 31;
       {  // sa[m][k]
@@ -380,8 +389,20 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int m = m0 + ty * 2 + i, n = n0 + tx * 2 + j;
-      if (m < M && n < N) Cm[(long)m * ldc + n] = alpha * acc[i][j] + (beta != 0.f ? beta * Cm[(long)m * ldc + n] : 0.f);
+      if (m < M && n < N) {
+        if (gridDim.z > 1) part[((long)blockIdx.z * M + m) * N + n] = acc[i][j];
+        else Cm[(long)m * ldc + n] = alpha * acc[i][j] + (beta != 0.f ? beta * Cm[(long)m * ldc + n] : 0.f);
+      }
     }
+}
+
+__global__ void gemm_f32_reduce_kernel(const float* __restrict__ part, int ks, float* __restrict__ Cm, long ldc, int M, int N, float alpha, float beta) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)M * N) return;
+  float s = 0.f;
+  for (int z = 0; z < ks; ++z) s += part[(long)z * M * N + i];   // fixed order
+  const long o = (i / N) * ldc + (i % N);
+  Cm[o] = alpha * s + (beta != 0.f ? beta * Cm[o] : 0.f);
 }
 
 // mode 0: out = silu(x); mode 1: out = dy * silu'(x)
@@ -466,7 +487,7 @@ extern "C" int stedm_gn_bwd(const float* x1, int c1, const float* x2, int c2, co
   hipStream_t st = as_stream(stream);
   gn_bwd_stats_kernel<<<dim3(B, nslab, (Q + 63) / 64), 256, 0, st>>>(a);
   gn_bwd_fold_kernel<<<B, 256, (size_t)C * 8, st>>>(part, nslab, C, groups, HW, gamma, bc, gm);
-  gn_bwd_param_kernel<<<(C + 255) / 256, 256, 0, st>>>(bc, B, C, dgamma, dbeta, acc_param);
+  gn_bwd_param_kernel<<<(C + 63) / 64, 256, 0, st>>>(bc, B, C, dgamma, dbeta, acc_param);
   const dim3 grid(B, (unsigned)(((long)HW * Q + 1023) / 1024));
   if (mm_dtype == STEDM_F16) gn_bwd_apply_kernel<_Float16><<<grid, 256, 0, st>>>(a);
   else gn_bwd_apply_kernel<__bf16><<<grid, 256, 0, st>>>(a);
@@ -534,9 +555,18 @@ extern "C" int stedm_attn_legacy_bwd(const float* qkv, const float* d_out, float
 }
 
 extern "C" int stedm_gemm_f32(const float* A, long lda, int trans_a, const float* Bm, long ldb, int trans_b, float* Cm, long ldc, int M, int N, int K, float alpha,
-                              float beta, void* stream) {
+                              float beta, float* ws, long ws_floats, void* stream) {
   STEDM_CHECK_ARG(A && Bm && Cm && M > 0 && N > 0 && K > 0, "gemm_f32: bad args");
-  gemm_f32_kernel<<<dim3((N + 31) / 32, (M + 31) / 32), 256, 0, as_stream(stream)>>>(A, lda, trans_a, Bm, ldb, trans_b, Cm, ldc, M, N, K, alpha, beta);
+  const int tiles = ((N + 31) / 32) * ((M + 31) / 32);
+  int ks = 1;
+  if (ws && tiles < 128 && K >= 1024) {          // few output tiles, long K: slices of K on separate blocks, fixed-order reduce
+    ks = K / 256 < 64 ? K / 256 : 64;
+    while (ks > 1 && (long)ks * M * N > ws_floats) --ks;
+  }
+  const int kchunk = ks > 1 ? ((K + ks - 1) / ks + 31) / 32 * 32 : K;
+  if (ks > 1) ks = (K + kchunk - 1) / kchunk;
+  gemm_f32_kernel<<<dim3((N + 31) / 32, (M + 31) / 32, ks), 256, 0, as_stream(stream)>>>(A, lda, trans_a, Bm, ldb, trans_b, Cm, ldc, M, N, K, alpha, beta, kchunk, ws);
+  if (ks > 1) gemm_f32_reduce_kernel<<<(unsigned)(((long)M * N + 255) / 256), 256, 0, as_stream(stream)>>>(ws, ks, Cm, ldc, M, N, alpha, beta);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

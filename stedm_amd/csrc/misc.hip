@@ -31,14 +31,14 @@ extern "C" int stedm_device_cus(void) {
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, T* __restrict__ hi, T* __restrict__ lo, int cout,
-                                        int cin, int taps) {
+                                        int cin, int taps, long sn, long sc, int flip) {
   const long total = (long)cout * taps * cin;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int ci = (int)(i % cin);
     const long r = i / cin;
     const int tap = (int)(r % taps);
     const int co = (int)(r / taps);
-    const float v = w[((long)co * cin + ci) * taps + tap];
+    const float v = w[(long)co * sn + (long)ci * sc + (flip ? taps - 1 - tap : tap)];
     const T h = (T)v;
     hi[i] = h;
     if (lo) lo[i] = (T)(v - (float)h);
@@ -54,10 +54,10 @@ extern "C" int stedm_pack_conv_weight(const float* w, void* w_hi, void* w_lo, in
   const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   if (mm_dtype == STEDM_F16)
     pack_conv_weight_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(w, (_Float16*)w_hi, (_Float16*)w_lo, cout, cin,
-                                                                         ks * ks);
+                                                                         ks * ks, (long)cin * ks * ks, ks * ks, 0);
   else
     pack_conv_weight_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(w, (__bf16*)w_hi, (__bf16*)w_lo, cout, cin,
-                                                                       ks * ks);
+                                                                       ks * ks, (long)cin * ks * ks, ks * ks, 0);
   STEDM_LAUNCH_CHECK();
   return 0;
 }
@@ -101,7 +101,8 @@ extern "C" int stedm_pack_conv_weight_up(const float* w, void* w_hi, void* w_lo,
 //   out[tn][chunk][tap][q][lane][e] = W[n = tn*128 + (q>>1)*64 + (q&1)*32 + (lane&31)][ci = chunk*16 + (lane>>5)*8 + e][tap]
 // (rows beyond cout are zero). One wave-wide 16-B load = one MFMA B fragment, 1 KiB contiguous.
 template <typename T>
-__global__ void pack_conv_weight_frag_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, int taps, long total) {
+__global__ void pack_conv_weight_frag_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, int taps, long total, long sn, long sc,
+                                             int flip) {
   const int nch = cin / 16;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int e = (int)(i & 7);
@@ -113,7 +114,7 @@ __global__ void pack_conv_weight_frag_kernel(const float* __restrict__ w, T* __r
     const int tn = (int)(r / nch);
     const int n = tn * 128 + (q >> 1) * 64 + (q & 1) * 32 + (lane & 31);
     const int ci = chunk * 16 + (lane >> 5) * 8 + e;
-    out[i] = n < cout ? (T)w[((long)n * cin + ci) * taps + tap] : (T)0.f;
+    out[i] = n < cout ? (T)w[(long)n * sn + (long)ci * sc + (flip ? taps - 1 - tap : tap)] : (T)0.f;
   }
 }
 
@@ -123,8 +124,34 @@ extern "C" int stedm_pack_conv_weight_frag(const float* w, void* out, int cout, 
   STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "pack_conv_weight_frag: bad mm_dtype %d", mm_dtype);
   const long total = (long)((cout + 127) / 128) * (cin / 16) * taps * 4 * 64 * 8;
   const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  if (mm_dtype == STEDM_F16) pack_conv_weight_frag_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(w, (_Float16*)out, cout, cin, taps, total);
-  else pack_conv_weight_frag_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(w, (__bf16*)out, cout, cin, taps, total);
+  if (mm_dtype == STEDM_F16) pack_conv_weight_frag_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(w, (_Float16*)out, cout, cin, taps, total, (long)cin * taps, taps, 0);
+  else pack_conv_weight_frag_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(w, (__bf16*)out, cout, cin, taps, total, (long)cin * taps, taps, 0);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+// Same packs from an arbitrarily strided source: element (n, ci, tap) = w[n*sn + ci*sc + (flip ? taps-1-tap : tap)]. The backward pass
+// packs the dgrad filter (n = forward cin, ci = forward cout, taps reversed) straight from the OIHW parameter, and dY^T of the
+// wgrad GEMM (n = channel, ci = pixel) straight from the NHWC gradient. Any of w_hi / w_lo / w_frag may be NULL.
+extern "C" int stedm_pack_conv_weight_strided(const float* w, long sn, long sc, int flip, void* w_hi, void* w_lo, void* w_frag, int cout, int cin, int ks,
+                                              int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(w && (w_hi || w_frag) && (ks == 1 || ks == 3), "pack_conv_weight_strided: bad args");
+  STEDM_CHECK_ARG(!w_frag || cin % 16 == 0, "pack_conv_weight_strided: fragment order needs cin %% 16 == 0");
+  STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "pack_conv_weight_strided: bad mm_dtype %d", mm_dtype);
+  const int taps = ks * ks;
+  hipStream_t st = as_stream(stream);
+  if (w_hi) {
+    const long total = (long)cout * cin * taps;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (mm_dtype == STEDM_F16) pack_conv_weight_kernel<_Float16><<<grid, 256, 0, st>>>(w, (_Float16*)w_hi, (_Float16*)w_lo, cout, cin, taps, sn, sc, flip);
+    else pack_conv_weight_kernel<__bf16><<<grid, 256, 0, st>>>(w, (__bf16*)w_hi, (__bf16*)w_lo, cout, cin, taps, sn, sc, flip);
+  }
+  if (w_frag) {
+    const long total = (long)((cout + 127) / 128) * (cin / 16) * taps * 4 * 64 * 8;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (mm_dtype == STEDM_F16) pack_conv_weight_frag_kernel<_Float16><<<grid, 256, 0, st>>>(w, (_Float16*)w_frag, cout, cin, taps, total, sn, sc, flip);
+    else pack_conv_weight_frag_kernel<__bf16><<<grid, 256, 0, st>>>(w, (__bf16*)w_frag, cout, cin, taps, total, sn, sc, flip);
+  }
   STEDM_LAUNCH_CHECK();
   return 0;
 }

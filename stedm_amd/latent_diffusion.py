@@ -215,6 +215,52 @@ class LatentDiffusion(nn.Module):
         self._trainer.optimizer_step()
         return loss
 
+    # ------------------------------------------------------------------------------------------ checkpoints (reference key layout)
+    @staticmethod
+    def _ema_name(param_name: str) -> str:
+        """LitEma registers its shadow of `model.<name>` as a buffer named `<name>` without dots (ema.py:17-21)."""
+        return param_name.replace('.', '')
+
+    @torch.no_grad()
+    def load_reference_state_dict(self, ckpt: dict, use_ema: bool = False):
+        """Load a checkpoint written by the reference: a Lightning checkpoint ({"state_dict": ...}) of `LDM_Diffusion`, whose keys carry
+        the `_model.` prefix (modules/ldm_diffusion.py:38), or a bare `LatentDiffusion.state_dict()`. U-Net, cond stage and
+        aggregation block load by name (same parameter names and OIHW shapes); `model_ema.*` (ema.py) goes to the trainer's EMA
+        shadows, or — with use_ema, like `ema_scope` (ddpm.py:174-188) — into the U-Net itself. `first_stage_model.*` is loaded only
+        when a first stage was supplied. Returns (missing, unexpected) key lists like `load_state_dict(strict=False)`."""
+        sd = ckpt.get("state_dict", ckpt)
+        sd = {(k[len("_model."):] if k.startswith("_model.") else k): v for k, v in sd.items()}
+        ema = {k[len("model_ema."):]: v for k, v in sd.items() if k.startswith("model_ema.")}
+        rest = {k: v for k, v in sd.items() if not k.startswith("model_ema.")
+                and (self.first_stage_model is not None or not k.startswith("first_stage_model."))}
+        res = self.load_state_dict(rest, strict=False)
+        missing, unexpected = list(res.missing_keys), list(res.unexpected_keys)
+        named = dict(self.model.named_parameters())
+        if use_ema and ema:
+            for name, p in named.items():
+                key = self._ema_name(name)
+                if key in ema:
+                    p.copy_(ema[key].to(p.device, p.dtype))
+            self.model.diffusion_model.invalidate()
+        self._ema_loaded = {name: ema[self._ema_name(name)] for name in named if self._ema_name(name) in ema}
+        self._ema_num_updates = int(ema["num_updates"]) if "num_updates" in ema else 0
+        tr = getattr(self, "_trainer", None)
+        if tr is not None:
+            tr.load_ema({n[len("diffusion_model."):]: v for n, v in self._ema_loaded.items()}, self._ema_num_updates)
+        return missing, unexpected
+
+    def reference_state_dict(self, prefix: str = "_model.") -> dict:
+        """State dict in the reference's key layout (see load_reference_state_dict), including `model_ema.*` when a trainer holds
+        EMA shadows."""
+        out = {prefix + k: v for k, v in self.state_dict().items()}
+        tr = getattr(self, "_trainer", None)
+        if tr is not None and tr.ema_named() is not None:
+            out[prefix + "model_ema.decay"] = torch.tensor(tr.ema_decay, dtype=torch.float32)
+            out[prefix + "model_ema.num_updates"] = torch.tensor(tr.ema_updates, dtype=torch.int)
+            for name, v in tr.ema_named().items():
+                out[prefix + "model_ema." + self._ema_name("diffusion_model." + name)] = v
+        return out
+
     # ------------------------------------------------------------------------------------------ sampling
     @torch.no_grad()
     def sample_log(self, cond, batch_size, ddim, ddim_steps, **kwargs):

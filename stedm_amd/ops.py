@@ -484,6 +484,19 @@ def step_set_t(ts_table: torch.Tensor, step_idx: torch.Tensor, t_buf: torch.Tens
 
 
 # ------------------------------------------------------------------------------------------- training step (backward)
+def pack_conv_weight_strided(w: torch.Tensor, sn: int, sc: int, flip: bool, cout: int, cin: int, ks: int, prec: Precision, want_hi: bool = True,
+                             want_frag: bool = False):
+    """(hi, lo, frag) packs of the filter whose element (n, ci, tap) is w.flatten()[n*sn + ci*sc + tap'] (see stedm_pack_conv_weight_strided)."""
+    _chk(w, name="w")
+    taps = ks * ks
+    hi = torch.empty((cout, taps, cin), dtype=torch.int16, device=w.device) if want_hi else None
+    lo = torch.empty_like(hi) if (want_hi and prec.npass == 3) else None
+    frag = torch.empty(((cout + 127) // 128, cin // 16, taps, 4, 64, 8), dtype=torch.int16, device=w.device) if want_frag else None
+    check(lib().stedm_pack_conv_weight_strided(w.data_ptr(), sn, sc, int(flip), _ptr(hi), _ptr(lo), _ptr(frag), cout, cin, ks, prec.mm_dtype, _stream()),
+          "stedm_pack_conv_weight_strided")
+    return hi, lo, frag
+
+
 def gn_fold(cs1: torch.Tensor, cs2: Optional[torch.Tensor], groups: int, HW: int, eps: float, out: torch.Tensor) -> torch.Tensor:
     """chan partials of [x1|x2] -> out [B][groups][2] = {mean, rstd}."""
     B, c1 = cs1.shape[0], cs1.shape[2]
@@ -549,7 +562,8 @@ def attn_legacy_bwd(qkv: torch.Tensor, d_out: torch.Tensor, d_qkv: torch.Tensor,
           "stedm_attn_legacy_bwd")
 
 
-def gemm_f32(A: torch.Tensor, ta: bool, Bm: torch.Tensor, tb: bool, Cm: torch.Tensor, alpha: float = 1.0, beta: float = 0.0) -> torch.Tensor:
+def gemm_f32(A: torch.Tensor, ta: bool, Bm: torch.Tensor, tb: bool, Cm: torch.Tensor, alpha: float = 1.0, beta: float = 0.0,
+             ws: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Cm = alpha * op(A) @ op(Bm) + beta * Cm on 2-D fp32 tensors (rows may be strided views: last stride must be 1)."""
     for t in (A, Bm, Cm):
         assert t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.is_cuda
@@ -557,7 +571,7 @@ def gemm_f32(A: torch.Tensor, ta: bool, Bm: torch.Tensor, tb: bool, Cm: torch.Te
     K = A.shape[0] if ta else A.shape[1]
     assert (A.shape[1] if ta else A.shape[0]) == M and (Bm.shape[0] if tb else Bm.shape[1]) == N and (Bm.shape[1] if tb else Bm.shape[0]) == K
     check(lib().stedm_gemm_f32(A.data_ptr(), A.stride(0), int(ta), Bm.data_ptr(), Bm.stride(0), int(tb), Cm.data_ptr(), Cm.stride(0), M, N, K,
-                               float(alpha), float(beta), _stream()), "stedm_gemm_f32")
+                               float(alpha), float(beta), _ptr(ws), 0 if ws is None else ws.numel(), _stream()), "stedm_gemm_f32")
     return Cm
 
 

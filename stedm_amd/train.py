@@ -118,17 +118,19 @@ class UNetTrainer:
         if hit is not None:
             return hit
         bp = self.bprec
-        w = self._w4(conv)
-        wt = w.flip(2, 3).transpose(0, 1).contiguous()       # [cin_fwd][cout_fwd][k][k]: maps dY (cout_fwd channels) -> dX
-        if pad_cin or pad_cout:
+        w = self._w4(conv).contiguous()
+        co_f, ci_f, ks = w.shape[0], w.shape[1], w.shape[-1]
+        taps = ks * ks
+        if pad_cin or pad_cout:    # first / last convolution (7 and 4 channels): padded copy (layout shuffle), generic kernels
+            wt = w.flip(2, 3).transpose(0, 1).contiguous()
             full = torch.zeros((pad_cout or wt.shape[0], pad_cin or wt.shape[1]) + tuple(wt.shape[2:]), dtype=torch.float32, device=wt.device)
             full[:wt.shape[0], :wt.shape[1]] = wt
-            wt = full
-        ks = wt.shape[-1]
-        hi, lo = ops.pack_conv_weight(wt, bp)
-        frag = None
-        if self.m.conv_path == "dma" and bp.npass == 1 and ((ks == 3 and wt.shape[1] % 16 == 0) or (ks == 1 and wt.shape[1] % 64 == 0)):
-            frag = ops.pack_conv_weight_frag(wt, bp)
+            hi, lo = ops.pack_conv_weight(full, bp)
+            frag = None
+        else:
+            # packed straight from the OIHW parameter: row n = forward input channel, column ci = forward output channel, taps reversed
+            want_frag = self.m.conv_path == "dma" and bp.npass == 1 and ((ks == 3 and co_f % 16 == 0) or (ks == 1 and co_f % 64 == 0))
+            hi, lo, frag = ops.pack_conv_weight_strided(w, taps, ci_f * taps, True, ci_f, co_f, ks, bp, want_hi=True, want_frag=want_frag)
         self._dpacks[key] = (hi, lo, frag, ks)
         return self._dpacks[key]
 
@@ -159,7 +161,7 @@ class UNetTrainer:
         frag = None
         if self.m.conv_path == "dma" and bp.npass == 1 and P == Ppad and dy_f32 is not None and dy_f32.numel() == P * co:
             # register-streamed kernel (splits K = B*H*W over blocks): dY^T in MFMA-fragment order
-            frag = ops.pack_conv_weight_frag(ops.transpose(dy_f32.view(P, co)).view(co, P, 1, 1), bp)
+            frag = ops.pack_conv_weight_strided(dy_f32, 1, co, False, co, P, 1, bp, want_hi=False, want_frag=True)[2]
         dw = self._buf("dw", (taps, Cs, 1, co))
         ops.conv_igemm(None, dyt[0].view(co, 1, Ppad), None if dyt[1] is None else dyt[1].view(co, 1, Ppad), dw, prec=bp, ks=1,
                        src16=(col[0].view(taps, Cs, 1, Ppad), None if col[1] is None else col[1].view(taps, Cs, 1, Ppad)), w_frag=frag,
@@ -385,8 +387,8 @@ class UNetTrainer:
         S = ops.silu(emb, self._buf("emb.S", (B, ted)))
         self._param_grad(m._emb_layout[0][0].emb_layers[1].weight)
         ops.gemm_f32(self.dE, True, S, False, self._dWcat)       # the emb_layers weight gradients are row blocks of this matrix
-        dS = self._buf("emb.dS", (B, ted))
-        ops.gemm_f32(self.dE, False, c["emb_wt"], True, dS)
+        gws = self._buf("emb.gws", (64 * B * ted,))
+        dS = ops.gemm_f32(self.dE, False, c["emb_w"], False, self._buf("emb.dS", (B, ted)), ws=gws)    # dE @ Wcat: few rows, long K -> split-K
         demb = ops.silu(emb, self._buf("emb.demb", (B, ted)), dy=dS)
         # ---- time_embed: emb = silu(te @ W0^T + b0) @ W2^T + b2
         l0, l2 = m.time_embed[0], m.time_embed[2]
@@ -439,6 +441,8 @@ class UNetTrainer:
         st["co"] = torch.tensor(co, dtype=torch.int64, device=dev)
         st["gptrs"] = [p.grad.data_ptr() for p in params]
         self._opt = st
+        if getattr(self, "_ema_resume", None) is not None:
+            self._apply_ema_resume()
 
     @torch.no_grad()
     def all_reduce_grads(self, group=None, bucket_mb: int = 256) -> int:
@@ -470,6 +474,30 @@ class UNetTrainer:
 
     def ema_parameters(self) -> Optional[List[torch.Tensor]]:
         return None if self._opt is None else self._opt["ema"]
+
+    def ema_named(self) -> Optional[Dict[str, torch.Tensor]]:
+        """EMA shadows by U-Net parameter name (None before the first optimizer step or without EMA)."""
+        if self._opt is None or self._opt["ema"] is None:
+            return None
+        names = {id(p): n for n, p in self.m.named_parameters()}
+        return {names[id(p)]: e for p, e in zip(self._opt["params"], self._opt["ema"])}
+
+    @torch.no_grad()
+    def load_ema(self, shadows: Dict[str, torch.Tensor], num_updates: int) -> None:
+        """Resume the EMA of a checkpoint (LitEma buffers by U-Net parameter name + its update counter)."""
+        self._ema_resume = (dict(shadows), int(num_updates))
+        if self._opt is not None:
+            self._apply_ema_resume()
+
+    def _apply_ema_resume(self) -> None:
+        shadows, n = self._ema_resume
+        named = self.ema_named()
+        if named is not None:
+            for name, e in named.items():
+                if name in shadows:
+                    e.copy_(shadows[name].to(e.device, e.dtype))
+        self.ema_updates = n
+        self._ema_resume = None
 
     @torch.no_grad()
     def train_step(self, x, c_concat, t, context, target, group=None) -> torch.Tensor:

@@ -332,7 +332,8 @@ class UNetModel(nn.Module):
             self._emb_layout.append((rb, off))
             off += rb.out_channels
         wcat = torch.cat([rb.emb_layers[1].weight.detach().float() for rb in tblocks], dim=0)  # [Ntot, ted]
-        c["emb_wt"] = ops.transpose(wcat.contiguous())
+        c["emb_w"] = wcat.contiguous()                          # [Ntot][ted]: K-major operand of the embedding path's backward
+        c["emb_wt"] = ops.transpose(c["emb_w"])
         c["emb_b"] = torch.cat([rb.emb_layers[1].bias.detach().float() for rb in tblocks]).contiguous()
         self._emb_off = {id(rb): o for rb, o in self._emb_layout}
         self._emb_ntot = off

@@ -45,3 +45,40 @@ def test_unet_module_surface_cpu():
     from stedm_amd._lib import StedmHipError
     with pytest.raises(StedmHipError):
         m(torch.zeros(1, 7, 16, 16), torch.zeros(1, dtype=torch.long), context=torch.zeros(1, 128))
+
+
+def test_reference_checkpoint_key_layout_roundtrip():
+    """A Lightning checkpoint of the reference (`_model.` prefix, LitEma buffers named without dots, ema.py:17-21) loads into the
+    module surface; with use_ema the shadows replace the U-Net weights (ema_scope, ddpm.py:174-188)."""
+    from stedm_amd.latent_diffusion import LatentDiffusion
+    from stedm_amd.style import SpatialRescaler
+    from stedm_amd.unet import UNetModel
+    from stedm_amd.utils import prng
+    tiny = dict(image_size=16, in_channels=7, model_channels=32, out_channels=4, num_res_blocks=2,
+                attention_resolutions=[32, 16, 8], channel_mult=[1, 2, 4], num_heads=4)
+
+    def make(seed):
+        unet = UNetModel(**tiny)
+        prng.fill_module_(unet, seed=seed)
+        return LatentDiffusion(unet, linear_start=0.0015, linear_end=0.0205, loss_type="l1", image_size=16, channels=4,
+                               conditioning_key="hybrid", cond_stage_config=SpatialRescaler(n_stages=2, in_channels=2, out_channels=3))
+
+    src, dst = make(1), make(2)
+    sd = {"_model." + k: v.clone() for k, v in src.state_dict().items()}
+    ema_vals = {}
+    for name, p in src.model.named_parameters():            # what LitEma(self.model) would hold
+        ema_vals[name] = p.detach() * 0.5
+        sd["_model.model_ema." + name.replace(".", "")] = ema_vals[name]
+    sd["_model.model_ema.decay"] = torch.tensor(0.9999)
+    sd["_model.model_ema.num_updates"] = torch.tensor(7, dtype=torch.int)
+    sd["_model.first_stage_model.encoder.conv_in.weight"] = torch.zeros(3)     # first stage not supplied: skipped, not an error
+    missing, unexpected = dst.load_reference_state_dict({"state_dict": sd})
+    assert not missing and not unexpected
+    for (k, a), (_, b) in zip(src.state_dict().items(), dst.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert dst._ema_num_updates == 7 and set(dst._ema_loaded) == set(ema_vals)
+    dst.load_reference_state_dict({"state_dict": sd}, use_ema=True)
+    for name, p in dst.model.named_parameters():
+        assert torch.equal(p.detach(), ema_vals[name]), name
+    out = dst.reference_state_dict()
+    assert all(k.startswith("_model.") for k in out) and "_model.model.diffusion_model.out.2.weight" in out
