@@ -168,6 +168,9 @@ typedef struct stedm_conv_args {
 int stedm_conv_igemm(const stedm_conv_args* args, void* stream);
 /* 1 when stedm_conv_igemm would run `args` (with src16b_hi / w_frag_b / cb set) as one fused kernel, else 0. No launch. */
 int stedm_conv_fused_skip_ok(const stedm_conv_args* args);
+/* 1 when the register-streamed kernel (w_frag) takes this problem: w_hi / w_lo are then never read, so the caller may skip packing
+ * them and pass any non-NULL w_hi. Same decision path as stedm_conv_igemm; nothing is launched. */
+int stedm_conv_rs_ok(const stedm_conv_args* args);
 
 /* ---- boundary convs (NCHW <-> NHWC) ------------------------------------------------------- */
 /* input_blocks.0: conv3x3(cat([x, c_concat],1)) — DiffusionWrapper hybrid ddpm.py:1414-1417 +

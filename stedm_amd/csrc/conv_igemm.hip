@@ -324,6 +324,17 @@ extern "C" int stedm_conv_fused_skip_ok(const stedm_conv_args* args) {
   return conv_launch_dma(p, nullptr, /*dry=*/true) == 0 ? 1 : 0;
 }
 
+// Would the register-streamed kernel (fragment-order weights, conv_rs.inc) run this problem? Then w_hi / w_lo are never read and the
+// caller may skip packing them (pass any non-NULL w_hi). Same decision path as stedm_conv_igemm, nothing is launched.
+extern "C" int stedm_conv_rs_ok(const stedm_conv_args* args) {
+  if (!args || !args->src16_hi || !args->w_frag || args->npass != 1) return 0;
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.a = *args;
+  if (conv_setup(p) != 0) return 0;
+  return conv_launch_dma(p, nullptr, /*dry=*/true) == 0 ? 1 : 0;
+}
+
 extern "C" int stedm_conv_igemm(const stedm_conv_args* args, void* stream) {
   STEDM_CHECK_ARG(args, "conv_igemm: null args");
   ConvParams p;

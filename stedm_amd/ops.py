@@ -214,6 +214,20 @@ def gn_apply16c(x1: torch.Tensor, cs1: torch.Tensor, x2: Optional[torch.Tensor],
 
 
 # ------------------------------------------------------------------------------------------- conv
+class LazyPlanes:
+    """[cout][tap][cin] hi (/lo) weight planes packed on first need. The register-streamed kernel reads only the fragment-order
+    weights; the planes are packed when a problem falls to the LDS-operand kernels (asked through stedm_conv_rs_ok)."""
+
+    def __init__(self, fn):
+        self._fn, self._val = fn, None
+
+    def get(self):
+        if self._val is None:
+            self._val = self._fn()
+            self._fn = None
+        return self._val
+
+
 def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[torch.Tensor], out: torch.Tensor, *, prec: Precision,
                ks: int = 3, mode: int = CONV_S1, src2: Optional[torch.Tensor] = None, src2_bmod: int = 0,
                scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, act: int = 0,
@@ -262,6 +276,9 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
     a.B, a.Hin, a.Win = B, Hin, Win
     a.mode, a.ks = mode, ks
     a.scale, a.shift, a.act = _ptr(scale), _ptr(shift), act
+    lazy = w_hi if isinstance(w_hi, LazyPlanes) else None
+    if lazy is not None:
+        w_hi, w_lo = lazy._val if lazy._val is not None else (w_frag, None)     # placeholder pointer until the planes are known to be needed
     a.w_hi, a.w_lo = _ptr(w_hi), (_ptr(w_lo) if prec.npass == 3 else None)
     a.bias = _ptr(bias)
     a.emb = None if emb is None else emb.data_ptr() + 4 * emb_offset
@@ -270,7 +287,11 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
     a.out = _ptr(out)
     a.cout = oshape[-1]
     a.npass, a.mm_dtype = prec.npass, prec.mm_dtype
-    if mode == CONV_UP_SUBPIXEL:
+    if lazy is not None and lazy._val is None:
+        if src16 is None or w_frag is None or prec.npass != 1 or not lib().stedm_conv_rs_ok(C.byref(a)):
+            w_hi, w_lo = lazy.get()
+            a.w_hi, a.w_lo = _ptr(w_hi), (_ptr(w_lo) if prec.npass == 3 else None)
+    elif mode == CONV_UP_SUBPIXEL:
         assert w_hi.shape == (4 * a.cout, 4, a.c1 + a.c2), (w_hi.shape, a.cout, a.c1, a.c2)
     elif mode == CONV_S2D:
         assert w_hi is None and w_frag is not None and src1 is None, "the space-to-depth form runs on the register-streamed kernel only"

@@ -130,9 +130,19 @@ class UNetTrainer:
         else:
             # packed straight from the OIHW parameter: row n = forward input channel, column ci = forward output channel, taps reversed
             want_frag = self.m.conv_path == "dma" and bp.npass == 1 and ((ks == 3 and co_f % 16 == 0) or (ks == 1 and co_f % 64 == 0))
-            hi, lo, frag = ops.pack_conv_weight_strided(w, taps, ci_f * taps, True, ci_f, co_f, ks, bp, want_hi=True, want_frag=want_frag)
+            args = (w, taps, ci_f * taps, True, ci_f, co_f, ks, bp)
+            if want_frag:   # the planes are only read when a problem falls to the LDS-operand kernels: packed on first need
+                frag = ops.pack_conv_weight_strided(*args, want_hi=False, want_frag=True)[2]
+                hi, lo = ops.LazyPlanes(lambda: ops.pack_conv_weight_strided(*args, want_hi=True, want_frag=False)[:2]), None
+            else:
+                hi, lo, frag = ops.pack_conv_weight_strided(*args, want_hi=True, want_frag=False)
         self._dpacks[key] = (hi, lo, frag, ks)
         return self._dpacks[key]
+
+    def _cus(self) -> int:
+        if not hasattr(self, "_ncus"):
+            self._ncus = ops.device_cus() or 256
+        return self._ncus
 
     def _ws(self, nel: int) -> Optional[torch.Tensor]:
         if nel > (1 << 23):
@@ -163,9 +173,25 @@ class UNetTrainer:
             # register-streamed kernel (splits K = B*H*W over blocks): dY^T in MFMA-fragment order
             frag = ops.pack_conv_weight_strided(dy_f32, 1, co, False, co, P, 1, bp, want_hi=False, want_frag=True)[2]
         dw = self._buf("dw", (taps, Cs, 1, co))
-        ops.conv_igemm(None, dyt[0].view(co, 1, Ppad), None if dyt[1] is None else dyt[1].view(co, 1, Ppad), dw, prec=bp, ks=1,
-                       src16=(col[0].view(taps, Cs, 1, Ppad), None if col[1] is None else col[1].view(taps, Cs, 1, Ppad)), w_frag=frag,
-                       ws=self._ws(dw.numel()))
+        rows = taps * Cs
+        w_hi = dyt[0].view(co, 1, Ppad)
+        w_lo = None if dyt[1] is None else dyt[1].view(co, 1, Ppad)
+
+        def gemm(r0, r1):
+            n = r1 - r0
+            src = (col[0][r0:r1].view(1, n, 1, Ppad), None if col[1] is None else col[1][r0:r1].view(1, n, 1, Ppad))
+            ops.conv_igemm(None, w_hi, w_lo, dw.view(rows, co)[r0:r1].view(1, n, 1, co), prec=bp, ks=1, src16=src, w_frag=frag, ws=self._ws(dw.numel()))
+
+        # tile-count-aware launch split: the kernel runs one 256 x 128 tile per workgroup, one workgroup per CU; a grid of, say, 288 tiles
+        # costs two full rounds. Rows that fill whole rounds go first, the remainder goes separately (where split-K refills the chip).
+        tm, tn, cus = (rows + 255) // 256, (co + 127) // 128, self._cus()
+        total = tm * tn
+        m_full = (total // cus) * cus // tn
+        if frag is not None and total > cus and 0 < total % cus < 0.6 * cus and 0 < m_full < tm:
+            gemm(0, m_full * 256)
+            gemm(m_full * 256, rows)
+        else:
+            gemm(0, rows)
         ops.wgrad_to_oihw(dw, self._param_grad(wparam), Cs, co, False)
 
     def _bias_grad(self, dy: torch.Tensor, bias: Optional[nn.Parameter], per_sample: Optional[torch.Tensor] = None, ld: int = 0) -> None:

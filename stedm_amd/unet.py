@@ -282,8 +282,7 @@ class UNetModel(nn.Module):
         prec = self.precision
 
         def pack(conv):
-            hi, lo = ops.pack_conv_weight(conv.weight.float(), prec)
-            frag = None
+            hi = lo = frag = None
             w4 = conv.weight.float()
             if w4.dim() == 3:     # Conv1d qkv / proj_out of the AttentionBlock
                 w4 = w4.unsqueeze(-1)
@@ -291,6 +290,10 @@ class UNetModel(nn.Module):
             k1 = tuple(w4.shape[2:]) == (1, 1) and conv.in_channels % 64 == 0
             if self.conv_path == "dma" and prec.npass == 1 and (k3 or k1):
                 frag = ops.pack_conv_weight_frag(w4, prec)   # register-streamed weights
+                # the [cout][tap][cin] planes are read only by the LDS-operand kernels: packed on first need
+                hi = ops.LazyPlanes(lambda w=conv.weight: ops.pack_conv_weight(w.float(), prec))
+            else:
+                hi, lo = ops.pack_conv_weight(conv.weight.float(), prec)
             self._packed[id(conv)] = _Packed(hi, lo, None if conv.bias is None else conv.bias.detach().float().contiguous(), frag)
 
         for m in self.modules():
