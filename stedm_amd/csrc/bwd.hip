@@ -459,9 +459,52 @@ __global__ void __launch_bounds__(256) adamw_ema_kernel(const OptTensor* __restr
   }
 }
 
+// SpatialRescaler (encoders/modules.py:123-130) weight gradient: dW[co][ci] = sum_{b,p} d_out[b][co][p] * boxmean_f(x)[b][ci][p].
+// grid B (one block per sample, per-sample partials), then a fixed-order sum over the batch.
+__global__ void __launch_bounds__(256) rescale_wgrad_partial_kernel(const float* __restrict__ x, const float* __restrict__ d_out, float* __restrict__ part, int cin,
+                                                                    int cout, int H, int W, int f) {
+  __shared__ float red[256];
+  const int b = blockIdx.x, Ho = H / f, Wo = W / f, np = Ho * Wo;
+  for (int e = 0; e < cin * cout; ++e) {
+    const int co = e / cin, ci = e % cin;
+    float s = 0.f;
+    for (int p = threadIdx.x; p < np; p += 256) {
+      const int yo = p / Wo, xo = p % Wo;
+      const float* px = x + (((long)b * cin + ci) * H + (long)yo * f) * W + (long)xo * f;
+      float m = 0.f;
+      for (int dy = 0; dy < f; ++dy)
+        for (int dx = 0; dx < f; ++dx) m += px[(long)dy * W + dx];
+      s += d_out[((long)b * cout + co) * np + p] * (m / (float)(f * f));
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) part[(long)b * cin * cout + e] = red[0];
+    __syncthreads();
+  }
+}
+__global__ void rescale_wgrad_final_kernel(const float* __restrict__ part, int B, int n, float* __restrict__ dw, int accumulate) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += part[(long)b * n + e];
+  dw[e] = (accumulate ? dw[e] : 0.f) + s;
+}
+
 }  // namespace
 
 // ================================================================================================ C ABI
+extern "C" int stedm_spatial_rescale_wgrad(const float* x, const float* d_out, float* ws, float* dw, int B, int cin, int cout, int H, int W, int n_stages,
+                                           int accumulate, void* stream) {
+  STEDM_CHECK_ARG(x && d_out && ws && dw && n_stages >= 0 && n_stages < 8 && cin * cout <= 1024, "spatial_rescale_wgrad: bad args");
+  const int f = 1 << n_stages;
+  STEDM_CHECK_ARG(H % f == 0 && W % f == 0, "spatial_rescale_wgrad: H, W must be divisible by 2^n_stages");
+  rescale_wgrad_partial_kernel<<<B, 256, 0, as_stream(stream)>>>(x, d_out, ws, cin, cout, H, W, f);
+  rescale_wgrad_final_kernel<<<(cin * cout + 63) / 64, 64, 0, as_stream(stream)>>>(ws, B, cin * cout, dw, accumulate);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int stedm_gn_fold(const float* cs1, int nslab1, int c1, const float* cs2, int nslab2, int c2, int groups, int B, int HW, float eps, float* mean_rstd,
                              void* stream) {
   STEDM_CHECK_ARG(cs1 && mean_rstd && groups > 0 && groups <= 64 && (c1 + c2) % groups == 0 && (cs2 != nullptr) == (c2 > 0), "gn_fold: bad args");

@@ -189,10 +189,11 @@ class LatentDiffusion(nn.Module):
         return self._trainer
 
     @torch.no_grad()
-    def p_losses_backward(self, x_start, cond, t, noise=None):
+    def p_losses_backward(self, x_start, cond, t, noise=None, cond_input=None):
         """p_losses (ddpm.py:1015-1048) followed by the backward pass autograd runs for the reference in training_step
         (ddpm.py:345-358): loss_type l1, eps-parameterisation, logvar == 0. Fills `.grad` of the U-Net's parameters and returns
-        (loss, loss_dict, dL/dx_noisy over [x | c_concat], dL/dc_crossattn). The cond-stage modules are not trained here."""
+        (loss, loss_dict, dL/dx_noisy over [x | c_concat], dL/dc_crossattn). With `cond_input` (the raw layout fed to the cond stage) the
+        SpatialRescaler's channel-mapper gradient is filled too; the style encoder's backward is not built."""
         if self.loss_type != 'l1':
             raise NotImplementedError("the training step is built for loss_type 'l1' (conf/diffusion/ldm_based.yaml)")
         tr = getattr(self, "_trainer", None) or self.configure_trainer()
@@ -203,6 +204,9 @@ class LatentDiffusion(nn.Module):
         xc = cc[0] if len(cc) == 1 else torch.cat(cc, 1)
         ctx = ca[0] if len(ca) == 1 else torch.cat(ca, 1)
         loss, dx, dctx = tr.loss_and_backward(x_noisy, xc, t, ctx, noise)
+        if cond_input is not None and hasattr(self.cond_stage_model, "backward"):
+            # cond_stage_trainable (s_zss_dm.py:46-48): the layout conditioner's channel mapper receives the c_concat slice of dL/dx
+            self.cond_stage_model.backward(cond_input, dx[:, x_noisy.shape[1]:].contiguous())
         return loss, {"train/loss_simple": loss, "train/loss": loss}, dx, dctx
 
     @torch.no_grad()

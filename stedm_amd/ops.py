@@ -611,6 +611,18 @@ def l1_loss(pred: torch.Tensor, target: torch.Tensor, d_pred: Optional[torch.Ten
     return loss
 
 
+def spatial_rescale_wgrad(x: torch.Tensor, d_out: torch.Tensor, dw: torch.Tensor, n_stages: int, accumulate: bool = False) -> torch.Tensor:
+    """channel_mapper weight gradient of the SpatialRescaler: x [B,cin,H,W], d_out [B,cout,H>>n,W>>n] -> dw [cout,cin(,1,1)]."""
+    _chk(x, name="x"); _chk(d_out, name="d_out"); _chk(dw, name="dw")
+    B, cin, H, W = x.shape
+    cout = d_out.shape[1]
+    assert dw.numel() == cout * cin and tuple(d_out.shape) == (B, cout, H >> n_stages, W >> n_stages)
+    ws = torch.empty((B * cin * cout,), dtype=torch.float32, device=x.device)
+    check(lib().stedm_spatial_rescale_wgrad(x.data_ptr(), d_out.data_ptr(), ws.data_ptr(), dw.data_ptr(), B, cin, cout, H, W, n_stages, int(accumulate),
+                                            _stream()), "stedm_spatial_rescale_wgrad")
+    return dw
+
+
 def adamw_ema(table: torch.Tensor, chunk_tensor: torch.Tensor, chunk_off: torch.Tensor, lr: float, beta1: float, beta2: float, eps: float,
               weight_decay: float, step: int, ema_decay: float, grad_scale: float = 1.0) -> None:
     check(lib().stedm_adamw_ema(table.data_ptr(), chunk_tensor.data_ptr(), chunk_off.data_ptr(), chunk_tensor.numel(), float(lr), float(beta1),

@@ -306,3 +306,15 @@ class SpatialRescaler(nn.Module):
 
     def encode(self, x):
         return self(x)
+
+    @torch.no_grad()
+    def backward(self, x, d_out, accumulate: bool = False):
+        """Gradient of the only trainable tensor of the shipped cond stage (channel_mapper.weight, `cond_stage_trainable`) given
+        d_out = dL/d(forward(x)) — the c_concat slice of the U-Net's input gradient (UNetTrainer.backward). Fills `.grad`."""
+        if not self.remap_output:
+            return None
+        wt = self.channel_mapper.weight
+        if wt.grad is None:
+            wt.grad = torch.zeros_like(wt, dtype=torch.float32)
+        ops.spatial_rescale_wgrad(x.float().contiguous(), d_out.float().contiguous(), wt.grad, self.n_stages, accumulate)
+        return wt.grad

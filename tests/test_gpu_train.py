@@ -146,3 +146,21 @@ def test_train_steps_reduce_the_loss(dev):
     losses = [float(tr.train_step(x[:, :4].contiguous(), x[:, 4:].contiguous(), t, ctx, target)) for _ in range(6)]
     print("losses", ["%.4f" % v for v in losses])
     assert losses[-1] < losses[0] - 0.01
+
+
+def test_spatial_rescaler_weight_gradient_vs_oracle(dev):
+    """cond_stage_trainable: channel_mapper.weight gradient from the c_concat slice of the U-Net's input gradient, against autograd
+    over the oracle's restatement of SpatialRescaler.forward (encoders/modules.py:123-130)."""
+    from oracle import style as ostyle
+    from stedm_amd.style import SpatialRescaler
+    m = SpatialRescaler(n_stages=2, in_channels=2, out_channels=3).to(dev)
+    prng.fill_module_(m, seed=9)
+    x = prng.uniform(9, "resc.x", (3, 2, 64, 64))
+    d = prng.normal(9, "resc.d", (3, 3, 16, 16))
+    w = m.channel_mapper.weight.detach().cpu().clone().requires_grad_(True)
+    with torch.enable_grad():
+        (ostyle.spatial_rescaler.__wrapped__(x, w, 2) * d).sum().backward()
+    g = m.backward(x.to(dev), d.to(dev))
+    assert torch.allclose(g.cpu(), w.grad, rtol=1e-5, atol=1e-5)
+    g2 = m.backward(x.to(dev), d.to(dev), accumulate=True)
+    assert torch.allclose(g2.cpu(), 2 * w.grad, rtol=1e-5, atol=1e-5)
