@@ -181,6 +181,27 @@ def cpu_baseline(seconds_budget=15.0):
                       f"{el:.1f} s; scaled by {Bc}/64", "sample_steps_per_s": sample_steps_per_s}
 
 
+def cpu_baseline_train():
+    """The CPU oracle's training-step arithmetic (forward + L1 + reverse-mode gradients by autograd over the fixture-pinned
+    restatement; no optimizer) on this host's cores, one bounded sample."""
+    from oracle import train as otrain
+    from oracle import unet as ou
+    from stedm_amd.utils import prng
+    cores = int(os.environ.get("STEDM_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
+    torch.set_num_threads(cores)
+    cfg = ou.UNetConfig()
+    P = prng.fill_state_dict(ou.build_plan(cfg).shapes, 0)
+    Bc = 2
+    x = prng.normal(1, "cput.x", (Bc, 7, 32, 32)); ctx = prng.normal(3, "cput.ctx", (Bc, 512)); tgt = prng.normal(4, "cput.t", (Bc, 4, 32, 32))
+    t = torch.tensor([951, 21], dtype=torch.long)
+    t0 = time.perf_counter()
+    otrain.unet_loss_and_grads(P, cfg, x, t, ctx, tgt)
+    el = time.perf_counter() - t0
+    torch.set_grad_enabled(False)
+    return {"value": Bc / el, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"1 forward + L1 + backward at batch {Bc} (fp32 torch-CPU oracle under autograd, {cores} threads), {el:.1f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -300,6 +321,8 @@ def main():
                                          "gradients match the reference's autograd to 1e-5 in parity mode (tests/test_gpu_train.py)",
                                  "loss": round(float(loss), 4)}
             del tr
+            if not args.no_cpu_baseline:
+                out["train_step"]["cpu_baseline"] = cpu_baseline_train()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         elif world == 1:

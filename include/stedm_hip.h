@@ -324,6 +324,12 @@ int stedm_spatial_rescale_wgrad(const float* x, const float* d_out, float* ws, f
 int stedm_adamw_ema(const void* table, const int* chunk_tensor, const long* chunk_off, int nchunks, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int step, float ema_decay, float grad_scale, void* stream);
 
+/* ---- image epilogue of predict_step (integer work, bit-exact) -------------------------------------------------------
+ * modules/ldm_diffusion.py:93-95: ((clip(x, -1, 1).permute(0,2,3,1) + 1) * 127.5).astype(uint8): x NCHW fp32 -> out NHWC uint8. */
+int stedm_image_to_uint8(const float* x, unsigned char* out, int B, int C, int H, int W, void* stream);
+/* modules/ldm_diffusion.py:98: torch.argmax(segmentation, dim=-1).astype(uint8): seg [N][ncls] fp32 -> out [N] (first maximum). */
+int stedm_argmax_u8(const float* seg, unsigned char* out, long N, int ncls, void* stream);
+
 /* ---- HIP graph capture helpers (plumbing for the sampling loop) ---------------------------- */
 int stedm_graph_begin(void* stream);
 int stedm_graph_end(void* stream, void** graph_exec_out);

@@ -100,21 +100,48 @@ extern "C" int stedm_pack_conv_weight_up(const float* w, void* w_hi, void* w_lo,
 // Fragment-order packing for the register-streamed 3x3 kernel (conv_rs.inc):
 //   out[tn][chunk][tap][q][lane][e] = W[n = tn*128 + (q>>1)*64 + (q&1)*32 + (lane&31)][ci = chunk*16 + (lane>>5)*8 + e][tap]
 // (rows beyond cout are zero). One wave-wide 16-B load = one MFMA B fragment, 1 KiB contiguous.
-template <typename T>
-__global__ void pack_conv_weight_frag_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, int taps, long total, long sn, long sc,
-                                             int flip) {
+// One block = one (128-row tile tn, 16-channel chunk, 64-row half): the 64 x 16 x taps source values go through LDS so that both the
+// gather from the source (runs along its contiguous index: (ci, tap) for an OIHW filter, (n, tap) for the transposed forms) and the
+// 16-B fragment stores are coalesced.
+template <typename T, int taps>
+__global__ void __launch_bounds__(256) pack_conv_weight_frag_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, long total,
+                                                                    long sn, long sc, int flip) {
+  typedef T V8 __attribute__((ext_vector_type(8)));
+  __shared__ float tile[64][16 * taps + 1];
   const int nch = cin / 16;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int e = (int)(i & 7);
-    const int lane = (int)((i >> 3) & 63);
-    const int q = (int)((i >> 9) & 3);
-    long r = i >> 11;
-    const int tap = (int)(r % taps); r /= taps;
-    const int chunk = (int)(r % nch);
-    const int tn = (int)(r / nch);
-    const int n = tn * 128 + (q >> 1) * 64 + (q & 1) * 32 + (lane & 31);
-    const int ci = chunk * 16 + (lane >> 5) * 8 + e;
-    out[i] = n < cout ? (T)w[(long)n * sn + (long)ci * sc + (flip ? taps - 1 - tap : tap)] : (T)0.f;
+  const int half = blockIdx.x & 1;
+  const int chunk = (blockIdx.x >> 1) % nch, tn = (blockIdx.x >> 1) / nch;
+  const int n0 = tn * 128 + half * 64, ci0 = chunk * 16;
+  const int per = 64 * 16 * taps;
+  const bool n_fast = sn <= sc;       // which source index is contiguous
+  for (int idx = threadIdx.x; idx < per; idx += 256) {
+    int row, cil, tap;
+    if (n_fast) { cil = idx / (64 * taps); const int r = idx - cil * 64 * taps; row = r / taps; tap = r - row * taps; }
+    else { row = idx / (16 * taps); const int r = idx - row * 16 * taps; cil = r / taps; tap = r - cil * taps; }
+    const int n = n0 + row;
+    tile[row][cil * taps + tap] = n < cout ? w[(long)n * sn + (long)(ci0 + cil) * sc + (flip ? taps - 1 - tap : tap)] : 0.f;
+  }
+  __syncthreads();
+  // stores: (tap, q&1, lane) -> one 16-B vector of 8 consecutive channels
+  for (int v = threadIdx.x; v < taps * 2 * 64; v += 256) {
+    const int lane = v & 63, ql = (v >> 6) & 1, tap = v >> 7;
+    const int row = ql * 32 + (lane & 31), c8 = (lane >> 5) * 8;
+    V8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (T)tile[row][(c8 + e) * taps + tap];
+    const int q = half * 2 + ql;
+    *reinterpret_cast<V8*>(out + ((((long)tn * nch + chunk) * taps + tap) * 4 + q) * 512 + lane * 8) = o;
+  }
+}
+
+static void launch_pack_frag(const float* w, void* out, int cout, int cin, int taps, long total, long sn, long sc, int flip, int mm_dtype, int grid,
+                             hipStream_t st) {
+  if (mm_dtype == STEDM_F16) {
+    if (taps == 9) pack_conv_weight_frag_kernel<_Float16, 9><<<grid, 256, 0, st>>>(w, (_Float16*)out, cout, cin, total, sn, sc, flip);
+    else pack_conv_weight_frag_kernel<_Float16, 1><<<grid, 256, 0, st>>>(w, (_Float16*)out, cout, cin, total, sn, sc, flip);
+  } else {
+    if (taps == 9) pack_conv_weight_frag_kernel<__bf16, 9><<<grid, 256, 0, st>>>(w, (__bf16*)out, cout, cin, total, sn, sc, flip);
+    else pack_conv_weight_frag_kernel<__bf16, 1><<<grid, 256, 0, st>>>(w, (__bf16*)out, cout, cin, total, sn, sc, flip);
   }
 }
 
@@ -123,9 +150,8 @@ extern "C" int stedm_pack_conv_weight_frag(const float* w, void* out, int cout, 
   const int taps = ks * ks;
   STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "pack_conv_weight_frag: bad mm_dtype %d", mm_dtype);
   const long total = (long)((cout + 127) / 128) * (cin / 16) * taps * 4 * 64 * 8;
-  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  if (mm_dtype == STEDM_F16) pack_conv_weight_frag_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(w, (_Float16*)out, cout, cin, taps, total, (long)cin * taps, taps, 0);
-  else pack_conv_weight_frag_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(w, (__bf16*)out, cout, cin, taps, total, (long)cin * taps, taps, 0);
+  const int grid = ((cout + 127) / 128) * (cin / 16) * 2;
+  launch_pack_frag(w, out, cout, cin, taps, total, (long)cin * taps, taps, 0, mm_dtype, grid, as_stream(stream));
   STEDM_LAUNCH_CHECK();
   return 0;
 }
@@ -148,9 +174,8 @@ extern "C" int stedm_pack_conv_weight_strided(const float* w, long sn, long sc, 
   }
   if (w_frag) {
     const long total = (long)((cout + 127) / 128) * (cin / 16) * taps * 4 * 64 * 8;
-    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    if (mm_dtype == STEDM_F16) pack_conv_weight_frag_kernel<_Float16><<<grid, 256, 0, st>>>(w, (_Float16*)w_frag, cout, cin, taps, total, sn, sc, flip);
-    else pack_conv_weight_frag_kernel<__bf16><<<grid, 256, 0, st>>>(w, (__bf16*)w_frag, cout, cin, taps, total, sn, sc, flip);
+    const int grid = ((cout + 127) / 128) * (cin / 16) * 2;
+    launch_pack_frag(w, w_frag, cout, cin, taps, total, sn, sc, flip, mm_dtype, grid, st);
   }
   STEDM_LAUNCH_CHECK();
   return 0;

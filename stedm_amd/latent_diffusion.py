@@ -364,3 +364,13 @@ def predict_latents(model: S_ZSS_DM, ldm_batch: dict, ddim_steps: int, eta: floa
         out, _ = model.sample_log(c_0, batch_size=len(z), ddim=True, ddim_steps=ddim_steps, eta=eta, log_every_t=1000,
                                   unconditional_conditioning=c_uncond, unconditional_guidance_scale=cfg_scale, **kw)
     return out
+
+
+@torch.no_grad()
+def images_for_saving(decoded: torch.Tensor, segmentation_nhwc: Optional[torch.Tensor] = None):
+    """The array work of predict_step after decode_first_stage (modules/ldm_diffusion.py:93-99): decoded [B,3,H,W] fp32 -> uint8
+    [B,H,W,3] (clip to [-1,1], scale, truncate), segmentation [B,H,W,ncls] -> uint8 class map. Returned on the device; PNG
+    encoding stays with the caller."""
+    img = ops.image_to_uint8(decoded.float().contiguous())
+    seg = None if segmentation_nhwc is None else ops.argmax_u8(segmentation_nhwc.float().contiguous())
+    return img, seg

@@ -628,6 +628,24 @@ def adamw_ema(table: torch.Tensor, chunk_tensor: torch.Tensor, chunk_off: torch.
     check(lib().stedm_adamw_ema(table.data_ptr(), chunk_tensor.data_ptr(), chunk_off.data_ptr(), chunk_tensor.numel(), float(lr), float(beta1),
                                 float(beta2), float(eps), float(weight_decay), int(step), float(ema_decay), float(grad_scale), _stream()), "stedm_adamw_ema")
 
+# ------------------------------------------------------------------------------------------- image epilogue
+def image_to_uint8(x: torch.Tensor) -> torch.Tensor:
+    """((clip(x, -1, 1).permute(0, 2, 3, 1) + 1) * 127.5).astype(uint8) — x [B,C,H,W] fp32 -> [B,H,W,C] uint8 (ldm_diffusion.py:93-95)."""
+    _chk(x, name="x")
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, H, W, Cc), dtype=torch.uint8, device=x.device)
+    check(lib().stedm_image_to_uint8(x.data_ptr(), out.data_ptr(), B, Cc, H, W, _stream()), "stedm_image_to_uint8")
+    return out
+
+
+def argmax_u8(seg: torch.Tensor) -> torch.Tensor:
+    """torch.argmax(seg, dim=-1) as uint8 (ldm_diffusion.py:98): seg [..., ncls] fp32."""
+    _chk(seg, name="seg")
+    out = torch.empty(tuple(seg.shape[:-1]), dtype=torch.uint8, device=seg.device)
+    check(lib().stedm_argmax_u8(seg.data_ptr(), out.data_ptr(), out.numel(), seg.shape[-1], _stream()), "stedm_argmax_u8")
+    return out
+
+
 # ------------------------------------------------------------------------------------------- graphs
 class Graph:
     """hipGraph captured on the current torch stream (all buffers must be allocated beforehand)."""

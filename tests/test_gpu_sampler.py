@@ -201,3 +201,27 @@ def test_bench_step_graph_replay_equals_eager_and_tracks_parity_mode(dev):
     l2 = float((a - b).norm() / b.norm())
     print(f"[bench step x{nsteps}] bf16 vs parity mode latents: rel-L2 {l2:.3e}")
     assert l2 < 5e-3
+
+
+@pytest.mark.gpu
+def test_image_epilogue_is_bit_exact(dev):
+    """predict_step's uint8 conversion + segmentation argmax (ldm_diffusion.py:93-99): integer outputs, bit-exact against numpy,
+    including the clip limits, values next to them, and values that land on integer boundaries."""
+    from oracle import post as opost
+    from stedm_amd import ops
+    from stedm_amd.latent_diffusion import images_for_saving
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 3, 40, 24, generator=g) * 0.9
+    flat = x.view(-1)
+    k = torch.arange(256, dtype=torch.float32)
+    edge = torch.cat([k / 127.5 - 1.0, torch.nextafter(k / 127.5 - 1.0, torch.tensor(2.0)), torch.nextafter(k / 127.5 - 1.0, torch.tensor(-2.0)),
+                      torch.tensor([-1.0, 1.0, -1.5, 1.5, 0.0, -0.0, 0.9999999, -0.9999999])])
+    flat[: edge.numel()] = edge
+    seg = torch.rand(3, 40, 24, 2, generator=g)
+    seg[0, 0, :4] = torch.tensor([[0.5, 0.5], [1.0, 0.0], [0.0, 1.0], [0.25, 0.25]])     # ties -> first index
+    img, cls = images_for_saving(x.to(dev), seg.to(dev))
+    assert img.dtype == torch.uint8 and tuple(img.shape) == (3, 40, 24, 3)
+    assert np.array_equal(img.cpu().numpy(), opost.image_to_uint8(x.numpy()))
+    assert np.array_equal(cls.cpu().numpy(), opost.segmentation_to_uint8(seg.numpy()))
+    seg5 = torch.rand(2, 8, 8, 5, generator=g)
+    assert np.array_equal(ops.argmax_u8(seg5.to(dev)).cpu().numpy(), opost.segmentation_to_uint8(seg5.numpy()))
