@@ -319,6 +319,9 @@ int stedm_l1_loss(const float* pred, const float* target, long n, float grad_sca
  * [B][cin][H][W], d_out [B][cout][H>>n][W>>n] (= the c_concat slice of the U-Net's input gradient) -> dw [cout][cin]. ws: B*cin*cout floats. */
 int stedm_spatial_rescale_wgrad(const float* x, const float* d_out, float* ws, float* dw, int B, int cin, int cout, int H, int W,
                                 int n_stages, int accumulate, void* stream);
+/* y = alpha x + beta y over n floats (n %% 4 == 0): gradient accumulation across micro-batches (Trainer(accumulate_grad_batches),
+ * train_diff.py). */
+int stedm_axpby_f32(const float* x, float* y, long n, float alpha, float beta, void* stream);
 /* AdamW + EMA over many tensors: table [ntensors] of {float* p, const float* g, float* m, float* v, float* ema|NULL, long n};
  * block i updates elements [chunk_off[i], chunk_off[i] + 4096) of tensor chunk_tensor[i]. step counts from 1. */
 int stedm_adamw_ema(const void* table, const int* chunk_tensor, const long* chunk_off, int nchunks, float lr, float beta1,

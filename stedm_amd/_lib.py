@@ -97,6 +97,7 @@ SIGNATURES = {
     "stedm_silu": (_I, [_P, _P, _P, C.c_long, _I, _P]),
     "stedm_l1_loss": (_I, [_P, _P, C.c_long, _F, _P, _P, _P, _P]),
     "stedm_spatial_rescale_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "stedm_axpby_f32": (_I, [_P, _P, C.c_long, _F, _F, _P]),
     "stedm_adamw_ema": (_I, [_P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _F, _F, _P]),
     "stedm_image_to_uint8": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "stedm_argmax_u8": (_I, [_P, _P, C.c_long, _I, _P]),

@@ -412,6 +412,16 @@ __global__ void silu_kernel(const float* __restrict__ x, const float* __restrict
   out[i] = mode == 0 ? silu_f(x[i]) : dy[i] * silu_grad(x[i]);
 }
 
+// y = alpha * x + beta * y (gradient accumulation over micro-batches: accumulate_grad_batches of the reference's Trainer)
+__global__ void axpby_kernel(const float* __restrict__ x, float* __restrict__ y, long n4, float alpha, float beta) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 a = reinterpret_cast<const float4*>(x)[i];
+  float4 b = reinterpret_cast<float4*>(y)[i];
+  b.x = alpha * a.x + beta * b.x; b.y = alpha * a.y + beta * b.y; b.z = alpha * a.z + beta * b.z; b.w = alpha * a.w + beta * b.w;
+  reinterpret_cast<float4*>(y)[i] = b;
+}
+
 // ------------------------------------------------------------------------------------------------ loss
 // L1 (ddpm.py:282-295, 1030-1040): loss = mean |target - pred|; dpred = sign(pred - target) * scale / n
 __global__ void __launch_bounds__(256) l1_partial_kernel(const float* __restrict__ pred, const float* __restrict__ target, float* __restrict__ dpred, long n,
@@ -617,6 +627,13 @@ extern "C" int stedm_gemm_f32(const float* A, long lda, int trans_a, const float
 extern "C" int stedm_silu(const float* x, const float* dy, float* out, long n, int mode, void* stream) {
   STEDM_CHECK_ARG(x && out && (mode == 0 || dy), "silu: bad args");
   silu_kernel<<<(unsigned)((n + 255) / 256), 256, 0, as_stream(stream)>>>(x, dy, out, n, mode);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int stedm_axpby_f32(const float* x, float* y, long n, float alpha, float beta, void* stream) {
+  STEDM_CHECK_ARG(x && y && n > 0 && n % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0), "axpby_f32: n %% 4 and 16-B alignment required");
+  axpby_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, as_stream(stream)>>>(x, y, n / 4, alpha, beta);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

@@ -623,6 +623,14 @@ def spatial_rescale_wgrad(x: torch.Tensor, d_out: torch.Tensor, dw: torch.Tensor
     return dw
 
 
+def axpby(x: torch.Tensor, y: torch.Tensor, alpha: float = 1.0, beta: float = 1.0) -> torch.Tensor:
+    """y = alpha * x + beta * y (flat fp32 tensors, numel % 4 == 0)."""
+    _chk(x, name="x"); _chk(y, name="y")
+    assert x.numel() == y.numel()
+    check(lib().stedm_axpby_f32(x.data_ptr(), y.data_ptr(), x.numel(), float(alpha), float(beta), _stream()), "stedm_axpby_f32")
+    return y
+
+
 def adamw_ema(table: torch.Tensor, chunk_tensor: torch.Tensor, chunk_off: torch.Tensor, lr: float, beta1: float, beta2: float, eps: float,
               weight_decay: float, step: int, ema_decay: float, grad_scale: float = 1.0) -> None:
     check(lib().stedm_adamw_ema(table.data_ptr(), chunk_tensor.data_ptr(), chunk_off.data_ptr(), chunk_tensor.numel(), float(lr), float(beta1),

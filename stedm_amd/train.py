@@ -35,8 +35,10 @@ class UNetTrainer:
     land in their `.grad`, so DDP-style all-reduce and checkpointing see the usual tensors)."""
 
     def __init__(self, unet: UNetModel, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                 ema_decay: Optional[float] = 0.9999):
+                 ema_decay: Optional[float] = 0.9999, accumulate_grad_batches: int = 1):
         self.m = unet
+        self.accumulate_grad_batches = int(accumulate_grad_batches)      # Trainer(accumulate_grad_batches=...) of train_diff.py
+        self._micro = 0
         self.lr, self.betas, self.eps, self.wd = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
         self.ema_decay = ema_decay
         self.step_count = 0
@@ -92,7 +94,7 @@ class UNetTrainer:
         emb_w = [rb.emb_layers[1].weight for rb, _ in m._emb_layout]
         seen = {id(p) for p in emb_w}
         order = emb_w + [p for p in m.parameters() if id(p) not in seen]
-        total = sum(p.numel() for p in order)
+        total = (sum(p.numel() for p in order) + 3) // 4 * 4
         self.grad_arena = torch.zeros((total,), dtype=torch.float32, device=order[0].device)
         off = 0
         for p in order:
@@ -527,8 +529,25 @@ class UNetTrainer:
 
     @torch.no_grad()
     def train_step(self, x, c_concat, t, context, target, group=None) -> torch.Tensor:
+        """One micro-batch: loss + backward; every `accumulate_grad_batches`-th call also all-reduces (data parallel) and steps the
+        optimizer on the mean of the accumulated gradients (Lightning divides the loss by the accumulation count)."""
         import torch.distributed as dist
         loss, _, _ = self.loss_and_backward(x, c_concat, t, context, target)
+        k = self.accumulate_grad_batches
+        if k > 1:
+            if self._micro == 0:
+                self._acc_arena = getattr(self, "_acc_arena", None)
+                if self._acc_arena is None:
+                    self._acc_arena = torch.empty_like(self.grad_arena)
+                ops.axpby(self.grad_arena, self._acc_arena, 1.0 / k, 0.0)
+            else:
+                ops.axpby(self.grad_arena, self._acc_arena, 1.0 / k, 1.0)
+            self._micro += 1
+            if self._micro < k:
+                self._grads_ready = False
+                return loss
+            ops.axpby(self._acc_arena, self.grad_arena, 1.0, 0.0)      # the optimizer table points at the gradient arena
+            self._micro = 0
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             self.all_reduce_grads(group)
         self.optimizer_step()

@@ -164,3 +164,19 @@ def test_spatial_rescaler_weight_gradient_vs_oracle(dev):
     assert torch.allclose(g.cpu(), w.grad, rtol=1e-5, atol=1e-5)
     g2 = m.backward(x.to(dev), d.to(dev), accumulate=True)
     assert torch.allclose(g2.cpu(), 2 * w.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_gradient_accumulation_equals_the_full_batch(dev, golden):
+    """accumulate_grad_batches = 2 over the two samples of the F14 case reproduces the full-batch gradient of the reference (the L1 loss is a
+    mean of per-sample means); the optimizer runs only on the second micro-batch."""
+    from stedm_amd.train import UNetTrainer
+    fx = golden("f14_grads_tiny")
+    m = build(TINY, 6, dev)
+    tr = UNetTrainer(m, lr=0.0, weight_decay=0.0, accumulate_grad_batches=2)
+    x, ctx, target = _inputs("tiny", TINY, 2, 16, 6, dev)
+    t = torch.from_numpy(fx["t"]).to(dev)
+    for i in range(2):
+        sl = slice(i, i + 1)
+        tr.train_step(x[sl, :4].contiguous(), x[sl, 4:].contiguous(), t[sl], ctx[sl].contiguous(), target[sl].contiguous())
+        assert tr.step_count == i          # 0 after the first micro-batch, 1 after the second
+    _check_grads(m, fx, 1e-3, "accumulated")
