@@ -237,14 +237,29 @@ __global__ void __launch_bounds__(256) im2col_t16_kernel(const uint16_t* __restr
   }
 }
 
-// dw [taps][cin_ld][cout_ld] fp32 (GEMM result) -> grad OIHW [cout][cin][taps] (+= when accumulate)
-__global__ void wgrad_to_oihw_kernel(const float* __restrict__ dw, float* __restrict__ grad, int cout, int cin, int taps, int cin_ld, int cout_ld,
-                                     int accumulate, long total) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int tap = (int)(i % taps), ci = (int)((i / taps) % cin), co = (int)(i / ((long)taps * cin));
-  const float v = dw[((long)tap * cin_ld + ci) * cout_ld + co];
-  grad[i] = (accumulate ? grad[i] : 0.f) + v;
+// dw [taps][cin_ld][cout_ld] fp32 (GEMM result) -> grad OIHW [cout][cin][taps] (+= when accumulate).
+// grid (ceil(cout/32), ceil(cin/16)): a [taps][16 ci][32 co] block goes through LDS: 128-B runs in, (16 ci x taps)-float runs out.
+__global__ void __launch_bounds__(256) wgrad_to_oihw_kernel(const float* __restrict__ dw, float* __restrict__ grad, int cout, int cin, int taps, int cin_ld,
+                                                            int cout_ld, int accumulate) {
+  __shared__ float tile[9 * 16][33];
+  const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 16;
+  for (int e = threadIdx.x; e < taps * 16 * 32; e += 256) {
+    const int col = e & 31, r = e >> 5;               // r = tap * 16 + ci_local
+    const int tap = r >> 4, cil = r & 15;
+    const int co = co0 + col, ci = ci0 + cil;
+    tile[r][col] = (co < cout && ci < cin) ? dw[((long)tap * cin_ld + ci) * cout_ld + co] : 0.f;
+  }
+  __syncthreads();
+  const int run = 16 * taps;                          // contiguous floats of one output row: [ci0 .. ci0+15][taps]
+  for (int e = threadIdx.x; e < 32 * run; e += 256) {
+    const int col = e / run, k = e - col * run;       // k = ci_local * taps + tap
+    const int cil = k / taps, tap = k - cil * taps;
+    const int co = co0 + col, ci = ci0 + cil;
+    if (co < cout && ci < cin) {
+      const long o = ((long)co * cin + ci) * taps + tap;
+      grad[o] = (accumulate ? grad[o] : 0.f) + tile[tap * 16 + cil][col];
+    }
+  }
 }
 
 // cs [B][nslab][C][2] (sums in [..][0]) -> per_sample[b*ld + c] (optional) and total[c] (+= when accumulate; optional)
@@ -300,12 +315,15 @@ __global__ void zero_insert16_kernel(const float* __restrict__ in, T* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------ attention backward
-// QKVAttentionLegacy (openaimodel.py:378-394) reversed; one block per (sample, head); P and dS live in LDS ([T][T] fp32 each).
+// QKVAttentionLegacy (openaimodel.py:378-394) reversed; one block per (sample, head); P and dS live in LDS ([T][T] fp32 each), the
+// q / k / v / dO operands are staged through LDS 32 channels at a time ([T][33] images).
 __global__ void __launch_bounds__(256) attn_legacy_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, float* __restrict__ dqkv, int T,
                                                               int heads, int ch) {
   extern __shared__ float sm[];
   float* P = sm;
   float* dS = sm + (long)T * T;
+  float* st = dS + (long)T * T;            // 4 staging images [T][33]
+  float* sq = st; float* sk = st + T * 33; float* sv = st + 2 * T * 33; float* sg = st + 3 * T * 33;
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
   const long ld = (long)heads * 3 * ch, ldo = (long)heads * ch;
   const float* q = qkv + (long)b * T * ld + (long)h * 3 * ch;
@@ -316,21 +334,34 @@ __global__ void __launch_bounds__(256) attn_legacy_bwd_kernel(const float* __res
   float* dk = dq + ch;
   float* dv = dq + 2 * ch;
   const float s2 = 1.0f / sqrtf((float)ch);   // (ch^-1/4)^2: the scale sits on both q and k
-  for (int e = threadIdx.x; e < T * T; e += 256) {
-    const int i = e / T, j = e % T;
-    float acc = 0.f, accp = 0.f;
-    for (int c = 0; c < ch; c += 4) {
-      const float4 a = *reinterpret_cast<const float4*>(q + i * ld + c), bb = *reinterpret_cast<const float4*>(k + j * ld + c);
-      acc += a.x * bb.x + a.y * bb.y + a.z * bb.z + a.w * bb.w;
-      const float4 g = *reinterpret_cast<const float4*>(go + i * ldo + c), vv = *reinterpret_cast<const float4*>(v + j * ld + c);
-      accp += g.x * vv.x + g.y * vv.y + g.z * vv.z + g.w * vv.w;
+  auto stage = [&](int c0) {
+    for (int e = threadIdx.x; e < T * 32; e += 256) {
+      const int r = e >> 5, c = e & 31;
+      const bool ok = c0 + c < ch;
+      sq[r * 33 + c] = ok ? q[r * ld + c0 + c] : 0.f;
+      sk[r * 33 + c] = ok ? k[r * ld + c0 + c] : 0.f;
+      sv[r * 33 + c] = ok ? v[r * ld + c0 + c] : 0.f;
+      sg[r * 33 + c] = ok ? go[r * ldo + c0 + c] : 0.f;
     }
-    P[e] = acc * s2; dS[e] = accp;
+  };
+  // S = s2 q k^T and dP = dO v^T, accumulated over channel chunks (each thread owns entries e = tid + 256 n of the T x T matrices)
+  for (int e = threadIdx.x; e < T * T; e += 256) { P[e] = 0.f; dS[e] = 0.f; }
+  for (int c0 = 0; c0 < ch; c0 += 32) {
+    __syncthreads();
+    stage(c0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < T * T; e += 256) {
+      const int i = e / T, j = e - i * T;
+      float acc = 0.f, accp = 0.f;
+#pragma unroll 8
+      for (int c = 0; c < 32; ++c) { acc += sq[i * 33 + c] * sk[j * 33 + c]; accp += sg[i * 33 + c] * sv[j * 33 + c]; }
+      P[e] += acc; dS[e] += accp;
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < T; i += 256) {   // softmax row i, then dS = P * (dP - sum_j P*dP)
     float m = -INFINITY;
-    for (int j = 0; j < T; ++j) m = fmaxf(m, P[i * T + j]);
+    for (int j = 0; j < T; ++j) { const float x = P[i * T + j] * s2; P[i * T + j] = x; m = fmaxf(m, x); }
     float s = 0.f;
     for (int j = 0; j < T; ++j) { const float e = __expf(P[i * T + j] - m); P[i * T + j] = e; s += e; }
     const float inv = 1.0f / s;
@@ -338,16 +369,22 @@ __global__ void __launch_bounds__(256) attn_legacy_bwd_kernel(const float* __res
     for (int j = 0; j < T; ++j) { const float p = P[i * T + j] * inv; P[i * T + j] = p; delta += p * dS[i * T + j]; }
     for (int j = 0; j < T; ++j) dS[i * T + j] = P[i * T + j] * (dS[i * T + j] - delta);
   }
-  __syncthreads();
-  for (int e = threadIdx.x; e < T * ch; e += 256) {
-    const int r = e / ch, c = e % ch;
-    float av = 0.f, aq = 0.f, ak = 0.f;
-    for (int j = 0; j < T; ++j) {
-      av += P[j * T + r] * go[j * ldo + c];       // dV[r] = sum_i P[i][r] dO[i]
-      aq += dS[r * T + j] * k[j * ld + c];        // dQ[r] = s2 sum_j dS[r][j] K[j]
-      ak += dS[j * T + r] * q[j * ld + c];        // dK[r] = s2 sum_i dS[i][r] Q[i]
+  // dV[r] = sum_i P[i][r] dO[i]; dQ[r] = s2 sum_j dS[r][j] K[j]; dK[r] = s2 sum_i dS[i][r] Q[i], 32 channels at a time
+  for (int c0 = 0; c0 < ch; c0 += 32) {
+    __syncthreads();
+    stage(c0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < T * 32; e += 256) {
+      const int r = e >> 5, c = e & 31;
+      if (c0 + c >= ch) continue;
+      float av = 0.f, aq = 0.f, ak = 0.f;
+      for (int j = 0; j < T; ++j) {
+        av += P[j * T + r] * sg[j * 33 + c];
+        aq += dS[r * T + j] * sk[j * 33 + c];
+        ak += dS[j * T + r] * sq[j * 33 + c];
+      }
+      dv[r * ld + c0 + c] = av; dq[r * ld + c0 + c] = aq * s2; dk[r * ld + c0 + c] = ak * s2;
     }
-    dv[r * ld + c] = av; dq[r * ld + c] = aq * s2; dk[r * ld + c] = ak * s2;
   }
 }
 
@@ -565,8 +602,8 @@ extern "C" int stedm_im2col_t16(const void* src16, void* dst16, int B, int Hs, i
 
 extern "C" int stedm_wgrad_to_oihw(const float* dw, float* grad, int cout, int cin, int taps, int cin_ld, int cout_ld, int accumulate, void* stream) {
   STEDM_CHECK_ARG(dw && grad && cin_ld >= cin && cout_ld >= cout, "wgrad_to_oihw: bad args");
-  const long total = (long)cout * cin * taps;
-  wgrad_to_oihw_kernel<<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(dw, grad, cout, cin, taps, cin_ld, cout_ld, accumulate, total);
+  STEDM_CHECK_ARG(taps >= 1 && taps <= 9, "wgrad_to_oihw: taps must be 1..9");
+  wgrad_to_oihw_kernel<<<dim3((cout + 31) / 32, (cin + 15) / 16), 256, 0, as_stream(stream)>>>(dw, grad, cout, cin, taps, cin_ld, cout_ld, accumulate);
   STEDM_LAUNCH_CHECK();
   return 0;
 }
@@ -598,8 +635,8 @@ extern "C" int stedm_zero_insert16(const float* in, void* hi, void* lo, int B, i
 
 extern "C" int stedm_attn_legacy_bwd(const float* qkv, const float* d_out, float* d_qkv, int B, int T, int heads, int ch, void* stream) {
   STEDM_CHECK_ARG(qkv && d_out && d_qkv && ch % 4 == 0, "attn_legacy_bwd: bad args");
-  const size_t lds = (size_t)T * T * 8;
-  STEDM_CHECK_ARG(lds <= 160 * 1024 - 1024, "attn_legacy_bwd: T = %d tokens exceed the LDS-resident form (T <= 140)", T);
+  const size_t lds = (size_t)T * T * 8 + (size_t)4 * T * 33 * 4;
+  STEDM_CHECK_ARG(lds <= 160 * 1024 - 1024, "attn_legacy_bwd: T = %d tokens exceed the LDS-resident form (T <= 128)", T);
   static bool attr = false;
   if (!attr) { STEDM_HIP_TRY(hipFuncSetAttribute((const void*)attn_legacy_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)); attr = true; }
   attn_legacy_bwd_kernel<<<B * heads, 256, lds, as_stream(stream)>>>(qkv, d_out, d_qkv, T, heads, ch);
