@@ -292,9 +292,17 @@ long stedm_gn_bwd_ws_floats(int B, int HW, int C, int groups);
 /* 16-bit NHWC planes [B][Hs][Ws][C] -> transposed im2col [(tap*C + c)][Ppad] over the conv's output grid (mode 0 stride 1,
  * 1 nearest-2x upsample + conv (openaimodel.py:129-131), 2 stride 2 pad 1 (:164-166)); pixels >= P are zero. */
 int stedm_im2col_t16(const void* src16, void* dst16, int B, int Hs, int Ws, int C, int ks, int mode, long Ppad, void* stream);
-/* GEMM result dw [taps][cin_ld][cout_ld] -> OIHW gradient [cout][cin][taps] (accumulate: +=). */
+/* GEMM result dw [nsplit][taps][cin_ld][cout_ld] (nsplit split-K partials, summed in order) -> OIHW gradient [cout][cin][taps]
+ * (accumulate: +=). */
 int stedm_wgrad_to_oihw(const float* dw, float* grad, int cout, int cin, int taps, int cin_ld, int cout_ld, int accumulate,
-                        void* stream);
+                        int nsplit, void* stream);
+/* Direct weight gradient of a stride-1 3x3 pad-1 convolution from the NHWC 16-bit planes (no im2col): x16 [B][H][W][Cin], dy16
+ * [B][H][W][Cout] (bf16) -> part [ksplit][9][Cin][Cout] fp32 partials (then stedm_wgrad_to_oihw with nsplit = ksplit).
+ * stedm_wgrad3x3_plan returns 1 when the shape is supported (W in {8,16,32}, H %% (64/W) == 0, Cin %% 128 == 0, Cout %% 64 == 0) and
+ * the split it will use. */
+int stedm_wgrad3x3_plan(int B, int H, int W, int Cin, int Cout, int* ksplit);
+int stedm_wgrad3x3(const void* x16, const void* dy16, float* part, int B, int H, int W, int Cin, int Cout, int mm_dtype,
+                   void* stream);
 /* chan partials cs [B][nslab][C][2] -> per-sample channel sums per_sample[b*ld + c] (NULL: skip) and their batch total
  * total[c] (bias gradients; the per-sample sums are the gradient of the emb_layers output, openaimodel.py:277-280). */
 int stedm_chan_sum_fold(const float* cs, int B, int nslab, int C, float* per_sample, long ld, float* total, int accumulate,

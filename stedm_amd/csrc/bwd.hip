@@ -240,14 +240,17 @@ __global__ void __launch_bounds__(256) im2col_t16_kernel(const uint16_t* __restr
 // dw [taps][cin_ld][cout_ld] fp32 (GEMM result) -> grad OIHW [cout][cin][taps] (+= when accumulate).
 // grid (ceil(cout/32), ceil(cin/16)): a [taps][16 ci][32 co] block goes through LDS: 128-B runs in, (16 ci x taps)-float runs out.
 __global__ void __launch_bounds__(256) wgrad_to_oihw_kernel(const float* __restrict__ dw, float* __restrict__ grad, int cout, int cin, int taps, int cin_ld,
-                                                            int cout_ld, int accumulate) {
+                                                            int cout_ld, int accumulate, int nsplit) {
   __shared__ float tile[9 * 16][33];
   const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 16;
   for (int e = threadIdx.x; e < taps * 16 * 32; e += 256) {
     const int col = e & 31, r = e >> 5;               // r = tap * 16 + ci_local
     const int tap = r >> 4, cil = r & 15;
     const int co = co0 + col, ci = ci0 + cil;
-    tile[r][col] = (co < cout && ci < cin) ? dw[((long)tap * cin_ld + ci) * cout_ld + co] : 0.f;
+    float v = 0.f;
+    if (co < cout && ci < cin)
+      for (int z = 0; z < nsplit; ++z) v += dw[(((long)z * taps + tap) * cin_ld + ci) * cout_ld + co];    // split-K partials, fixed order
+    tile[r][col] = v;
   }
   __syncthreads();
   const int run = 16 * taps;                          // contiguous floats of one output row: [ci0 .. ci0+15][taps]
@@ -600,10 +603,11 @@ extern "C" int stedm_im2col_t16(const void* src16, void* dst16, int B, int Hs, i
   return 0;
 }
 
-extern "C" int stedm_wgrad_to_oihw(const float* dw, float* grad, int cout, int cin, int taps, int cin_ld, int cout_ld, int accumulate, void* stream) {
-  STEDM_CHECK_ARG(dw && grad && cin_ld >= cin && cout_ld >= cout, "wgrad_to_oihw: bad args");
+extern "C" int stedm_wgrad_to_oihw(const float* dw, float* grad, int cout, int cin, int taps, int cin_ld, int cout_ld, int accumulate, int nsplit,
+                                   void* stream) {
+  STEDM_CHECK_ARG(dw && grad && cin_ld >= cin && cout_ld >= cout && nsplit >= 1, "wgrad_to_oihw: bad args");
   STEDM_CHECK_ARG(taps >= 1 && taps <= 9, "wgrad_to_oihw: taps must be 1..9");
-  wgrad_to_oihw_kernel<<<dim3((cout + 31) / 32, (cin + 15) / 16), 256, 0, as_stream(stream)>>>(dw, grad, cout, cin, taps, cin_ld, cout_ld, accumulate);
+  wgrad_to_oihw_kernel<<<dim3((cout + 31) / 32, (cin + 15) / 16), 256, 0, as_stream(stream)>>>(dw, grad, cout, cin, taps, cin_ld, cout_ld, accumulate, nsplit);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,194 @@
+// Direct weight-gradient kernel of the stride-1 3x3 convolutions (training step):
+//   dW[tap][ci][co] = sum over (b, y, x) of X[b][y + ky - 1][x + kx - 1][ci] * dY[b][y][x][co]        (zero padding)
+// as nine GEMMs that share both operands: the contraction index is the PIXEL, which is the slow index of the NHWC planes, so the
+// MFMA fragments (8 consecutive k per lane) are read from LDS with the transposing read ds_read_b64_tr_b16. A workgroup owns a
+// 128 (ci) x 64 (co) block of all nine taps (8 waves, two per SIMD, each 32 x 32 x 9 taps = 144 accumulator registers) and walks the pixels in
+// units of 64 (whole rows of one image): per unit the haloed patch of X (zero rows / columns for the padding) and the 64 dY rows
+// are brought to LDS once and serve all nine taps — the tap is just a different LDS row per k. Compared with the im2col + GEMM form
+// (stedm_im2col_t16 + conv_rs_kernel) no 9x expanded copy of X exists and the L1 traffic per MFMA is ~5x lower.
+// K (the units) is split over `ksplit` workgroups per block of dW; partials are summed in a fixed order by stedm_wgrad_to_oihw.
+#include "conv_common.hpp"
+
+using namespace stedm;
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct WgradArgs {
+  const uint16_t* x16;    // [B][H][W][Cin]
+  const uint16_t* dy16;   // [B][H][W][Cout]
+  float* part;            // [ksplit][9][Cin][Cout]
+  int B, H, W, Cin, Cout;
+  int wshift;             // log2(W)
+  int upr;                // image rows per unit (64 / W)
+  int upi;                // units per image (H / upr)
+  int nunits;             // B * upi
+  int ksplit, tiles_n;    // tiles_n = Cout / 64
+  int NP, PW;             // patch positions (upr + 2) * (W + 2), patch width W + 2
+};
+
+constexpr int WG_NPMAX = 136;                 // (2 + 2) * (32 + 2)
+// LDS images are plain rows with a padded pitch: the 4 rows x 32 B a 16-lane group reads transposed land on banks 16q + 8(g&1) + 2p
+// (X: 128 channels = 256 B + 64 B pad) / 48q + ... (dY: 64 channels = 128 B + 64 B pad), distinct for 4 consecutive rows. A linear
+// image keeps every read address = per-lane base + compile-time constant (tap and block offsets are ds_read immediates).
+constexpr int WG_XS = 320, WG_YS = 192;
+constexpr int WG_XBUF = WG_NPMAX * WG_XS;
+constexpr int WG_YBUF = 64 * WG_YS;
+
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* base, int off_lo, int off_hi) {
+  typedef __attribute__((address_space(3))) s16x4* lp;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base + off_lo));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base + off_hi));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int W>
+__global__ void __launch_bounds__(512) wgrad3x3_kernel(WgradArgs a) {
+  constexpr int PW = W + 2, WSH = W == 8 ? 3 : (W == 16 ? 4 : 5), NP = (64 / W + 2) * PW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sX = smem;                   // [2][WG_XBUF]
+  unsigned char* sY = smem + 2 * WG_XBUF;     // [2][WG_YBUF]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 3, wn = wave >> 2;   // 8 waves (2 per SIMD): each 32 input channels x 32 output channels x 9 taps = 144 accumulators
+  const int ntile = (a.Cin / 128) * a.tiles_n;
+  const int tile = blockIdx.x % ntile, kz = blockIdx.x / ntile;
+  const int ci0 = (tile / a.tiles_n) * 128, co0 = (tile % a.tiles_n) * 64;
+  const int per = (a.nunits + a.ksplit - 1) / a.ksplit;
+  const int u0 = kz * per, u1 = min(a.nunits, u0 + per);
+
+  // ---- staging registers: 16-B chunks of the next unit's X patch (<= 9 per thread) and dY rows (2 per thread)
+  constexpr int NXI = (WG_NPMAX * 16 + 511) / 512;
+  uint4 rx[NXI], ry[1];
+  auto load_unit = [&](int u) {
+    const int b = u / a.upi, y0 = (u - b * a.upi) * a.upr;
+#pragma unroll
+    for (int j = 0; j < NXI; ++j) {
+      const int i = tid + 512 * j, row = i >> 4, ch = i & 15;
+      rx[j] = make_uint4(0, 0, 0, 0);
+      if (row < NP) {
+        const int pr = row / PW, pc = row - pr * PW;
+        const int y = y0 + pr - 1, x = pc - 1;
+        if (y >= 0 && y < a.H && x >= 0 && x < W)
+          rx[j] = *reinterpret_cast<const uint4*>(a.x16 + (((long)b * a.H + y) * W + x) * a.Cin + ci0 + ch * 8);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 1; ++j) {
+      const int i = tid + 512 * j, k = i >> 3, ch = i & 7;
+      const int y = y0 + (k >> WSH), x = k & (W - 1);
+      ry[j] = *reinterpret_cast<const uint4*>(a.dy16 + (((long)b * a.H + y) * W + x) * a.Cout + co0 + ch * 8);
+    }
+  };
+  auto store_unit = [&](int buf) {
+    unsigned char* dx = sX + buf * WG_XBUF;
+    unsigned char* dy = sY + buf * WG_YBUF;
+#pragma unroll
+    for (int j = 0; j < NXI; ++j) {
+      const int i = tid + 512 * j, row = i >> 4, ch = i & 15;
+      if (row < NP) *reinterpret_cast<uint4*>(dx + row * WG_XS + ch * 16) = rx[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 1; ++j) {
+      const int i = tid + 512 * j, k = i >> 3, ch = i & 7;
+      *reinterpret_cast<uint4*>(dy + k * WG_YS + ch * 16) = ry[j];
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  // ---- per-lane constants of the transposed reads: group g = lane >> 4 (h = g >> 1 selects k 8h..8h+7, g & 1 the 16-column half),
+  //      lane 4q + p of the group addresses row q, columns 4p..4p+3 of the 4 x 16 block
+  const int g = lane >> 4, h = g >> 1, q = (lane & 15) >> 2, p = lane & 3;
+  const int colA = (wm * 32 + 16 * (g & 1)) * 2 + 8 * p;   // byte offset of this lane's 4 columns inside an X row
+  const int colB = (wn * 32 + 16 * (g & 1)) * 2 + 8 * p;   // ... inside a dY row
+
+  if (u0 < u1) { load_unit(u0); store_unit(0); }
+  __syncthreads();
+  for (int u = u0; u < u1; ++u) {
+    const int buf = (u - u0) & 1;
+    if (u + 1 < u1) load_unit(u + 1);
+    const unsigned char* px = sX + buf * WG_XBUF;
+    const unsigned char* py = sY + buf * WG_YBUF;
+#pragma unroll 1
+    for (int s = 0; s < 4; ++s) {
+      const int k_lo = 16 * s + 8 * h + q, k_hi = k_lo + 4;            // this lane's block rows (pixels of the unit)
+      const bf16x8 bf = tr_pair(py, k_lo * WG_YS + colB, k_hi * WG_YS + colB);
+      // patch row of tap (0, 0); tap (ky, kx) adds the compile-time constant (ky * PW + kx) rows
+      const int a_lo = ((k_lo >> WSH) * PW + (k_lo & (W - 1))) * WG_XS + colA;
+      const int a_hi = ((k_hi >> WSH) * PW + (k_hi & (W - 1))) * WG_XS + colA;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int toff = ((t / 3) * PW + (t % 3)) * WG_XS;
+        const bf16x8 af = tr_pair(px, a_lo + toff, a_hi + toff);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+      }
+    }
+    if (u + 1 < u1) store_unit(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- partial dW[kz][tap][ci][co]
+  const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float* dst = a.part + (((long)kz * 9 + t) * a.Cin + ci0 + wm * 32) * a.Cout + co0 + wn * 32 + col;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dst[(long)((e & 3) + 8 * (e >> 2) + 4 * hh) * a.Cout] = acc[t][e];
+  }
+}
+
+}  // namespace
+
+// 1 when stedm_wgrad3x3 supports the shape, and the split it would use in *ksplit (for sizing `part`: ksplit * 9 * Cin * Cout floats)
+extern "C" int stedm_wgrad3x3_plan(int B, int H, int W, int Cin, int Cout, int* ksplit) {
+  if (ksplit) *ksplit = 0;
+  if (B <= 0 || H <= 0 || (W != 8 && W != 16 && W != 32) || Cin % 128 != 0 || Cout % 64 != 0 || H % (64 / W) != 0) return 0;
+  static int cus = 0;
+  if (cus == 0) { cus = stedm_device_cus(); if (cus <= 0) cus = 256; }
+  const int tiles = (Cin / 128) * (Cout / 64), nunits = B * (H / (64 / W));
+  int ks = (cus + tiles - 1) / tiles;            // one round of the chip (one workgroup is resident per CU); every extra slice costs a
+  if (ks > 16) ks = 16;                          // 9*Cin*Cout partial in HBM (written here, read by the reduce)
+  if (ks > nunits / 4) ks = nunits / 4;          // and >= 4 units per slice
+  if (ks < 1) ks = 1;
+  const int per = (nunits + ks - 1) / ks;
+  ks = (nunits + per - 1) / per;                 // no empty slices
+  if (ksplit) *ksplit = ks;
+  return 1;
+}
+
+extern "C" int stedm_wgrad3x3(const void* x16, const void* dy16, float* part, int B, int H, int W, int Cin, int Cout, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(x16 && dy16 && part, "wgrad3x3: null pointer");
+  STEDM_CHECK_ARG(mm_dtype == STEDM_BF16, "wgrad3x3: bf16 operands only (the backward pass's operand format)");
+  int ks = 0;
+  STEDM_CHECK_ARG(stedm_wgrad3x3_plan(B, H, W, Cin, Cout, &ks) == 1, "wgrad3x3: unsupported shape (W in {8,16,32}, H %% (64/W) == 0, Cin %% 128 == 0, Cout %% 64 == 0)");
+  STEDM_CHECK_ARG((long)B * H * W * (Cin > Cout ? Cin : Cout) < (1L << 31), "wgrad3x3: tensor too large");
+  WgradArgs a;
+  a.x16 = (const uint16_t*)x16; a.dy16 = (const uint16_t*)dy16; a.part = part;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.wshift = W == 8 ? 3 : (W == 16 ? 4 : 5);
+  a.upr = 64 / W; a.upi = H / a.upr; a.nunits = B * a.upi;
+  a.ksplit = ks; a.tiles_n = Cout / 64;
+  a.PW = W + 2; a.NP = (a.upr + 2) * a.PW;
+  const size_t lds = 2 * WG_XBUF + 2 * WG_YBUF;
+  static bool attr = false;
+  if (!attr) {
+    STEDM_HIP_TRY(hipFuncSetAttribute((const void*)wgrad3x3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    STEDM_HIP_TRY(hipFuncSetAttribute((const void*)wgrad3x3_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    STEDM_HIP_TRY(hipFuncSetAttribute((const void*)wgrad3x3_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  const int grid = (Cin / 128) * a.tiles_n * ks;
+  hipStream_t st = as_stream(stream);
+  if (W == 8) wgrad3x3_kernel<8><<<grid, 512, lds, st>>>(a);
+  else if (W == 16) wgrad3x3_kernel<16><<<grid, 512, lds, st>>>(a);
+  else wgrad3x3_kernel<32><<<grid, 512, lds, st>>>(a);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}

@@ -553,11 +553,27 @@ def im2col_t16(src16: torch.Tensor, dst16: torch.Tensor, ks: int, mode: int) -> 
     check(lib().stedm_im2col_t16(src16.data_ptr(), dst16.data_ptr(), B, Hs, Ws, Cc, ks, mode, dst16.shape[1], _stream()), "stedm_im2col_t16")
 
 
-def wgrad_to_oihw(dw: torch.Tensor, grad: torch.Tensor, cin_ld: int, cout_ld: int, accumulate: bool) -> None:
+def wgrad_to_oihw(dw: torch.Tensor, grad: torch.Tensor, cin_ld: int, cout_ld: int, accumulate: bool, nsplit: int = 1) -> None:
     cout, cin = grad.shape[0], grad.shape[1]
     taps = grad.numel() // (cout * cin)
     _chk(grad, name="grad")
-    check(lib().stedm_wgrad_to_oihw(dw.data_ptr(), grad.data_ptr(), cout, cin, taps, cin_ld, cout_ld, int(accumulate), _stream()), "stedm_wgrad_to_oihw")
+    check(lib().stedm_wgrad_to_oihw(dw.data_ptr(), grad.data_ptr(), cout, cin, taps, cin_ld, cout_ld, int(accumulate), nsplit, _stream()),
+          "stedm_wgrad_to_oihw")
+
+
+def wgrad3x3_plan(B: int, H: int, W: int, cin: int, cout: int) -> int:
+    """split count of the direct 3x3 weight-gradient kernel for this shape, 0 when the shape is not supported"""
+    ks = C.c_int(0)
+    return ks.value if lib().stedm_wgrad3x3_plan(B, H, W, cin, cout, C.byref(ks)) else 0
+
+
+def wgrad3x3(x16: torch.Tensor, dy16: torch.Tensor, part: torch.Tensor, prec: Precision) -> None:
+    """x16 [B,H,W,cin], dy16 [B,H,W,cout] bf16 planes -> part [ksplit, 9, cin, cout] fp32 partial weight gradients"""
+    B, H, W, cin = x16.shape
+    cout = dy16.shape[-1]
+    assert x16.dtype == torch.int16 and dy16.dtype == torch.int16 and tuple(dy16.shape[:3]) == (B, H, W) and part.dtype == torch.float32
+    assert part.numel() >= wgrad3x3_plan(B, H, W, cin, cout) * 9 * cin * cout
+    check(lib().stedm_wgrad3x3(x16.data_ptr(), dy16.data_ptr(), part.data_ptr(), B, H, W, cin, cout, prec.mm_dtype, _stream()), "stedm_wgrad3x3")
 
 
 def chan_sum_fold(cs: torch.Tensor, per_sample: Optional[torch.Tensor], ld: int, total: Optional[torch.Tensor], accumulate: bool) -> None:

@@ -15,6 +15,7 @@ The backward is a reverse walk over the tape `UNetModel._forward_impl` records i
 Gradients are bitwise reproducible (no atomics)."""
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -37,6 +38,7 @@ class UNetTrainer:
     def __init__(self, unet: UNetModel, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
                  ema_decay: Optional[float] = 0.9999, accumulate_grad_batches: int = 1):
         self.m = unet
+        self.direct_wgrad = os.environ.get("STEDM_WGRAD_GEMM") is None    # STEDM_WGRAD_GEMM=1: im2col + GEMM form everywhere (A/B switch)
         self.accumulate_grad_batches = int(accumulate_grad_batches)      # Trainer(accumulate_grad_batches=...) of train_diff.py
         self._micro = 0
         self.lr, self.betas, self.eps, self.wd = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
@@ -162,6 +164,13 @@ class UNetTrainer:
         bp = self.bprec
         B, Hs, Ws, Cs = src16[0].shape
         Bo, Ho, Wo, co = dy16[0].shape
+        if ks == 3 and mode == 0 and bp.npass == 1 and self.m.conv_path == "dma" and self.direct_wgrad:
+            nsplit = ops.wgrad3x3_plan(B, Hs, Ws, Cs, co)
+            if nsplit > 0:    # direct kernel: both operands straight from the NHWC planes, transposed in the LDS reads
+                part = self._buf("wg.part", (nsplit * 9 * Cs * co,))
+                ops.wgrad3x3(src16[0], dy16[0], part, bp)
+                ops.wgrad_to_oihw(part, self._param_grad(wparam), Cs, co, False, nsplit)
+                return
         P = Bo * Ho * Wo
         Ppad = _r64(P)
         taps = ks * ks

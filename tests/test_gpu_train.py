@@ -180,3 +180,25 @@ def test_gradient_accumulation_equals_the_full_batch(dev, golden):
         tr.train_step(x[sl, :4].contiguous(), x[sl, 4:].contiguous(), t[sl], ctx[sl].contiguous(), target[sl].contiguous())
         assert tr.step_count == i          # 0 after the first micro-batch, 1 after the second
     _check_grads(m, fx, 1e-3, "accumulated")
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(3, 8, 8, 128, 64), (2, 16, 16, 256, 128), (2, 32, 32, 128, 64), (5, 16, 8, 128, 192), (64, 8, 8, 256, 128)])
+def test_direct_wgrad3x3_kernel(dev, B, H, W, cin, cout):
+    """stedm_wgrad3x3 (both operands from the NHWC bf16 planes, transposed LDS reads, split over pixel units) + the fixed-order
+    reduce/scatter against conv2d's weight gradient computed in float64 from the same bf16-rounded operands."""
+    from stedm_amd import ops
+    prec = ops.Precision.parse("bf16")
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = torch.randn(B, H, W, cin, generator=g).bfloat16()
+    dy = (torch.randn(B, H, W, cout, generator=g) * 0.1).bfloat16()
+    ks = ops.wgrad3x3_plan(B, H, W, cin, cout)
+    assert ks >= 1
+    part = torch.empty((ks * 9 * cin * cout,), dtype=torch.float32, device=dev)
+    ops.wgrad3x3(x.view(torch.int16).to(dev), dy.view(torch.int16).to(dev), part, prec)
+    grad = torch.zeros((cout, cin, 3, 3), dtype=torch.float32, device=dev)
+    ops.wgrad_to_oihw(part, grad, cin, cout, False, ks)
+    ref = torch.nn.grad.conv2d_weight(x.double().permute(0, 3, 1, 2), (cout, cin, 3, 3), dy.double().permute(0, 3, 1, 2), padding=1)
+    err = float((grad.cpu().double() - ref).abs().max() / ref.abs().max())
+    print(f"wgrad3x3 B={B} {H}x{W} {cin}->{cout}: ksplit {ks}, max err / max {err:.2e}")
+    assert err < 1e-5
+    assert ops.wgrad3x3_plan(B, H, 12, cin, cout) == 0 and ops.wgrad3x3_plan(B, H, W, 96, cout) == 0      # unsupported shapes are declined
