@@ -7,6 +7,8 @@
 // are brought to LDS once and serve all nine taps — the tap is just a different LDS row per k. Compared with the im2col + GEMM form
 // (stedm_im2col_t16 + conv_rs_kernel) no 9x expanded copy of X exists and the L1 traffic per MFMA is ~5x lower.
 // K (the units) is split over `ksplit` workgroups per block of dW; partials are summed in a fixed order by stedm_wgrad_to_oihw.
+#include <stdlib.h>
+
 #include "conv_common.hpp"
 
 using namespace stedm;
@@ -26,6 +28,7 @@ struct WgradArgs {
   int nunits;             // B * upi
   int ksplit, tiles_n;    // tiles_n = Cout / 64
   int NP, PW;             // patch positions (upr + 2) * (W + 2), patch width W + 2
+  int dbg;                // timing experiments (STEDM_WGRAD_DBG): 1 no global loads, 2 no MFMA phase, 4 no LDS stores
 };
 
 constexpr int WG_NPMAX = 136;                 // (2 + 2) * (32 + 2)
@@ -113,11 +116,11 @@ __global__ void __launch_bounds__(512) wgrad3x3_kernel(WgradArgs a) {
   __syncthreads();
   for (int u = u0; u < u1; ++u) {
     const int buf = (u - u0) & 1;
-    if (u + 1 < u1) load_unit(u + 1);
+    if (u + 1 < u1 && !(a.dbg & 1)) load_unit(u + 1);
     const unsigned char* px = sX + buf * WG_XBUF;
     const unsigned char* py = sY + buf * WG_YBUF;
 #pragma unroll 1
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < ((a.dbg & 2) ? 0 : 4); ++s) {
       const int k_lo = 16 * s + 8 * h + q, k_hi = k_lo + 4;            // this lane's block rows (pixels of the unit)
       const bf16x8 bf = tr_pair(py, k_lo * WG_YS + colB, k_hi * WG_YS + colB);
       // patch row of tap (0, 0); tap (ky, kx) adds the compile-time constant (ky * PW + kx) rows
@@ -130,7 +133,7 @@ __global__ void __launch_bounds__(512) wgrad3x3_kernel(WgradArgs a) {
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
       }
     }
-    if (u + 1 < u1) store_unit(buf ^ 1);
+    if (u + 1 < u1 && !(a.dbg & 4)) store_unit(buf ^ 1);
     __syncthreads();
   }
 
@@ -176,6 +179,8 @@ extern "C" int stedm_wgrad3x3(const void* x16, const void* dy16, float* part, in
   a.upr = 64 / W; a.upi = H / a.upr; a.nunits = B * a.upi;
   a.ksplit = ks; a.tiles_n = Cout / 64;
   a.PW = W + 2; a.NP = (a.upr + 2) * a.PW;
+  static const int dbg = getenv("STEDM_WGRAD_DBG") ? atoi(getenv("STEDM_WGRAD_DBG")) : 0;
+  a.dbg = dbg;
   const size_t lds = 2 * WG_XBUF + 2 * WG_YBUF;
   static bool attr = false;
   if (!attr) {

@@ -386,7 +386,13 @@ class UNetTrainer:
         dout16 = self._cast16(dout, kind="dy")
         self._bias_grad(dout, layer.conv.bias)
         src16 = self._cast16(hin, kind="x16")
-        self._wgrad(src16, dout16, dout, layer.conv.weight, 3, 1)
+        if self.direct_wgrad and self.bprec.npass == 1 and ops.wgrad3x3_plan(B, 2 * H, 2 * W, Cc, out.shape[-1]) > 0:
+            # the direct kernel reads plain NHWC planes: materialise the nearest-2x plane once (16-bit copy, layout only)
+            up = self._buf(f"up.x16.{B}x{H}x{W}x{Cc}", (B, 2 * H, 2 * W, Cc), torch.int16)
+            up.view(B, H, 2, W, 2, Cc).copy_(src16[0].view(B, H, 1, W, 1, Cc).expand(B, H, 2, W, 2, Cc))
+            self._wgrad((up, None), dout16, dout, layer.conv.weight, 3, 0)
+        else:
+            self._wgrad(src16, dout16, dout, layer.conv.weight, 3, 1)
         tmp = self._buf(f"up.t.{B}x{H}x{W}x{Cc}", (B, 2 * H, 2 * W, Cc))
         self._dgrad(layer.conv, dout16, tmp)
         g, acc = self._grad_of(hin)
