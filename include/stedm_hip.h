@@ -319,6 +319,10 @@ int stedm_gemm_f32(const float* A, long lda, int trans_a, const float* B, long l
                    int N, int K, float alpha, float beta, float* ws, long ws_floats, void* stream);
 /* mode 0: out = silu(x); mode 1: out = dy * silu'(x). */
 int stedm_silu(const float* x, const float* dy, float* out, long n, int mode, void* stream);
+/* q_sample (ddpm.py:277-280): out[b] = sqrt_ac[t[b]] * x0[b] + sqrt_1mac[t[b]] * noise[b]; n elements per sample, t int64 [B]
+ * (tables: the fp32 buffers sqrt_alphas_cumprod / sqrt_one_minus_alphas_cumprod of ddpm.py:155-156). Bit-exact vs the fp32 reference. */
+int stedm_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac,
+                   float* out, int B, long n, void* stream);
 /* loss = mean|target - pred| (ddpm.py:282-295 'l1' + :1030-1040), d_pred = grad_scale * sign(pred - target) / n (NULL: skip).
  * ws: 1024 doubles. */
 int stedm_l1_loss(const float* pred, const float* target, long n, float grad_scale, float* d_pred, double* ws, float* loss,

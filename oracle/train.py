@@ -27,7 +27,7 @@ def unet_loss_and_grads(P: Dict[str, torch.Tensor], cfg: ounet.UNetConfig, x: to
         y = ounet.unet_forward.__wrapped__(Pg, cfg, xg, t, cg)
         loss = l1_loss(y, target)
         loss.backward()
-    return float(loss), {k: v.grad for k, v in Pg.items()}, xg.grad, cg.grad, y.detach()
+    return float(loss.detach()), {k: v.grad for k, v in Pg.items()}, xg.grad, cg.grad, y.detach()
 
 
 def adamw_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float, beta1: float = 0.9,

@@ -97,6 +97,7 @@ SIGNATURES = {
     "stedm_attn_legacy_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "stedm_gemm_f32": (_I, [_P, C.c_long, _I, _P, C.c_long, _I, _P, C.c_long, _I, _I, _I, _F, _F, _P, C.c_long, _P]),
     "stedm_silu": (_I, [_P, _P, _P, C.c_long, _I, _P]),
+    "stedm_q_sample": (_I, [_P, _P, _P, _P, _P, _P, _I, C.c_long, _P]),
     "stedm_l1_loss": (_I, [_P, _P, C.c_long, _F, _P, _P, _P, _P]),
     "stedm_spatial_rescale_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "stedm_axpby_f32": (_I, [_P, _P, C.c_long, _F, _F, _P]),

@@ -462,6 +462,15 @@ __global__ void axpby_kernel(const float* __restrict__ x, float* __restrict__ y,
   reinterpret_cast<float4*>(y)[i] = b;
 }
 
+// q_sample (ddpm.py:277-280 + extract_into_tensor util.py:96-99): out = sqrt_ac[t[b]] * x0 + sqrt_1mac[t[b]] * noise; n = elements per sample
+__global__ void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const int64_t* __restrict__ t, const float* __restrict__ sa,
+                                const float* __restrict__ s1, float* __restrict__ out, long n, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t tb = t[i / n];
+  out[i] = __fadd_rn(__fmul_rn(sa[tb], x0[i]), __fmul_rn(s1[tb], noise[i]));     // two products then a sum, like the reference (no FMA contraction)
+}
+
 // ------------------------------------------------------------------------------------------------ loss
 // L1 (ddpm.py:282-295, 1030-1040): loss = mean |target - pred|; dpred = sign(pred - target) * scale / n
 __global__ void __launch_bounds__(256) l1_partial_kernel(const float* __restrict__ pred, const float* __restrict__ target, float* __restrict__ dpred, long n,
@@ -675,6 +684,15 @@ extern "C" int stedm_silu(const float* x, const float* dy, float* out, long n, i
 extern "C" int stedm_axpby_f32(const float* x, float* y, long n, float alpha, float beta, void* stream) {
   STEDM_CHECK_ARG(x && y && n > 0 && n % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0), "axpby_f32: n %% 4 and 16-B alignment required");
   axpby_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, as_stream(stream)>>>(x, y, n / 4, alpha, beta);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int stedm_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac, float* out, int B, long n,
+                              void* stream) {
+  STEDM_CHECK_ARG(x0 && noise && t && sqrt_ac && sqrt_1mac && out && B > 0 && n > 0, "q_sample: bad args");
+  const long total = (long)B * n;
+  q_sample_kernel<<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(x0, noise, t, sqrt_ac, sqrt_1mac, out, n, total);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

@@ -159,24 +159,25 @@ class LatentDiffusion(nn.Module):
     # ------------------------------------------------------------------------------------------ training-side forward values
     @torch.no_grad()
     def q_sample(self, x_start, t, noise=None):
-        """ddpm.py:277-280 (+ extract_into_tensor util.py:96-99). Elementwise; torch ops on the caller's device."""
+        """ddpm.py:277-280 (+ extract_into_tensor util.py:96-99): one elementwise HIP kernel, per-sample scalars gathered from the
+        fp32 schedule buffers by t."""
         noise = torch.randn_like(x_start) if noise is None else noise
-        sh = (x_start.shape[0],) + (1,) * (x_start.dim() - 1)
-        return (self.sqrt_alphas_cumprod.gather(-1, t).reshape(sh) * x_start
-                + self.sqrt_one_minus_alphas_cumprod.gather(-1, t).reshape(sh) * noise)
+        return ops.q_sample(x_start.float().contiguous(), noise.float().contiguous(), t.to(torch.int64).contiguous(),
+                            self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod)
 
     @torch.no_grad()
     def p_losses(self, x_start, cond, t, noise=None):
-        """ddpm.py:1015-1048, forward value only (loss_type l1/l2, logvar == 0). The backward kernels are a later
-        row; calling this under autograd does not produce gradients."""
+        """ddpm.py:1015-1048, forward value only (loss_type l1 on the HIP loss kernel, l2 reported through torch for completeness;
+        logvar == 0). For the loss WITH gradients see p_losses_backward."""
         noise = torch.randn_like(x_start) if noise is None else noise
         x_noisy = self.q_sample(x_start, t, noise)
         model_output = self.apply_model(x_noisy, t, cond)
         if self.loss_type == 'l1':
-            loss_simple = (noise - model_output).abs().mean([1, 2, 3])
+            loss = ops.l1_loss(model_output.contiguous(), noise.float().contiguous(), None,
+                               torch.empty((1024,), dtype=torch.float64, device=x_noisy.device),
+                               torch.empty((1,), dtype=torch.float32, device=x_noisy.device))[0]
         else:
-            loss_simple = ((noise - model_output) ** 2).mean([1, 2, 3])
-        loss = loss_simple.mean()
+            loss = ((noise - model_output) ** 2).mean([1, 2, 3]).mean()
         return loss, {"val/loss_simple": loss, "val/loss": loss}
 
     # ------------------------------------------------------------------------------------------ training step (U-Net parameters)

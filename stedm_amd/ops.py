@@ -619,6 +619,16 @@ def silu(x: torch.Tensor, out: torch.Tensor, dy: Optional[torch.Tensor] = None) 
     return out
 
 
+def q_sample(x0: torch.Tensor, noise: torch.Tensor, t: torch.Tensor, sqrt_ac: torch.Tensor, sqrt_1mac: torch.Tensor) -> torch.Tensor:
+    """ddpm.py:277-280: sqrt_ac[t] * x0 + sqrt_1mac[t] * noise (per-sample scalars from the fp32 schedule buffers)."""
+    _chk(x0, name="x0"); _chk(noise, name="noise"); _chk(t, torch.int64, "t")
+    out = torch.empty_like(x0)
+    B = x0.shape[0]
+    check(lib().stedm_q_sample(x0.data_ptr(), noise.data_ptr(), t.data_ptr(), sqrt_ac.data_ptr(), sqrt_1mac.data_ptr(), out.data_ptr(), B,
+                               x0.numel() // B, _stream()), "stedm_q_sample")
+    return out
+
+
 def l1_loss(pred: torch.Tensor, target: torch.Tensor, d_pred: Optional[torch.Tensor], ws: torch.Tensor, loss: torch.Tensor, grad_scale: float = 1.0):
     _chk(pred, name="pred"); _chk(target, name="target")
     assert ws.dtype == torch.float64 and ws.numel() >= 1024 and pred.numel() == target.numel()

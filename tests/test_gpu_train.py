@@ -226,3 +226,49 @@ def test_direct_wgrad_path_equals_im2col_gemm_path(dev, golden):
         worst = max(worst, float((a - b).norm() / (b.norm() + 1e-30)) if float(b.norm()) > 1e-12 else 0.0)
     print(f"direct vs GEMM wgrad: worst relative difference over all parameters {worst:.2e}")
     assert worst < 1e-4
+
+
+def test_latent_diffusion_training_surface(dev):
+    """LatentDiffusion.q_sample (bit-exact vs the oracle's fp32 arithmetic), p_losses (forward value) and p_losses_backward /
+    training_step_hip (ddpm.py:277-280, 1015-1048, 345-358) on the module surface, incl. the cond stage's channel-mapper gradient."""
+    from oracle import ddim as oddim
+    from oracle import style as ostyle
+    from oracle import train as otrain
+    from oracle import unet as ounet
+    from stedm_amd.latent_diffusion import LatentDiffusion
+    from stedm_amd.style import SpatialRescaler
+    unet = build(TINY, 6, dev)
+    resc = SpatialRescaler(n_stages=2, in_channels=2, out_channels=3)
+    prng.fill_module_(resc, seed=9)
+    ld = LatentDiffusion(unet, linear_start=0.0015, linear_end=0.0205, loss_type="l1", image_size=16, channels=4, conditioning_key="hybrid",
+                         cond_stage_config=resc).to(dev)
+    B = 2
+    x0 = prng.normal(21, "ld.x0", (B, 4, 16, 16)); noise = prng.normal(21, "ld.noise", (B, 4, 16, 16))
+    layout = prng.uniform(21, "ld.layout", (B, 2, 64, 64)); ctx = prng.normal(21, "ld.ctx", (B, 128))
+    t = torch.tensor([951, 21], dtype=torch.long)
+    sched = oddim.Schedule()
+    xq_ref = oddim.q_sample(sched, x0, t, noise)
+    xq = ld.q_sample(x0.to(dev), t.to(dev), noise.to(dev))
+    assert torch.equal(xq.cpu(), xq_ref)                         # same fp32 products and sum
+    # oracle: rescaler -> concat -> U-Net -> L1, under autograd
+    ocfg = ounet.UNetConfig(image_size=16, in_channels=7, model_channels=32, out_channels=4, channel_mult=(1, 2, 4), num_heads=4)
+    P = prng.fill_state_dict(ounet.build_plan(ocfg).shapes, 6)
+    wm = resc.channel_mapper.weight.detach().cpu().clone().requires_grad_(True)
+    with torch.enable_grad():
+        cc_ref = ostyle.spatial_rescaler.__wrapped__(layout, wm, 2)
+    loss_ref, grads, dx_ref, dctx_ref, _ = otrain.unet_loss_and_grads(P, ocfg, torch.cat([xq_ref, cc_ref.detach()], 1), t, ctx, noise)
+    with torch.enable_grad():
+        (cc_ref * dx_ref[:, 4:]).sum().backward()
+    cc = ld.get_learned_conditioning(layout.to(dev))
+    cond = {"c_concat": [cc], "c_crossattn": [ctx.to(dev)]}
+    lv, _ = ld.p_losses(x0.to(dev), cond, t.to(dev), noise.to(dev))
+    assert abs(float(lv) - loss_ref) < 1e-4 * loss_ref
+    loss, _, dx, dctx = ld.p_losses_backward(x0.to(dev), cond, t.to(dev), noise.to(dev), cond_input=layout.to(dev))
+    assert abs(float(loss) - loss_ref) < 1e-4 * loss_ref
+    assert float((dctx.cpu() - dctx_ref).norm() / dctx_ref.norm()) < 1e-3
+    assert float((resc.channel_mapper.weight.grad.cpu() - wm.grad).norm() / wm.grad.norm()) < 1e-3
+    gw = unet.input_blocks[1][0].in_layers[2].weight.grad.cpu()
+    assert float((gw - grads["input_blocks.1.0.in_layers.2.weight"]).norm() / grads["input_blocks.1.0.in_layers.2.weight"].norm()) < 1e-3
+    before = unet.out[2].weight.detach().clone()
+    ld.training_step_hip(x0.to(dev), cond, t.to(dev), noise.to(dev))
+    assert not torch.equal(before, unet.out[2].weight.detach())   # the optimizer ran
