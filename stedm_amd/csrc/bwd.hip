@@ -249,6 +249,7 @@ __global__ void __launch_bounds__(256) wgrad_to_oihw_kernel(const float* __restr
     const int co = co0 + col, ci = ci0 + cil;
     float v = 0.f;
     if (co < cout && ci < cin)
+#pragma unroll 4
       for (int z = 0; z < nsplit; ++z) v += dw[(((long)z * taps + tap) * cin_ld + ci) * cout_ld + co];    // split-K partials, fixed order
     tile[r][col] = v;
   }

@@ -63,9 +63,10 @@ __global__ void __launch_bounds__(512) wgrad3x3_kernel(WgradArgs a) {
   const int u0 = kz * per, u1 = min(a.nunits, u0 + per);
 
   // ---- staging registers: 16-B chunks of the next unit's X patch (<= 9 per thread) and dY rows (2 per thread)
-  constexpr int NXI = (WG_NPMAX * 16 + 511) / 512;
-  uint4 rx[NXI], ry[1];
-  auto load_unit = [&](int u) {
+  constexpr int NXI = (NP * 16 + 511) / 512;
+  constexpr bool DEEP = NXI <= 4;     // W <= 16: registers for a second staging set -> a unit's loads get two compute phases to land
+  uint4 rxA[NXI], ryA[1], rxB[DEEP ? NXI : 1], ryB[1];
+  auto load_unit = [&](int u, auto& rx, auto& ry) {
     const int b = u / a.upi, y0 = (u - b * a.upi) * a.upr;
 #pragma unroll
     for (int j = 0; j < NXI; ++j) {
@@ -85,7 +86,7 @@ __global__ void __launch_bounds__(512) wgrad3x3_kernel(WgradArgs a) {
       ry[j] = *reinterpret_cast<const uint4*>(a.dy16 + (((long)b * a.H + y) * W + x) * a.Cout + co0 + ch * 8);
     }
   };
-  auto store_unit = [&](int buf) {
+  auto store_unit = [&](int buf, auto& rx, auto& ry) {
     unsigned char* dx = sX + buf * WG_XBUF;
     unsigned char* dy = sY + buf * WG_YBUF;
 #pragma unroll
@@ -112,11 +113,7 @@ __global__ void __launch_bounds__(512) wgrad3x3_kernel(WgradArgs a) {
   const int colA = (wm * 32 + 16 * (g & 1)) * 2 + 8 * p;   // byte offset of this lane's 4 columns inside an X row
   const int colB = (wn * 32 + 16 * (g & 1)) * 2 + 8 * p;   // ... inside a dY row
 
-  if (u0 < u1) { load_unit(u0); store_unit(0); }
-  __syncthreads();
-  for (int u = u0; u < u1; ++u) {
-    const int buf = (u - u0) & 1;
-    if (u + 1 < u1 && !(a.dbg & 1)) load_unit(u + 1);
+  auto compute_unit = [&](int buf) {
     const unsigned char* px = sX + buf * WG_XBUF;
     const unsigned char* py = sY + buf * WG_YBUF;
 #pragma unroll 1
@@ -133,8 +130,34 @@ __global__ void __launch_bounds__(512) wgrad3x3_kernel(WgradArgs a) {
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
       }
     }
-    if (u + 1 < u1 && !(a.dbg & 4)) store_unit(buf ^ 1);
+  };
+  const bool ld_on = !(a.dbg & 1), st_on = !(a.dbg & 4);
+  if (u0 < u1) { load_unit(u0, rxA, ryA); store_unit(0, rxA, ryA); }
+  if constexpr (DEEP) {
+    // LDS holds unit u (computed) and u+1; registers hold u+1 / u+2 (sets A / B alternating)
+    if (u0 + 1 < u1 && ld_on) load_unit(u0 + 1, rxA, ryA);
+    if (u0 + 2 < u1 && ld_on) load_unit(u0 + 2, rxB, ryB);
     __syncthreads();
+    for (int u = u0; u < u1; u += 2) {
+      compute_unit(0);
+      if (u + 1 < u1 && st_on) store_unit(1, rxA, ryA);
+      if (u + 3 < u1 && ld_on) load_unit(u + 3, rxA, ryA);
+      __syncthreads();
+      if (u + 1 >= u1) break;
+      compute_unit(1);
+      if (u + 2 < u1 && st_on) store_unit(0, rxB, ryB);
+      if (u + 4 < u1 && ld_on) load_unit(u + 4, rxB, ryB);
+      __syncthreads();
+    }
+  } else {
+    __syncthreads();
+    for (int u = u0; u < u1; ++u) {
+      const int buf = (u - u0) & 1;
+      if (u + 1 < u1 && ld_on) load_unit(u + 1, rxA, ryA);
+      compute_unit(buf);
+      if (u + 1 < u1 && st_on) store_unit(buf ^ 1, rxA, ryA);
+      __syncthreads();
+    }
   }
 
   // ---- partial dW[kz][tap][ci][co]
@@ -156,8 +179,11 @@ extern "C" int stedm_wgrad3x3_plan(int B, int H, int W, int Cin, int Cout, int* 
   static int cus = 0;
   if (cus == 0) { cus = stedm_device_cus(); if (cus <= 0) cus = 256; }
   const int tiles = (Cin / 128) * (Cout / 64), nunits = B * (H / (64 / W));
-  int ks = (cus + tiles - 1) / tiles;            // one round of the chip (one workgroup is resident per CU); every extra slice costs a
-  if (ks > 16) ks = 16;                          // 9*Cin*Cout partial in HBM (written here, read by the reduce)
+  int ks = cus / tiles;                          // whole slices that fit ONE round of the chip (one workgroup is resident per CU)
+  const long wbytes = 9L * Cin * Cout * 4;       // every slice costs a partial of this size in HBM (written here, read by the reduce):
+  int cap = (int)((64L << 20) / wbytes);         // <= 64 MB of partials, between 16 and 32 slices (the reduce walks them serially)
+  cap = cap < 16 ? 16 : (cap > 32 ? 32 : cap);
+  if (ks > cap) ks = cap;
   if (ks > nunits / 4) ks = nunits / 4;          // and >= 4 units per slice
   if (ks < 1) ks = 1;
   const int per = (nunits + ks - 1) / ks;
