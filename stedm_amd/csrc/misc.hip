@@ -114,6 +114,27 @@ __global__ void __launch_bounds__(256) pack_conv_weight_frag_kernel(const float*
   const int n0 = tn * 128 + half * 64, ci0 = chunk * 16;
   const int per = 64 * 16 * taps;
   const bool n_fast = sn <= sc;       // which source index is contiguous
+  // 16-B loads along the contiguous source run when the layout allows it (rows inside the matrix, 16-B aligned runs): the pack is a
+  // pure stream, its speed is the bytes in flight
+  const bool vec = n0 + 64 <= cout && (n_fast ? (sn == taps && (sc * 4) % 16 == 0) : (sc == taps && (sn * 4) % 16 == 0)) &&
+                   ((reinterpret_cast<uintptr_t>(w) & 15) == 0) && ((n_fast ? 64 : 16) * taps) % 4 == 0;
+  if (vec) {
+    const int run = (n_fast ? 64 : 16) * taps;          // contiguous floats per outer index (ci for n_fast, n otherwise)
+    const int nouter = n_fast ? 16 : 64;
+    for (int v4 = threadIdx.x; v4 < nouter * (run / 4); v4 += 256) {
+      const int o = v4 / (run / 4), r0 = (v4 - o * (run / 4)) * 4;
+      const float* src = n_fast ? w + (long)n0 * sn + (long)(ci0 + o) * sc + r0 : w + (long)(n0 + o) * sn + (long)ci0 * sc + r0;
+      const float4 f = *reinterpret_cast<const float4*>(src);
+      const float fv[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = r0 + j, a = r / taps, ts = r - a * taps;       // a = n_local (n_fast) or ci_local; ts = source tap
+        const int tap = flip ? taps - 1 - ts : ts;
+        if (n_fast) tile[a][o * taps + tap] = fv[j];
+        else tile[o][a * taps + tap] = fv[j];
+      }
+    }
+  } else
   for (int idx = threadIdx.x; idx < per; idx += 256) {
     int row, cil, tap;
     if (n_fast) { cil = idx / (64 * taps); const int r = idx - cil * 64 * taps; row = r / taps; tap = r - row * taps; }
