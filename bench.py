@@ -212,6 +212,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-leg", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true")
+    ap.add_argument("--no-e2e-leg", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -296,6 +297,38 @@ def main():
             dtp, _ = run_steps(ld, xT, cond, unc, 2, max(4, args.steps // 2), 1)
             out["parity_mode"] = {"dtype": "f16x3", "value": round(max(4, args.steps // 2) / dtp, 3), "unit": "steps/s",
                                   "note": "split-precision mode that meets the 1e-3 fp32 parity tolerance (tests/test_gpu_unet.py)"}
+        if not args.no_e2e_leg and world == 1:
+            # BASELINE config 3 end to end up to the sampled latents: style encoder (sViT, 4 style images of 512^2 per sample) + layout
+            # rescaler + DDIM-50 with CFG, the call sequence of LDM_Diffusion.predict_step
+            from stedm_amd.latent_diffusion import S_ZSS_DM, predict_latents
+            from stedm_amd.utils import prng
+            unet = ld.model.diffusion_model
+            unet.set_precision(args.precision)
+            agg = dict(name="svit", patch_size=8, dim=256, depth=6, heads=12, mlp_dim=256, pool="mean", channels=3, dropout=0.1, emb_dropout=0.1,
+                       t_dim=256)
+            zm = S_ZSS_DM("swin_v2_t", dict(name="mp", num_patches=4), agg, {"data": {"patch_size": 512}}, unet, linear_start=0.0015,
+                          linear_end=0.0205, image_size=32, channels=4, conditioning_key="hybrid", loss_type="l1", cond_stage_key="segmentation",
+                          use_graph=True, cond_stage_config={"target": "ldm.modules.encoders.modules.SpatialRescaler",
+                                                             "params": {"n_stages": 3, "in_channels": 2, "out_channels": 3}})
+            prng.fill_module_(zm.agg_block, seed=51)
+            prng.fill_module_(zm.cond_stage_model, seed=52)
+            zm = zm.to(dev).eval()
+            zm.agg_block.set_precision(args.precision)
+            g = torch.Generator(device="cpu").manual_seed(7)
+            batch = {"image": torch.zeros(B, 256, 256, 3, device=dev),
+                     "segmentation": (torch.rand(B, 256, 256, 2, generator=g) > 0.5).float().to(dev),
+                     "style_imgs": (torch.rand(B, 4, 512, 512, 3, generator=g) * 2 - 1).to(dev)}
+            predict_latents(zm, batch, ddim_steps=50, cfg_scale=1.5, x_T=xT)          # warm-up: packs weights, captures the step graph
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            lat = predict_latents(zm, batch, ddim_steps=50, cfg_scale=1.5, x_T=xT)
+            torch.cuda.synchronize()
+            dte = time.perf_counter() - t0
+            assert bool(torch.isfinite(lat).all())
+            out["sampling_run"] = {"seconds": round(dte, 4), "latents_per_s": round(B / dte, 1), "batch": B, "ddim_steps": 50,
+                                   "what": "S_ZSS_DM.get_input (sViT over 4 x 512^2 style images per sample + SpatialRescaler) + unconditional style vector "
+                                           "(one constant sample, broadcast) + DDIM-50 with CFG 1.5: predict_step up to the sampled latents"}
+            del zm, batch
         if not args.no_train_leg and world == 1:
             # BASELINE config 2: one training step (forward + L1 + backward + AdamW/EMA) on the same U-Net and batch
             from stedm_amd.train import UNetTrainer

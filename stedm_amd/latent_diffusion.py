@@ -351,17 +351,28 @@ class S_ZSS_DM(LatentDiffusion):
 
 @torch.no_grad()
 def predict_latents(model: S_ZSS_DM, ldm_batch: dict, ddim_steps: int, eta: float = 0.0, cfg_scale: float = 1.0,
-                    style_sampling: str = "nearby", x_T: Optional[torch.Tensor] = None):
+                    style_sampling: str = "nearby", x_T: Optional[torch.Tensor] = None, dedup_uncond: bool = True):
     """Lightning-free restatement of LDM_Diffusion.predict_step (modules/ldm_diffusion.py:76-91) up to the sampled latents:
-    conditional get_input, unconditional batch {image: 0, segmentation: same, style_imgs: -2}, DDIM + CFG."""
+    conditional get_input, unconditional batch {image: 0, segmentation: same, style_imgs: -2}, DDIM + CFG.
+
+    dedup_uncond: the unconditional style input is the same constant (-2) image stack for every sample (ldm_diffusion.py:86) and the
+    style encoder works per sample, so its output is one vector: it is computed for ONE sample and broadcast instead of running the
+    encoder over the whole constant batch; the layout conditioning of the unconditional batch is the conditional one (same
+    segmentation). False: the reference's literal second get_input."""
     z, c_0 = model.get_input(ldm_batch, "image")
     kw = {} if x_T is None else {"x_T": x_T}
     if cfg_scale == 1 or style_sampling == "none":
         out, _ = model.sample_log(c_0, batch_size=len(z), ddim=True, ddim_steps=ddim_steps, eta=eta, log_every_t=1000, **kw)
     else:
-        unc_batch = {"image": torch.zeros_like(ldm_batch["image"]), "segmentation": ldm_batch["segmentation"],
-                     "style_imgs": torch.zeros_like(ldm_batch["style_imgs"]) - 2}
-        z, c_uncond = model.get_input(unc_batch, "image")
+        if dedup_uncond:
+            sty = ldm_batch["style_imgs"]
+            one = torch.full((1,) + tuple(sty.shape[1:]), -2.0, dtype=torch.float32, device=model.device)
+            unc_style = model._agg_block(one).expand(len(z), -1).contiguous()
+            c_uncond = {"c_concat": c_0["c_concat"], "c_crossattn": [unc_style]}
+        else:
+            unc_batch = {"image": torch.zeros_like(ldm_batch["image"]), "segmentation": ldm_batch["segmentation"],
+                         "style_imgs": torch.zeros_like(ldm_batch["style_imgs"]) - 2}
+            z, c_uncond = model.get_input(unc_batch, "image")
         out, _ = model.sample_log(c_0, batch_size=len(z), ddim=True, ddim_steps=ddim_steps, eta=eta, log_every_t=1000,
                                   unconditional_conditioning=c_uncond, unconditional_guidance_scale=cfg_scale, **kw)
     return out

@@ -159,6 +159,9 @@ def test_predict_step_surface_end_to_end(dev):
     err = rel(got, ref)
     print(f"[predict_step surface] rel err vs oracle pipeline: {err:.3e}")
     assert err < 1e-3
+    # the reference's literal second get_input over the constant batch gives the same latents as the one-sample broadcast
+    lit = predict_latents(model, batch, ddim_steps=4, eta=0.0, cfg_scale=1.5, x_T=xT.to(dev), dedup_uncond=False)
+    assert rel(lit, ref) < 1e-3 and rel(lit, got.cpu()) < 1e-4
 
 
 def test_bench_step_graph_replay_equals_eager_and_tracks_parity_mode(dev):
