@@ -186,7 +186,14 @@ class LatentDiffusion(nn.Module):
         """AdamW over the U-Net's parameters (modules/ldm_diffusion.py:224-234 builds `torch.optim.AdamW(self._model.model.parameters()
         ...)`) + the EMA shadow of ddpm.py:369-371 / ema.py:25-44, as one fused kernel (stedm_amd/train.py)."""
         from .train import UNetTrainer
-        self._trainer = UNetTrainer(self.model.diffusion_model, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, ema_decay=ema_decay)
+        # the reference's parameter list: model.model (the U-Net) + cond_stage_model when cond_stage_trainable (true in
+        # conf/diffusion/ldm_based.yaml:13 at configure time); the aggregation block is NOT in it (`hasattr(self.model, "embedder")` is
+        # False, ldm_diffusion.py:230) — the style encoder is not trained by the reference as wired
+        extra = []
+        if self.cond_stage_trainable and self.cond_stage_model is not None and hasattr(self.cond_stage_model, "backward"):
+            extra = [p for p in self.cond_stage_model.parameters() if p.requires_grad]
+        self._trainer = UNetTrainer(self.model.diffusion_model, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, ema_decay=ema_decay,
+                                    extra_params=extra)
         return self._trainer
 
     @torch.no_grad()
@@ -204,6 +211,9 @@ class LatentDiffusion(nn.Module):
         cc, ca = cd["c_concat"], cd["c_crossattn"]
         xc = cc[0] if len(cc) == 1 else torch.cat(cc, 1)
         ctx = ca[0] if len(ca) == 1 else torch.cat(ca, 1)
+        if tr.extra_params and cond_input is None:
+            raise ValueError("the cond stage is in the optimizer (cond_stage_trainable): pass cond_input (the raw layout given to the cond stage) so "
+                             "that its gradient can be computed")
         loss, dx, dctx = tr.loss_and_backward(x_noisy, xc, t, ctx, noise)
         if cond_input is not None and hasattr(self.cond_stage_model, "backward"):
             # cond_stage_trainable (s_zss_dm.py:46-48): the layout conditioner's channel mapper receives the c_concat slice of dL/dx
@@ -211,12 +221,12 @@ class LatentDiffusion(nn.Module):
         return loss, {"train/loss_simple": loss, "train/loss": loss}, dx, dctx
 
     @torch.no_grad()
-    def training_step_hip(self, x_start, cond, t=None, noise=None):
+    def training_step_hip(self, x_start, cond, t=None, noise=None, cond_input=None):
         """One optimisation step on a prepared batch (latents + conditioning as `get_input` returns them): t ~ U{0..T-1}
         (ddpm.py:878), p_losses + backward, AdamW + EMA. Returns the loss (device tensor)."""
         if t is None:
             t = torch.randint(0, self.num_timesteps, (x_start.shape[0],), device=x_start.device).long()
-        loss, _, _, _ = self.p_losses_backward(x_start, cond, t, noise)
+        loss, _, _, _ = self.p_losses_backward(x_start, cond, t, noise, cond_input=cond_input)
         self._trainer.optimizer_step()
         return loss
 

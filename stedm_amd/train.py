@@ -36,8 +36,11 @@ class UNetTrainer:
     land in their `.grad`, so DDP-style all-reduce and checkpointing see the usual tensors)."""
 
     def __init__(self, unet: UNetModel, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                 ema_decay: Optional[float] = 0.9999, accumulate_grad_batches: int = 1):
+                 ema_decay: Optional[float] = 0.9999, accumulate_grad_batches: int = 1, extra_params=()):
         self.m = unet
+        # parameters outside the U-Net that the same AdamW instance updates (the reference adds cond_stage_model's when
+        # cond_stage_trainable, ldm_diffusion.py:224-234); their gradients are filled by the caller; no EMA (LitEma covers `model` only)
+        self.extra_params = list(extra_params)
         self.direct_wgrad = os.environ.get("STEDM_WGRAD_GEMM") is None    # STEDM_WGRAD_GEMM=1: im2col + GEMM form everywhere (A/B switch)
         self.accumulate_grad_batches = int(accumulate_grad_batches)      # Trainer(accumulate_grad_batches=...) of train_diff.py
         self._micro = 0
@@ -95,7 +98,8 @@ class UNetTrainer:
         m = self.m
         emb_w = [rb.emb_layers[1].weight for rb, _ in m._emb_layout]
         seen = {id(p) for p in emb_w}
-        order = emb_w + [p for p in m.parameters() if id(p) not in seen]
+        order = emb_w + [p for p in m.parameters() if id(p) not in seen] + self.extra_params
+        self._n_unet_params = len(order) - len(self.extra_params)
         total = (sum(p.numel() for p in order) + 3) // 4 * 4
         self.grad_arena = torch.zeros((total,), dtype=torch.float32, device=order[0].device)
         off = 0
@@ -470,13 +474,14 @@ class UNetTrainer:
         params = list(self._arena_params)
         dev = params[0].device
         st = {"m": [torch.zeros_like(p, dtype=torch.float32) for p in params], "v": [torch.zeros_like(p, dtype=torch.float32) for p in params],
-              "ema": [p.detach().clone() for p in params] if self.ema_decay is not None else None, "params": params}
+              "ema": [p.detach().clone() if i < self._n_unet_params else None for i, p in enumerate(params)] if self.ema_decay is not None else None,
+              "params": params}
         tab = np.zeros((len(params), 6), dtype=np.int64)
         ct, co = [], []
         for i, p in enumerate(params):
             assert p.is_contiguous() and p.grad is not None and p.grad.is_contiguous(), "run backward() before the first optimizer step"
             tab[i] = (p.data_ptr(), p.grad.data_ptr(), st["m"][i].data_ptr(), st["v"][i].data_ptr(),
-                      st["ema"][i].data_ptr() if st["ema"] is not None else 0, p.numel())
+                      st["ema"][i].data_ptr() if st["ema"] is not None and st["ema"][i] is not None else 0, p.numel())
             for o in range(0, p.numel(), 4096):
                 ct.append(i); co.append(o)
         st["table"] = torch.from_numpy(tab).to(dev)
@@ -523,7 +528,7 @@ class UNetTrainer:
         if self._opt is None or self._opt["ema"] is None:
             return None
         names = {id(p): n for n, p in self.m.named_parameters()}
-        return {names[id(p)]: e for p, e in zip(self._opt["params"], self._opt["ema"])}
+        return {names[id(p)]: e for p, e in zip(self._opt["params"], self._opt["ema"]) if e is not None}
 
     @torch.no_grad()
     def load_ema(self, shadows: Dict[str, torch.Tensor], num_updates: int) -> None:

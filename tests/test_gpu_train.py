@@ -272,3 +272,14 @@ def test_latent_diffusion_training_surface(dev):
     before = unet.out[2].weight.detach().clone()
     ld.training_step_hip(x0.to(dev), cond, t.to(dev), noise.to(dev))
     assert not torch.equal(before, unet.out[2].weight.detach())   # the optimizer ran
+    # cond_stage_trainable (conf/diffusion/ldm_based.yaml:13): the channel mapper joins the same AdamW instance, as in the reference's
+    # configure_optimizers; the aggregation block does not
+    ld.cond_stage_trainable = True
+    tr = ld.configure_trainer(lr=1e-3, weight_decay=0.0)
+    assert [id(p) for p in tr.extra_params] == [id(resc.channel_mapper.weight)]
+    wm0 = resc.channel_mapper.weight.detach().clone()
+    with pytest.raises(ValueError):
+        ld.training_step_hip(x0.to(dev), cond, t.to(dev), noise.to(dev))
+    ld.training_step_hip(x0.to(dev), cond, t.to(dev), noise.to(dev), cond_input=layout.to(dev))
+    step = (resc.channel_mapper.weight.detach() - wm0).abs()
+    assert float(step.max()) > 5e-4 and float(step.max()) < 1.1e-3            # first AdamW step: |delta| = lr for every entry with a gradient
