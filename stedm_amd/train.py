@@ -75,6 +75,9 @@ class UNetTrainer:
 
     def _norm16(self, norm: nn.GroupNorm, act: int, x1, x2=None):
         m = self.m
+        kept = m._saved16.get((id(norm), x1.data_ptr()))
+        if kept is not None and self.bprec.npass == 1:       # the forward ran in the backward's operand format and kept this plane
+            return kept
         shape = tuple(x1.shape[:-1]) + (x1.shape[-1] + (0 if x2 is None else x2.shape[-1]),)
         hi, lo = self._planes("a16", shape)
         ops.gn_apply16c(x1, m._chan_stats(x1), x2, None if x2 is None else m._chan_stats(x2), hi, lo, self.bprec, norm.weight, norm.bias,
@@ -333,7 +336,7 @@ class UNetTrainer:
         if has_skip:
             sk = rb.skip_connection
             self._param_grad(sk.bias).copy_(conv2.bias.grad)             # same sums: both biases add onto `out`
-            x16 = self._cast16(x1, x2, kind="x16")
+            x16 = self.m._saved16.get(("raw", x1.data_ptr())) or self._cast16(x1, x2, kind="x16")
             self._wgrad(x16, dout16, dout, sk.weight, 1, 0)
             add = self._buf(f"add.{B}x{H}x{W}x{cin}", (B, H, W, cin))
             self._dgrad(sk, dout16, add)

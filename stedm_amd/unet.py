@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._lib import CONV_S2D, CONV_DOWN, CONV_S1, CONV_UP, CONV_UP_SUBPIXEL, StedmHipError
+from ._lib import BF16, CONV_S2D, CONV_DOWN, CONV_S1, CONV_UP, CONV_UP_SUBPIXEL, StedmHipError
 from .ops import Precision
 
 
@@ -229,6 +229,8 @@ class UNetModel(nn.Module):
         self._style_cache: Dict[Tuple, torch.Tensor] = {}
         self._cs: Dict[int, torch.Tensor] = {}
         self._raw16: Dict[int, Tuple] = {}
+        self._saved16: Dict = {}
+        self._plane_ctr = 0
         self._tape: Optional[list] = None     # training forward (stedm_amd/train.py): one record per layer for the backward pass
 
     # ------------------------------------------------------------------------------------ engine plumbing
@@ -384,11 +386,23 @@ class UNetModel(nn.Module):
         plain conversion of [x1|x2] (operand of the 1x1 skip_connection) produced by the same pass."""
         B, H, W, _ = x1.shape
         C = x1.shape[-1] + (0 if x2 is None else x2.shape[-1])
-        hi, lo = self._planes(B, H, W, C)
+        # training forward in the backward's operand format (bf16 single product): each normalised plane gets its own buffer and is kept
+        # for the weight-gradient pass instead of being recomputed there
+        keep = self._tape is not None and norm is not None and self.precision.npass == 1 and self.precision.mm_dtype == BF16
+        if keep:
+            self._plane_ctr += 1
+            hi, lo = self._planes(B, H, W, C, f"keep{self._plane_ctr}.a16")
+            self._saved16[(id(norm), x1.data_ptr())] = (hi, lo)
+        else:
+            hi, lo = self._planes(B, H, W, C)
         if norm is None:
             ops.gn_apply16(x1, x2, hi, lo, self.precision, x2_bmod=x2_bmod)
             return hi, lo
-        raw = self._planes(B, H, W, C, "raw16") if want_raw else None
+        if want_raw and keep:
+            raw = self._planes(B, H, W, C, f"keep{self._plane_ctr}.raw16")
+            self._saved16[("raw", x1.data_ptr())] = raw
+        else:
+            raw = self._planes(B, H, W, C, "raw16") if want_raw else None
         ops.gn_apply16c(x1, self._chan_stats(x1), x2, None if x2 is None else self._chan_stats(x2), hi, lo, self.precision,
                         norm.weight, norm.bias, norm.eps, norm.num_groups, act, x2_bmod, raw)
         return ((hi, lo), raw) if want_raw else (hi, lo)
@@ -609,6 +623,8 @@ class UNetModel(nn.Module):
         self._prepare()
         self._cs = {}
         self._raw16 = {}
+        self._saved16 = {}
+        self._plane_ctr = 0
         x = x.float().contiguous()
         B, c1, H, W = x.shape
         nrep = len(contexts)
