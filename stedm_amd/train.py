@@ -11,7 +11,8 @@ The backward is a reverse walk over the tape `UNetModel._forward_impl` records i
     im2col planes (stedm_im2col_t16); K = B*H*W is split over blocks by the register-streamed kernel's split-K;
   * GroupNorm+SiLU, attention, embeddings, reductions: fp32 kernels of csrc/bwd.hip;
   * 16-bit operands of the backward contractions are bf16 (fp32 exponent range: no loss scaling), single product or
-    hi/lo 3-product following the forward's mode; activations are recomputed from the saved fp32 tensors, not stored.
+    hi/lo 3-product following the forward's mode; normalised operand planes are kept by a bf16 forward, recomputed from the saved
+    fp32 tensors otherwise.
 Gradients are bitwise reproducible (no atomics)."""
 from __future__ import annotations
 
