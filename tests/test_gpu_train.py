@@ -283,3 +283,30 @@ def test_latent_diffusion_training_surface(dev):
     ld.training_step_hip(x0.to(dev), cond, t.to(dev), noise.to(dev), cond_input=layout.to(dev))
     step = (resc.channel_mapper.weight.detach() - wm0).abs()
     assert float(step.max()) > 5e-4 and float(step.max()) < 1.1e-3            # first AdamW step: |delta| = lr for every entry with a gradient
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 32, 16), (1, 16, 64)])
+def test_unet_backward_odd_shapes_vs_oracle(dev, B, H, W):
+    """ragged cases: odd batch sizes and non-square latents (pixel counts that are not multiples of 64 exercise the padded K of the
+    wgrad GEMMs, the stride-2 zero-insert and the 2x2 sums on rectangles) against autograd over the oracle."""
+    from oracle import train as otrain
+    from oracle import unet as ounet
+    from stedm_amd.train import UNetTrainer
+    cfg = dict(image_size=16, in_channels=7, model_channels=32, out_channels=4, num_res_blocks=1, attention_resolutions=[32, 16, 8],
+               channel_mult=[1, 2, 2], num_heads=4)
+    m = build(cfg, 31, dev)
+    ocfg = ounet.UNetConfig(image_size=16, in_channels=7, model_channels=32, out_channels=4, num_res_blocks=1, channel_mult=(1, 2, 2), num_heads=4)
+    P = prng.fill_state_dict(ounet.build_plan(ocfg).shapes, 31)
+    x = prng.normal(31, "odd.x", (B, 7, H, W)); ctx = prng.normal(31, "odd.ctx", (B, 128)); target = prng.normal(31, "odd.t", (B, 4, H, W))
+    t = torch.tensor(([951, 21, 500] * B)[:B], dtype=torch.long)
+    loss_ref, grads, dx_ref, dctx_ref, _ = otrain.unet_loss_and_grads(P, ocfg, x, t, ctx, target)
+    tr = UNetTrainer(m)
+    loss, dx, dctx = tr.loss_and_backward(x[:, :4].contiguous().to(dev), x[:, 4:].contiguous().to(dev), t.to(dev), ctx.to(dev), target.to(dev))
+    assert abs(float(loss) - loss_ref) < 1e-4 * loss_ref
+    assert float((dx.cpu() - dx_ref).norm() / dx_ref.norm()) < 1e-3
+    assert float((dctx.cpu() - dctx_ref).norm() / dctx_ref.norm()) < 1e-3
+    gmax = max(float(g.norm()) for g in grads.values())
+    for n, p in m.named_parameters():
+        gn = float(grads[n].norm())
+        if gn > 1e-6 * gmax:
+            assert float((p.grad.cpu() - grads[n]).norm()) / gn < 1e-3, n
