@@ -298,6 +298,18 @@ def main():
             out["parity_mode"] = {"dtype": "f16x3", "value": round(max(4, args.steps // 2) / dtp, 3), "unit": "steps/s",
                                   "note": "split-precision mode that meets the 1e-3 fp32 parity tolerance (tests/test_gpu_unet.py)"}
         if not args.no_e2e_leg and world == 1:
+            # BASELINE config 5's latent size (64x64x4, CATCH 512^2): the same denoising step on 4x the pixels, reported beside the headline
+            ld.model.diffusion_model.set_precision(args.precision)
+            g = torch.Generator(device="cpu").manual_seed(11)
+            x64 = torch.randn(B, 4, 64, 64, generator=g).to(dev)
+            lay64 = (torch.randn(B, 3, 64, 64, generator=g) > 0).float().to(dev)
+            c64 = {"c_concat": [lay64], "c_crossattn": cond["c_crossattn"]}
+            u64 = {"c_concat": [lay64], "c_crossattn": unc["c_crossattn"]}
+            dt64, _ = run_steps(ld, x64, c64, u64, 2, 6, 1)
+            fl64 = 2 * B * 217.31 / 1e3        # TFLOP per CFG step (217.31 GFLOP per sample-forward at 64^2)
+            out["ns64_step"] = {"value": round(6 / dt64, 3), "unit": "steps/s", "ms_per_step": round(1e3 * dt64 / 6, 3), "latent": "64x64x4", "batch": B,
+                                "step_algorithmic_tflops": round(fl64 / (dt64 / 6), 1), "step_frac_of_mfma_peak": round(fl64 / (dt64 / 6) / PEAK_MFMA_TFLOPS, 4)}
+            del x64, lay64
             # BASELINE config 3 end to end up to the sampled latents: style encoder (sViT, 4 style images of 512^2 per sample) + layout
             # rescaler + DDIM-50 with CFG, the call sequence of LDM_Diffusion.predict_step
             from stedm_amd.latent_diffusion import S_ZSS_DM, predict_latents
