@@ -184,7 +184,7 @@ class UNetTrainer:
         taps = ks * ks
         col = self._planes("col", (taps * Cs, Ppad))
         dyt = self._planes("dyt", (co, Ppad))
-        for i in range(bp.npass == 3 and 2 or 1):
+        for i in range(2 if bp.npass == 3 else 1):
             ops.im2col_t16(src16[i], col[i], ks, mode)
             ops.im2col_t16(dy16[i], dyt[i], 1, 0)
         frag = None
