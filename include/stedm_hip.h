@@ -342,6 +342,9 @@ int stedm_adamw_ema(const void* table, const int* chunk_tensor, const long* chun
 /* ---- image epilogue of predict_step (integer work, bit-exact) -------------------------------------------------------
  * modules/ldm_diffusion.py:93-95: ((clip(x, -1, 1).permute(0,2,3,1) + 1) * 127.5).astype(uint8): x NCHW fp32 -> out NHWC uint8. */
 int stedm_image_to_uint8(const float* x, unsigned char* out, int B, int C, int H, int W, void* stream);
+/* LDM_Diffusion.prepare_batch, modules/ldm_diffusion.py:52-56: seg NCHW [B][K][H][W] -> NHWC [B][H][W][2] = {class 0, sum of classes
+ * 1..K-1}. */
+int stedm_seg_merge(const float* seg, float* out, int B, int K, int H, int W, void* stream);
 /* modules/ldm_diffusion.py:98: torch.argmax(segmentation, dim=-1).astype(uint8): seg [N][ncls] fp32 -> out [N] (first maximum). */
 int stedm_argmax_u8(const float* seg, unsigned char* out, long N, int ncls, void* stream);
 

@@ -103,6 +103,7 @@ SIGNATURES = {
     "stedm_axpby_f32": (_I, [_P, _P, C.c_long, _F, _F, _P]),
     "stedm_adamw_ema": (_I, [_P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _F, _F, _P]),
     "stedm_image_to_uint8": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "stedm_seg_merge": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "stedm_argmax_u8": (_I, [_P, _P, C.c_long, _I, _P]),
     "stedm_graph_begin": (_I, [_P]),
     "stedm_graph_end": (_I, [_P, C.POINTER(C.c_void_p)]),

@@ -30,7 +30,28 @@ __global__ void argmax_u8_kernel(const float* __restrict__ seg, uint8_t* __restr
   out[i] = (uint8_t)best;
 }
 
+// LDM_Diffusion.prepare_batch's segmentation handling (modules/ldm_diffusion.py:52-56): seg NCHW [B][K][H][W] one-hot ->
+// NHWC [B][H][W][2] with channel 0 = class 0 and channel 1 = sum of classes 1..K-1 (in class order, like torch.sum over the last dim)
+__global__ void seg_merge_kernel(const float* __restrict__ seg, float* __restrict__ out, int K, long HW, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over B * HW pixels
+  if (i >= total) return;
+  const long b = i / HW, p = i - b * HW;
+  const float* s = seg + b * K * HW + p;
+  float fg = 0.f;
+  for (int k = 1; k < K; ++k) fg += s[(long)k * HW];
+  out[i * 2] = s[0];
+  out[i * 2 + 1] = fg;
+}
+
 }  // namespace
+
+extern "C" int stedm_seg_merge(const float* seg, float* out, int B, int K, int H, int W, void* stream) {
+  STEDM_CHECK_ARG(seg && out && B > 0 && K >= 2 && H > 0 && W > 0, "seg_merge: bad args (K >= 2)");
+  const long total = (long)B * H * W;
+  seg_merge_kernel<<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(seg, out, K, (long)H * W, total);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int stedm_image_to_uint8(const float* x, unsigned char* out, int B, int C, int H, int W, void* stream) {
   STEDM_CHECK_ARG(x && out && B > 0 && C > 0 && H > 0 && W > 0, "image_to_uint8: bad args");

@@ -360,6 +360,16 @@ class S_ZSS_DM(LatentDiffusion):
 
 
 @torch.no_grad()
+def prepare_batch(batch, device=None) -> dict:
+    """LDM_Diffusion.prepare_batch (modules/ldm_diffusion.py:51-60): the DataModule's tuple (image [B,3,H,W], one-hot segmentation
+    [B,K,H,W], _, style images [B,n,3,H,W], ...) -> the NHWC dict `get_input` reads. The class merge of the segmentation (channel 1 =
+    sum of the classes >= 1) and its NHWC layout come from one HIP kernel; image and style stack are views, as in the reference."""
+    dev = device or batch[1].device
+    seg = ops.seg_merge(batch[1].to(dev).float().contiguous())
+    return {"image": batch[0].permute(0, 2, 3, 1), "segmentation": seg, "style_imgs": batch[3].permute(0, 1, 3, 4, 2)}
+
+
+@torch.no_grad()
 def predict_latents(model: S_ZSS_DM, ldm_batch: dict, ddim_steps: int, eta: float = 0.0, cfg_scale: float = 1.0,
                     style_sampling: str = "nearby", x_T: Optional[torch.Tensor] = None, dedup_uncond: bool = True):
     """Lightning-free restatement of LDM_Diffusion.predict_step (modules/ldm_diffusion.py:76-91) up to the sampled latents:

@@ -672,6 +672,15 @@ def image_to_uint8(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def seg_merge(seg_nchw: torch.Tensor) -> torch.Tensor:
+    """seg [B,K,H,W] one-hot -> [B,H,W,2] = {class 0, sum of the other classes} (prepare_batch, ldm_diffusion.py:52-56)."""
+    _chk(seg_nchw, name="segmentation")
+    B, K, H, W = seg_nchw.shape
+    out = torch.empty((B, H, W, 2), dtype=torch.float32, device=seg_nchw.device)
+    check(lib().stedm_seg_merge(seg_nchw.data_ptr(), out.data_ptr(), B, K, H, W, _stream()), "stedm_seg_merge")
+    return out
+
+
 def argmax_u8(seg: torch.Tensor) -> torch.Tensor:
     """torch.argmax(seg, dim=-1) as uint8 (ldm_diffusion.py:98): seg [..., ncls] fp32."""
     _chk(seg, name="seg")

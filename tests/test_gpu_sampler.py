@@ -228,3 +228,19 @@ def test_image_epilogue_is_bit_exact(dev):
     assert np.array_equal(cls.cpu().numpy(), opost.segmentation_to_uint8(seg.numpy()))
     seg5 = torch.rand(2, 8, 8, 5, generator=g)
     assert np.array_equal(ops.argmax_u8(seg5.to(dev)).cpu().numpy(), opost.segmentation_to_uint8(seg5.numpy()))
+
+
+@pytest.mark.gpu
+def test_prepare_batch_matches_the_reference_lines(dev):
+    """prepare_batch (ldm_diffusion.py:51-60): NHWC views + the segmentation class merge, against the reference's torch lines restated."""
+    from stedm_amd.latent_diffusion import prepare_batch
+    g = torch.Generator().manual_seed(8)
+    img = torch.rand(3, 3, 20, 12, generator=g)
+    cls = torch.randint(0, 4, (3, 20, 12), generator=g)
+    seg = torch.nn.functional.one_hot(cls, 4).permute(0, 3, 1, 2).float()
+    sty = torch.rand(3, 2, 3, 16, 16, generator=g)
+    out = prepare_batch((img.to(dev), seg.to(dev), None, sty.to(dev)))
+    ref = seg.permute(0, 2, 3, 1).clone()
+    ref[:, :, :, 1] = torch.sum(ref[:, :, :, 1:], dim=-1)
+    assert torch.equal(out["segmentation"].cpu(), ref[:, :, :, :2])
+    assert torch.equal(out["image"].cpu(), img.permute(0, 2, 3, 1)) and torch.equal(out["style_imgs"].cpu(), sty.permute(0, 1, 3, 4, 2))
