@@ -23,8 +23,10 @@ def main():
         if os.environ.get("PHASES_ZERO_A"): h16.zero_()        # data-dependence experiment: all-zero activations
         if os.environ.get("PHASES_ZERO_W"): wf.zero_()
         out = torch.empty(B, H, W, cout, device=dev); bias = torch.randn(cout, device=dev)
+        cs = torch.empty(B, (H * W + 255) // 256, cout, 2, device=dev)
         for _ in range(3):
-            ops.conv_igemm(None, hi, lo, out, prec=prec, src16=(h16, None), bias=bias, w_frag=wf)
+            ops.conv_igemm(None, hi, lo, out, prec=prec, src16=(h16, None), bias=bias, w_frag=wf, res=(out if os.environ.get("PHASES_RES") else None),
+                           chan_stats=(cs if os.environ.get("PHASES_STATS") else None))
         torch.cuda.synchronize()
         nb = min(2048, (B * H * W // 256) * ((cout + 127) // 128))
         buf = np.zeros((nb, 8), dtype=np.uint64)
@@ -33,6 +35,10 @@ def main():
         rel = (t - t0) / 100.0   # us
         d = np.diff(rel, axis=1)
         loop = rel[:, 3] - rel[:, 1]    # tables built -> main loop done (first patch wait included)
+        stg = (buf[:, 5].astype(np.int64) - buf[:, 3].astype(np.int64)) / 100.0      # loop done -> tile staged in LDS (barriers #3, #4)
+        sto = (buf[:, 6].astype(np.int64) - buf[:, 5].astype(np.int64)) / 100.0      # staged -> store loop issued (incl. statistics)
+        ret = (buf[:, 4].astype(np.int64) - buf[:, 6].astype(np.int64)) / 100.0      # issued -> stores retired (vmcnt(0); not paid by a real run)
+        print(f"    epilogue split: staging {stg.mean():.2f} us, store loop {sto.mean():.2f} us, drain {ret.mean():.2f} us")
         print(f"{name}: blocks {nb}  start skew max {rel[:,0].max():.1f} us | tables {d[:,0].mean():.1f}  loop {loop.mean():.1f} (min {loop.min():.1f} "
               f"max {loop.max():.1f})  epilogue {d[:,3].mean():.1f} (max {d[:,3].max():.1f}) | last end {rel[:,4].max():.1f} us", flush=True)
 
