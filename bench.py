@@ -221,10 +221,17 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # rehearsal knobs for a one-GPU box (the driver's runs never set them): all ranks on one device, gloo instead of RCCL
+    if os.environ.get("STEDM_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("STEDM_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
     torch.set_grad_enabled(False)
 
     B = args.batch
