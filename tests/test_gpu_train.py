@@ -310,3 +310,53 @@ def test_unet_backward_odd_shapes_vs_oracle(dev, B, H, W):
         gn = float(grads[n].norm())
         if gn > 1e-6 * gmax:
             assert float((p.grad.cpu() - grads[n]).norm()) / gn < 1e-3, n
+
+
+def _ddp_worker(rank, world, port, q):
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from stedm_amd.train import UNetTrainer
+    dev = torch.device("cuda:0")
+    m = build(TINY, 6, dev)
+    tr = UNetTrainer(m, lr=1e-3, weight_decay=0.0)
+    x, ctx, target = _inputs("tiny", TINY, 2, 16, 6, dev)
+    t = torch.tensor([951, 21], device=dev)
+    sl = slice(rank, rank + 1)                       # each rank trains on its own sample
+    tr.train_step(x[sl, :4].contiguous(), x[sl, 4:].contiguous(), t[sl], ctx[sl].contiguous(), target[sl].contiguous())
+    if rank == 0:
+        q.put({n: p.detach().cpu().numpy() for n, p in m.named_parameters()})       # numpy: no shared-memory handles across the exit
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_step_equals_gradient_accumulation(dev):
+    """Data-parallel training path on the GPU: two ranks (one process each, gloo over the device tensors of the gradient arena, the same
+    code path RCCL takes on a node) train on one sample each, all-reduce the arena in buckets and step AdamW with the 1/world average;
+    the resulting weights equal a single process accumulating the two samples (accumulate_grad_batches = 2)."""
+    import os
+    import torch.multiprocessing as mp
+    from stedm_amd.train import UNetTrainer
+    m = build(TINY, 6, dev)
+    tr = UNetTrainer(m, lr=1e-3, weight_decay=0.0, accumulate_grad_batches=2)
+    x, ctx, target = _inputs("tiny", TINY, 2, 16, 6, dev)
+    t = torch.tensor([951, 21], device=dev)
+    for i in range(2):
+        sl = slice(i, i + 1)
+        tr.train_step(x[sl, :4].contiguous(), x[sl, 4:].contiguous(), t[sl], ctx[sl].contiguous(), target[sl].contiguous())
+    ref = {n: p.detach().cpu() for n, p in m.named_parameters()}
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctxm.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    worst = max(float(np.abs(got[n] - ref[n].numpy()).max()) for n in ref)
+    print(f"two-rank data-parallel step vs gradient accumulation: max |dw| = {worst:.2e} (lr 1e-3)")
+    assert worst < 2e-5
