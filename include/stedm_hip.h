@@ -298,7 +298,7 @@ int stedm_wgrad_to_oihw(const float* dw, float* grad, int cout, int cin, int tap
                         int nsplit, void* stream);
 /* Direct weight gradient of a stride-1 3x3 pad-1 convolution from the NHWC 16-bit planes (no im2col): x16 [B][H][W][Cin], dy16
  * [B][H][W][Cout] (bf16) -> part [ksplit][9][Cin][Cout] fp32 partials (then stedm_wgrad_to_oihw with nsplit = ksplit).
- * stedm_wgrad3x3_plan returns 1 when the shape is supported (W in {8,16,32}, H %% (64/W) == 0, Cin %% 128 == 0, Cout %% 64 == 0) and
+ * stedm_wgrad3x3_plan returns 1 when the shape is supported (W in {8,16,32,64}, H %% (64/W) == 0, Cin %% 128 == 0, Cout %% 64 == 0) and
  * the split it will use. */
 int stedm_wgrad3x3_plan(int B, int H, int W, int Cin, int Cout, int* ksplit);
 int stedm_wgrad3x3(const void* x16, const void* dy16, float* part, int B, int H, int W, int Cin, int Cout, int mm_dtype,
@@ -311,8 +311,10 @@ int stedm_chan_sum_fold(const float* cs, int B, int nslab, int C, float* per_sam
 int stedm_sum2x2(const float* in, float* out, int B, int H, int W, int C, int accumulate, void* stream);
 /* in [B][Ho][Wo][C] fp32 -> 16-bit planes [B][2Ho][2Wo][C], value at even positions, zero elsewhere (stride-2 dgrad). */
 int stedm_zero_insert16(const float* in, void* hi, void* lo, int B, int Ho, int Wo, int C, int mm_dtype, void* stream);
-/* backward of QKVAttentionLegacy (openaimodel.py:378-394): qkv, d_qkv [B][T][heads*3*ch]; d_out [B][T][heads*ch]. */
-int stedm_attn_legacy_bwd(const float* qkv, const float* d_out, float* d_qkv, int B, int T, int heads, int ch, void* stream);
+/* backward of QKVAttentionLegacy (openaimodel.py:378-394): qkv, d_qkv [B][T][heads*3*ch]; d_out [B][T][heads*ch]. ws: workspace of
+ * stedm_attn_legacy_bwd_ws_floats(B, T, heads) floats (0 = none: both T x T matrices stay in LDS, T <= 128). */
+long stedm_attn_legacy_bwd_ws_floats(int B, int T, int heads);
+int stedm_attn_legacy_bwd(const float* qkv, const float* d_out, float* d_qkv, int B, int T, int heads, int ch, float* ws, void* stream);
 /* C = alpha op(A) op(B) + beta C (fp32; the embedding Linears' backward: rows = batch). ws (optional, ws_floats floats): partial
  * sums of the split-K form taken when the output is small and K long (fixed-order reduce). */
 int stedm_gemm_f32(const float* A, long lda, int trans_a, const float* B, long ldb, int trans_b, float* C, long ldc, int M,

@@ -94,7 +94,8 @@ SIGNATURES = {
     "stedm_chan_sum_fold": (_I, [_P, _I, _I, _I, _P, C.c_long, _P, _I, _P]),
     "stedm_sum2x2": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "stedm_zero_insert16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "stedm_attn_legacy_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "stedm_attn_legacy_bwd_ws_floats": (C.c_long, [_I, _I, _I]),
+    "stedm_attn_legacy_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "stedm_gemm_f32": (_I, [_P, C.c_long, _I, _P, C.c_long, _I, _P, C.c_long, _I, _I, _I, _F, _F, _P, C.c_long, _P]),
     "stedm_silu": (_I, [_P, _P, _P, C.c_long, _I, _P]),
     "stedm_q_sample": (_I, [_P, _P, _P, _P, _P, _P, _I, C.c_long, _P]),

@@ -392,6 +392,83 @@ __global__ void __launch_bounds__(256) attn_legacy_bwd_kernel(const float* __res
   }
 }
 
+// General-T form (T too large for both T x T matrices in LDS): two kernels over a global scratch [B*heads][2][T][T] (P, then dS).
+// A: grid (B*heads, ceil(T/QT)) — the QT query rows of this block against all keys: S, dP in LDS, softmax, dS, dQ; P and dS rows go to
+//    the scratch. B: grid (B*heads, ceil(T/32)) — 32 key rows: dV = P^T dO, dK = s2 dS^T Q reading scratch columns.
+__global__ void __launch_bounds__(256) attn_bwd_rows_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, float* __restrict__ dqkv,
+                                                            float* __restrict__ scratch, int T, int heads, int ch, int QT) {
+  extern __shared__ float sm[];
+  float* P = sm;                    // [QT][T]
+  float* dS = sm + (long)QT * T;    // [QT][T]
+  const int bh = blockIdx.x, b = bh / heads, h = bh % heads, i0 = blockIdx.y * QT;
+  const int nq = min(QT, T - i0);
+  const long ld = (long)heads * 3 * ch, ldo = (long)heads * ch;
+  const float* q = qkv + (long)b * T * ld + (long)h * 3 * ch;
+  const float* k = q + ch;
+  const float* v = q + 2 * ch;
+  const float* go = dO + (long)b * T * ldo + (long)h * ch;
+  float* dq = dqkv + (long)b * T * ld + (long)h * 3 * ch;
+  const float s2 = 1.0f / sqrtf((float)ch);
+  for (int e = threadIdx.x; e < nq * T; e += 256) {
+    const int il = e / T, j = e - il * T, i = i0 + il;
+    float acc = 0.f, accp = 0.f;
+    for (int c = 0; c < ch; c += 4) {
+      const float4 a4 = *reinterpret_cast<const float4*>(q + i * ld + c), b4 = *reinterpret_cast<const float4*>(k + j * ld + c);
+      acc += a4.x * b4.x + a4.y * b4.y + a4.z * b4.z + a4.w * b4.w;
+      const float4 g4 = *reinterpret_cast<const float4*>(go + i * ldo + c), v4 = *reinterpret_cast<const float4*>(v + j * ld + c);
+      accp += g4.x * v4.x + g4.y * v4.y + g4.z * v4.z + g4.w * v4.w;
+    }
+    P[il * T + j] = acc * s2; dS[il * T + j] = accp;
+  }
+  __syncthreads();
+  for (int il = threadIdx.x; il < nq; il += 256) {
+    float m = -INFINITY;
+    for (int j = 0; j < T; ++j) m = fmaxf(m, P[il * T + j]);
+    float s = 0.f;
+    for (int j = 0; j < T; ++j) { const float e = __expf(P[il * T + j] - m); P[il * T + j] = e; s += e; }
+    const float inv = 1.0f / s;
+    float delta = 0.f;
+    for (int j = 0; j < T; ++j) { const float pp = P[il * T + j] * inv; P[il * T + j] = pp; delta += pp * dS[il * T + j]; }
+    for (int j = 0; j < T; ++j) dS[il * T + j] = P[il * T + j] * (dS[il * T + j] - delta);
+  }
+  __syncthreads();
+  float* sp = scratch + (long)bh * 2 * T * T;
+  for (int e = threadIdx.x; e < nq * T; e += 256) {
+    const int il = e / T, j = e - il * T;
+    sp[(long)(i0 + il) * T + j] = P[e];
+    sp[(long)T * T + (long)(i0 + il) * T + j] = dS[e];
+  }
+  for (int e = threadIdx.x; e < nq * ch; e += 256) {
+    const int il = e / ch, c = e - il * ch;
+    float aq = 0.f;
+    for (int j = 0; j < T; ++j) aq += dS[il * T + j] * k[j * ld + c];
+    dq[(long)(i0 + il) * ld + c] = aq * s2;
+  }
+}
+
+__global__ void __launch_bounds__(256) attn_bwd_cols_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, float* __restrict__ dqkv,
+                                                            const float* __restrict__ scratch, int T, int heads, int ch) {
+  const int bh = blockIdx.x, b = bh / heads, h = bh % heads, j0 = blockIdx.y * 32;
+  const int nk = min(32, T - j0);
+  const long ld = (long)heads * 3 * ch, ldo = (long)heads * ch;
+  const float* q = qkv + (long)b * T * ld + (long)h * 3 * ch;
+  const float* go = dO + (long)b * T * ldo + (long)h * ch;
+  float* dk = dqkv + (long)b * T * ld + (long)h * 3 * ch + ch;
+  float* dv = dk + ch;
+  const float* Pm = scratch + (long)bh * 2 * T * T;
+  const float* dSm = Pm + (long)T * T;
+  const float s2 = 1.0f / sqrtf((float)ch);
+  for (int e = threadIdx.x; e < nk * ch; e += 256) {
+    const int jl = e / ch, c = e - jl * ch, j = j0 + jl;
+    float av = 0.f, ak = 0.f;
+    for (int i = 0; i < T; ++i) {
+      av += Pm[(long)i * T + j] * go[i * ldo + c];
+      ak += dSm[(long)i * T + j] * q[i * ld + c];
+    }
+    dv[(long)j * ld + c] = av; dk[(long)j * ld + c] = ak * s2;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ small fp32 GEMM
 // C[M][N] = alpha * op(A) op(B) + beta * C; op(A)[m][k] = ta ? A[k*lda + m] : A[m*lda + k]; op(B)[k][n] = tb ? B[n*ldb + k] : B[k*ldb + n]
 __global__ void __launch_bounds__(256) gemm_f32_kernel(const float* __restrict__ A, long lda, int ta, const float* __restrict__ Bm, long ldb, int tb,
@@ -647,13 +724,30 @@ extern "C" int stedm_zero_insert16(const float* in, void* hi, void* lo, int B, i
   return 0;
 }
 
-extern "C" int stedm_attn_legacy_bwd(const float* qkv, const float* d_out, float* d_qkv, int B, int T, int heads, int ch, void* stream) {
+extern "C" long stedm_attn_legacy_bwd_ws_floats(int B, int T, int heads) {
+  const size_t lds = (size_t)T * T * 8 + (size_t)4 * T * 33 * 4;
+  return lds <= 160 * 1024 - 1024 ? 0 : (long)B * heads * 2 * T * T;     // the LDS-resident form needs no workspace
+}
+
+extern "C" int stedm_attn_legacy_bwd(const float* qkv, const float* d_out, float* d_qkv, int B, int T, int heads, int ch, float* ws, void* stream) {
   STEDM_CHECK_ARG(qkv && d_out && d_qkv && ch % 4 == 0, "attn_legacy_bwd: bad args");
   const size_t lds = (size_t)T * T * 8 + (size_t)4 * T * 33 * 4;
-  STEDM_CHECK_ARG(lds <= 160 * 1024 - 1024, "attn_legacy_bwd: T = %d tokens exceed the LDS-resident form (T <= 128)", T);
   static bool attr = false;
-  if (!attr) { STEDM_HIP_TRY(hipFuncSetAttribute((const void*)attn_legacy_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)); attr = true; }
-  attn_legacy_bwd_kernel<<<B * heads, 256, lds, as_stream(stream)>>>(qkv, d_out, d_qkv, T, heads, ch);
+  if (!attr) {
+    STEDM_HIP_TRY(hipFuncSetAttribute((const void*)attn_legacy_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    STEDM_HIP_TRY(hipFuncSetAttribute((const void*)attn_bwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    attr = true;
+  }
+  if (lds <= 160 * 1024 - 1024) {
+    attn_legacy_bwd_kernel<<<B * heads, 256, lds, as_stream(stream)>>>(qkv, d_out, d_qkv, T, heads, ch);
+  } else {
+    STEDM_CHECK_ARG(ws, "attn_legacy_bwd: T = %d tokens need the workspace of stedm_attn_legacy_bwd_ws_floats", T);
+    int QT = 32;
+    while (QT > 1 && (size_t)QT * T * 8 > 128 * 1024) QT >>= 1;
+    STEDM_CHECK_ARG((size_t)QT * T * 8 <= 159 * 1024, "attn_legacy_bwd: T = %d tokens too many", T);
+    attn_bwd_rows_kernel<<<dim3(B * heads, (T + QT - 1) / QT), 256, (size_t)QT * T * 8, as_stream(stream)>>>(qkv, d_out, d_qkv, ws, T, heads, ch, QT);
+    attn_bwd_cols_kernel<<<dim3(B * heads, (T + 31) / 32), 256, 0, as_stream(stream)>>>(qkv, d_out, d_qkv, ws, T, heads, ch);
+  }
   STEDM_LAUNCH_CHECK();
   return 0;
 }

@@ -31,7 +31,7 @@ struct WgradArgs {
   int dbg;                // timing experiments (STEDM_WGRAD_DBG): 1 no global loads, 2 no MFMA phase, 4 no LDS stores
 };
 
-constexpr int WG_NPMAX = 136;                 // (2 + 2) * (32 + 2)
+constexpr int WG_NPMAX = 198;                 // max over W of (64 / W + 2) * (W + 2): W = 64 -> 3 * 66
 // LDS images are plain rows with a padded pitch: the 4 rows x 32 B a 16-lane group reads transposed land on banks 16q + 8(g&1) + 2p
 // (X: 128 channels = 256 B + 64 B pad) / 48q + ... (dY: 64 channels = 128 B + 64 B pad), distinct for 4 consecutive rows. A linear
 // image keeps every read address = per-lane base + compile-time constant (tap and block offsets are ds_read immediates).
@@ -50,7 +50,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* base, int off_lo,
 
 template <int W>
 __global__ void __launch_bounds__(512) wgrad3x3_kernel(WgradArgs a) {
-  constexpr int PW = W + 2, WSH = W == 8 ? 3 : (W == 16 ? 4 : 5), NP = (64 / W + 2) * PW;
+  constexpr int PW = W + 2, WSH = W == 8 ? 3 : (W == 16 ? 4 : (W == 32 ? 5 : 6)), NP = (64 / W + 2) * PW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sX = smem;                   // [2][WG_XBUF]
   unsigned char* sY = smem + 2 * WG_XBUF;     // [2][WG_YBUF]
@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(512) wgrad3x3_kernel(WgradArgs a) {
 // 1 when stedm_wgrad3x3 supports the shape, and the split it would use in *ksplit (for sizing `part`: ksplit * 9 * Cin * Cout floats)
 extern "C" int stedm_wgrad3x3_plan(int B, int H, int W, int Cin, int Cout, int* ksplit) {
   if (ksplit) *ksplit = 0;
-  if (B <= 0 || H <= 0 || (W != 8 && W != 16 && W != 32) || Cin % 128 != 0 || Cout % 64 != 0 || H % (64 / W) != 0) return 0;
+  if (B <= 0 || H <= 0 || (W != 8 && W != 16 && W != 32 && W != 64) || Cin % 128 != 0 || Cout % 64 != 0 || H % (64 / W) != 0) return 0;
   static int cus = 0;
   if (cus == 0) { cus = stedm_device_cus(); if (cus <= 0) cus = 256; }
   const int tiles = (Cin / 128) * (Cout / 64), nunits = B * (H / (64 / W));
@@ -196,12 +196,12 @@ extern "C" int stedm_wgrad3x3(const void* x16, const void* dy16, float* part, in
   STEDM_CHECK_ARG(x16 && dy16 && part, "wgrad3x3: null pointer");
   STEDM_CHECK_ARG(mm_dtype == STEDM_BF16, "wgrad3x3: bf16 operands only (the backward pass's operand format)");
   int ks = 0;
-  STEDM_CHECK_ARG(stedm_wgrad3x3_plan(B, H, W, Cin, Cout, &ks) == 1, "wgrad3x3: unsupported shape (W in {8,16,32}, H %% (64/W) == 0, Cin %% 128 == 0, Cout %% 64 == 0)");
+  STEDM_CHECK_ARG(stedm_wgrad3x3_plan(B, H, W, Cin, Cout, &ks) == 1, "wgrad3x3: unsupported shape (W in {8,16,32,64}, H %% (64/W) == 0, Cin %% 128 == 0, Cout %% 64 == 0)");
   STEDM_CHECK_ARG((long)B * H * W * (Cin > Cout ? Cin : Cout) < (1L << 31), "wgrad3x3: tensor too large");
   WgradArgs a;
   a.x16 = (const uint16_t*)x16; a.dy16 = (const uint16_t*)dy16; a.part = part;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-  a.wshift = W == 8 ? 3 : (W == 16 ? 4 : 5);
+  a.wshift = W == 8 ? 3 : (W == 16 ? 4 : (W == 32 ? 5 : 6));
   a.upr = 64 / W; a.upi = H / a.upr; a.nunits = B * a.upi;
   a.ksplit = ks; a.tiles_n = Cout / 64;
   a.PW = W + 2; a.NP = (a.upr + 2) * a.PW;
@@ -213,13 +213,15 @@ extern "C" int stedm_wgrad3x3(const void* x16, const void* dy16, float* part, in
     STEDM_HIP_TRY(hipFuncSetAttribute((const void*)wgrad3x3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     STEDM_HIP_TRY(hipFuncSetAttribute((const void*)wgrad3x3_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     STEDM_HIP_TRY(hipFuncSetAttribute((const void*)wgrad3x3_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    STEDM_HIP_TRY(hipFuncSetAttribute((const void*)wgrad3x3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
   const int grid = (Cin / 128) * a.tiles_n * ks;
   hipStream_t st = as_stream(stream);
   if (W == 8) wgrad3x3_kernel<8><<<grid, 512, lds, st>>>(a);
   else if (W == 16) wgrad3x3_kernel<16><<<grid, 512, lds, st>>>(a);
-  else wgrad3x3_kernel<32><<<grid, 512, lds, st>>>(a);
+  else if (W == 32) wgrad3x3_kernel<32><<<grid, 512, lds, st>>>(a);
+  else wgrad3x3_kernel<64><<<grid, 512, lds, st>>>(a);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

@@ -595,7 +595,9 @@ def zero_insert16(x: torch.Tensor, hi: torch.Tensor, lo: Optional[torch.Tensor],
 
 def attn_legacy_bwd(qkv: torch.Tensor, d_out: torch.Tensor, d_qkv: torch.Tensor, heads: int) -> None:
     B, T, C3 = qkv.shape
-    check(lib().stedm_attn_legacy_bwd(qkv.data_ptr(), d_out.data_ptr(), d_qkv.data_ptr(), B, T, heads, C3 // (3 * heads), _stream()),
+    nws = lib().stedm_attn_legacy_bwd_ws_floats(B, T, heads)
+    ws = torch.empty((nws,), dtype=torch.float32, device=qkv.device) if nws else None
+    check(lib().stedm_attn_legacy_bwd(qkv.data_ptr(), d_out.data_ptr(), d_qkv.data_ptr(), B, T, heads, C3 // (3 * heads), _ptr(ws), _stream()),
           "stedm_attn_legacy_bwd")
 
 

@@ -179,6 +179,18 @@ class UNetTrainer:
                 ops.wgrad3x3(src16[0], dy16[0], part, bp)
                 ops.wgrad_to_oihw(part, self._param_grad(wparam), Cs, co, False, nsplit)
                 return
+        # GEMM form. Its contraction length K = (samples) * Ho * Wo is bounded by the conv kernels' zero page (65 536): larger problems go in
+        # batch chunks that accumulate into the gradient
+        Bc = max(1, 65536 // (Ho * Wo))
+        for b0 in range(0, Bo, Bc):
+            b1 = min(Bo, b0 + Bc)
+            self._wgrad_gemm(tuple(None if t is None else t[b0:b1] for t in src16), tuple(None if t is None else t[b0:b1] for t in dy16),
+                             None if dy_f32 is None else dy_f32[b0:b1], wparam, ks, mode, accumulate=b0 > 0)
+
+    def _wgrad_gemm(self, src16, dy16, dy_f32, wparam, ks: int, mode: int, accumulate: bool) -> None:
+        bp = self.bprec
+        B, Hs, Ws, Cs = src16[0].shape
+        Bo, Ho, Wo, co = dy16[0].shape
         P = Bo * Ho * Wo
         Ppad = _r64(P)
         taps = ks * ks
@@ -211,7 +223,7 @@ class UNetTrainer:
             gemm(m_full * 256, rows)
         else:
             gemm(0, rows)
-        ops.wgrad_to_oihw(dw, self._param_grad(wparam), Cs, co, False)
+        ops.wgrad_to_oihw(dw, self._param_grad(wparam), Cs, co, accumulate)
 
     def _bias_grad(self, dy: torch.Tensor, bias: Optional[nn.Parameter], per_sample: Optional[torch.Tensor] = None, ld: int = 0) -> None:
         """bias.grad = sum over (batch, pixels) of dy [B,H,W,C]; per_sample[b*ld + c] = sum over pixels (optional)"""

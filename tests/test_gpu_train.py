@@ -182,7 +182,8 @@ def test_gradient_accumulation_equals_the_full_batch(dev, golden):
     _check_grads(m, fx, 1e-3, "accumulated")
 
 
-@pytest.mark.parametrize("B,H,W,cin,cout", [(3, 8, 8, 128, 64), (2, 16, 16, 256, 128), (2, 32, 32, 128, 64), (5, 16, 8, 128, 192), (64, 8, 8, 256, 128)])
+@pytest.mark.parametrize("B,H,W,cin,cout", [(3, 8, 8, 128, 64), (2, 16, 16, 256, 128), (2, 32, 32, 128, 64), (5, 16, 8, 128, 192), (64, 8, 8, 256, 128),
+                                             (2, 64, 64, 128, 128), (1, 5, 64, 128, 64)])
 def test_direct_wgrad3x3_kernel(dev, B, H, W, cin, cout):
     """stedm_wgrad3x3 (both operands from the NHWC bf16 planes, transposed LDS reads, split over pixel units) + the fixed-order
     reduce/scatter against conv2d's weight gradient computed in float64 from the same bf16-rounded operands."""
@@ -360,3 +361,23 @@ def test_two_rank_data_parallel_step_equals_gradient_accumulation(dev):
     worst = max(float(np.abs(got[n] - ref[n].numpy()).max()) for n in ref)
     print(f"two-rank data-parallel step vs gradient accumulation: max |dw| = {worst:.2e} (lr 1e-3)")
     assert worst < 2e-5
+
+
+@pytest.mark.parametrize("B,T,heads,ch", [(2, 64, 4, 32), (2, 256, 4, 32), (1, 1024, 2, 64), (3, 100, 2, 16)])
+def test_attention_backward_vs_autograd(dev, B, T, heads, ch):
+    """QKVAttentionLegacy backward: the LDS-resident form (T <= 128) and the two-kernel general form (T = 256 of the 64x64 latents, T = 1024 of
+    the reference-native 128x128 ones) against autograd over the oracle's restatement."""
+    from oracle import unet as ounet
+    from stedm_amd import ops
+    g = torch.Generator().manual_seed(T + heads)
+    qkv = torch.randn(B, T, heads * 3 * ch, generator=g)
+    d = torch.randn(B, T, heads * ch, generator=g)
+    x = qkv.permute(0, 2, 1).clone().requires_grad_(True)          # oracle layout [B, heads*3*ch, T]
+    with torch.enable_grad():
+        y = ounet.qkv_attention_legacy(x, heads)                   # [B, heads*ch, T]
+        (y * d.permute(0, 2, 1)).sum().backward()
+    dq = torch.empty_like(qkv, device=dev)
+    ops.attn_legacy_bwd(qkv.to(dev), d.to(dev), dq, heads)
+    ref = x.grad.permute(0, 2, 1)
+    err = float((dq.cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-5, err

@@ -13,6 +13,7 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--precision", default="bf16")
 ap.add_argument("--parts", action="store_true")
+ap.add_argument("--latent", type=int, default=32)
 a = ap.parse_args()
 NS32 = dict(image_size=32, in_channels=7, model_channels=128, out_channels=4, num_res_blocks=2, attention_resolutions=[32, 16, 8], channel_mult=[1, 4, 8], num_heads=8)
 dev = torch.device("cuda:0")
@@ -20,8 +21,9 @@ m = UNetModel(precision=a.precision, **NS32).eval(); prng.fill_module_(m, seed=0
 tr = UNetTrainer(m, lr=1e-5)
 B = a.batch
 g = torch.Generator(device="cpu").manual_seed(1)
-x = torch.randn(B, 4, 32, 32, generator=g).to(dev); cc = torch.randn(B, 3, 32, 32, generator=g).to(dev)
-ctx = torch.randn(B, 512, generator=g).to(dev); tgt = torch.randn(B, 4, 32, 32, generator=g).to(dev)
+L = a.latent
+x = torch.randn(B, 4, L, L, generator=g).to(dev); cc = torch.randn(B, 3, L, L, generator=g).to(dev)
+ctx = torch.randn(B, 512, generator=g).to(dev); tgt = torch.randn(B, 4, L, L, generator=g).to(dev)
 t = torch.randint(0, 1000, (B,), generator=g).to(dev)
 for _ in range(a.warmup):
     loss = tr.train_step(x, cc, t, ctx, tgt)
@@ -31,14 +33,14 @@ for _ in range(a.steps):
     loss = tr.train_step(x, cc, t, ctx, tgt)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
-print(f"train step B={B} {a.precision}: {dt * 1e3:.2f} ms  ({1 / dt:.2f} steps/s, {B / dt:.0f} samples/s)  loss {float(loss):.4f}")
+print(f"train step B={B} latent {L}x{L} {a.precision}: {dt * 1e3:.2f} ms  ({1 / dt:.2f} steps/s, {B / dt:.0f} samples/s)  loss {float(loss):.4f}")
 if a.parts:
     def tm(f, n=3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(n): f()
         torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
     print("forward   %.2f ms" % tm(lambda: tr.forward(x, cc, t, ctx)))
-    dp = torch.randn(B, 4, 32, 32, device=dev) * 1e-5
+    dp = torch.randn(B, 4, L, L, device=dev) * 1e-5
     print("backward  %.2f ms" % tm(lambda: tr.backward(dp)))
     tr._grads_ready = True
     def opt():
