@@ -381,3 +381,28 @@ def test_attention_backward_vs_autograd(dev, B, T, heads, ch):
     ref = x.grad.permute(0, 2, 1)
     err = float((dq.cpu() - ref).abs().max() / ref.abs().max())
     assert err < 2e-5, err
+
+
+def test_unet_backward_reference_native_128_latents_vs_oracle(dev):
+    """REF128 (the reference's own configuration: 128x128x3 latents, 6 input / 3 output channels, attention over 1024 tokens): one
+    loss + backward at batch 1 against autograd over the oracle — the general-T attention backward, batch-chunked GEMM weight gradients
+    (W = 128 is outside the direct kernel) and the padded first / last convolutions at full size."""
+    from oracle import train as otrain
+    from oracle import unet as ounet
+    from stedm_amd.train import UNetTrainer
+    cfg = dict(image_size=128, in_channels=6, model_channels=128, out_channels=3, num_res_blocks=2, attention_resolutions=[32, 16, 8],
+               channel_mult=[1, 4, 8], num_heads=8)
+    m = build(cfg, 12, dev, "bf16")
+    ocfg = ounet.UNetConfig(image_size=128, in_channels=6, out_channels=3)
+    P = prng.fill_state_dict(ounet.build_plan(ocfg).shapes, 12)
+    x = prng.normal(12, "ref.x", (1, 6, 128, 128)); ctx = prng.normal(12, "ref.ctx", (1, 512)); target = prng.normal(12, "ref.t", (1, 3, 128, 128))
+    t = torch.tensor([500], dtype=torch.long)
+    loss_ref, grads, dx_ref, dctx_ref, _ = otrain.unet_loss_and_grads(P, ocfg, x, t, ctx, target)
+    tr = UNetTrainer(m)
+    loss, dx, dctx = tr.loss_and_backward(x[:, :3].contiguous().to(dev), x[:, 3:].contiguous().to(dev), t.to(dev), ctx.to(dev), target.to(dev))
+    errs = [abs(float(p.grad.double().norm().cpu()) - float(grads[n].double().norm())) / float(grads[n].double().norm())
+            for n, p in m.named_parameters() if float(grads[n].norm()) > 1e-6 * max(float(g.norm()) for g in grads.values())]
+    print(f"REF128 bf16 training step: loss {float(loss):.5f} (oracle {loss_ref:.5f}); grad-norm error median {np.median(errs):.2e} max {max(errs):.2e}; "
+          f"dctx rel {float((dctx.cpu() - dctx_ref).norm() / dctx_ref.norm()):.2e}")
+    assert abs(float(loss) - loss_ref) < 2e-2 * loss_ref
+    assert np.median(errs) < 2e-2
