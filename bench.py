@@ -369,7 +369,7 @@ def main():
             out["train_step"] = {"ms": round(dtt * 1e3, 2), "steps_per_s": round(1 / dtt, 2), "samples_per_s": round(B / dtt, 1),
                                  "dtype": unet.precision.label + " forward, bf16 backward operands, fp32 master/optimizer", "batch": B,
                                  "algorithmic_tflops": round(3 * B * GFLOP_PER_SAMPLE_FORWARD / 1e3 / dtt, 1),
-                                 "what": "forward + L1 loss + backward (dgrad/wgrad on the MFMA conv kernels) + fused AdamW + EMA, 234.6M params; "
+                                 "what": "forward + L1 loss + backward (dgrad on the forward's MFMA conv kernels, direct 3x3 wgrad kernel) + fused AdamW + EMA, 234.6M params; "
                                          "gradients match the reference's autograd to 1e-5 in parity mode (tests/test_gpu_train.py)",
                                  "loss": round(float(loss), 4)}
             del tr
