@@ -7,8 +7,10 @@ Mirrors what autograd does for the reference in `LatentDiffusion.p_losses` / `tr
 The backward is a reverse walk over the tape `UNetModel._forward_impl` records in training mode:
   * convolution dgrad  = the forward's MFMA convolution kernel with the flipped / transposed filter (stride-2: over the
     zero-inserted gradient; nearest-2x upsample: at the high resolution, then 2x2 sums);
-  * convolution wgrad  = one GEMM dW[(tap,ci)][co] = sum_p col[(tap,ci)][p] dY^T[co][p] on the same kernels, over transposed
-    im2col planes (stedm_im2col_t16); K = B*H*W is split over blocks by the register-streamed kernel's split-K;
+  * convolution wgrad  = stride-1 3x3 (and the Upsample convs over the nearest-2x plane): the direct kernel stedm_wgrad3x3 (both
+    operands from the NHWC planes, transposed in the LDS reads, all nine taps from one LDS image); other shapes: one GEMM
+    dW[(tap,ci)][co] = sum_p col[(tap,ci)][p] dY^T[co][p] on the forward's kernels over transposed im2col planes (stedm_im2col_t16),
+    K = B*H*W split over blocks by the register-streamed kernel's split-K, in batch chunks beyond 65 536;
   * GroupNorm+SiLU, attention, embeddings, reductions: fp32 kernels of csrc/bwd.hip;
   * 16-bit operands of the backward contractions are bf16 (fp32 exponent range: no loss scaling), single product or
     hi/lo 3-product following the forward's mode; normalised operand planes are kept by a bf16 forward, recomputed from the saved
