@@ -7,9 +7,15 @@ DDIM update. Synthetic inputs resident in HBM, PRNG-recipe weights of the NS32 a
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--precision bf16|f16|parity] [--batch 64]
 
-N > 1: launched by torch.distributed.run, one rank per GPU; every rank denoises its own 64 latents (weak
-scaling, no collective inside the loop — samples are independent); the final latents are all-gathered over
-RCCL once after the timed region. Prints ONE JSON line on rank 0.
+N > 1: one rank per GPU; every rank denoises its own 64 latents (weak scaling, no collective inside the loop —
+samples are independent); the final latents are all-gathered over RCCL once after the timed region. Launched either by
+torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or by this script itself:
+`python bench.py --gpus N` without WORLD_SIZE starts N rank processes (the parent never touches the GPU) and exits
+with their return code. `--gpus` must equal WORLD_SIZE when both are given. Prints ONE JSON line on rank 0.
+
+Rehearsal knobs for boxes without N GPUs (never set by the driver): STEDM_BENCH_ONE_DEVICE=1 puts every rank on
+cuda:0, STEDM_BENCH_BACKEND=gloo replaces RCCL, STEDM_BENCH_DRY=1 skips the HIP work altogether (CPU tensors: only the
+launcher, the process group, the barriers, the max-over-ranks timing and the all-gather run; the line says dry_run).
 """
 from __future__ import annotations
 
@@ -138,9 +144,11 @@ def run_steps(ld, xT, cond, unc, warmup, steps, world):
     return dt, img
 
 
-def cpu_baseline(seconds_budget=15.0):
+def cpu_baseline(seconds_budget=15.0, gpu_eval=None):
     """The CPU oracle (fixture-pinned restatement of the reference's PyTorch-CPU path) on this host's cores:
-    CFG denoising steps (2 sequential U-Net forwards + update, as the reference does) at a bounded batch."""
+    CFG denoising steps (2 sequential U-Net forwards + update, as the reference does) at a bounded batch.
+    gpu_eval (optional): callable(x, c_concat, ctx, ctx_u, t) -> {mode: (e_c, e_u)} evaluating the SAME 4 samples inside a bench-sized
+    batch on the HIP path; the oracle's outputs of the first step then label every mode with its measured deviation (checker role)."""
     from oracle import ddim as od
     from oracle import unet as ou
     from stedm_amd.utils import prng
@@ -163,11 +171,23 @@ def cpu_baseline(seconds_budget=15.0):
     t = torch.full((Bc,), 951, dtype=torch.long)
     ds = od.DDIMSchedule(od.Schedule(), 50, 0.0)
 
+    def evals(xx):
+        return (ou.unet_forward(P, cfg, torch.cat([xx, cc], 1), t, ctx, plan=plan),
+                ou.unet_forward(P, cfg, torch.cat([xx, cc], 1), t, ctx_u, plan=plan))
+
     def step(xx):
-        e_c = ou.unet_forward(P, cfg, torch.cat([xx, cc], 1), t, ctx, plan=plan)
-        e_u = ou.unet_forward(P, cfg, torch.cat([xx, cc], 1), t, ctx_u, plan=plan)
+        e_c, e_u = evals(xx)
         return od.ddim_update(xx, od.cfg_combine(e_c, e_u, 1.5), *ds.scalars(49))[0]
 
+    deviation = None
+    if gpu_eval is not None:
+        r_c, r_u = evals(x)
+        ref = torch.cat([r_c, r_u]).double()
+        deviation = {"rows": Bc, "what": "eps of 4 samples inside the bench-sized CFG batch (cond + uncond) vs the fp32 CPU oracle on the same samples: "
+                                         "rel-L2 and max|diff|/std; north_star tolerance 1e-3"}
+        for mode, (g_c, g_u) in gpu_eval(x, cc, ctx, ctx_u, 951).items():
+            got = torch.cat([g_c, g_u]).double()
+            deviation[mode] = {"rel_l2": float((got - ref).norm() / ref.norm()), "max_over_std": float((got - ref).abs().max() / ref.std())}
     x = step(x)  # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
@@ -176,9 +196,10 @@ def cpu_baseline(seconds_budget=15.0):
         if el > seconds_budget or n >= 200:
             break
     sample_steps_per_s = n * Bc / el
-    return {"value": sample_steps_per_s / 64.0, "unit": "steps/s (bs=64 equivalent)", "cores": cores, "kind": "port",
-            "sample": f"{n} CFG denoising steps at batch {Bc} (fp32 torch-CPU oracle, {cores} threads), "
-                      f"{el:.1f} s; scaled by {Bc}/64", "sample_steps_per_s": sample_steps_per_s}
+    out = {"value": sample_steps_per_s / 64.0, "unit": "steps/s (bs=64 equivalent)", "cores": cores, "kind": "port",
+           "sample": f"{n} CFG denoising steps at batch {Bc} (fp32 torch-CPU oracle, {cores} threads), "
+                     f"{el:.1f} s; scaled by {Bc}/64", "sample_steps_per_s": sample_steps_per_s}
+    return out, deviation
 
 
 def cpu_baseline_train():
@@ -202,6 +223,80 @@ def cpu_baseline_train():
             "sample": f"1 forward + L1 + backward at batch {Bc} (fp32 torch-CPU oracle under autograd, {cores} threads), {el:.1f} s"}
 
 
+def csrc_fingerprint():
+    """sha1 over the kernel sources: a profile-derived figure (roofline.traffic) is only reported for the binary it was taken on"""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "stedm_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".inc", ".hpp")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside a launcher: start N rank processes of this script (what torch.distributed.run does for
+    train_diff.py:75 / predict_diff.py:86 in the reference) and return their exit code. Runs before anything initialises HIP."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0 and rc == 0:
+                rc = r
+                for q in live:          # a dead rank leaves the others waiting at a barrier: stop exactly the processes started here
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def dry_run(args, rank, world):
+    """STEDM_BENCH_DRY: the multi-rank plumbing of this file on CPU tensors (gloo), no HIP work, no throughput claim."""
+    from stedm_amd import parallel as par
+    if world > 1:
+        torch.distributed.init_process_group("gloo")
+    lo, hi = par.shard_range(args.batch * world, rank, world)
+    final = par.per_sample_normal(1, list(range(lo, hi)), (4, 32, 32))
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        final = final * 1.0
+    if world > 1:
+        torch.distributed.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    ranks_seen = 1
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        gathered = par.all_gather_samples(final, args.batch * world)
+        assert gathered.shape[0] == args.batch * world
+        ranks_seen = torch.distributed.get_world_size()
+        ref = par.per_sample_normal(1, list(range(args.batch * world)), (4, 32, 32))
+        assert torch.equal(gathered, ref), "gathered samples differ from the single-rank stream"
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "U-Net denoising steps/sec (32x32x4 latent, bs=64)", "value": None, "unit": "steps/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "dry_run": True, "rccl_ranks": ranks_seen, "scaling": "weak",
+                          "config": {"workload": "launcher rehearsal only (no HIP work)", "batch_per_gpu": args.batch,
+                                     "global_batch": args.batch * world}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -215,12 +310,19 @@ def main():
     ap.add_argument("--no-e2e-leg", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with matching values "
+                         f"(python bench.py --gpus N starts the ranks itself)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ.get("STEDM_BENCH_DRY"):
+        return dry_run(args, rank, world)
     # rehearsal knobs for a one-GPU box (the driver's runs never set them): all ranks on one device, gloo instead of RCCL
     if os.environ.get("STEDM_BENCH_ONE_DEVICE"):
         local_rank = 0
@@ -244,6 +346,7 @@ def main():
         from stedm_amd import parallel as par
         gathered = par.all_gather_samples(final, B * world)                # prediction-side RCCL all-gather of the samples
         assert gathered.shape[0] == B * world and bool(torch.isfinite(gathered).all())
+    ranks_seen = torch.distributed.get_world_size() if world > 1 else 1
     dt = float(t.item())
     steps_per_s = world * args.steps / dt
     ms_per_step = 1e3 * dt / args.steps
@@ -262,21 +365,30 @@ def main():
         for _ in range(2):
             sg.step_eager()
         cs = ct.summary(); ct.remove()
-        traffic = None
+        # HBM-side bytes per launch from the PMC passes (tools/pmc_traffic.py); reported only when the profile was taken on THIS
+        # binary (fingerprint of the kernel sources), null otherwise — never a stale constant
+        traffic, traffic_note = None, "no PMC traffic profile for this build (tools/pmc_traffic.py)"
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("conv_igemm_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                if tj.get("csrc_fingerprint") == csrc_fingerprint():
+                    traffic, traffic_note = tj.get("conv_igemm_hbm_bytes_per_launch"), "profiles/traffic.json (same kernel sources)"
+                else:
+                    traffic_note = "profiles/traffic.json was taken on other kernel sources: not reported"
             except Exception:
-                traffic = None
+                pass
         roofline = {"bound": "mfma", "kernel": "all stedm_conv_igemm launches of a step: conv_rs_kernel (3x3, 3x3 + fused 1x1 skip, sub-pixel upsample, space-to-depth "
                               "downsample, 1x1) incl. their conv_splitk_reduce passes; one conv_dma_kernel 1x1", "achieved": round(cs["tflops"], 2),
                     "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(cs["tflops"] / PEAK_MFMA_TFLOPS, 4),
-                    "traffic": traffic, "launches_per_step": cs["launches"] // 2, "avg_launch_us": round(cs["avg_us"], 2),
+                    "traffic": traffic, "traffic_source": traffic_note, "launches_per_step": cs["launches"] // 2, "avg_launch_us": round(cs["avg_us"], 2),
                     "algorithmic_gflop_per_launch": round(cs["flops_per_launch"] / 1e9, 3),
                     "conv_ms_per_step": round(cs["total_ms"] / 2, 3)}
-        # whole-step figure against the same peak (2 reference forwards of algorithmic work per step)
+        # whole-step figures against the same peak: (a) reference-equivalent = the FLOPs of the reference's two full forwards per step
+        # (what a user gets per second, in the reference's currency); (b) executed = the conv FLOPs the hardware really runs per step
+        # (shared encoder evaluated once, sub-pixel upsample at 4/9 of the MACs): the honest MFMA utilisation of the whole step
         step_tflops = 2 * B * GFLOP_PER_SAMPLE_FORWARD / 1e3 / (ms_per_step * 1e-3) * 1.0
+        exec_tflops = cs["flops_per_launch"] * (cs["launches"] // 2) / 1e12 / (ms_per_step * 1e-3)
         out = {
             "metric": "U-Net denoising steps/sec (32x32x4 latent, bs=64)", "value": round(steps_per_s, 3), "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -287,7 +399,10 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "latent": "32x32x4", "cfg": "cond+uncond per step",
                        "parallelism": f"dp{world} (independent latents, no in-loop collective)"},
             "sample_steps_per_s": round(steps_per_s * B, 1),
-            "step_algorithmic_tflops": round(step_tflops, 1), "step_frac_of_mfma_peak": round(step_tflops / PEAK_MFMA_TFLOPS, 4),
+            "rccl_ranks": ranks_seen,
+            "step_reference_equivalent_tflops": round(step_tflops, 1),
+            "step_reference_equivalent_frac_of_mfma_peak": round(step_tflops / PEAK_MFMA_TFLOPS, 4),
+            "step_executed_conv_tflops": round(exec_tflops, 1), "step_executed_frac_of_mfma_peak": round(exec_tflops / PEAK_MFMA_TFLOPS, 4),
             "roofline": roofline,
         }
         if not args.no_parity_leg and world == 1:
@@ -297,13 +412,13 @@ def main():
                 ld.model.diffusion_model.set_precision("f16")
                 dtf, _ = run_steps(ld, xT, cond, unc, 2, max(4, args.steps // 2), 1)
                 out["f16_mode"] = {"dtype": "f16", "value": round(max(4, args.steps // 2) / dtf, 3), "unit": "steps/s",
-                                   "note": "fp16 single product; NS32 U-Net output vs the reference golden: rel-L2 7e-4 (bf16: 6e-3), "
-                                           "tests/test_gpu_unet.py::test_unet_fast_modes_reported"}
+                                   "note": "fp16 single product; measured deviation from the CPU oracle: deviation_vs_cpu_oracle.f16"}
             # fp32-parity mode (fp16 x3 split products) throughput next to the fast mode, same workload
             ld.model.diffusion_model.set_precision("parity")
             dtp, _ = run_steps(ld, xT, cond, unc, 2, max(4, args.steps // 2), 1)
             out["parity_mode"] = {"dtype": "f16x3", "value": round(max(4, args.steps // 2) / dtp, 3), "unit": "steps/s",
-                                  "note": "split-precision mode that meets the 1e-3 fp32 parity tolerance (tests/test_gpu_unet.py)"}
+                                  "note": "split-precision mode that meets the 1e-3 fp32 parity tolerance (deviation_vs_cpu_oracle.f16x3; "
+                                          "tests/test_gpu_unet.py, tests/test_gpu_bench_config.py)"}
         if not args.no_e2e_leg and world == 1:
             # BASELINE config 5's latent size (64x64x4, CATCH 512^2): the same denoising step on 4x the pixels, reported beside the headline
             ld.model.diffusion_model.set_precision(args.precision)
@@ -315,7 +430,8 @@ def main():
             dt64, _ = run_steps(ld, x64, c64, u64, 2, 6, 1)
             fl64 = 2 * B * 217.31 / 1e3        # TFLOP per CFG step (217.31 GFLOP per sample-forward at 64^2)
             out["ns64_step"] = {"value": round(6 / dt64, 3), "unit": "steps/s", "ms_per_step": round(1e3 * dt64 / 6, 3), "latent": "64x64x4", "batch": B,
-                                "step_algorithmic_tflops": round(fl64 / (dt64 / 6), 1), "step_frac_of_mfma_peak": round(fl64 / (dt64 / 6) / PEAK_MFMA_TFLOPS, 4)}
+                                "step_reference_equivalent_tflops": round(fl64 / (dt64 / 6), 1),
+                                "step_reference_equivalent_frac_of_mfma_peak": round(fl64 / (dt64 / 6) / PEAK_MFMA_TFLOPS, 4)}
             del x64, lay64
             # BASELINE config 3 end to end up to the sampled latents: style encoder (sViT, 4 style images of 512^2 per sample) + layout
             # rescaler + DDIM-50 with CFG, the call sequence of LDM_Diffusion.predict_step
@@ -376,7 +492,27 @@ def main():
             if not args.no_cpu_baseline:
                 out["train_step"]["cpu_baseline"] = cpu_baseline_train()
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            unet = ld.model.diffusion_model
+
+            def gpu_eval(x4, cc4, ctx4, ctxu4, tval):
+                # the oracle's 4 samples as rows 0..3 of a bench-sized batch (rows are independent): the kernels selected are the bench's
+                n4 = x4.shape[0]
+                xb, ccb = xT.clone(), cond["c_concat"][0].clone()
+                cb, ub = cond["c_crossattn"][0].clone(), unc["c_crossattn"][0].clone()
+                xb[:n4], ccb[:n4], cb[:n4], ub[:n4] = x4.to(dev), cc4.to(dev), ctx4.to(dev), ctxu4.to(dev)
+                tb = torch.full((B,), int(tval), dtype=torch.long, device=dev)
+                res = {}
+                for mode in dict.fromkeys([args.precision, "f16", "parity"]):
+                    unet.set_precision(mode)
+                    ec, eu = unet.forward_cfg(xb, ccb, tb, cb, ub, uniform_t=True)
+                    res[unet.precision.label] = (ec[:n4].float().cpu(), eu[:n4].float().cpu())
+                unet.set_precision(args.precision)
+                return res
+
+            out["cpu_baseline"], dev_rep = cpu_baseline(gpu_eval=gpu_eval)
+            out["deviation_vs_cpu_oracle"] = dev_rep
+            if dev_rep and out["dtype"] in dev_rep:
+                out["headline_rel_l2_vs_oracle"] = round(dev_rep[out["dtype"]]["rel_l2"], 6)
         elif world == 1:
             out["cpu_baseline"] = None
     if world > 1:

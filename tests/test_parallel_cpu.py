@@ -89,3 +89,30 @@ def test_two_rank_gloo_gradient_buckets_sum():
     assert world == 2
     assert torch.allclose(torch.from_numpy(got), ref, rtol=0, atol=1e-6)
     assert par.all_reduce_buckets(torch.ones(8), 4) == 1     # not initialised: identity
+
+
+def _bench(args, env_extra):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_flag_launches_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks (rehearsed on CPU tensors over gloo: the launcher, the
+    process group, the barriers, the max-over-ranks timing, the sample all-gather and the rank-0 line) and say n_gpus 2."""
+    r, line = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "3"], {"STEDM_BENCH_DRY": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["dry_run"] is True and line["value"] is None
+    assert line["config"]["global_batch"] == 6
+    assert sum(ln.startswith("{") for ln in r.stdout.splitlines()) == 1          # ONE line, from rank 0
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    r, line = _bench(["--gpus", "1"], {"STEDM_BENCH_DRY": "1", "WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and line is None and "WORLD_SIZE=2" in r.stderr
