@@ -1,7 +1,8 @@
 """TEST INFRASTRUCTURE ONLY — CPU restatement of the training step's arithmetic: U-Net forward, L1 loss of
 ddpm.py:1030-1040 (loss_type l1, logvar == 0, l_simple_weight 1, original_elbo_weight 0), reverse-mode gradients by autograd
 over oracle/unet.py's functional forward, AdamW as torch.optim.AdamW computes it, and LitEma's update (ema.py:25-44).
-Pinned by tests/golden/f14_grads_*.npz (the reference's own UNetModel run forward + backward, make_golden_grads.py).
+Pinned by tests/golden/f14_grads_*.npz (the reference's own UNetModel run forward + backward, make_golden_grads.py) and, for the
+optimizer side, by tests/golden/f13_ema_adamw.npz (traces of torch.optim.AdamW and of the reference's own LitEma, make_golden_opt.py).
 Only tests/, smoke() and bench.py's cpu_baseline leg may import this package."""
 from __future__ import annotations
 

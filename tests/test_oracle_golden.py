@@ -230,3 +230,32 @@ def test_f14_gradients(golden, tag, B, hw, seed, cfg):
         assert abs(float(a.norm()) - n) <= 2e-4 * n + 1e-12, name
         pick = a[torch.from_numpy(pick_index(a.numel()))].numpy()
         assert np.abs(pick - fx[f"g.{name}.pick"]).max() <= 2e-4 * n / np.sqrt(a.numel()) * 30 + 1e-9, name
+
+
+def test_f13_adamw_and_litema(golden):
+    """oracle/train.py's AdamW and EMA restatements against traces of `torch.optim.AdamW` and of the reference's own `LitEma`
+    (tests/golden/make_golden_opt.py imports ldm.modules.ema): parameters, both moments and the shadows after each of three steps,
+    plus one update in the saturated branch of LitEma's decay schedule."""
+    from oracle import train as otrain
+    fx = golden("f13_ema_adamw")
+    lr, b1, b2, eps, wd, dec = [float(v) for v in fx["hyper"]]
+    names = sorted(k[3:] for k in fx.files if k.startswith("p0."))
+    p = {n: torch.from_numpy(fx[f"p0.{n}"].copy()) for n in names}
+    m = {n: torch.zeros_like(p[n]) for n in names}
+    v = {n: torch.zeros_like(p[n]) for n in names}
+    sh = {n: p[n].clone() for n in names}
+    for step in (1, 2, 3):
+        assert int(fx[f"num_updates{step}"]) == step
+        d = otrain.ema_decay(step, dec)
+        for n in names:
+            g = prng.normal(13, f"f13.g{step}.{n}", tuple(p[n].shape)) * 0.3
+            otrain.adamw_step(p[n], g, m[n], v[n], step, lr, b1, b2, eps, wd)
+            otrain.ema_update(sh[n], p[n], d)
+            for got, key in ((p[n], "p"), (m[n], "m"), (v[n], "v"), (sh[n], "ema")):
+                ref = torch.from_numpy(fx[f"{key}{step}.{n}"])
+                assert torch.allclose(got, ref, rtol=2e-6, atol=1e-7), (key, step, n, float((got - ref).abs().max()))
+    nL = int(fx["num_updatesL"])
+    assert nL == 200001 and otrain.ema_decay(nL, dec) == dec
+    for n in names:
+        otrain.ema_update(sh[n], torch.from_numpy(fx[f"pL.{n}"]), otrain.ema_decay(nL, dec))
+        assert torch.allclose(sh[n], torch.from_numpy(fx[f"emaL.{n}"]), rtol=2e-6, atol=1e-7), n
