@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STEDM_ABI_VERSION 1
+#define STEDM_ABI_VERSION 2
 
 #define STEDM_F16 0
 #define STEDM_BF16 1
@@ -340,6 +340,10 @@ int stedm_axpby_f32(const float* x, float* y, long n, float alpha, float beta, v
  * block i updates elements [chunk_off[i], chunk_off[i] + 4096) of tensor chunk_tensor[i]. step counts from 1. */
 int stedm_adamw_ema(const void* table, const int* chunk_tensor, const long* chunk_off, int nchunks, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int step, float ema_decay, float grad_scale, void* stream);
+/* LitEma.forward alone (ldm/modules/ema.py:25-44; on_train_batch_end, ddpm.py:369-371, runs it once per micro-batch, also on the
+ * micro-batches of an accumulation window that do not step the optimizer): ema -= (1 - ema_decay) * (ema - p) over the same table
+ * (entries without a shadow are skipped; g / m / v are not read). */
+int stedm_ema_update(const void* table, const int* chunk_tensor, const long* chunk_off, int nchunks, float ema_decay, void* stream);
 
 /* ---- image epilogue of predict_step (integer work, bit-exact) -------------------------------------------------------
  * modules/ldm_diffusion.py:93-95: ((clip(x, -1, 1).permute(0,2,3,1) + 1) * 127.5).astype(uint8): x NCHW fp32 -> out NHWC uint8. */

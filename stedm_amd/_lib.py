@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STEDM_HIP_LIB") or os.path.join(_HERE, "libstedm_hip.so")     # STEDM_HIP_LIB: A/B timing of another build
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 F16, BF16 = 0, 1
 CONV_S1, CONV_DOWN, CONV_UP, CONV_UP_SUBPIXEL, CONV_S2D = 0, 1, 2, 3, 4
 
@@ -103,6 +103,7 @@ SIGNATURES = {
     "stedm_spatial_rescale_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "stedm_axpby_f32": (_I, [_P, _P, C.c_long, _F, _F, _P]),
     "stedm_adamw_ema": (_I, [_P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _F, _F, _P]),
+    "stedm_ema_update": (_I, [_P, _P, _P, _I, _F, _P]),
     "stedm_image_to_uint8": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "stedm_seg_merge": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "stedm_argmax_u8": (_I, [_P, _P, C.c_long, _I, _P]),

@@ -596,6 +596,21 @@ __global__ void __launch_bounds__(256) adamw_ema_kernel(const OptTensor* __restr
   }
 }
 
+// LitEma.forward alone (ema.py:25-44, called from on_train_batch_end, ddpm.py:369-371): shadow -= (1 - decay) * (shadow - p) over the
+// optimizer's pointer table; tensors without a shadow are skipped.
+__global__ void __launch_bounds__(256) ema_update_kernel(const OptTensor* __restrict__ table, const int* __restrict__ chunk_tensor,
+                                                         const long* __restrict__ chunk_off, float one_minus_decay) {
+  const OptTensor t = table[chunk_tensor[blockIdx.x]];
+  if (!t.ema) return;
+  const long o0 = chunk_off[blockIdx.x];
+  for (int k = 0; k < 16; ++k) {
+    const long i = o0 + k * 256 + threadIdx.x;
+    if (i >= t.n) return;
+    const float s = t.ema[i];
+    t.ema[i] = s - one_minus_decay * (s - t.p[i]);
+  }
+}
+
 // SpatialRescaler (encoders/modules.py:123-130) weight gradient: dW[co][ci] = sum_{b,p} d_out[b][co][p] * boxmean_f(x)[b][ci][p].
 // grid B (one block per sample, per-sample partials), then a fixed-order sum over the batch.
 __global__ void __launch_bounds__(256) rescale_wgrad_partial_kernel(const float* __restrict__ x, const float* __restrict__ d_out, float* __restrict__ part, int cin,
@@ -808,6 +823,13 @@ extern "C" int stedm_adamw_ema(const void* table, const int* chunk_tensor, const
   const float bc2 = (float)(1.0 - pow((double)beta2, (double)step));
   adamw_ema_kernel<<<nchunks, 256, 0, as_stream(stream)>>>((const OptTensor*)table, chunk_tensor, chunk_off, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2),
                                                           ema_decay, grad_scale);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int stedm_ema_update(const void* table, const int* chunk_tensor, const long* chunk_off, int nchunks, float ema_decay, void* stream) {
+  STEDM_CHECK_ARG(table && chunk_tensor && chunk_off && nchunks > 0 && ema_decay >= 0.f && ema_decay <= 1.f, "ema_update: bad args");
+  ema_update_kernel<<<nchunks, 256, 0, as_stream(stream)>>>((const OptTensor*)table, chunk_tensor, chunk_off, 1.0f - ema_decay);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

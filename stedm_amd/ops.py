@@ -664,6 +664,13 @@ def adamw_ema(table: torch.Tensor, chunk_tensor: torch.Tensor, chunk_off: torch.
     check(lib().stedm_adamw_ema(table.data_ptr(), chunk_tensor.data_ptr(), chunk_off.data_ptr(), chunk_tensor.numel(), float(lr), float(beta1),
                                 float(beta2), float(eps), float(weight_decay), int(step), float(ema_decay), float(grad_scale), _stream()), "stedm_adamw_ema")
 
+
+def ema_update(table: torch.Tensor, chunk_tensor: torch.Tensor, chunk_off: torch.Tensor, ema_decay: float) -> None:
+    """LitEma.forward (ema.py:25-44) over the optimizer's pointer table: shadow -= (1 - decay) * (shadow - p)."""
+    check(lib().stedm_ema_update(table.data_ptr(), chunk_tensor.data_ptr(), chunk_off.data_ptr(), chunk_tensor.numel(), float(ema_decay), _stream()),
+          "stedm_ema_update")
+
+
 # ------------------------------------------------------------------------------------------- image epilogue
 def image_to_uint8(x: torch.Tensor) -> torch.Tensor:
     """((clip(x, -1, 1).permute(0, 2, 3, 1) + 1) * 127.5).astype(uint8) — x [B,C,H,W] fp32 -> [B,H,W,C] uint8 (ldm_diffusion.py:93-95)."""

@@ -109,16 +109,22 @@ class UNetTrainer:
         total = (sum(p.numel() for p in order) + 3) // 4 * 4
         self.grad_arena = torch.zeros((total,), dtype=torch.float32, device=order[0].device)
         off = 0
+        self._arena_off = []
         for p in order:
             p.grad = self.grad_arena[off:off + p.numel()].view(p.shape)
+            self._arena_off.append(off)
             off += p.numel()
         ted = m.model_channels * 4
         self._dWcat = self.grad_arena[:m._emb_ntot * ted].view(m._emb_ntot, ted)
         self._arena_params = order
+        self._int_views = [p.grad for p in order]
+        self._pub_arena = None
 
     def _param_grad(self, p: nn.Parameter) -> torch.Tensor:
-        if p.grad is None or getattr(self, "grad_arena", None) is None:
+        if getattr(self, "grad_arena", None) is None:
             self._alloc_grads()
+        elif p.grad is None:          # e.g. after optimizer.zero_grad(set_to_none=True): the arena stays, the views come back
+            self.internal_grads()
         return p.grad
 
     def _w4(self, conv) -> torch.Tensor:
@@ -272,6 +278,7 @@ class UNetTrainer:
         m = self.m
         self.G = {}
         self._dpacks = {}
+        self.internal_grads()
         B = d_eps.shape[0]
         ted = m.model_channels * 4
         self.dE = self._buf("dE", (B, m._emb_ntot))
@@ -486,29 +493,49 @@ class UNetTrainer:
         dx, dctx = self.backward(dpred)
         return loss, dx, dctx
 
-    def _build_opt(self):
-        import ctypes as C
+    def _chunks(self, params, dev):
+        ct, co = [], []
+        for i, p in enumerate(params):
+            for o in range(0, p.numel(), 4096):
+                ct.append(i); co.append(o)
+        return torch.tensor(ct, dtype=torch.int32, device=dev), torch.tensor(co, dtype=torch.int64, device=dev)
+
+    def _build_ema(self):
+        """EMA shadows of the U-Net's parameters (LitEma is built over `model`, ddpm.py:86-88; the cond stage has none) and the
+        pointer table the EMA-only kernel walks. Independent of the optimizer state: a training loop that keeps torch.optim.AdamW
+        (the autograd bridge of latent_diffusion.py) still gets on_train_batch_end's EMA from here."""
         import numpy as np
+        if getattr(self, "grad_arena", None) is None:
+            self._alloc_grads()
+        params = list(self._arena_params)
+        dev = params[0].device
+        ema = [p.detach().clone() if i < self._n_unet_params else None for i, p in enumerate(params)] if self.ema_decay is not None else None
+        tab = np.zeros((len(params), 6), dtype=np.int64)
+        for i, p in enumerate(params):
+            assert p.is_contiguous()
+            tab[i] = (p.data_ptr(), 0, 0, 0, ema[i].data_ptr() if ema is not None and ema[i] is not None else 0, p.numel())
+        ct, co = self._chunks(params, dev)
+        self._ema = {"ema": ema, "params": params, "tab_np": tab, "table": torch.from_numpy(tab).to(dev), "ct": ct, "co": co}
+        if getattr(self, "_ema_resume", None) is not None:
+            self._apply_ema_resume()
+
+    def _build_opt(self):
+        import numpy as np
+        if getattr(self, "_ema", None) is None:
+            self._build_ema()
         params = list(self._arena_params)
         dev = params[0].device
         st = {"m": [torch.zeros_like(p, dtype=torch.float32) for p in params], "v": [torch.zeros_like(p, dtype=torch.float32) for p in params],
-              "ema": [p.detach().clone() if i < self._n_unet_params else None for i, p in enumerate(params)] if self.ema_decay is not None else None,
-              "params": params}
-        tab = np.zeros((len(params), 6), dtype=np.int64)
-        ct, co = [], []
+              "ema": self._ema["ema"], "params": params}
+        tab = self._ema["tab_np"].copy()
         for i, p in enumerate(params):
-            assert p.is_contiguous() and p.grad is not None and p.grad.is_contiguous(), "run backward() before the first optimizer step"
-            tab[i] = (p.data_ptr(), p.grad.data_ptr(), st["m"][i].data_ptr(), st["v"][i].data_ptr(),
-                      st["ema"][i].data_ptr() if st["ema"] is not None and st["ema"][i] is not None else 0, p.numel())
-            for o in range(0, p.numel(), 4096):
-                ct.append(i); co.append(o)
+            g = self.grad_arena[self._arena_off[i]:self._arena_off[i] + p.numel()]
+            tab[i, 1:4] = (g.data_ptr(), st["m"][i].data_ptr(), st["v"][i].data_ptr())
         st["table"] = torch.from_numpy(tab).to(dev)
-        st["ct"] = torch.tensor(ct, dtype=torch.int32, device=dev)
-        st["co"] = torch.tensor(co, dtype=torch.int64, device=dev)
-        st["gptrs"] = [p.grad.data_ptr() for p in params]
+        st["ct"], st["co"] = self._ema["ct"], self._ema["co"]
         self._opt = st
-        if getattr(self, "_ema_resume", None) is not None:
-            self._apply_ema_resume()
+        if getattr(self, "_opt_resume", None) is not None:
+            self._apply_opt_resume()
 
     @torch.no_grad()
     def all_reduce_grads(self, group=None, bucket_mb: int = 256) -> int:
@@ -520,39 +547,52 @@ class UNetTrainer:
         self._grad_scale = 1.0 / world
         return world
 
+    def _next_ema_decay(self) -> float:
+        """ema.py:28-31: the counter is incremented first, decay = min(decay, (1 + n) / (10 + n))."""
+        self.ema_updates += 1
+        return min(self.ema_decay, (1 + self.ema_updates) / (10 + self.ema_updates))
+
     @torch.no_grad()
     def optimizer_step(self) -> None:
-        """AdamW over every parameter + EMA shadow update (ema.py:25-44: decay = min(decay, (1+n)/(10+n)))."""
+        """AdamW over every parameter + EMA shadow update (ema.py:25-44: decay = min(decay, (1+n)/(10+n))) in one launch; gradients
+        are read from the flat arena."""
         assert self._grads_ready, "optimizer_step() needs gradients from backward()"
         if self._opt is None:
             self._build_opt()
         st = self._opt
-        assert st["gptrs"] == [p.grad.data_ptr() for p in st["params"]], "gradient tensors moved since the optimizer table was built"
         self.step_count += 1
-        decay = 0.0
-        if self.ema_decay is not None:
-            self.ema_updates += 1
-            decay = min(self.ema_decay, (1 + self.ema_updates) / (10 + self.ema_updates))
+        decay = self._next_ema_decay() if self.ema_decay is not None else 0.0
         ops.adamw_ema(st["table"], st["ct"], st["co"], self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, decay,
                       grad_scale=getattr(self, "_grad_scale", 1.0))
         self.m.invalidate()      # parameters changed through raw pointers: repack on the next forward
         self._grads_ready = False
 
+    @torch.no_grad()
+    def ema_step(self) -> None:
+        """LitEma.forward alone: what `on_train_batch_end` (ddpm.py:369-371) runs after EVERY micro-batch, also those of an
+        accumulation window that did not step the optimizer (the shadows then move towards unchanged parameters)."""
+        if self.ema_decay is None:
+            return
+        if getattr(self, "_ema", None) is None:
+            self._build_ema()
+        e = self._ema
+        ops.ema_update(e["table"], e["ct"], e["co"], self._next_ema_decay())
+
     def ema_parameters(self) -> Optional[List[torch.Tensor]]:
-        return None if self._opt is None else self._opt["ema"]
+        return None if getattr(self, "_ema", None) is None else self._ema["ema"]
 
     def ema_named(self) -> Optional[Dict[str, torch.Tensor]]:
-        """EMA shadows by U-Net parameter name (None before the first optimizer step or without EMA)."""
-        if self._opt is None or self._opt["ema"] is None:
+        """EMA shadows by U-Net parameter name (None before the shadows exist or without EMA)."""
+        if getattr(self, "_ema", None) is None or self._ema["ema"] is None:
             return None
         names = {id(p): n for n, p in self.m.named_parameters()}
-        return {names[id(p)]: e for p, e in zip(self._opt["params"], self._opt["ema"]) if e is not None}
+        return {names[id(p)]: e for p, e in zip(self._ema["params"], self._ema["ema"]) if e is not None}
 
     @torch.no_grad()
     def load_ema(self, shadows: Dict[str, torch.Tensor], num_updates: int) -> None:
         """Resume the EMA of a checkpoint (LitEma buffers by U-Net parameter name + its update counter)."""
         self._ema_resume = (dict(shadows), int(num_updates))
-        if self._opt is not None:
+        if getattr(self, "_ema", None) is not None:
             self._apply_ema_resume()
 
     def _apply_ema_resume(self) -> None:
@@ -565,12 +605,97 @@ class UNetTrainer:
         self.ema_updates = n
         self._ema_resume = None
 
+    # ------------------------------------------------------------------------------------------------ optimizer state (checkpoints)
+    def _torch_param_order(self) -> List[nn.Parameter]:
+        """the order `configure_optimizers` hands the parameters to torch.optim.AdamW (modules/ldm_diffusion.py:224-234):
+        model.model.parameters() then cond_stage_model's; optimizer state dicts index them by that position"""
+        return list(self.m.parameters()) + list(self.extra_params)
+
     @torch.no_grad()
-    def train_step(self, x, c_concat, t, context, target, group=None) -> torch.Tensor:
+    def optimizer_state_dict(self) -> dict:
+        """AdamW state in `torch.optim.AdamW.state_dict()` layout (what a Lightning checkpoint keeps under `optimizer_states[0]`):
+        {"state": {i: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...]}, i in the reference's parameter order."""
+        if self._opt is None:
+            self._build_opt()
+        pos = {id(p): i for i, p in enumerate(self._opt["params"])}
+        state = {}
+        order = self._torch_param_order()
+        for i, p in enumerate(order):
+            j = pos[id(p)]
+            state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self._opt["m"][j].detach().clone(),
+                        "exp_avg_sq": self._opt["v"][j].detach().clone()}
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.wd, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(order)))}
+        return {"state": state, "param_groups": [group]}
+
+    @torch.no_grad()
+    def load_optimizer_state_dict(self, sd: dict) -> None:
+        """Resume AdamW from a state dict in torch's layout (see optimizer_state_dict): both moments and the step counter (bias
+        correction continues instead of restarting); lr / betas / eps / weight_decay of the first param group are taken over."""
+        self._opt_resume = sd
+        if self._opt is not None:
+            self._apply_opt_resume()
+
+    def _apply_opt_resume(self) -> None:
+        sd, self._opt_resume = self._opt_resume, None
+        pos = {id(p): i for i, p in enumerate(self._opt["params"])}
+        order = self._torch_param_order()
+        steps = set()
+        for i, p in enumerate(order):
+            st = sd["state"].get(i, sd["state"].get(str(i)))
+            if st is None:
+                continue
+            j = pos[id(p)]
+            self._opt["m"][j].copy_(st["exp_avg"].to(self._opt["m"][j].device, torch.float32).view_as(self._opt["m"][j]))
+            self._opt["v"][j].copy_(st["exp_avg_sq"].to(self._opt["v"][j].device, torch.float32).view_as(self._opt["v"][j]))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"optimizer state with per-parameter step counts {sorted(steps)}: the fused AdamW kernel keeps one counter")
+        if steps:
+            self.step_count = steps.pop()
+        g = (sd.get("param_groups") or [{}])[0]
+        self.lr = float(g.get("lr", self.lr))
+        self.betas = tuple(float(b) for b in g.get("betas", self.betas))
+        self.eps, self.wd = float(g.get("eps", self.eps)), float(g.get("weight_decay", self.wd))
+
+    # ------------------------------------------------------------------------------------------------ autograd bridge support
+    @torch.no_grad()
+    def publish_grads(self, scale: float, accumulate: bool) -> None:
+        """acc_arena = scale * grad_arena (+ acc_arena when `accumulate`) and every parameter's `.grad` becomes a view of acc_arena:
+        autograd's accumulate-into-.grad semantics for the bridge of latent_diffusion.py (`loss.backward()` called several times
+        between two `optimizer.zero_grad()`), while the backward kernels keep overwriting grad_arena."""
+        if self._pub_arena is None:
+            self._pub_arena = torch.zeros_like(self.grad_arena)
+            self._pub_views = [self._pub_arena[o:o + p.numel()].view(p.shape) for o, p in zip(self._arena_off, self._arena_params)]
+        ops.axpby(self.grad_arena, self._pub_arena, float(scale), 1.0 if accumulate else 0.0)
+        for p, v in zip(self._arena_params, self._pub_views):
+            p.grad = v
+
+    def internal_grads(self) -> bool:
+        """Point every `.grad` back at the kernels' arena before a backward pass; returns whether the caller-visible gradients held a
+        contribution (they were the published views: no zero_grad(set_to_none=True) since the last publish_grads)."""
+        if getattr(self, "grad_arena", None) is None:
+            self._alloc_grads()
+            return False
+        if self._pub_arena is None:
+            if any(p.grad is None for p in self._arena_params):
+                for p, v in zip(self._arena_params, self._int_views):
+                    p.grad = v
+            return False
+        had = all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(self._arena_params, self._pub_views))
+        for p, v in zip(self._arena_params, self._int_views):
+            p.grad = v
+        return had
+
+    @torch.no_grad()
+    def train_step(self, x, c_concat, t, context, target, group=None, after_backward=None) -> torch.Tensor:
         """One micro-batch: loss + backward; every `accumulate_grad_batches`-th call also all-reduces (data parallel) and steps the
-        optimizer on the mean of the accumulated gradients (Lightning divides the loss by the accumulation count)."""
+        optimizer on the mean of the accumulated gradients (Lightning divides the loss by the accumulation count); LitEma's update
+        runs after every micro-batch. after_backward(dx, dcontext): fills the gradients of `extra_params` (cond stage)."""
         import torch.distributed as dist
-        loss, _, _ = self.loss_and_backward(x, c_concat, t, context, target)
+        loss, dx, dctx = self.loss_and_backward(x, c_concat, t, context, target)
+        if after_backward is not None:
+            after_backward(dx, dctx)
         k = self.accumulate_grad_batches
         if k > 1:
             if self._micro == 0:
@@ -583,6 +708,7 @@ class UNetTrainer:
             self._micro += 1
             if self._micro < k:
                 self._grads_ready = False
+                self.ema_step()          # on_train_batch_end runs LitEma after every micro-batch (ddpm.py:369-371)
                 return loss
             ops.axpby(self._acc_arena, self.grad_arena, 1.0, 0.0)      # the optimizer table points at the gradient arena
             self._micro = 0

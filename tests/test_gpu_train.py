@@ -406,3 +406,255 @@ def test_unet_backward_reference_native_128_latents_vs_oracle(dev):
           f"dctx rel {float((dctx.cpu() - dctx_ref).norm() / dctx_ref.norm()):.2e}")
     assert abs(float(loss) - loss_ref) < 2e-2 * loss_ref
     assert np.median(errs) < 2e-2
+
+
+# ---------------------------------------------------------------------------------------------------- the reference's training seam
+def _tiny_ld(dev, seed=6, use_ema=True, trainable=True):
+    from stedm_amd.latent_diffusion import LatentDiffusion
+    from stedm_amd.style import SpatialRescaler
+    unet = build(TINY, seed, dev)
+    resc = SpatialRescaler(n_stages=2, in_channels=2, out_channels=3)
+    prng.fill_module_(resc, seed=9)
+    ld = LatentDiffusion(unet, linear_start=0.0015, linear_end=0.0205, loss_type="l1", image_size=16, channels=4, conditioning_key="hybrid",
+                         cond_stage_config=resc, cond_stage_trainable=trainable, use_ema=use_ema).to(dev)
+    return ld, unet, resc
+
+
+def _seam_inputs(dev, B=2, seed=21):
+    x0 = prng.normal(seed, "ld.x0", (B, 4, 16, 16)); noise = prng.normal(seed, "ld.noise", (B, 4, 16, 16))
+    layout = prng.uniform(seed, "ld.layout", (B, 2, 64, 64)); ctx = prng.normal(seed, "ld.ctx", (B, 128))
+    t = torch.tensor(([951, 21, 500, 3] * B)[:B], dtype=torch.long)
+    return x0, noise, layout, ctx, t
+
+
+def test_p_losses_autograd_bridge_with_torch_adamw(dev):
+    """The seam Lightning's automatic optimisation uses (ddpm.py:345-358 -> 1015-1048): in training mode p_losses returns a loss with
+    a grad_fn; `loss.backward()` fills `.grad` (checked against autograd over the oracle, incl. the cond stage's channel mapper and the
+    gradient handed upstream to the style vector), a second backward ACCUMULATES, zero_grad(set_to_none=True) resets, and
+    torch.optim.AdamW steps the parameters; on_train_batch_end then runs LitEma's update (oracle restatement pinned by F13)."""
+    from oracle import ddim as oddim
+    from oracle import style as ostyle
+    from oracle import train as otrain
+    from oracle import unet as ounet
+    ld, unet, resc = _tiny_ld(dev)
+    x0, noise, layout, ctx, t = _seam_inputs(dev)
+    ocfg = ounet.UNetConfig(image_size=16, in_channels=7, model_channels=32, out_channels=4, channel_mult=(1, 2, 4), num_heads=4)
+    P = prng.fill_state_dict(ounet.build_plan(ocfg).shapes, 6)
+    wm = resc.channel_mapper.weight.detach().cpu().clone().requires_grad_(True)
+    with torch.enable_grad():
+        cc_ref = ostyle.spatial_rescaler.__wrapped__(layout, wm, 2)
+    xq_ref = oddim.q_sample(oddim.Schedule(), x0, t, noise)
+    loss_ref, grads, dx_ref, dctx_ref, _ = otrain.unet_loss_and_grads(P, ocfg, torch.cat([xq_ref, cc_ref.detach()], 1), t, ctx, noise)
+    with torch.enable_grad():
+        (cc_ref * dx_ref[:, 4:]).sum().backward()
+
+    ld.train()
+    params = list(ld.model.parameters()) + list(ld.cond_stage_model.parameters())       # configure_optimizers, ldm_diffusion.py:224-234
+    opt = ld.attach_optimizer(torch.optim.AdamW(params, lr=1e-3))
+    ctx_d = ctx.to(dev).requires_grad_(True)                        # stands for the output of an autograd-run style encoder
+    with torch.enable_grad():
+        ld.cond_stage_trainable = True
+        cc = ld.get_learned_conditioning(layout.to(dev))
+        loss, ldict = ld.p_losses(x0.to(dev), {"c_concat": [cc], "c_crossattn": [ctx_d]}, t.to(dev), noise.to(dev), cond_input=layout.to(dev))
+        assert loss.requires_grad and "train/loss" in ldict
+        (loss * 0.5).backward()
+    assert abs(float(loss) - loss_ref) < 1e-4 * loss_ref
+    assert float((ctx_d.grad.cpu() - 0.5 * dctx_ref).norm() / (0.5 * dctx_ref).norm()) < 1e-3
+    with torch.enable_grad():
+        loss2, _ = ld.p_losses(x0.to(dev), {"c_concat": [cc], "c_crossattn": [ctx_d]}, t.to(dev), noise.to(dev), cond_input=layout.to(dev))
+        (loss2 * 0.5).backward()                                     # second micro-batch of an accumulation window: sums into .grad
+    gmax = max(float(g.norm()) for g in grads.values())
+    for n, p in unet.named_parameters():
+        gn = float(grads[n].norm())
+        if gn > 1e-6 * gmax:
+            assert float((p.grad.cpu() - grads[n]).norm()) / gn < 1e-3, n
+    assert float((resc.channel_mapper.weight.grad.cpu() - wm.grad).norm() / wm.grad.norm()) < 1e-3
+    before = {n: p.detach().clone() for n, p in unet.named_parameters()}
+    opt.step()
+    ld.on_train_batch_end()
+    opt.zero_grad(set_to_none=True)
+    w = unet.out[2].weight
+    assert not torch.equal(before["out.2.weight"], w.detach())
+    # torch's AdamW did the update: first step moves every entry with a gradient by ~lr
+    assert float((w.detach() - before["out.2.weight"]).abs().max()) < 1.1e-3
+    # EMA after one update: shadow = p0 - (1 - d)(p0 - p1), d = (1 + 1) / (10 + 1)
+    ema = ld._trainer.ema_named()
+    d = otrain.ema_decay(1)
+    ref = before["out.2.weight"].cpu().clone()
+    otrain.ema_update(ref, w.detach().cpu(), d)
+    assert torch.allclose(ema["out.2.weight"].cpu(), ref, rtol=2e-6, atol=1e-7) and ld._trainer.ema_updates == 1
+    # the next window starts from None gradients
+    with torch.enable_grad():
+        loss3, _ = ld.p_losses(x0.to(dev), {"c_concat": [cc], "c_crossattn": [ctx_d]}, t.to(dev), noise.to(dev), cond_input=layout.to(dev))
+        loss3.backward()
+    assert float(loss3) != float(loss) and all(p.grad is not None for p in params)
+    # eval mode / no_grad: forward value only, 'val' prefix (ddpm.py:1021)
+    ld.eval()
+    lv, dv = ld.p_losses(x0.to(dev), {"c_concat": [cc], "c_crossattn": [ctx_d.detach()]}, t.to(dev), noise.to(dev))
+    assert not lv.requires_grad and "val/loss" in dv
+
+
+class _PoolStage(torch.nn.Module):
+    """stand-in first stage for the seam tests (the seam is what is tested, not the autoencoder): 4x4 box mean to 4 channels"""
+
+    def encode(self, x):
+        z = torch.nn.functional.avg_pool2d(x, 4)
+        return torch.cat([z, z[:, :1]], 1)
+
+    def decode(self, z):
+        return torch.nn.functional.interpolate(z[:, :3], scale_factor=4)
+
+
+def _module_cfg():
+    return {"lr": 1e-3, "cfg_scale": 1.5, "ddim_steps": 4, "eta": 0.0, "data": {"patch_size": 64},
+            "style_sampling": {"name": "mp", "num_patches": 2},
+            "style_agg": dict(name="svit", patch_size=8, dim=64, depth=1, heads=2, mlp_dim=64, pool="mean", channels=3, dropout=0.0, emb_dropout=0.0,
+                              t_dim=64),
+            "diffusion": dict(linear_start=0.0015, linear_end=0.0205, timesteps=1000, loss_type="l1", first_stage_key="image",
+                              cond_stage_key="segmentation", image_size=16, channels=4, conditioning_key="hybrid", cond_stage_trainable=True,
+                              unet_config={"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": dict(TINY)},
+                              cond_stage_config={"target": "ldm.modules.encoders.modules.SpatialRescaler",
+                                                 "params": {"n_stages": 2, "in_channels": 2, "out_channels": 3}})}
+
+
+def _module_batches(dev, n, B=2):
+    out = []
+    for i in range(n):
+        g = torch.Generator().manual_seed(100 + i)
+        img = torch.rand(B, 3, 64, 64, generator=g) * 2 - 1
+        seg = torch.nn.functional.one_hot(torch.randint(0, 3, (B, 64, 64), generator=g), 3).permute(0, 3, 1, 2).float()
+        sty = torch.rand(B, 2, 3, 64, 64, generator=g) * 2 - 1
+        out.append((img.to(dev), seg.to(dev), None, sty.to(dev), torch.arange(B) + i * B))
+    return out
+
+
+def _build_module(dev):
+    from stedm_amd.ldm_module import LDM_Diffusion
+    mod = LDM_Diffusion(_module_cfg(), accumulate_grad_batches=2)
+    mod._model.first_stage_model = _PoolStage()
+    prng.fill_module_(mod._model.model.diffusion_model, seed=6)
+    prng.fill_module_(mod._model.cond_stage_model, seed=9)
+    prng.fill_module_(mod._model.agg_block, seed=51)
+    return mod.to(dev)
+
+
+def test_ldm_module_training_loop_as_the_reference_drives_it(dev):
+    """stedm_amd.ldm_module.LDM_Diffusion driven exactly as Lightning drives modules/ldm_diffusion.py:63-73, 110-115: per batch
+    on_train_batch_start -> training_step(batch, batch_idx) -> on_train_batch_end, accumulate_grad_batches = 2 over 4 micro-batches:
+    2 AdamW steps, 4 LitEma updates (ddpm.py:369-371 runs after every micro-batch). The weights equal those of the same micro-batches
+    pushed through UNetTrainer.train_step by hand (same RNG draws), and the checkpoint written afterwards continues a run (EMA
+    history, AdamW moments and bias-correction step) in a freshly built module."""
+    from stedm_amd.latent_diffusion import StedmHipError
+    batches = _module_batches(dev, 5)
+    mod = _build_module(dev)
+    mod.train()
+    assert mod.configure_optimizers() is None and mod.automatic_optimization is False
+    sd_keys = set(mod.state_dict())
+    assert "_model.model.diffusion_model.out.2.weight" in sd_keys and "model.model.diffusion_model.out.2.weight" in sd_keys   # both aliases
+    torch.manual_seed(1234)
+    losses = []
+    for idx, b in enumerate(batches[:4]):
+        mod.on_train_batch_start(b, idx)
+        losses.append(float(mod.training_step(b, idx)))
+        mod.on_train_batch_end()
+    tr = mod._model._trainer
+    assert tr.step_count == 2 and tr.ema_updates == 4 and [id(p) for p in tr.extra_params] == [id(mod._model.cond_stage_model.channel_mapper.weight)]
+    assert abs(mod.train_loss() - sum(losses) / 4) < 1e-6
+
+    # the same four micro-batches by hand
+    ref = _build_module(dev)
+    ref.train()
+    m2 = ref._model
+    tr2 = m2.configure_trainer(lr=1e-3, accumulate_grad_batches=2)
+    torch.manual_seed(1234)
+    for b in batches[:4]:
+        lb = ref.prepare_batch(b)
+        x, c = m2.get_input(lb, "image")[:2]
+        t = torch.randint(0, 1000, (x.shape[0],), device=dev).long()
+        noise = torch.randn_like(x)
+        layout = lb["segmentation"].permute(0, 3, 1, 2).float().contiguous()
+        xn = m2.q_sample(x, t, noise)
+        tr2.train_step(xn, c["c_concat"][0], t, c["c_crossattn"][0], noise,
+                       after_backward=lambda dx, dctx: m2.cond_stage_model.backward(layout, dx[:, 4:].contiguous()))
+    for (n, p), (_, q) in zip(mod._model.model.named_parameters(), m2.model.named_parameters()):
+        assert torch.equal(p, q), n
+    assert torch.equal(mod._model.cond_stage_model.channel_mapper.weight, m2.cond_stage_model.channel_mapper.weight)
+
+    # checkpoint -> fresh module -> one more window; against the uninterrupted run
+    ck = mod._model.reference_checkpoint()
+    ck = {"state_dict": {k: v.detach().cpu().clone() for k, v in ck["state_dict"].items()},
+          "optimizer_states": [{"state": {i: {k: v.detach().cpu().clone() for k, v in s.items()} for i, s in ck["optimizer_states"][0]["state"].items()},
+                                "param_groups": ck["optimizer_states"][0]["param_groups"]}]}
+    assert int(ck["state_dict"]["_model.model_ema.num_updates"]) == 4
+    res = _build_module(dev)
+    res.train()
+    res._model.load_reference_state_dict(ck)                        # build, load, THEN configure (the usual order)
+    res.configure_optimizers()
+    for who in (mod, res):
+        torch.manual_seed(99)
+        for idx, b in enumerate(batches[3:5]):
+            who.training_step(b, idx)
+            who.on_train_batch_end()
+    ta, tb = mod._model._trainer, res._model._trainer
+    assert ta.step_count == tb.step_count == 3 and ta.ema_updates == tb.ema_updates == 6
+    ea, eb = ta.ema_named(), tb.ema_named()
+    for (n, p), (_, q) in zip(mod._model.model.diffusion_model.named_parameters(), res._model.model.diffusion_model.named_parameters()):
+        assert torch.equal(p, q), n
+        assert torch.equal(ea[n], eb[n]), n
+    out = res._model.reference_checkpoint()
+    assert int(out["state_dict"]["_model.model_ema.num_updates"]) == 6 and float(out["optimizer_states"][0]["state"][0]["step"]) == 3.0
+    # training mode without a first stage must not hand zero latents to the optimizer
+    res._model.first_stage_model = None
+    with pytest.raises(StedmHipError):
+        res.training_step(batches[0], 0)
+
+
+def _surface_worker(rank, world, port, q):
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    ld, unet, resc = _tiny_ld(dev)
+    ld.configure_trainer(lr=1e-3, weight_decay=0.0)
+    x0, noise, layout, ctx, t = _seam_inputs(dev)
+    sl = slice(rank, rank + 1)
+    cc = ld.get_learned_conditioning(layout[sl].to(dev))
+    ld.training_step_hip(x0[sl].to(dev), {"c_concat": [cc], "c_crossattn": [ctx[sl].to(dev)]}, t[sl].to(dev), noise[sl].to(dev), cond_input=layout[sl].to(dev))
+    if rank == 0:
+        sd = {n: p.detach().cpu().numpy() for n, p in unet.named_parameters()}
+        sd["mapper"] = resc.channel_mapper.weight.detach().cpu().numpy()
+        q.put(sd)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_through_the_latent_diffusion_surface(dev):
+    """training_step_hip under torch.distributed (two processes, gloo over the device arena — the RCCL code path): each rank one sample;
+    the bucketed all-reduce + 1/world average inside the step give the weights of one process accumulating both samples."""
+    import os
+    import torch.multiprocessing as mp
+    ld, unet, resc = _tiny_ld(dev)
+    ld.configure_trainer(lr=1e-3, weight_decay=0.0, accumulate_grad_batches=2)
+    x0, noise, layout, ctx, t = _seam_inputs(dev)
+    for i in range(2):
+        sl = slice(i, i + 1)
+        cc = ld.get_learned_conditioning(layout[sl].to(dev))
+        ld.training_step_hip(x0[sl].to(dev), {"c_concat": [cc], "c_crossattn": [ctx[sl].to(dev)]}, t[sl].to(dev), noise[sl].to(dev),
+                             cond_input=layout[sl].to(dev))
+    ref = {n: p.detach().cpu().numpy() for n, p in unet.named_parameters()}
+    ref["mapper"] = resc.channel_mapper.weight.detach().cpu().numpy()
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctxm.Process(target=_surface_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    worst = max(float(np.abs(got[n] - ref[n]).max()) for n in ref)
+    print(f"two-rank training_step_hip vs accumulation: max |dw| = {worst:.2e} (lr 1e-3)")
+    assert worst < 2e-5

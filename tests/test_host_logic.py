@@ -82,3 +82,37 @@ def test_reference_checkpoint_key_layout_roundtrip():
         assert torch.equal(p.detach(), ema_vals[name]), name
     out = dst.reference_state_dict()
     assert all(k.startswith("_model.") for k in out) and "_model.model.diffusion_model.out.2.weight" in out
+
+
+def test_training_seam_members_have_the_reference_signatures():
+    """What modules/ldm_diffusion.py:63-73, 110-115 calls on the model (SURVEY §8b seam 2): names and positional arguments of
+    ddpm.py:345-371, 479-494, 868-882."""
+    import inspect
+    from stedm_amd.latent_diffusion import LatentDiffusion, S_ZSS_DM
+    sig = lambda f: list(inspect.signature(f).parameters)
+    assert sig(LatentDiffusion.training_step) == ["self", "batch", "batch_idx"]
+    assert sig(LatentDiffusion.shared_step)[:2] == ["self", "batch"]
+    assert sig(LatentDiffusion.forward)[:3] == ["self", "x", "c"]
+    assert sig(LatentDiffusion.on_train_batch_start)[:4] == ["self", "batch", "batch_idx", "dataloader_idx"]
+    assert sig(LatentDiffusion.p_losses)[:5] == ["self", "x_start", "cond", "t", "noise"]
+    assert sig(S_ZSS_DM.get_input)[:5] == ["self", "batch", "k", "cond_key", "bs"]
+    for name in ("on_train_batch_end", "apply_model", "sample_log", "decode_first_stage", "q_sample", "ema_scope", "get_learned_conditioning"):
+        assert callable(getattr(LatentDiffusion, name)), name
+
+
+def test_first_stage_config_is_built_or_refused_never_dropped():
+    """A {target, params} first_stage_config (what the reference's YAML passes) must not silently become `first_stage_model = None`:
+    get_input would then feed all-zero latents to a training loop."""
+    import pytest
+    from stedm_amd.latent_diffusion import LatentDiffusion, S_ZSS_DM, StedmHipError
+    from stedm_amd.unet import UNetModel
+    tiny = dict(image_size=16, in_channels=7, model_channels=32, out_channels=4, num_res_blocks=1, attention_resolutions=[32], channel_mult=[1, 2],
+                num_heads=4)
+    with pytest.raises((ImportError, NotImplementedError)):
+        LatentDiffusion(UNetModel(**tiny), conditioning_key="hybrid", first_stage_config={"target": "no.such.module.Stage", "params": {}})
+    zm = S_ZSS_DM("swin_v2_t", {"name": "none"}, {"name": "linear"}, {"data": {"patch_size": 64}}, UNetModel(**tiny), conditioning_key="hybrid",
+                  image_size=16, channels=4, cond_stage_key="segmentation")
+    batch = {"image": torch.zeros(1, 64, 64, 3), "segmentation": torch.zeros(1, 64, 64, 2), "style_imgs": torch.zeros(1, 1, 64, 64, 3)}
+    zm.train()
+    with pytest.raises(StedmHipError):
+        zm.get_input(batch, "image")
