@@ -54,6 +54,7 @@ class UNetTrainer:
         self._grads_ready = False
         self._dpacks: Dict[int, tuple] = {}
         self._opt = None
+        self._ema = None
         self.G: Dict[int, torch.Tensor] = {}
 
     # ------------------------------------------------------------------------------------------------ helpers
@@ -268,6 +269,8 @@ class UNetTrainer:
         self.tape = m._tape
         self.tape_emb = m._tape_emb
         m._tape = None
+        if self.ema_decay is not None and getattr(self, "_ema", None) is None:
+            self._build_ema()        # LitEma clones the parameters when it is built (ema.py:17-21): before anything updates them
         return out
 
     # ------------------------------------------------------------------------------------------------ backward
