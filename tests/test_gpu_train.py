@@ -505,6 +505,11 @@ class _PoolStage(torch.nn.Module):
         return torch.nn.functional.interpolate(z[:, :3], scale_factor=4)
 
 
+# S_ZSS_DM builds the style encoder with num_classes = 512 (s_zss_dm.py:33-38): the U-Net's embedding width must be 4 * 128
+MODULE_UNET = dict(image_size=16, in_channels=7, model_channels=128, out_channels=4, num_res_blocks=1, attention_resolutions=[32, 16, 8],
+                   channel_mult=[1, 2], num_heads=4)
+
+
 def _module_cfg():
     return {"lr": 1e-3, "cfg_scale": 1.5, "ddim_steps": 4, "eta": 0.0, "data": {"patch_size": 64},
             "style_sampling": {"name": "mp", "num_patches": 2},
@@ -512,7 +517,7 @@ def _module_cfg():
                               t_dim=64),
             "diffusion": dict(linear_start=0.0015, linear_end=0.0205, timesteps=1000, loss_type="l1", first_stage_key="image",
                               cond_stage_key="segmentation", image_size=16, channels=4, conditioning_key="hybrid", cond_stage_trainable=True,
-                              unet_config={"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": dict(TINY)},
+                              unet_config={"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": dict(MODULE_UNET)},
                               cond_stage_config={"target": "ldm.modules.encoders.modules.SpatialRescaler",
                                                  "params": {"n_stages": 2, "in_channels": 2, "out_channels": 3}})}
 
