@@ -496,6 +496,9 @@ def main():
 
             def gpu_eval(x4, cc4, ctx4, ctxu4, tval):
                 # the oracle's 4 samples as rows 0..3 of a bench-sized batch (rows are independent): the kernels selected are the bench's
+                from stedm_amd.utils import prng
+                prng.fill_module_(unet, seed=0)          # the training leg stepped the weights: back to the PRNG recipe the oracle holds
+                unet.invalidate()
                 n4 = x4.shape[0]
                 xb, ccb = xT.clone(), cond["c_concat"][0].clone()
                 cb, ub = cond["c_crossattn"][0].clone(), unc["c_crossattn"][0].clone()

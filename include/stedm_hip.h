@@ -71,7 +71,7 @@ int stedm_pack_conv_weight_up_frag(const float* w_oihw, void* out, int cout, int
  * [ceil(cout/128)][4*cin/16][4 taps (a*2+b)][4][64][8] of the equivalent 2x2 conv: tap (a, b) of parity block (py, px) is
  * W[dy][dx] with dy = {(0,1):0, (1,0):1, (1,1):2}[(a, py)] (none for (0,0)), same for dx. cin %% 4 == 0. */
 int stedm_space_to_depth16(const float* x, int C, int B, int H, int W, void* out_hi, void* out_lo, int mm_dtype, void* stream);
-int stedm_pack_conv_weight_s2d_frag(const float* w_oihw, void* out, int cout, int cin, int mm_dtype, void* stream);
+int stedm_pack_conv_weight_s2d_frag(const float* w_oihw, void* out, int cout, int cin, int mm_dtype, int pad_br, void* stream);
 /* [rows][cols] fp32 -> [cols][rows] fp32 (Linear weights are consumed K-major). */
 int stedm_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
 
@@ -161,6 +161,10 @@ typedef struct stedm_conv_args {
   float* ws;
   int64_t ws_floats;
   int32_t chan_nslab; /* slot count of chan_stats (see there) */
+  int32_t pad_br;     /* STEDM_CONV_S2D only. 0: the stride-2 conv pads 1 on every side (openaimodel.py:164-166). 1: it pads bottom and
+                       * right only — F.pad(x, (0,1,0,1)) + conv(stride 2, padding 0), the VQ encoder's Downsample (model.py:59-76):
+                       * the 2x2 taps of the space-to-depth form then sit at offsets (0, +1); weights from
+                       * stedm_pack_conv_weight_s2d_frag(..., pad_br = 1) */
 } stedm_conv_args;
 /* Replaces: GN->SiLU->conv3x3(+bias)(+emb)(+skip) of ResBlock._forward openaimodel.py:268-288,
  * Downsample/Upsample convs (:122-132,:156-173), 1x1 skip_connection (:254), and the 1x1
@@ -344,6 +348,20 @@ int stedm_adamw_ema(const void* table, const int* chunk_tensor, const long* chun
  * micro-batches of an accumulation window that do not step the optimizer): ema -= (1 - ema_decay) * (ema - p) over the same table
  * (entries without a shadow are skipped; g / m / v are not read). */
 int stedm_ema_update(const void* table, const int* chunk_tensor, const long* chunk_off, int nchunks, float ema_decay, void* stream);
+
+/* ---- first stage (VQ-f4 autoencoder; ldm/models/autoencoder.py:264-282, ldm/modules/diffusionmodules/model.py:368-568) ---------
+ * Its ResnetBlocks, Up/Downsample convs and GroupNorms (eps 1e-6) run on stedm_conv_igemm / stedm_gn_apply16c; these are the rest.
+ * VectorQuantizer2.forward of taming-transformers (un-vendored dependency, autoencoder.py:6,39-41,277) on the eval path: z NCHW
+ * [B][e_dim][HW], codebook [n_e][e_dim] -> idx[B*HW] = argmin_n (|z|^2 + |e_n|^2 - 2 z.e_n) (fp32, no FMA contraction, sums left to
+ * right, first index on ties: an integer result) and zq NCHW = z + (e_idx - z) (the straight-through form's forward value). */
+int stedm_vq_nearest(const float* z, const float* codebook, int n_e, int e_dim, int B, long HW, long long* idx, float* zq, void* stream);
+/* quant_conv / post_quant_conv (autoencoder.py:42-43, 268, 280): 1x1 conv over a few channels (cin, cout <= 16), NCHW -> NCHW,
+ * w [cout][cin], bias [cout] or NULL. */
+int stedm_conv1x1_nchw(const float* x, const float* w, const float* bias, float* out, int B, int cin, int cout, long HW, void* stream);
+/* AttnBlock's softmax (model.py:166-169: softmax(w_ * c^-0.5, dim=2)): rows of x [rows][ld_in] (first n columns) -> softmax(scale * x) as
+ * 16-bit operand planes [rows][ld_out] (hi, lo = v - hi or NULL), columns n..ld_out-1 zero. */
+int stedm_softmax_rows16(const float* x, long ld_in, float scale, void* out_hi, void* out_lo, long rows, int n, long ld_out, int mm_dtype,
+                         void* stream);
 
 /* ---- image epilogue of predict_step (integer work, bit-exact) -------------------------------------------------------
  * modules/ldm_diffusion.py:93-95: ((clip(x, -1, 1).permute(0,2,3,1) + 1) * 127.5).astype(uint8): x NCHW fp32 -> out NHWC uint8. */

@@ -242,7 +242,7 @@ extern "C" int stedm_pack_conv_weight_up_frag(const float* w, void* out, int cou
 
 // STEDM_CONV_S2D weights: the stride-2 3x3 as a 2x2 conv over the 4 parity blocks of the space-to-depth planes, fragment order
 template <typename T>
-__global__ void pack_conv_weight_s2d_frag_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, long total) {
+__global__ void pack_conv_weight_s2d_frag_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, long total, int pad_br) {
   const int nch = 4 * cin / 16;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int e = (int)(i & 7);
@@ -256,19 +256,21 @@ __global__ void pack_conv_weight_s2d_frag_kernel(const float* __restrict__ w, T*
     const int cc = chunk * 16 + (lane >> 5) * 8 + e;          // channel of the planes: parity block * cin + c
     const int par = cc / cin, c = cc - par * cin;
     const int py = par >> 1, px = par & 1, a = tap >> 1, b = tap & 1;
-    const int dy = a == 0 ? (py == 1 ? 0 : -1) : (py == 0 ? 1 : 2);
-    const int dx = b == 0 ? (px == 1 ? 0 : -1) : (px == 0 ? 1 : 2);
+    // symmetric pad 1: plane rows (y-1, y) hold image rows 2y-2 .. 2y+1, the filter covers 2y-1 .. 2y+1;
+    // bottom/right pad (pad_br): plane rows (y, y+1) hold image rows 2y .. 2y+3, the filter covers 2y .. 2y+2
+    const int dy = pad_br ? (a == 0 ? py : (py == 0 ? 2 : -1)) : (a == 0 ? (py == 1 ? 0 : -1) : (py == 0 ? 1 : 2));
+    const int dx = pad_br ? (b == 0 ? px : (px == 0 ? 2 : -1)) : (b == 0 ? (px == 1 ? 0 : -1) : (px == 0 ? 1 : 2));
     out[i] = (n < cout && dy >= 0 && dx >= 0) ? (T)w[((long)n * cin + c) * 9 + dy * 3 + dx] : (T)0.f;
   }
 }
 
-extern "C" int stedm_pack_conv_weight_s2d_frag(const float* w, void* out, int cout, int cin, int mm_dtype, void* stream) {
+extern "C" int stedm_pack_conv_weight_s2d_frag(const float* w, void* out, int cout, int cin, int mm_dtype, int pad_br, void* stream) {
   STEDM_CHECK_ARG(w && out && cin % 8 == 0, "pack_conv_weight_s2d_frag: bad args (cin %% 8)");
   STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "pack_conv_weight_s2d_frag: bad mm_dtype %d", mm_dtype);
   const long total = (long)((cout + 127) / 128) * (4 * cin / 16) * 4 * 4 * 64 * 8;
   const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  if (mm_dtype == STEDM_F16) pack_conv_weight_s2d_frag_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(w, (_Float16*)out, cout, cin, total);
-  else pack_conv_weight_s2d_frag_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(w, (__bf16*)out, cout, cin, total);
+  if (mm_dtype == STEDM_F16) pack_conv_weight_s2d_frag_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(w, (_Float16*)out, cout, cin, total, pad_br);
+  else pack_conv_weight_s2d_frag_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(w, (__bf16*)out, cout, cin, total, pad_br);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

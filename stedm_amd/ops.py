@@ -109,14 +109,15 @@ def pack_conv_weight_up_frag(w: torch.Tensor, prec: Precision) -> torch.Tensor:
     return out
 
 
-def pack_conv_weight_s2d_frag(w: torch.Tensor, prec: Precision) -> torch.Tensor:
-    """OIHW 3x3 fp32 (stride-2 Downsample.op) -> fragment-order weights of the equivalent 2x2 conv over space-to-depth planes."""
+def pack_conv_weight_s2d_frag(w: torch.Tensor, prec: Precision, pad_br: bool = False) -> torch.Tensor:
+    """OIHW 3x3 fp32 (stride-2 Downsample.op) -> fragment-order weights of the equivalent 2x2 conv over space-to-depth planes.
+    pad_br: the conv pads bottom/right only (the VQ encoder's Downsample, model.py:59-76) instead of 1 on every side."""
     w = w.detach().contiguous()
     _chk(w, name="conv weight")
     cout, cin, ks, _ = w.shape
     assert ks == 3 and cin % 8 == 0
     out = torch.empty(((cout + 127) // 128, 4 * cin // 16, 4, 4, 64, 8), dtype=torch.int16, device=w.device)
-    check(lib().stedm_pack_conv_weight_s2d_frag(w.data_ptr(), out.data_ptr(), cout, cin, prec.mm_dtype, _stream()), "stedm_pack_conv_weight_s2d_frag")
+    check(lib().stedm_pack_conv_weight_s2d_frag(w.data_ptr(), out.data_ptr(), cout, cin, prec.mm_dtype, int(pad_br), _stream()), "stedm_pack_conv_weight_s2d_frag")
     return out
 
 
@@ -237,13 +238,14 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
                out16: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None, w_frag: Optional[torch.Tensor] = None,
                chan_stats: Optional[torch.Tensor] = None,
                skip: Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = None, query_fused: bool = False,
-               ws: Optional[torch.Tensor] = None):
+               ws: Optional[torch.Tensor] = None, pad_br: bool = False):
     """src1 [B,Hin,Win,c1] NHWC fp32 (fused path) and/or src16 = (hi, lo) 16-bit NHWC planes [B,Hin,Win,Cin] from
     gn_apply16 (DMA path) -> out [B,Hout,Wout,cout] NHWC fp32 (see stedm_conv_igemm)."""
     if out is not None:
         _chk(out, name="out")
     a = ConvArgs()
     a.act_out = act_out
+    a.pad_br = int(pad_br)
     a.w_frag = _ptr(w_frag) if prec.npass == 1 else None
     a.chan_stats = _ptr(chan_stats)
     a.chan_nslab = 0 if chan_stats is None else chan_stats.shape[1]
@@ -669,6 +671,38 @@ def ema_update(table: torch.Tensor, chunk_tensor: torch.Tensor, chunk_off: torch
     """LitEma.forward (ema.py:25-44) over the optimizer's pointer table: shadow -= (1 - decay) * (shadow - p)."""
     check(lib().stedm_ema_update(table.data_ptr(), chunk_tensor.data_ptr(), chunk_off.data_ptr(), chunk_tensor.numel(), float(ema_decay), _stream()),
           "stedm_ema_update")
+
+
+# ------------------------------------------------------------------------------------------- first stage (VQ-f4)
+def vq_nearest(z: torch.Tensor, codebook: torch.Tensor):
+    """z [B,e,H,W] fp32, codebook [n_e,e] -> (indices int64 [B,H,W], z_q [B,e,H,W] = z + (e_idx - z)); see stedm_vq_nearest."""
+    _chk(z, name="z"); _chk(codebook, name="codebook")
+    B, e, H, W = z.shape
+    assert codebook.shape[1] == e
+    idx = torch.empty((B, H, W), dtype=torch.int64, device=z.device)
+    zq = torch.empty_like(z)
+    check(lib().stedm_vq_nearest(z.data_ptr(), codebook.data_ptr(), codebook.shape[0], e, B, H * W, idx.data_ptr(), zq.data_ptr(), _stream()),
+          "stedm_vq_nearest")
+    return idx, zq
+
+
+def conv1x1_nchw(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """1x1 conv over a few channels, NCHW -> NCHW (quant_conv / post_quant_conv)."""
+    _chk(x, name="x")
+    B, cin, H, W = x.shape
+    cout = w.shape[0]
+    w2 = w.detach().float().reshape(cout, cin).contiguous()
+    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+    check(lib().stedm_conv1x1_nchw(x.data_ptr(), w2.data_ptr(), _ptr(None if bias is None else bias.detach().float().contiguous()), out.data_ptr(),
+                                   B, cin, cout, H * W, _stream()), "stedm_conv1x1_nchw")
+    return out
+
+
+def softmax_rows16(x: torch.Tensor, scale: float, hi: torch.Tensor, lo: Optional[torch.Tensor], prec: Precision) -> None:
+    """x [rows, n] fp32 (row stride x.stride(0)) -> softmax(scale * x) as 16-bit planes hi (/lo) [rows, ld_out >= n], zero beyond n."""
+    assert x.dim() == 2 and x.stride(1) == 1 and hi.dim() == 2 and hi.is_contiguous() and hi.shape[0] == x.shape[0] and hi.shape[1] >= x.shape[1]
+    check(lib().stedm_softmax_rows16(x.data_ptr(), x.stride(0), float(scale), hi.data_ptr(), _ptr(lo), x.shape[0], x.shape[1], hi.shape[1],
+                                     prec.mm_dtype, _stream()), "stedm_softmax_rows16")
 
 
 # ------------------------------------------------------------------------------------------- image epilogue
