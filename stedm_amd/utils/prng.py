@@ -43,7 +43,7 @@ def _is_norm_name(name: str) -> bool:
         leaf_parent.endswith("in_layers.0")
         or leaf_parent.endswith("out_layers.0")
         or leaf_parent == "out.0"
-        or parts[-2] in ("norm", "norm1", "norm2", "norm3")
+        or parts[-2] in ("norm", "norm1", "norm2", "norm3", "norm_out")     # norm_out: first-stage Encoder / Decoder (model.py:420, 519)
         or leaf_parent.endswith("to_patch_tokens.1")
         or leaf_parent.endswith("mlp_head.0")
     )

@@ -259,3 +259,40 @@ def test_f13_adamw_and_litema(golden):
     for n in names:
         otrain.ema_update(sh[n], torch.from_numpy(fx[f"pL.{n}"]), otrain.ema_decay(nL, dec))
         assert torch.allclose(sh[n], torch.from_numpy(fx[f"emaL.{n}"]), rtol=2e-6, atol=1e-7), n
+
+
+@pytest.mark.parametrize("tag,cfgkw,B,side", [("tiny", dict(ch=32, num_res_blocks=1), 2, 64), ("f4", {}, 1, 128)])
+def test_f15_vq_encoder_decoder(golden, tag, cfgkw, B, side):
+    """oracle/vq.py Encoder / Decoder against the reference's own model.Encoder / model.Decoder (make_golden_vq.py); `f4` is the shipped
+    vq-f4.yaml architecture (55.3 M parameters) at a 128^2 image."""
+    from oracle import vq as ovq
+    fx = golden(f"f15_vq_{tag}")
+    cfg = ovq.VQConfig(**cfgkw)
+    P = prng.fill_state_dict(ovq.shapes(cfg), 15)
+    assert sum(v.numel() for k, v in P.items() if k.startswith("encoder.")) == int(fx["n_enc"])
+    assert sum(v.numel() for k, v in P.items() if k.startswith("decoder.")) == int(fx["n_dec"])
+    x = prng.uniform(15, f"vq.{tag}.x", (B, 3, side, side))
+    z = prng.normal(15, f"vq.{tag}.z", (B, 3, side // 4, side // 4))
+    close(ovq.encoder(P, cfg, x), fx["enc_out"], 5e-5)
+    y = ovq.decoder(P, cfg, z)
+    check_summary(y, fx, "dec_out", 5e-5, tag)
+    if "dec_out" in fx.files:
+        close(y, fx["dec_out"], 5e-5)
+
+
+def test_vq_quantiser_restatement_properties():
+    """The quantiser (taming VectorQuantizer2; parity unpinned) restated with pinned-down fp32 arithmetic: the chosen entry is a nearest
+    one under exact arithmetic up to rounding, ties go to the first index, and the straight-through value is z + (e - z)."""
+    from oracle import vq as ovq
+    cb = prng.normal(16, "vq.cb", (512, 3)) * 0.5
+    z = prng.normal(16, "vq.z", (2, 3, 8, 8))
+    idx, zq = ovq.quantize(cb, z)
+    zf = z.permute(0, 2, 3, 1).reshape(-1, 3).double()
+    d = ((zf[:, None, :] - cb.double()[None]) ** 2).sum(-1)
+    best = d.min(dim=1).values
+    assert float((d[torch.arange(d.shape[0]), idx.reshape(-1)] - best).max()) < 1e-5
+    e = cb[idx.reshape(-1)]
+    assert torch.equal(zq.permute(0, 2, 3, 1).reshape(-1, 3), zf.float() + (e - zf.float()))
+    cb2 = torch.cat([cb, cb[:4]])                        # duplicated entries: the first occurrence must win
+    idx2, _ = ovq.quantize(cb2, z)
+    assert torch.equal(idx, idx2)
