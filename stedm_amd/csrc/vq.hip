@@ -5,7 +5,7 @@
 //   conv1x1_nchw     quant_conv / post_quant_conv (autoencoder.py:42-43): 1x1 convolutions over a handful of channels, NCHW
 //   softmax_rows16   the softmax of AttnBlock (ldm/modules/diffusionmodules/model.py:143-199: single head of width C, logits scaled by
 //                    C^-0.5) written as 16-bit operand planes for the P @ V GEMM
-//   nearest-codebook arithmetic is written WITHOUT fused multiply-adds and in a fixed order (see oracle/vq.py: the index is an integer
+//   nearest-codebook arithmetic is written WITHOUT fused multiply-adds and in a fixed order (the index is an integer
 //   result and must not depend on contraction choices of the compiler)
 #include "common.hpp"
 using namespace stedm;
