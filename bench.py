@@ -441,28 +441,48 @@ def main():
             unet.set_precision(args.precision)
             agg = dict(name="svit", patch_size=8, dim=256, depth=6, heads=12, mlp_dim=256, pool="mean", channels=3, dropout=0.1, emb_dropout=0.1,
                        t_dim=256)
+            # first stage: the vq-f4.yaml architecture (ch 128, ch_mult 1-2-4, 2 res blocks, 8192-entry codebook) with 4 latent channels
+            # for the synthetic 32x32x4 latents -> 128x128x3 images
+            fs_cfg = {"target": "ldm.models.autoencoder.VQModelInterface",
+                      "params": dict(embed_dim=4, n_embed=8192, lossconfig={"target": "torch.nn.Identity"}, precision=args.precision,
+                                     ddconfig=dict(double_z=False, z_channels=4, resolution=128, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4],
+                                                   num_res_blocks=2, attn_resolutions=[], dropout=0.0))}
             zm = S_ZSS_DM("swin_v2_t", dict(name="mp", num_patches=4), agg, {"data": {"patch_size": 512}}, unet, linear_start=0.0015,
                           linear_end=0.0205, image_size=32, channels=4, conditioning_key="hybrid", loss_type="l1", cond_stage_key="segmentation",
-                          use_graph=True, cond_stage_config={"target": "ldm.modules.encoders.modules.SpatialRescaler",
-                                                             "params": {"n_stages": 3, "in_channels": 2, "out_channels": 3}})
+                          use_graph=True, first_stage_config=fs_cfg,
+                          cond_stage_config={"target": "ldm.modules.encoders.modules.SpatialRescaler",
+                                             "params": {"n_stages": 3, "in_channels": 2, "out_channels": 3}})
             prng.fill_module_(zm.agg_block, seed=51)
             prng.fill_module_(zm.cond_stage_model, seed=52)
+            prng.fill_module_(zm.first_stage_model, seed=53)
             zm = zm.to(dev).eval()
             zm.agg_block.set_precision(args.precision)
             g = torch.Generator(device="cpu").manual_seed(7)
             batch = {"image": torch.zeros(B, 256, 256, 3, device=dev),
                      "segmentation": (torch.rand(B, 256, 256, 2, generator=g) > 0.5).float().to(dev),
                      "style_imgs": (torch.rand(B, 4, 512, 512, 3, generator=g) * 2 - 1).to(dev)}
-            predict_latents(zm, batch, ddim_steps=50, cfg_scale=1.5, x_T=xT)          # warm-up: packs weights, captures the step graph
+            from stedm_amd.latent_diffusion import images_for_saving
+
+            def predict_step():          # LDM_Diffusion.predict_step, ldm_diffusion.py:76-99, up to the uint8 arrays
+                lat = predict_latents(zm, batch, ddim_steps=50, cfg_scale=1.5, x_T=xT)
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                img, seg = images_for_saving(zm.decode_first_stage(lat), batch["segmentation"])
+                torch.cuda.synchronize()
+                return lat, img, t1
+
+            predict_step()          # warm-up: packs weights, captures the step graph
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            lat = predict_latents(zm, batch, ddim_steps=50, cfg_scale=1.5, x_T=xT)
-            torch.cuda.synchronize()
-            dte = time.perf_counter() - t0
-            assert bool(torch.isfinite(lat).all())
+            lat, img, t1 = predict_step()
+            t2 = time.perf_counter()
+            dte = t1 - t0
+            assert bool(torch.isfinite(lat).all()) and tuple(img.shape) == (B, 128, 128, 3)
             out["sampling_run"] = {"seconds": round(dte, 4), "latents_per_s": round(B / dte, 1), "batch": B, "ddim_steps": 50,
                                    "what": "S_ZSS_DM.get_input (sViT over 4 x 512^2 style images per sample + SpatialRescaler) + unconditional style vector "
-                                           "(one constant sample, broadcast) + DDIM-50 with CFG 1.5: predict_step up to the sampled latents"}
+                                           "(one constant sample, broadcast) + DDIM-50 with CFG 1.5: predict_step up to the sampled latents",
+                                   "decode_seconds": round(t2 - t1, 4), "images_per_s": round(B / (t2 - t0), 1),
+                                   "decode_what": "decode_first_stage (VQ-f4 architecture: quantise over 8192 codes, post_quant_conv, Decoder 32^2 -> 128^2, "
+                                                  "55 M parameters) + uint8 / class-map epilogue: predict_step end to end, images/s over the whole step"}
             del zm, batch
         if not args.no_train_leg and world == 1:
             # BASELINE config 2: one training step (forward + L1 + backward + AdamW/EMA) on the same U-Net and batch
