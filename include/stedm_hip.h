@@ -261,9 +261,12 @@ int stedm_qkv_pack(const float* qkv, float qscale, void* q_hi, void* q_lo, void*
 int stedm_lsa_flash(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi,
                     const void* vt_lo, void* out_hi, void* out_lo, int B, int T, int Tp, int heads, int npass,
                     int mm_dtype, void* stream);
-/* pool (0 mean, 1 cls, 2 sum) over tokens (+ c_old) -> mlp_head LayerNorm + Linear, vit_set.py:191-206. wt [dim][ncls]. */
+/* pool (0 mean, 1 cls, 2 sum) over tokens (+ c_old) -> mlp_head LayerNorm + Linear, vit_set.py:191-206. wt [dim][ncls].
+ * ws (optional, ws_floats >= B * 2 * dim): lets the token pooling run as slab partials over ~1024 blocks before the per-sample head
+ * (a batch of 8 alone would read its 34 MB of tokens on 8 of the 256 CUs); fixed summation order either way. */
 int stedm_svit_head(const float* x, int B, int T, int dim, int pool, const float* c_old, const float* ln_w,
-                    const float* ln_b, float eps, const float* wt, const float* bias, float* out, int ncls, void* stream);
+                    const float* ln_b, float eps, const float* wt, const float* bias, float* out, int ncls, float* ws, long ws_floats,
+                    void* stream);
 /* GEGLU attention.py:37-44: g [M][2*I] fp32 (value | gate) -> value * gelu_erf(gate) as 16-bit planes [M][I]. */
 int stedm_geglu16(const float* g, void* out_hi, void* out_lo, long M, int I, int mm_dtype, void* stream);
 /* Agg_Mean (mode 0) / Agg_Max (mode 1) over the set: feats [B*n][F] -> out [B][F]; agg_blocks.py:52,73. */

@@ -479,7 +479,35 @@ extern "C" int stedm_lsa_flash(const void* q_hi, const void* q_lo, const void* k
 }
 
 // ------------------------------------------------------------------------------------------------ pooled head
-__global__ void __launch_bounds__(256) svit_head_kernel(const float* __restrict__ x, int Tn, int dim, int pool,
+// stage 1 of the token pooling when the batch alone cannot fill the chip: block (b, slab) sums its run of tokens (16-B loads, fixed order)
+// into part[b][slab][dim]; the head kernel then pools the slabs
+__global__ void __launch_bounds__(256) svit_pool_partial_kernel(const float* __restrict__ x, int Tn, int dim, int nslab, float* __restrict__ part) {
+  extern __shared__ float spp[];                 // [lanes][dim]
+  const int b = blockIdx.x, slab = blockIdx.y;
+  const int per = (Tn + nslab - 1) / nslab;
+  const int t0 = slab * per, t1 = min(Tn, t0 + per);
+  const float* px = x + (long)b * Tn * dim;
+  const int Q = dim >> 2, lanes = 256 / Q;
+  const int q = threadIdx.x % Q, tl = threadIdx.x / Q;
+  if (tl < lanes) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int t = t0 + tl; t < t1; t += lanes) {
+      const float4 v = *reinterpret_cast<const float4*>(px + (long)t * dim + q * 4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(spp + (long)tl * dim + q * 4) = acc;
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < dim; n += 256) {
+    float s = 0.f;
+    for (int l = 0; l < lanes; ++l) s += spp[(long)l * dim + n];
+    part[((long)b * nslab + slab) * dim + n] = s;
+  }
+}
+
+// Tn tokens (or slab partials) of x are pooled; the mean divides by `mean_n` (the real token count)
+__global__ void __launch_bounds__(256) svit_head_kernel(const float* __restrict__ x, int Tn, int mean_n, int dim, int pool,
                                                         const float* __restrict__ c_old, const float* __restrict__ g,
                                                         const float* __restrict__ bt, float eps, const float* __restrict__ wt,
                                                         const float* __restrict__ bias, float* __restrict__ out, int ncls) {
@@ -505,7 +533,7 @@ __global__ void __launch_bounds__(256) svit_head_kernel(const float* __restrict_
     for (int n = threadIdx.x; n < dim; n += 256) {
       float s = 0.f;
       for (int l = 0; l < lanes; ++l) s += spart[(long)l * dim + n];
-      if (pool == 0) s /= (float)Tn;
+      if (pool == 0) s /= (float)mean_n;
       if (c_old) s += c_old[(long)b * dim + n];
       sp[n] = s;
     }
@@ -515,7 +543,7 @@ __global__ void __launch_bounds__(256) svit_head_kernel(const float* __restrict_
       if (pool == 1) s = px[n];
       else {
         for (int t = 0; t < Tn; ++t) s += px[(long)t * dim + n];
-        if (pool == 0) s /= (float)Tn;
+        if (pool == 0) s /= (float)mean_n;
       }
       if (c_old) s += c_old[(long)b * dim + n];
       sp[n] = s;
@@ -540,11 +568,27 @@ __global__ void __launch_bounds__(256) svit_head_kernel(const float* __restrict_
 
 extern "C" int stedm_svit_head(const float* x, int B, int T, int dim, int pool, const float* c_old, const float* ln_w,
                                const float* ln_b, float eps, const float* wt, const float* bias, float* out, int ncls,
-                               void* stream) {
+                               float* ws, long ws_floats, void* stream) {
   STEDM_CHECK_ARG(x && ln_w && ln_b && wt && bias && out, "svit_head: null pointer");
   STEDM_CHECK_ARG(pool >= 0 && pool <= 2, "svit_head: pool must be 0 (mean), 1 (cls) or 2 (sum)");
-  const int lanes = (dim % 4 == 0 && dim <= 1024) ? 256 / (dim / 4) : 0;
-  svit_head_kernel<<<B, 256, (size_t)(1 + lanes) * dim * sizeof(float), as_stream(stream)>>>(x, T, dim, pool, c_old, ln_w, ln_b, eps, wt, bias, out, ncls);
+  const bool vec = dim % 4 == 0 && dim <= 1024;
+  const int lanes = vec ? 256 / (dim / 4) : 0;
+  const size_t lds = (size_t)(1 + lanes) * dim * sizeof(float);
+  // token pooling over many blocks when B alone leaves the chip idle (B = 8: 8 of 256 CUs read 34 MB): slabs of >= 32 tokens, about
+  // 1024 blocks in all, as many as the caller's workspace admits
+  int nslab = 1;
+  if (pool != 1 && vec && ws && T >= 256) {
+    nslab = (1024 + B - 1) / B;
+    if (nslab > T / 32) nslab = T / 32;
+    if ((long)B * nslab * dim > ws_floats) nslab = (int)(ws_floats / ((long)B * dim));
+  }
+  if (nslab >= 2) {
+    svit_pool_partial_kernel<<<dim3(B, nslab), 256, (size_t)lanes * dim * sizeof(float), as_stream(stream)>>>(x, T, dim, nslab, ws);
+    STEDM_LAUNCH_CHECK();
+    svit_head_kernel<<<B, 256, lds, as_stream(stream)>>>(ws, nslab, T, dim, pool, c_old, ln_w, ln_b, eps, wt, bias, out, ncls);
+  } else {
+    svit_head_kernel<<<B, 256, lds, as_stream(stream)>>>(x, T, T, dim, pool, c_old, ln_w, ln_b, eps, wt, bias, out, ncls);
+  }
   STEDM_LAUNCH_CHECK();
   return 0;
 }

@@ -431,10 +431,11 @@ def lsa_flash(q, k, vt, out, B: int, T: int, Tp: int, heads: int, prec: Precisio
                                 out[0].data_ptr(), _ptr(out[1]), B, T, Tp, heads, prec.npass, prec.mm_dtype, _stream()), "stedm_lsa_flash")
 
 
-def svit_head(x, pool: int, c_old, ln_w, ln_b, eps, wt, bias, out):
+def svit_head(x, pool: int, c_old, ln_w, ln_b, eps, wt, bias, out, ws: Optional[torch.Tensor] = None):
+    """ws: fp32 workspace for the slab partials of the token pooling (any size >= 2 * B * dim; 1024 * dim covers every batch)."""
     B, T, dim = x.shape
     check(lib().stedm_svit_head(x.data_ptr(), B, T, dim, pool, _ptr(c_old), ln_w.data_ptr(), ln_b.data_ptr(), float(eps), wt.data_ptr(),
-                                bias.data_ptr(), out.data_ptr(), out.shape[-1], _stream()), "stedm_svit_head")
+                                bias.data_ptr(), out.data_ptr(), out.shape[-1], _ptr(ws), 0 if ws is None else ws.numel(), _stream()), "stedm_svit_head")
     return out
 
 

@@ -200,7 +200,7 @@ class sViT(nn.Module):
         out = torch.empty((B, self.mlp_head[1].out_features), dtype=torch.float32, device=img.device)
         pool = {"mean": 0, "cls": 1, "sum": 2}[self.pool]
         ops.svit_head(x, pool, None if c_old is None else c_old.float().contiguous(), self.mlp_head[0].weight, self.mlp_head[0].bias,
-                      self.mlp_head[0].eps, P["head_wt"], self.mlp_head[1].bias, out)
+                      self.mlp_head[0].eps, P["head_wt"], self.mlp_head[1].bias, out, ws=self._buf("head.ws", (1024 * dim,)))
         return out
 
 
