@@ -98,6 +98,24 @@ def pack_conv_weight_frag(w: torch.Tensor, prec: Precision) -> torch.Tensor:
     return out
 
 
+def pack_conv_weight_frag16(w: torch.Tensor, prec: Precision, sn: Optional[int] = None, sc: Optional[int] = None, flip: bool = False,
+                            cout: Optional[int] = None, cin: Optional[int] = None) -> torch.Tensor:
+    """3x3 fp32 filter -> fragment order of the 16x16x32 MFMA kind (stedm_pack_conv_weight_frag16). Default: a plain OIHW filter;
+    sn / sc / flip / cout / cin describe a strided source like pack_conv_weight_strided (the dgrad filter of the training step)."""
+    w = w.detach()
+    _chk(w.contiguous() if sn is None else w, name="conv weight")
+    if sn is None:
+        w = w.contiguous()
+        cout, cin, ks, _ = w.shape
+        assert ks == 3
+        sn, sc = cin * 9, 9
+    assert cin % 32 == 0
+    out = torch.empty(((cout + 127) // 128, cin // 32, 9, 8, 64, 8), dtype=torch.int16, device=w.device)
+    check(lib().stedm_pack_conv_weight_frag16(w.data_ptr(), sn, sc, int(flip), out.data_ptr(), cout, cin, prec.mm_dtype, _stream()),
+          "stedm_pack_conv_weight_frag16")
+    return out
+
+
 def pack_conv_weight_up_frag(w: torch.Tensor, prec: Precision) -> torch.Tensor:
     """OIHW 3x3 fp32 -> fragment-order weights of the sub-pixel upsample form (4 parities x 4 pre-summed taps)."""
     w = w.detach().contiguous()
@@ -238,7 +256,7 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
                out16: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None, w_frag: Optional[torch.Tensor] = None,
                chan_stats: Optional[torch.Tensor] = None,
                skip: Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = None, query_fused: bool = False,
-               ws: Optional[torch.Tensor] = None, pad_br: bool = False):
+               ws: Optional[torch.Tensor] = None, pad_br: bool = False, w_frag16: Optional[torch.Tensor] = None):
     """src1 [B,Hin,Win,c1] NHWC fp32 (fused path) and/or src16 = (hi, lo) 16-bit NHWC planes [B,Hin,Win,Cin] from
     gn_apply16 (DMA path) -> out [B,Hout,Wout,cout] NHWC fp32 (see stedm_conv_igemm)."""
     if out is not None:
@@ -246,6 +264,7 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
     a = ConvArgs()
     a.act_out = act_out
     a.pad_br = int(pad_br)
+    a.w_frag16 = _ptr(w_frag16) if prec.npass == 1 else None
     a.w_frag = _ptr(w_frag) if prec.npass == 1 else None
     a.chan_stats = _ptr(chan_stats)
     a.chan_nslab = 0 if chan_stats is None else chan_stats.shape[1]

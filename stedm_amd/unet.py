@@ -119,10 +119,10 @@ class AttentionBlock(nn.Module):
 
 
 class _Packed:
-    __slots__ = ("hi", "lo", "bias", "frag")
+    __slots__ = ("hi", "lo", "bias", "frag", "frag16")
 
-    def __init__(self, hi, lo, bias, frag=None):
-        self.hi, self.lo, self.bias, self.frag = hi, lo, bias, frag
+    def __init__(self, hi, lo, bias, frag=None, frag16=None):
+        self.hi, self.lo, self.bias, self.frag, self.frag16 = hi, lo, bias, frag, frag16
 
 
 class UNetModel(nn.Module):
@@ -225,6 +225,7 @@ class UNetModel(nn.Module):
         #        LDS-DMA operands (default). "fused": GroupNorm applied inside the conv's patch loader (v1/v2 kernels).
         import os as _os
         self.conv_path = _os.environ.get("STEDM_CONV_PATH", "dma")
+        self._m16 = _os.environ.get("STEDM_CONV_M16", "1") != "0"     # 3x3 convs on v_mfma_f32_16x16x32 (conv_rs.inc RS_3X3M); 0: A/B runs
         self._gn_slot = 0
         self._style_cache: Dict[Tuple, torch.Tensor] = {}
         self._cs: Dict[int, torch.Tensor] = {}
@@ -290,13 +291,16 @@ class UNetModel(nn.Module):
                 w4 = w4.unsqueeze(-1)
             k3 = tuple(w4.shape[2:]) == (3, 3) and conv.stride == (1, 1) and conv.in_channels % 16 == 0
             k1 = tuple(w4.shape[2:]) == (1, 1) and conv.in_channels % 64 == 0
+            frag16 = None
             if self.conv_path == "dma" and prec.npass == 1 and (k3 or k1):
                 frag = ops.pack_conv_weight_frag(w4, prec)   # register-streamed weights
+                if k3 and conv.in_channels % 32 == 0 and self._m16:
+                    frag16 = ops.pack_conv_weight_frag16(w4, prec)    # the same, in the 16x16x32 MFMA kind's fragment order
                 # the [cout][tap][cin] planes are read only by the LDS-operand kernels: packed on first need
                 hi = ops.LazyPlanes(lambda w=conv.weight: ops.pack_conv_weight(w.float(), prec))
             else:
                 hi, lo = ops.pack_conv_weight(conv.weight.float(), prec)
-            self._packed[id(conv)] = _Packed(hi, lo, None if conv.bias is None else conv.bias.detach().float().contiguous(), frag)
+            self._packed[id(conv)] = _Packed(hi, lo, None if conv.bias is None else conv.bias.detach().float().contiguous(), frag, frag16)
 
         for m in self.modules():
             if isinstance(m, ResBlock):
@@ -427,7 +431,7 @@ class UNetModel(nn.Module):
             nel = B * H * W * co
             ws = self._buf("conv_ws", ((16 if nel <= (1 << 20) else (4 if nel <= (1 << 22) else 2)) * nel,)) if nel <= (1 << 23) else None
             ops.conv_igemm(None, pk.hi, pk.lo, h, prec=prec, src16=a16, bias=pk.bias, emb=emb_all, emb_offset=emb_off,
-                           emb_bstride=emb_bstride, w_frag=pk.frag, chan_stats=self._cs_new(h), ws=ws)
+                           emb_bstride=emb_bstride, w_frag=pk.frag, chan_stats=self._cs_new(h), ws=ws, w_frag16=pk.frag16)
         else:
             sc, sh = self._gn(tag + ".gn1", rb.in_layers[0], x1, x2, x2_bmod)
             ops.conv_igemm(x1, pk.hi, pk.lo, h, prec=prec, src2=x2, src2_bmod=x2_bmod, scale=sc, shift=sh, act=1, bias=pk.bias,
@@ -444,7 +448,7 @@ class UNetModel(nn.Module):
             h16 = self._norm16(rb.out_layers[0], 1, h)
             fuse_key = ("fuse", id(rb), B, H, W)
             fused = self._consts.get(fuse_key)
-            kw = dict(prec=prec, src16=h16, bias=pk2.bias, w_frag=pk2.frag, chan_stats=self._cs_new(out), ws=ws, out16=o16)
+            kw = dict(prec=prec, src16=h16, bias=pk2.bias, w_frag=pk2.frag, chan_stats=self._cs_new(out), ws=ws, out16=o16, w_frag16=pk2.frag16)
             if fused is None:
                 fused = bool(pk2.frag is not None and ps.frag is not None and
                              ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias), query_fused=True, **kw))
@@ -465,7 +469,7 @@ class UNetModel(nn.Module):
         if dma:
             h16 = self._norm16(rb.out_layers[0], 1, h)
             ops.conv_igemm(None, pk2.hi, pk2.lo, out, prec=prec, src16=h16, bias=pk2.bias, res=res, w_frag=pk2.frag,
-                           chan_stats=self._cs_new(out), ws=ws, out16=o16)
+                           chan_stats=self._cs_new(out), ws=ws, out16=o16, w_frag16=pk2.frag16)
         else:
             sc2, sh2 = self._gn(tag + ".gn2", rb.out_layers[0], h)
             ops.conv_igemm(h, pk2.hi, pk2.lo, out, prec=prec, scale=sc2, shift=sh2, act=1, bias=pk2.bias, res=res)

@@ -379,7 +379,7 @@ def test_conv_epilogue_chan_stats(dev, prec, B, H, W, cin, cout):
     assert torch.equal(cs, cs2)   # no atomics anywhere: bitwise reproducible
 
 
-def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_emb=True, use_res=True, seed=12, frag=False, ws=False):
+def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_emb=True, use_res=True, seed=12, frag=False, ws=False, m16=False):
     from stedm_amd import ops
     from stedm_amd._lib import CONV_DOWN, CONV_S1, CONV_UP, CONV_UP_SUBPIXEL
     prec = ops.Precision.parse(prec_name)
@@ -410,7 +410,8 @@ def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_em
                    emb=None if emb is None else emb.to(dev), emb_offset=8, emb_bstride=0 if emb is None else emb.shape[1],
                    res=None if res is None else nhwc(res).to(dev),
                    w_frag=None if not frag else (ops.pack_conv_weight_up_frag(w.to(dev), prec) if mode == "up2" else ops.pack_conv_weight_frag(w.to(dev), prec)),
-                   ws=torch.empty(16 * out.numel(), device=dev) if ws else None)
+                   ws=torch.empty(16 * out.numel(), device=dev) if ws else None,
+                   w_frag16=ops.pack_conv_weight_frag16(w.to(dev), prec) if m16 else None)
     torch.cuda.synchronize()
     err = rel_err(nchw(out), ref)
     assert err < tol, f"{prec_name}: rel err {err:.3e} >= {tol}"
@@ -432,6 +433,19 @@ def test_conv_dma_3x3_frag_weights(dev, prec, tol, B, H, W, cin, cout, emb, res)
     """256-row tile kernel with register-streamed fragment-order weights (conv_rs.inc); shapes fill >= 192 tiles so it is
     the kernel the dispatcher picks; ragged sample counts, cout not a multiple of 128, partial last tile."""
     _conv_dma_case(dev, prec, tol, B, H, W, cin, cout, "s1", 3, use_emb=emb, use_res=res, frag=True)
+
+
+@pytest.mark.parametrize("prec,tol", PRECS[1:])
+@pytest.mark.parametrize("B,H,W,cin,cout,emb,res,ws", [
+    (50, 32, 32, 32, 96, True, True, False), (200, 16, 16, 64, 128, True, False, False), (801, 8, 8, 32, 32, False, True, False),
+    (3, 128, 128, 32, 64, True, True, False), (12, 64, 64, 64, 32, False, False, False), (64, 32, 32, 128, 160, True, True, False),
+    (1601, 4, 4, 64, 128, True, True, False), (128, 8, 8, 1024, 1024, True, True, False), (64, 16, 16, 1536, 512, False, False, False),
+    (64, 8, 8, 2048, 1024, True, False, True), (2, 8, 8, 1024, 1024, False, True, True), (1, 32, 32, 256, 128, True, True, True)])
+def test_conv_3x3_mfma16x16x32_kind(dev, prec, tol, B, H, W, cin, cout, emb, res, ws):
+    """the 3x3 kind on v_mfma_f32_16x16x32 (conv_rs.inc RS_3X3M: two skewed 16-channel planes per 32-channel chunk, uniform tap
+    offsets, fragment-order weights of stedm_pack_conv_weight_frag16): full grids, ragged batches, partial N tiles, the bench's
+    large-K shapes, and the split-K form of small grids — against F.conv2d."""
+    _conv_dma_case(dev, prec, tol, B, H, W, cin, cout, "s1", 3, use_emb=emb, use_res=res, frag=True, ws=ws, m16=True)
 
 
 @pytest.mark.parametrize("prec,tol", PRECS[1:])
