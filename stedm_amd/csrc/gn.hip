@@ -479,6 +479,131 @@ __global__ void __launch_bounds__(256) gn_apply16c_kernel(GnApplyCArgs a, int sl
   }
 }
 
+
+// The same pass, 8 channels per thread: two 16-B loads in, ONE 16-B store per output plane (8-B stores run at 0.5-0.7 of the 16-B
+// rate, MI355X_MICROARCH.md), and the per-channel constants {mean, rstd * gamma, beta} come from LDS tables built once per block
+// (no per-element group arithmetic, no gamma / beta loads in the stream). Needs C % 8 == 0 and c1 % 8 == 0.
+template <typename T>
+__global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int slab) {
+  typedef T V8 __attribute__((ext_vector_type(8)));
+  __shared__ double dsu[256], dsq[256];
+  __shared__ float lmean[64], lrstd[64];
+  extern __shared__ __attribute__((aligned(16))) float tab[];   // [3][C]: mean, rstd * gamma, beta per channel
+  const int b = blockIdx.x, sl = blockIdx.y;
+  const int C = a.c1 + a.c2, Q = C >> 3;
+  const int cpg = C / a.groups;
+  const int b2 = a.bmod > 0 ? b % a.bmod : b;
+  const float* p1 = a.x1 + (long)b * a.HW * a.c1;
+  const float* p2 = a.x2 ? a.x2 + (long)b2 * a.HW * a.c2 : nullptr;
+  const int px0 = sl * slab, px1 = min(a.HW, px0 + slab);
+  const int total = (px1 - px0) * Q;
+  V8* oh = reinterpret_cast<V8*>(a.out_hi) + (long)b * a.HW * Q;
+  V8* ol = a.out_lo ? reinterpret_cast<V8*>(a.out_lo) + (long)b * a.HW * Q : nullptr;
+  V8* rh = a.raw_hi ? reinterpret_cast<V8*>(a.raw_hi) + (long)b * a.HW * Q : nullptr;
+  V8* rl = a.raw_lo ? reinterpret_cast<V8*>(a.raw_lo) + (long)b * a.HW * Q : nullptr;
+  constexpr int U = 2;            // 2 cursors x 32 B of loads per thread in flight
+  int pixs[U], qs[U];
+#pragma unroll
+  for (int k = 0; k < U; ++k) { const int e = threadIdx.x + k * 256; pixs[k] = px0 + e / Q; qs[k] = e % Q; }
+  const int dpix = (256 * U) / Q, dq = (256 * U) % Q;
+  float4 v[U][2];
+  auto load_batch = [&](int i) {
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      if (i + k * 256 < total) {
+        const int c = qs[k] * 8;
+        const float* src = c < a.c1 ? p1 + (long)pixs[k] * a.c1 + c : p2 + (long)pixs[k] * a.c2 + (c - a.c1);
+        v[k][0] = *reinterpret_cast<const float4*>(src);
+        v[k][1] = *reinterpret_cast<const float4*>(src + 4);
+      }
+    }
+  };
+  load_batch(threadIdx.x);
+  {
+    const int L = 256 / a.groups;                 // lanes per group (groups <= 64)
+    const int g = threadIdx.x / L, l = threadIdx.x % L;
+    double su = 0.0, sq = 0.0;
+    if (g < a.groups) {
+      const int nmax = a.nslab1 > a.nslab2 ? a.nslab1 : a.nslab2;
+      const int n = cpg * nmax;
+      for (int e = l; e < n; e += L) {            // entry = (slab k, channel cc of the group); tensors may be partitioned differently
+        const int k = e / cpg, c = g * cpg + (e - k * cpg);
+        if (c < a.c1) {
+          if (k < a.nslab1) { const float* p = a.cs1 + (((long)b * a.nslab1 + k) * a.c1 + c) * 2; su += (double)p[0]; sq += (double)p[1]; }
+        } else if (k < a.nslab2) {
+          const float* p = a.cs2 + (((long)b2 * a.nslab2 + k) * a.c2 + (c - a.c1)) * 2; su += (double)p[0]; sq += (double)p[1];
+        }
+      }
+    }
+    dsu[threadIdx.x] = su; dsq[threadIdx.x] = sq;
+    __syncthreads();
+    if (g < a.groups && l == 0) {
+      double s = 0.0, q = 0.0;
+      for (int i = 0; i < L; ++i) { s += dsu[threadIdx.x + i]; q += dsq[threadIdx.x + i]; }   // fixed order
+      const double inv_n = 1.0 / ((double)cpg * a.HW);
+      const double mean = s * inv_n;
+      double var = q * inv_n - mean * mean;
+      var = var > 0.0 ? var : 0.0;
+      lmean[g] = (float)mean;
+      lrstd[g] = (float)(1.0 / sqrt(var + (double)a.eps));
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const int gc = c / cpg;
+      tab[c] = lmean[gc];
+      tab[C + c] = lrstd[gc] * a.gamma[c];
+      tab[2 * C + c] = a.beta[c];
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < total; i += 256 * U) {
+    if (i != (int)threadIdx.x) load_batch(i);
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      if (i + k * 256 < total) {
+        const int c = qs[k] * 8;
+        const long o = (long)pixs[k] * Q + qs[k];
+        float w[8] = {v[k][0].x, v[k][0].y, v[k][0].z, v[k][0].w, v[k][1].x, v[k][1].y, v[k][1].z, v[k][1].w};
+        if (rh) {
+          V8 hi;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) hi[j] = (T)w[j];
+          rh[o] = hi;
+          if (rl) {
+            V8 lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) lo[j] = (T)(w[j] - (float)hi[j]);
+            rl[o] = lo;
+          }
+        }
+        float mn[8], sc[8], bt[8];
+        *reinterpret_cast<float4*>(mn) = *reinterpret_cast<const float4*>(tab + c);
+        *reinterpret_cast<float4*>(mn + 4) = *reinterpret_cast<const float4*>(tab + c + 4);
+        *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(tab + C + c);
+        *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(tab + C + c + 4);
+        *reinterpret_cast<float4*>(bt) = *reinterpret_cast<const float4*>(tab + 2 * C + c);
+        *reinterpret_cast<float4*>(bt + 4) = *reinterpret_cast<const float4*>(tab + 2 * C + c + 4);
+        V8 hi;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          w[j] = (w[j] - mn[j]) * sc[j] + bt[j];
+          if (a.act == 1) w[j] = silu_f(w[j]);
+          hi[j] = (T)w[j];
+        }
+        oh[o] = hi;
+        if (ol) {
+          V8 lo;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) lo[j] = (T)(w[j] - (float)hi[j]);
+          ol[o] = lo;
+        }
+      }
+      pixs[k] += dpix; qs[k] += dq;
+      if (qs[k] >= Q) { qs[k] -= Q; ++pixs[k]; }
+    }
+  }
+}
+
 extern "C" int stedm_gn_apply16c(const float* x1, int c1, const float* cs1, int nslab1, const float* x2, int c2, const float* cs2, int nslab2, int x2_bmod,
                                  const float* gamma, const float* beta, float eps, int groups, int act, int B, int HW,
                                  void* out_hi, void* out_lo, void* raw_hi, void* raw_lo, int mm_dtype, void* stream) {
@@ -496,6 +621,14 @@ extern "C" int stedm_gn_apply16c(const float* x1, int c1, const float* cs1, int 
   if (slab < 1) slab = 1;
   if (slab > HW) slab = HW;
   dim3 grid(B, (HW + slab - 1) / slab);
+  static const bool v4only = getenv("STEDM_GN_V4") != nullptr;     // A/B switch: the 4-channel-per-thread form
+  if (!v4only && C % 8 == 0 && c1 % 8 == 0 && (size_t)3 * C * sizeof(float) <= 48 * 1024) {
+    const size_t lds = (size_t)3 * C * sizeof(float);
+    if (mm_dtype == STEDM_F16) gn_apply16c_v8_kernel<_Float16><<<grid, 256, lds, as_stream(stream)>>>(a, slab);
+    else gn_apply16c_v8_kernel<__bf16><<<grid, 256, lds, as_stream(stream)>>>(a, slab);
+    STEDM_LAUNCH_CHECK();
+    return 0;
+  }
   if (mm_dtype == STEDM_F16)
     gn_apply16c_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(a, slab);
   else
