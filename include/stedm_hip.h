@@ -71,11 +71,13 @@ int stedm_pack_conv_weight_up_frag(const float* w_oihw, void* out, int cout, int
  * [ceil(cout/128)][4*cin/16][4 taps (a*2+b)][4][64][8] of the equivalent 2x2 conv: tap (a, b) of parity block (py, px) is
  * W[dy][dx] with dy = {(0,1):0, (1,0):1, (1,1):2}[(a, py)] (none for (0,0)), same for dx. cin %% 4 == 0. */
 int stedm_space_to_depth16(const float* x, int C, int B, int H, int W, void* out_hi, void* out_lo, int mm_dtype, void* stream);
-/* OIHW 3x3 fp32 -> fragment order of the 16x16x32 MFMA kind: [ceil(cout/128)][cin/32][9 taps][8 column fragments][64 lanes][8]; lane l
- * of column fragment c holds W[n = 128 tn + 16 c + (l & 15)][tap][ci = 32 chunk + 16 (g & 1) + 8 (g >> 1) + e], g = l >> 4 (the
- * k-group -> (plane, 16-B piece) assignment of conv_rs.inc RS_3X3M). Element (n, ci, tap) is read at w[n*sn + ci*sc + tap'] with
- * tap' = flip ? 8 - tap : tap (sn = cin*9, sc = 9, flip = 0 for a plain OIHW filter). */
-int stedm_pack_conv_weight_frag16(const float* w, long sn, long sc, int flip, void* out, int cout, int cin, int mm_dtype, void* stream);
+/* OIHW 3x3 (ks 3) or 1x1 (ks 1) fp32 -> fragment order of the 16x16x32 MFMA kind: [ceil(cout/128)][cin/32][ks*ks taps][8 column
+ * fragments][64 lanes][8]; lane l of column fragment c holds W[n = 128 tn + 16 c + (l & 15)][tap][ci], g = l >> 4:
+ * ks 3: ci = 32 chunk + 16 (g & 1) + 8 (g >> 1) + e (the k-group -> (plane, 16-B piece) assignment of conv_rs.inc RS_3X3M);
+ * ks 1: ci = 32 chunk + 8 g + e (the fused skip phase reads 128-B rows in natural piece order).
+ * Element (n, ci, tap) is read at w[n*sn + ci*sc + tap'] with tap' = flip ? taps - 1 - tap : tap (sn = cin*taps, sc = taps, flip = 0
+ * for a plain OIHW filter). */
+int stedm_pack_conv_weight_frag16(const float* w, long sn, long sc, int flip, void* out, int cout, int cin, int ks, int mm_dtype, void* stream);
 int stedm_pack_conv_weight_s2d_frag(const float* w_oihw, void* out, int cout, int cin, int mm_dtype, int pad_br, void* stream);
 /* [rows][cols] fp32 -> [cols][rows] fp32 (Linear weights are consumed K-major). */
 int stedm_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
@@ -169,6 +171,7 @@ typedef struct stedm_conv_args {
   const void* w_frag16; /* optional: the 3x3 weights in the fragment order of v_mfma_f32_16x16x32 (stedm_pack_conv_weight_frag16; cin %% 32 == 0).
                          * When given, the plain 3x3 stride-1 single-product problems of the register-streamed kernel run on that MFMA
                          * shape (same tiles, same LDS image; the chip holds a higher clock on it on real data) */
+  const void* w_frag_b16; /* with w_frag16 and the fused skip_connection: the 1x1 weights from stedm_pack_conv_weight_frag16(ks = 1) */
   int32_t pad_br;     /* STEDM_CONV_S2D only. 0: the stride-2 conv pads 1 on every side (openaimodel.py:164-166). 1: it pads bottom and
                        * right only — F.pad(x, (0,1,0,1)) + conv(stride 2, padding 0), the VQ encoder's Downsample (model.py:59-76):
                        * the 2x2 taps of the space-to-depth form then sit at offsets (0, +1); weights from

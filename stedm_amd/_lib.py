@@ -36,7 +36,7 @@ class ConvArgs(C.Structure):
         ("act_out", C.c_int32), ("out16_hi", C.c_void_p), ("out16_lo", C.c_void_p),
         ("w_frag", C.c_void_p), ("chan_stats", C.c_void_p),
         ("src16b_hi", C.c_void_p), ("w_frag_b", C.c_void_p), ("bias_b", C.c_void_p), ("cb", C.c_int32),
-        ("ws", C.c_void_p), ("ws_floats", C.c_int64), ("chan_nslab", C.c_int32), ("w_frag16", C.c_void_p), ("pad_br", C.c_int32),
+        ("ws", C.c_void_p), ("ws_floats", C.c_int64), ("chan_nslab", C.c_int32), ("w_frag16", C.c_void_p), ("w_frag_b16", C.c_void_p), ("pad_br", C.c_int32),
     ]
 
 
@@ -50,7 +50,7 @@ SIGNATURES = {
     "stedm_pack_conv_weight_up": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "stedm_pack_conv_weight_frag": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "stedm_pack_conv_weight_up_frag": (_I, [_P, _P, _I, _I, _I, _P]),
-    "stedm_pack_conv_weight_frag16": (_I, [_P, C.c_long, C.c_long, _I, _P, _I, _I, _I, _P]),
+    "stedm_pack_conv_weight_frag16": (_I, [_P, C.c_long, C.c_long, _I, _P, _I, _I, _I, _I, _P]),
     "stedm_pack_conv_weight_s2d_frag": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "stedm_space_to_depth16": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P]),
     "stedm_transpose_f32": (_I, [_P, _P, _I, _I, _P]),

@@ -242,30 +242,32 @@ extern "C" int stedm_pack_conv_weight_up_frag(const float* w, void* out, int cou
 
 // Fragment order of the 16x16x32 MFMA kind (conv_rs.inc RS_3X3M), see stedm_pack_conv_weight_frag16 in the header
 template <typename T>
-__global__ void pack_conv_weight_frag16_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, long total, long sn, long sc, int flip) {
+__global__ void pack_conv_weight_frag16_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, long total, long sn, long sc, int flip,
+                                               int taps) {
   const int nch = cin / 32;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int e = (int)(i & 7);
     const int lane = (int)((i >> 3) & 63);
     const int c = (int)((i >> 9) & 7);
     long r = i >> 12;
-    const int tap = (int)(r % 9); r /= 9;
+    const int tap = (int)(r % taps); r /= taps;
     const int chunk = (int)(r % nch);
     const int tn = (int)(r / nch);
     const int g = lane >> 4;
     const int n = tn * 128 + c * 16 + (lane & 15);
-    const int ci = chunk * 32 + (g & 1) * 16 + (g >> 1) * 8 + e;
-    out[i] = n < cout ? (T)w[(long)n * sn + (long)ci * sc + (flip ? 8 - tap : tap)] : (T)0.f;
+    const int ci = chunk * 32 + (taps == 9 ? (g & 1) * 16 + (g >> 1) * 8 : g * 8) + e;
+    out[i] = n < cout ? (T)w[(long)n * sn + (long)ci * sc + (flip ? taps - 1 - tap : tap)] : (T)0.f;
   }
 }
 
-extern "C" int stedm_pack_conv_weight_frag16(const float* w, long sn, long sc, int flip, void* out, int cout, int cin, int mm_dtype, void* stream) {
-  STEDM_CHECK_ARG(w && out && cin % 32 == 0 && cout > 0, "pack_conv_weight_frag16: bad args (cin %% 32)");
+extern "C" int stedm_pack_conv_weight_frag16(const float* w, long sn, long sc, int flip, void* out, int cout, int cin, int ks, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(w && out && cin % 32 == 0 && cout > 0 && (ks == 1 || ks == 3), "pack_conv_weight_frag16: bad args (cin %% 32, ks 1 or 3)");
+  const int taps = ks * ks;
   STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "pack_conv_weight_frag16: bad mm_dtype %d", mm_dtype);
-  const long total = (long)((cout + 127) / 128) * (cin / 32) * 9 * 8 * 64 * 8;
+  const long total = (long)((cout + 127) / 128) * (cin / 32) * taps * 8 * 64 * 8;
   const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-  if (mm_dtype == STEDM_F16) pack_conv_weight_frag16_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(w, (_Float16*)out, cout, cin, total, sn, sc, flip);
-  else pack_conv_weight_frag16_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(w, (__bf16*)out, cout, cin, total, sn, sc, flip);
+  if (mm_dtype == STEDM_F16) pack_conv_weight_frag16_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(w, (_Float16*)out, cout, cin, total, sn, sc, flip, taps);
+  else pack_conv_weight_frag16_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(w, (__bf16*)out, cout, cin, total, sn, sc, flip, taps);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

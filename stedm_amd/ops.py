@@ -99,19 +99,19 @@ def pack_conv_weight_frag(w: torch.Tensor, prec: Precision) -> torch.Tensor:
 
 
 def pack_conv_weight_frag16(w: torch.Tensor, prec: Precision, sn: Optional[int] = None, sc: Optional[int] = None, flip: bool = False,
-                            cout: Optional[int] = None, cin: Optional[int] = None) -> torch.Tensor:
-    """3x3 fp32 filter -> fragment order of the 16x16x32 MFMA kind (stedm_pack_conv_weight_frag16). Default: a plain OIHW filter;
-    sn / sc / flip / cout / cin describe a strided source like pack_conv_weight_strided (the dgrad filter of the training step)."""
+                            cout: Optional[int] = None, cin: Optional[int] = None, ks: Optional[int] = None) -> torch.Tensor:
+    """3x3 / 1x1 fp32 filter -> fragment order of the 16x16x32 MFMA kind (stedm_pack_conv_weight_frag16). Default: a plain OIHW filter;
+    sn / sc / flip / cout / cin / ks describe a strided source like pack_conv_weight_strided (the dgrad filter of the training step)."""
     w = w.detach()
-    _chk(w.contiguous() if sn is None else w, name="conv weight")
     if sn is None:
         w = w.contiguous()
         cout, cin, ks, _ = w.shape
-        assert ks == 3
-        sn, sc = cin * 9, 9
+        assert ks in (1, 3)
+        sn, sc = cin * ks * ks, ks * ks
+    _chk(w, name="conv weight")
     assert cin % 32 == 0
-    out = torch.empty(((cout + 127) // 128, cin // 32, 9, 8, 64, 8), dtype=torch.int16, device=w.device)
-    check(lib().stedm_pack_conv_weight_frag16(w.data_ptr(), sn, sc, int(flip), out.data_ptr(), cout, cin, prec.mm_dtype, _stream()),
+    out = torch.empty(((cout + 127) // 128, cin // 32, ks * ks, 8, 64, 8), dtype=torch.int16, device=w.device)
+    check(lib().stedm_pack_conv_weight_frag16(w.data_ptr(), sn, sc, int(flip), out.data_ptr(), cout, cin, ks, prec.mm_dtype, _stream()),
           "stedm_pack_conv_weight_frag16")
     return out
 
@@ -276,6 +276,7 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
         a.cb = skip[0].shape[-1]
         a.w_frag_b = skip[1].data_ptr()
         a.bias_b = _ptr(skip[2])
+        a.w_frag_b16 = _ptr(skip[3]) if len(skip) > 3 and prec.npass == 1 else None
     if out16 is not None:
         a.out16_hi = out16[0].data_ptr()
         a.out16_lo = _ptr(out16[1]) if prec.npass == 3 else None

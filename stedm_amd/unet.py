@@ -294,7 +294,7 @@ class UNetModel(nn.Module):
             frag16 = None
             if self.conv_path == "dma" and prec.npass == 1 and (k3 or k1):
                 frag = ops.pack_conv_weight_frag(w4, prec)   # register-streamed weights
-                if k3 and conv.in_channels % 32 == 0 and self._m16:
+                if (k3 or k1) and conv.in_channels % 32 == 0 and self._m16:
                     frag16 = ops.pack_conv_weight_frag16(w4, prec)    # the same, in the 16x16x32 MFMA kind's fragment order
                 # the [cout][tap][cin] planes are read only by the LDS-operand kernels: packed on first need
                 hi = ops.LazyPlanes(lambda w=conv.weight: ops.pack_conv_weight(w.float(), prec))
@@ -451,10 +451,10 @@ class UNetModel(nn.Module):
             kw = dict(prec=prec, src16=h16, bias=pk2.bias, w_frag=pk2.frag, chan_stats=self._cs_new(out), ws=ws, out16=o16, w_frag16=pk2.frag16)
             if fused is None:
                 fused = bool(pk2.frag is not None and ps.frag is not None and
-                             ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias), query_fused=True, **kw))
+                             ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias, ps.frag16), query_fused=True, **kw))
                 self._consts[fuse_key] = fused
             if fused:
-                ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias), **kw)
+                ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias, ps.frag16), **kw)
             else:
                 ops.conv_igemm(None, ps.hi, ps.lo, out, prec=prec, ks=1, src16=x16, bias=ps.bias, w_frag=ps.frag, ws=ws)
                 ops.conv_igemm(None, pk2.hi, pk2.lo, out, res=out, **kw)

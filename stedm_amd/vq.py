@@ -208,10 +208,10 @@ class VectorQuantizer(nn.Module):
 
 
 class _Packed:
-    __slots__ = ("hi", "lo", "bias", "frag", "extra")
+    __slots__ = ("hi", "lo", "bias", "frag", "extra", "frag16")
 
-    def __init__(self, hi, lo, bias, frag=None, extra=None):
-        self.hi, self.lo, self.bias, self.frag, self.extra = hi, lo, bias, frag, extra
+    def __init__(self, hi, lo, bias, frag=None, extra=None, frag16=None):
+        self.hi, self.lo, self.bias, self.frag, self.extra, self.frag16 = hi, lo, bias, frag, extra, frag16
 
 
 class VQModelInterface(nn.Module):
@@ -321,12 +321,15 @@ class VQModelInterface(nn.Module):
             ks = w4.shape[-1]
             hi = lo = frag = None
             ok = (ks == 3 and conv.in_channels % 16 == 0) or (ks == 1 and conv.in_channels % 64 == 0)
+            frag16 = None
             if prec.npass == 1 and ok and conv.stride == (1, 1):
                 frag = ops.pack_conv_weight_frag(w4, prec)
+                if conv.in_channels % 32 == 0:
+                    frag16 = ops.pack_conv_weight_frag16(w4, prec)     # 16x16x32 MFMA kind of the register-streamed kernel
                 hi = ops.LazyPlanes(lambda w=w4: ops.pack_conv_weight(w, prec))
             else:
                 hi, lo = ops.pack_conv_weight(w4, prec)
-            self._packed[id(conv)] = _Packed(hi, lo, None if conv.bias is None else conv.bias.detach().float().contiguous(), frag)
+            self._packed[id(conv)] = _Packed(hi, lo, None if conv.bias is None else conv.bias.detach().float().contiguous(), frag, None, frag16)
 
         for m in self.modules():
             if isinstance(m, ResnetBlock):
@@ -364,7 +367,8 @@ class VQModelInterface(nn.Module):
     def _conv(self, pk, src16, out, ks=3, res=None, stats=True, **kw):
         nel = out.numel() if out is not None else src16[0].numel() // src16[0].shape[-1] * kw["out16"][0].shape[-1]
         return ops.conv_igemm(None, pk.hi, pk.lo, out, prec=self.precision, ks=ks, src16=src16, bias=pk.bias, res=res, w_frag=pk.frag,
-                              chan_stats=self._cs_new(out) if (stats and out is not None) else None, ws=self._ws(nel), **kw)
+                              chan_stats=self._cs_new(out) if (stats and out is not None) else None, ws=self._ws(nel),
+                              w_frag16=pk.frag16 if ks == 3 else None, **kw)
 
     def _res(self, tag, rb: ResnetBlock, x):
         """ResnetBlock.forward model.py:117-140 with temb None."""
@@ -385,13 +389,14 @@ class VQModelInterface(nn.Module):
         ps = self._packed[id(rb.nin_shortcut)]
         fkey = ("fuse", id(rb), B, H, W)
         fused = self._packed.get(fkey)
-        kw = dict(prec=self.precision, src16=h16, bias=pk2.bias, w_frag=pk2.frag, chan_stats=self._cs_new(out), ws=self._ws(out.numel()))
+        kw = dict(prec=self.precision, src16=h16, bias=pk2.bias, w_frag=pk2.frag, chan_stats=self._cs_new(out), ws=self._ws(out.numel()),
+                  w_frag16=pk2.frag16)
         if fused is None:
             fused = bool(pk2.frag is not None and ps.frag is not None and
-                         ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias), query_fused=True, **kw))
+                         ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias, ps.frag16), query_fused=True, **kw))
             self._packed[fkey] = fused
         if fused:
-            return ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias), **kw)
+            return ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias, ps.frag16), **kw)
         self._conv(ps, x16, out, ks=1, stats=False)
         return ops.conv_igemm(None, pk2.hi, pk2.lo, out, res=out, **kw)
 

@@ -473,11 +473,14 @@ def test_conv_dma_up_subpixel_frag_weights(dev, prec, tol, B, H, W, c, cout):
 
 
 @pytest.mark.parametrize("prec,tol", PRECS[1:])
+@pytest.mark.parametrize("m16", [False, True])
 @pytest.mark.parametrize("B,H,W,cin,cb,cout,emb", [(64, 32, 32, 32, 64, 128, False), (200, 16, 16, 64, 192, 96, True), (801, 8, 8, 32, 128, 160, False),
-                                                   (128, 8, 8, 512, 1024, 768, False), (50, 32, 32, 128, 640, 128, True), (13, 64, 64, 32, 64, 32, False)])
-def test_conv_fused_skip(dev, prec, tol, B, H, W, cin, cb, cout, emb):
+                                                   (128, 8, 8, 512, 1024, 768, False), (50, 32, 32, 128, 640, 128, True), (13, 64, 64, 32, 64, 32, False),
+                                                   (128, 16, 16, 512, 1536, 512, True), (128, 32, 32, 256, 640, 128, True), (201, 8, 8, 1024, 2048, 1024, False)])
+def test_conv_fused_skip(dev, prec, tol, B, H, W, cin, cb, cout, emb, m16):
     """conv3x3(h) + conv1x1(x) + both biases in one kernel (ResBlock tail `skip_connection(x) + h`, openaimodel.py:288):
-    the 1x1 runs as a second K-phase of the register-streamed 3x3 kernel; per-channel statistics of the sum come with it."""
+    the 1x1 runs as a second K-phase of the register-streamed 3x3 kernel; per-channel statistics of the sum come with it.
+    m16: with the 16x16x32-MFMA fragment orders at hand (both phases on that shape from 256 input channels on)."""
     from stedm_amd import ops
     pr = ops.Precision.parse(prec)
     hsrc = F.silu(prng.normal(21, "fs.h", (B, cin, H, W)))
@@ -497,7 +500,8 @@ def test_conv_fused_skip(dev, prec, tol, B, H, W, cin, cb, cout, emb):
     cs = torch.full((B, ops.gn_chan_nslab(H * W), cout, 2), float("nan"), device=dev)
     kw = dict(prec=pr, src16=(h16, None), bias=b3.to(dev), emb=None if e is None else e.to(dev), emb_bstride=0 if e is None else cout,
               w_frag=ops.pack_conv_weight_frag(w3.to(dev), pr), chan_stats=cs,
-              skip=(x16, ops.pack_conv_weight_frag(w1.to(dev), pr), b1.to(dev)))
+              w_frag16=ops.pack_conv_weight_frag16(w3.to(dev), pr) if m16 else None,
+              skip=(x16, ops.pack_conv_weight_frag(w1.to(dev), pr), b1.to(dev)) + ((ops.pack_conv_weight_frag16(w1.to(dev), pr),) if m16 else ()))
     assert ops.conv_igemm(None, whi, wlo, out, query_fused=True, **kw)
     ops.conv_igemm(None, whi, wlo, out, **kw)
     torch.cuda.synchronize()
