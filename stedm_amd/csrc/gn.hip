@@ -480,41 +480,43 @@ __global__ void __launch_bounds__(256) gn_apply16c_kernel(GnApplyCArgs a, int sl
 }
 
 
-// The same pass, 8 channels per thread: two 16-B loads in, ONE 16-B store per output plane (8-B stores run at 0.5-0.7 of the 16-B
-// rate, MI355X_MICROARCH.md), and the per-channel constants {mean, rstd * gamma, beta} come from LDS tables built once per block
-// (no per-element group arithmetic, no gamma / beta loads in the stream). Needs C % 8 == 0 and c1 % 8 == 0.
+// The same pass with 16-B accesses on BOTH sides: a lane still loads one coalesced float4 (4 channels) per cursor — a wave instruction
+// reads 1 KiB contiguous — but works on TWO cursors at once (quads e and e + 256 of the block's run), and lane pairs swap halves before the
+// store: the even lane ends up with the 8 contiguous channels of cursor 0, the odd lane with those of cursor 1, so every store is 16 B
+// per lane (8-B stores run at 0.5-0.7 of the 16-B rate, MI355X_MICROARCH.md). The per-channel constants {mean, rstd * gamma, beta}
+// come from LDS tables built once per block (no per-element group arithmetic, no gamma / beta loads in the stream).
+// Needs C % 8 == 0, c1 % 8 == 0 and an even number of quads per block iteration (256 threads: always).
 template <typename T>
 __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int slab) {
-  typedef T V8 __attribute__((ext_vector_type(8)));
+  typedef T V4 __attribute__((ext_vector_type(4)));
   __shared__ double dsu[256], dsq[256];
   __shared__ float lmean[64], lrstd[64];
   extern __shared__ __attribute__((aligned(16))) float tab[];   // [3][C]: mean, rstd * gamma, beta per channel
   const int b = blockIdx.x, sl = blockIdx.y;
-  const int C = a.c1 + a.c2, Q = C >> 3;
+  const int C = a.c1 + a.c2, Q = C >> 2;
   const int cpg = C / a.groups;
   const int b2 = a.bmod > 0 ? b % a.bmod : b;
   const float* p1 = a.x1 + (long)b * a.HW * a.c1;
   const float* p2 = a.x2 ? a.x2 + (long)b2 * a.HW * a.c2 : nullptr;
   const int px0 = sl * slab, px1 = min(a.HW, px0 + slab);
-  const int total = (px1 - px0) * Q;
-  V8* oh = reinterpret_cast<V8*>(a.out_hi) + (long)b * a.HW * Q;
-  V8* ol = a.out_lo ? reinterpret_cast<V8*>(a.out_lo) + (long)b * a.HW * Q : nullptr;
-  V8* rh = a.raw_hi ? reinterpret_cast<V8*>(a.raw_hi) + (long)b * a.HW * Q : nullptr;
-  V8* rl = a.raw_lo ? reinterpret_cast<V8*>(a.raw_lo) + (long)b * a.HW * Q : nullptr;
-  constexpr int U = 2;            // 2 cursors x 32 B of loads per thread in flight
+  const int total = (px1 - px0) * Q;             // quads of this block; even (Q is even)
+  uint2* oh = reinterpret_cast<uint2*>(a.out_hi) + (long)b * a.HW * Q;      // 8-B units (one quad of 16-bit values)
+  uint2* ol = a.out_lo ? reinterpret_cast<uint2*>(a.out_lo) + (long)b * a.HW * Q : nullptr;
+  uint2* rh = a.raw_hi ? reinterpret_cast<uint2*>(a.raw_hi) + (long)b * a.HW * Q : nullptr;
+  uint2* rl = a.raw_lo ? reinterpret_cast<uint2*>(a.raw_lo) + (long)b * a.HW * Q : nullptr;
+  constexpr int U = 2;
   int pixs[U], qs[U];
 #pragma unroll
   for (int k = 0; k < U; ++k) { const int e = threadIdx.x + k * 256; pixs[k] = px0 + e / Q; qs[k] = e % Q; }
   const int dpix = (256 * U) / Q, dq = (256 * U) % Q;
-  float4 v[U][2];
+  float4 v[U];
   auto load_batch = [&](int i) {
 #pragma unroll
     for (int k = 0; k < U; ++k) {
       if (i + k * 256 < total) {
-        const int c = qs[k] * 8;
-        const float* src = c < a.c1 ? p1 + (long)pixs[k] * a.c1 + c : p2 + (long)pixs[k] * a.c2 + (c - a.c1);
-        v[k][0] = *reinterpret_cast<const float4*>(src);
-        v[k][1] = *reinterpret_cast<const float4*>(src + 4);
+        const int c = qs[k] * 4;
+        v[k] = c < a.c1 ? *reinterpret_cast<const float4*>(p1 + (long)pixs[k] * a.c1 + c)
+                        : *reinterpret_cast<const float4*>(p2 + (long)pixs[k] * a.c2 + (c - a.c1));
       }
     }
   };
@@ -556,48 +558,63 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
     }
     __syncthreads();
   }
+  const bool odd = threadIdx.x & 1;
+  auto pack4 = [](float x0, float x1, float x2, float x3) {
+    V4 h; h[0] = (T)x0; h[1] = (T)x1; h[2] = (T)x2; h[3] = (T)x3;
+    return *reinterpret_cast<uint2*>(&h);
+  };
+  // lane pair exchange: the even lane keeps cursor 0's quad and receives its partner's; the odd lane keeps cursor 1's. Returns the
+  // 16 B this lane stores: {even lane's quad, odd lane's quad} of the cursor it owns.
+  auto pair16 = [&](uint2 q0, uint2 q1) {
+    const uint2 give = odd ? q0 : q1;             // what the partner needs from me
+    uint2 got;
+    got.x = __shfl_xor(give.x, 1, 64); got.y = __shfl_xor(give.y, 1, 64);
+    uint4 r;
+    if (odd) { r.x = got.x; r.y = got.y; r.z = q1.x; r.w = q1.y; }      // cursor 1: even partner's quad first
+    else { r.x = q0.x; r.y = q0.y; r.z = got.x; r.w = got.y; }
+    return r;
+  };
   for (int i = threadIdx.x; i < total; i += 256 * U) {
     if (i != (int)threadIdx.x) load_batch(i);
+    // (total and 256 are even and the cursors advance together, so a lane pair is live or dead together for each cursor)
+    const bool live0 = i < total, live1 = i + 256 < total;
+    uint2 oq[U], rq[U], olq[U], rlq[U];
 #pragma unroll
     for (int k = 0; k < U; ++k) {
-      if (i + k * 256 < total) {
-        const int c = qs[k] * 8;
-        const long o = (long)pixs[k] * Q + qs[k];
-        float w[8] = {v[k][0].x, v[k][0].y, v[k][0].z, v[k][0].w, v[k][1].x, v[k][1].y, v[k][1].z, v[k][1].w};
-        if (rh) {
-          V8 hi;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) hi[j] = (T)w[j];
-          rh[o] = hi;
-          if (rl) {
-            V8 lo;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) lo[j] = (T)(w[j] - (float)hi[j]);
-            rl[o] = lo;
-          }
-        }
-        float mn[8], sc[8], bt[8];
-        *reinterpret_cast<float4*>(mn) = *reinterpret_cast<const float4*>(tab + c);
-        *reinterpret_cast<float4*>(mn + 4) = *reinterpret_cast<const float4*>(tab + c + 4);
-        *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(tab + C + c);
-        *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(tab + C + c + 4);
-        *reinterpret_cast<float4*>(bt) = *reinterpret_cast<const float4*>(tab + 2 * C + c);
-        *reinterpret_cast<float4*>(bt + 4) = *reinterpret_cast<const float4*>(tab + 2 * C + c + 4);
-        V8 hi;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          w[j] = (w[j] - mn[j]) * sc[j] + bt[j];
-          if (a.act == 1) w[j] = silu_f(w[j]);
-          hi[j] = (T)w[j];
-        }
-        oh[o] = hi;
-        if (ol) {
-          V8 lo;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) lo[j] = (T)(w[j] - (float)hi[j]);
-          ol[o] = lo;
+      const int c = qs[k] * 4;
+      float4 w = v[k];
+      const bool live = k == 0 ? live0 : live1;
+      if (!live) { w = make_float4(0.f, 0.f, 0.f, 0.f); }
+      if (rh) {
+        rq[k] = pack4(w.x, w.y, w.z, w.w);
+        if (rl) {
+          V4 hq = *reinterpret_cast<V4*>(&rq[k]);
+          rlq[k] = pack4(w.x - (float)hq[0], w.y - (float)hq[1], w.z - (float)hq[2], w.w - (float)hq[3]);
         }
       }
+      const int cc = live ? c : 0;
+      const float4 mn = *reinterpret_cast<const float4*>(tab + cc);
+      const float4 sc = *reinterpret_cast<const float4*>(tab + C + cc);
+      const float4 bt = *reinterpret_cast<const float4*>(tab + 2 * C + cc);
+      w.x = (w.x - mn.x) * sc.x + bt.x; w.y = (w.y - mn.y) * sc.y + bt.y; w.z = (w.z - mn.z) * sc.z + bt.z; w.w = (w.w - mn.w) * sc.w + bt.w;
+      if (a.act == 1) { w.x = silu_f(w.x); w.y = silu_f(w.y); w.z = silu_f(w.z); w.w = silu_f(w.w); }
+      oq[k] = pack4(w.x, w.y, w.z, w.w);
+      if (ol) {
+        V4 hq = *reinterpret_cast<V4*>(&oq[k]);
+        olq[k] = pack4(w.x - (float)hq[0], w.y - (float)hq[1], w.z - (float)hq[2], w.w - (float)hq[3]);
+      }
+    }
+    // my cursor: 0 on even lanes, 1 on odd lanes; the 16-B destination starts at the EVEN lane's quad of that cursor
+    const int mk = odd ? 1 : 0;
+    const bool mlive = odd ? live1 : live0;
+    const long o = (long)pixs[mk] * Q + (qs[mk] & ~1);
+    const uint4 so = pair16(oq[0], oq[1]);
+    if (mlive) *reinterpret_cast<uint4*>(oh + o) = so;
+    if (ol) { const uint4 t4 = pair16(olq[0], olq[1]); if (mlive) *reinterpret_cast<uint4*>(ol + o) = t4; }
+    if (rh) { const uint4 t4 = pair16(rq[0], rq[1]); if (mlive) *reinterpret_cast<uint4*>(rh + o) = t4; }
+    if (rl) { const uint4 t4 = pair16(rlq[0], rlq[1]); if (mlive) *reinterpret_cast<uint4*>(rl + o) = t4; }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
       pixs[k] += dpix; qs[k] += dq;
       if (qs[k] >= Q) { qs[k] -= Q; ++pixs[k]; }
     }
