@@ -322,22 +322,36 @@ __global__ void __launch_bounds__(256, 2) lsa_flash_kernel(FlashArgs a) {
   const int qidx = q0 + r;
 
   const int ntiles = (a.T + 63) / 64;
-  for (int kt = 0; kt < ntiles; ++kt) {
-    __syncthreads();
-    // stage K rows and V^T rows of this tile (64 x 128 B each per plane)
+  // K / V^T tiles travel global -> registers -> LDS with the loads of tile kt + 1 issued BEFORE the MFMAs of tile kt (async-stage
+  // split, cdna_hip_programming.md T14): their latency hides behind the tile's compute instead of sitting between two barriers
+  uint4 kreg[2][NPL], vreg[2][NPL];
+  auto fetch = [&](int kt) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int pc = tid + it * 256;
       const int row = pc >> 3, c = pc & 7;
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) {
-        *reinterpret_cast<uint4*>(&sK[pl][row * RS + c * 8]) =
-            *reinterpret_cast<const uint4*>(kg[pl] + ((long)bh * a.Tp + kt * 64 + row) * 64 + c * 8);
-        *reinterpret_cast<uint4*>(&sV[pl][row * RS + c * 8]) =
-            *reinterpret_cast<const uint4*>(vg[pl] + ((long)bh * 64 + row) * a.Tp + kt * 64 + c * 8);
+        kreg[it][pl] = *reinterpret_cast<const uint4*>(kg[pl] + ((long)bh * a.Tp + kt * 64 + row) * 64 + c * 8);
+        vreg[it][pl] = *reinterpret_cast<const uint4*>(vg[pl] + ((long)bh * 64 + row) * a.Tp + kt * 64 + c * 8);
+      }
+    }
+  };
+  fetch(0);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();   // every wave is done reading the previous tile
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int pc = tid + it * 256;
+      const int row = pc >> 3, c = pc & 7;
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        *reinterpret_cast<uint4*>(&sK[pl][row * RS + c * 8]) = kreg[it][pl];
+        *reinterpret_cast<uint4*>(&sV[pl][row * RS + c * 8]) = vreg[it][pl];
       }
     }
     __syncthreads();
+    if (kt + 1 < ntiles) fetch(kt + 1);
     // ---- S^T tiles (2 x 32 keys) x 32 queries
     f32x16 s[2];
 #pragma unroll
