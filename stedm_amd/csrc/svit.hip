@@ -324,34 +324,39 @@ __global__ void __launch_bounds__(256, 2) lsa_flash_kernel(FlashArgs a) {
   const int ntiles = (a.T + 63) / 64;
   // K / V^T tiles travel global -> registers -> LDS with the loads of tile kt + 1 issued BEFORE the MFMAs of tile kt (async-stage
   // split, cdna_hip_programming.md T14): their latency hides behind the tile's compute instead of sitting between two barriers
-  uint4 kreg[2][NPL], vreg[2][NPL];
-  auto fetch = [&](int kt) {
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int pc = tid + it * 256;
-      const int row = pc >> 3, c = pc & 7;
-#pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) {
-        kreg[it][pl] = *reinterpret_cast<const uint4*>(kg[pl] + ((long)bh * a.Tp + kt * 64 + row) * 64 + c * 8);
-        vreg[it][pl] = *reinterpret_cast<const uint4*>(vg[pl] + ((long)bh * 64 + row) * a.Tp + kt * 64 + c * 8);
-      }
-    }
-  };
-  fetch(0);
+  // (named registers, macro-expanded: an array captured by a lambda went to scratch)
+  uint4 kr0h, kr1h, vr0h, vr1h, kr0l, kr1l, vr0l, vr1l;
+  const int frow0 = tid >> 3, frow1 = (tid + 256) >> 3, fc = tid & 7;
+#define LSA_FETCH(KT)                                                                                                   \
+  {                                                                                                                     \
+    const long kb_ = ((long)bh * a.Tp + (KT) * 64) * 64 + fc * 8;                                                       \
+    const long vb_ = (long)bh * 64 * a.Tp + (KT) * 64 + fc * 8;                                                         \
+    kr0h = *reinterpret_cast<const uint4*>(kg[0] + kb_ + frow0 * 64);                                                   \
+    kr1h = *reinterpret_cast<const uint4*>(kg[0] + kb_ + frow1 * 64);                                                   \
+    vr0h = *reinterpret_cast<const uint4*>(vg[0] + vb_ + (long)frow0 * a.Tp);                                           \
+    vr1h = *reinterpret_cast<const uint4*>(vg[0] + vb_ + (long)frow1 * a.Tp);                                           \
+    if (NPASS == 3) {                                                                                                   \
+      kr0l = *reinterpret_cast<const uint4*>(kg[1] + kb_ + frow0 * 64);                                                 \
+      kr1l = *reinterpret_cast<const uint4*>(kg[1] + kb_ + frow1 * 64);                                                 \
+      vr0l = *reinterpret_cast<const uint4*>(vg[1] + vb_ + (long)frow0 * a.Tp);                                         \
+      vr1l = *reinterpret_cast<const uint4*>(vg[1] + vb_ + (long)frow1 * a.Tp);                                         \
+    }                                                                                                                   \
+  }
+  LSA_FETCH(0)
   for (int kt = 0; kt < ntiles; ++kt) {
     __syncthreads();   // every wave is done reading the previous tile
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int pc = tid + it * 256;
-      const int row = pc >> 3, c = pc & 7;
-#pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) {
-        *reinterpret_cast<uint4*>(&sK[pl][row * RS + c * 8]) = kreg[it][pl];
-        *reinterpret_cast<uint4*>(&sV[pl][row * RS + c * 8]) = vreg[it][pl];
-      }
+    *reinterpret_cast<uint4*>(&sK[0][frow0 * RS + fc * 8]) = kr0h;
+    *reinterpret_cast<uint4*>(&sK[0][frow1 * RS + fc * 8]) = kr1h;
+    *reinterpret_cast<uint4*>(&sV[0][frow0 * RS + fc * 8]) = vr0h;
+    *reinterpret_cast<uint4*>(&sV[0][frow1 * RS + fc * 8]) = vr1h;
+    if (NPASS == 3) {
+      *reinterpret_cast<uint4*>(&sK[NPL - 1][frow0 * RS + fc * 8]) = kr0l;
+      *reinterpret_cast<uint4*>(&sK[NPL - 1][frow1 * RS + fc * 8]) = kr1l;
+      *reinterpret_cast<uint4*>(&sV[NPL - 1][frow0 * RS + fc * 8]) = vr0l;
+      *reinterpret_cast<uint4*>(&sV[NPL - 1][frow1 * RS + fc * 8]) = vr1l;
     }
     __syncthreads();
-    if (kt + 1 < ntiles) fetch(kt + 1);
+    if (kt + 1 < ntiles) LSA_FETCH(kt + 1)
     // ---- S^T tiles (2 x 32 keys) x 32 queries
     f32x16 s[2];
 #pragma unroll
@@ -447,6 +452,7 @@ __global__ void __launch_bounds__(256, 2) lsa_flash_kernel(FlashArgs a) {
         }
       }
   }
+#undef LSA_FETCH
   // ---- epilogue: O^T / l through LDS so that every token row is written contiguously (token-major [B][T][H*64])
   __syncthreads();   // all waves are done with the K / V^T tiles: the block is reused for the transpose
   const float inv = 1.0f / l_run;
