@@ -272,6 +272,17 @@ int stedm_qkv_pack(const float* qkv, float qscale, void* q_hi, void* q_lo, void*
 int stedm_lsa_flash(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi,
                     const void* vt_lo, void* out_hi, void* out_lo, int B, int T, int Tp, int heads, int npass,
                     int mm_dtype, void* stream);
+/* fp8 (OCP e4m3) variant of the LSA attention (BASELINE config 5 "fp8 MFMA attention"; same algorithm as stedm_lsa_flash on
+ * v_mfma_f32_32x32x16_fp8_fp8): stedm_qkv_amax finds the per-tensor maxima amax[3] = {max |q * qscale|, max |k|, max |v|} of qkv fp32
+ * [M][3*heads*64] (device floats, zeroed inside); stedm_qkv_pack_fp8 writes q8 / k8 [B*heads][Tp][64] and vT8 [B*heads][64][Tp] e4m3
+ * bytes scaled by 448 / amax; stedm_lsa_flash_fp8 runs the flash attention on them (P as e4m3 of 256 p; fp32 logits / softmax /
+ * accumulation) and writes the 16-bit plane [B][T][heads*64] (type mm_dtype) that to_out consumes. A precision experiment: its
+ * deviation from the reference is reported, not asserted at 1e-3. */
+int stedm_qkv_amax(const float* qkv, float qscale, long M, int heads, float* amax, void* stream);
+int stedm_qkv_pack_fp8(const float* qkv, float qscale, const float* amax, void* q8, void* k8, void* vt8, int B, int T, int Tp, int heads,
+                       void* stream);
+int stedm_lsa_flash_fp8(const void* q8, const void* k8, const void* vt8, const float* amax, void* out16, int B, int T, int Tp, int heads,
+                        int mm_dtype, void* stream);
 /* pool (0 mean, 1 cls, 2 sum) over tokens (+ c_old) -> mlp_head LayerNorm + Linear, vit_set.py:191-206. wt [dim][ncls].
  * ws (optional, ws_floats >= B * 2 * dim): lets the token pooling run as slab partials over ~1024 blocks before the per-sample head
  * (a batch of 8 alone would read its 34 MB of tokens on 8 of the 256 CUs); fixed summation order either way. */

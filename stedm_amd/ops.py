@@ -23,18 +23,20 @@ class Precision:
     fast:   single product (fp16 or bf16 operands), fp32 accumulate / activations / GN / softmax."""
     mm_dtype: int = F16
     npass: int = 3
+    attn_fp8: bool = False      # style encoder's attention on e4m3 MFMA operands (BASELINE config 5); everything else as mm_dtype / npass say
 
     @staticmethod
     def parse(name: str) -> "Precision":
         table = {"parity": Precision(F16, 3), "parity_bf16": Precision(BF16, 3),
-                 "fast": Precision(F16, 1), "f16": Precision(F16, 1), "bf16": Precision(BF16, 1)}
+                 "fast": Precision(F16, 1), "f16": Precision(F16, 1), "bf16": Precision(BF16, 1),
+                 "fp8": Precision(BF16, 1, True), "bf16+fp8attn": Precision(BF16, 1, True)}
         if name not in table:
             raise ValueError(f"unknown precision {name!r}; choose from {sorted(table)}")
         return table[name]
 
     @property
     def label(self) -> str:
-        return ("f16" if self.mm_dtype == F16 else "bf16") + ("x3" if self.npass == 3 else "")
+        return ("f16" if self.mm_dtype == F16 else "bf16") + ("x3" if self.npass == 3 else "") + ("+fp8attn" if self.attn_fp8 else "")
 
 
 def _stream() -> int:
@@ -449,6 +451,23 @@ def qkv_pack(qkv, qscale: float, q, k, vt, B: int, T: int, Tp: int, heads: int, 
 def lsa_flash(q, k, vt, out, B: int, T: int, Tp: int, heads: int, prec: Precision):
     check(lib().stedm_lsa_flash(q[0].data_ptr(), _ptr(q[1]), k[0].data_ptr(), _ptr(k[1]), vt[0].data_ptr(), _ptr(vt[1]),
                                 out[0].data_ptr(), _ptr(out[1]), B, T, Tp, heads, prec.npass, prec.mm_dtype, _stream()), "stedm_lsa_flash")
+
+
+def qkv_amax(qkv: torch.Tensor, qscale: float, heads: int, amax: torch.Tensor) -> torch.Tensor:
+    """amax[3] = per-tensor maxima of |q * qscale|, |k|, |v| (device floats) for the fp8 attention."""
+    _chk(qkv, name="qkv")
+    check(lib().stedm_qkv_amax(qkv.data_ptr(), float(qscale), qkv.numel() // qkv.shape[-1], heads, amax.data_ptr(), _stream()), "stedm_qkv_amax")
+    return amax
+
+
+def qkv_pack_fp8(qkv, qscale: float, amax, q8, k8, vt8, B: int, T: int, Tp: int, heads: int):
+    check(lib().stedm_qkv_pack_fp8(qkv.data_ptr(), float(qscale), amax.data_ptr(), q8.data_ptr(), k8.data_ptr(), vt8.data_ptr(), B, T, Tp, heads, _stream()),
+          "stedm_qkv_pack_fp8")
+
+
+def lsa_flash_fp8(q8, k8, vt8, amax, out16, B: int, T: int, Tp: int, heads: int, prec: Precision):
+    check(lib().stedm_lsa_flash_fp8(q8.data_ptr(), k8.data_ptr(), vt8.data_ptr(), amax.data_ptr(), out16.data_ptr(), B, T, Tp, heads, prec.mm_dtype,
+                                    _stream()), "stedm_lsa_flash_fp8")
 
 
 def svit_head(x, pool: int, c_old, ln_w, ln_b, eps, wt, bias, out, ws: Optional[torch.Tensor] = None):

@@ -190,8 +190,15 @@ class sViT(nn.Module):
             mlp = ff.fn.net[0].out_features
             ops.ln_apply16(x, attn.norm.weight, attn.norm.bias, attn.norm.eps, ln[0], ln[1], prec)
             self._gemm(ln, P[f"qkv{l}"], M, 3 * heads * 64, out=qkv)
-            ops.qkv_pack(qkv, P[f"tau{l}"], q, k, vt, B, T, Tp, heads, prec)
-            ops.lsa_flash(q, k, vt, att, B, T, Tp, heads, prec)
+            if prec.attn_fp8:     # e4m3 operands with per-tensor scales (BASELINE config 5)
+                amax = self._buf("amax", (4,))
+                q8, k8, v8 = (self._buf(nm, shp, torch.uint8) for nm, shp in (("q8", (B * heads, Tp, 64)), ("k8", (B * heads, Tp, 64)), ("vt8", (B * heads, 64, Tp))))
+                ops.qkv_amax(qkv, P[f"tau{l}"], heads, amax)
+                ops.qkv_pack_fp8(qkv, P[f"tau{l}"], amax, q8, k8, v8, B, T, Tp, heads)
+                ops.lsa_flash_fp8(q8, k8, v8, amax, att[0], B, T, Tp, heads, prec)
+            else:
+                ops.qkv_pack(qkv, P[f"tau{l}"], q, k, vt, B, T, Tp, heads, prec)
+                ops.lsa_flash(q, k, vt, att, B, T, Tp, heads, prec)
             self._gemm(att, P[f"out{l}"], M, dim, bias=attn.fn.to_out[0].bias, res=x, out=x)          # x = attn(x) + x
             ops.ln_apply16(x, ff.norm.weight, ff.norm.bias, ff.norm.eps, ln[0], ln[1], prec)
             h16 = (self._buf("h.hi", (M, mlp), i16), self._buf("h.lo", (M, mlp), i16) if lo_ok else None)
