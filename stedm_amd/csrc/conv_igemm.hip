@@ -327,7 +327,7 @@ extern "C" int stedm_conv_fused_skip_ok(const stedm_conv_args* args) {
 // Would the register-streamed kernel (fragment-order weights, conv_rs.inc) run this problem? Then w_hi / w_lo are never read and the
 // caller may skip packing them (pass any non-NULL w_hi). Same decision path as stedm_conv_igemm, nothing is launched.
 extern "C" int stedm_conv_rs_ok(const stedm_conv_args* args) {
-  if (!args || !args->src16_hi || !args->w_frag || args->npass != 1) return 0;
+  if (!args || !args->src16_hi || (!args->w_frag && !args->w_frag16) || args->npass != 1) return 0;
   ConvParams p;
   memset(&p, 0, sizeof(p));
   p.a = *args;
@@ -353,6 +353,7 @@ extern "C" int stedm_conv_igemm(const stedm_conv_args* args, void* stream) {
 static int conv_setup(ConvParams& p) {
   const stedm_conv_args& a = p.a;
   STEDM_CHECK_ARG((a.src1 || a.src16_hi) && (a.w_hi || (a.mode == STEDM_CONV_S2D && a.w_frag)) && (a.out || a.out16_hi), "conv_igemm: null src/w_hi/out");
+  STEDM_CHECK_ARG(a.pad_br == 0 || a.mode == STEDM_CONV_S2D, "conv_igemm: pad_br belongs to the space-to-depth form");
   STEDM_CHECK_ARG(a.mode != STEDM_CONV_S2D || (a.src16_hi && !a.src1 && a.w_frag && a.ks == 3 && a.npass == 1 && !a.src16b_hi),
                   "conv_igemm: the space-to-depth form needs src16 planes, w_frag, ks=3, single product");
   STEDM_CHECK_ARG((!a.act_out && !a.out16_hi) || (a.src16_hi && !a.src1), "conv_igemm: act_out/out16 need the DMA path (src16 only)");
@@ -383,7 +384,7 @@ static int conv_setup(ConvParams& p) {
   p.M = a.B * p.HWout;
   STEDM_CHECK_ARG(p.Cin % 32 == 0 && (a.c2 == 0 || a.c1 % 32 == 0),
                   "conv_igemm: channel counts must be multiples of 32 (c1=%d c2=%d)", a.c1, a.c2);
-  STEDM_CHECK_ARG(!a.src16b_hi || (a.src16_hi && !a.src1 && a.w_frag && a.w_frag_b && a.ks == 3 && a.mode == STEDM_CONV_S1 && a.npass == 1 && !a.res &&
+  STEDM_CHECK_ARG(!a.src16b_hi || (a.src16_hi && !a.src1 && ((a.w_frag && a.w_frag_b) || (a.w_frag16 && a.w_frag_b16)) && a.ks == 3 && a.mode == STEDM_CONV_S1 && a.npass == 1 && !a.res &&
                                    a.cb > 0 && a.cb % 64 == 0),
                   "conv_igemm: the fused skip phase needs the DMA path (src16 only), 3x3 stride 1, single product, w_frag + w_frag_b, cb %% 64 == 0, no res");
   return 0;

@@ -302,7 +302,7 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
     a.scale, a.shift, a.act = _ptr(scale), _ptr(shift), act
     lazy = w_hi if isinstance(w_hi, LazyPlanes) else None
     if lazy is not None:
-        w_hi, w_lo = lazy._val if lazy._val is not None else (w_frag, None)     # placeholder pointer until the planes are known to be needed
+        w_hi, w_lo = lazy._val if lazy._val is not None else (w_frag if w_frag is not None else w_frag16, None)   # placeholder pointer until the planes are known to be needed
     a.w_hi, a.w_lo = _ptr(w_hi), (_ptr(w_lo) if prec.npass == 3 else None)
     a.bias = _ptr(bias)
     a.emb = None if emb is None else emb.data_ptr() + 4 * emb_offset
@@ -312,7 +312,7 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
     a.cout = oshape[-1]
     a.npass, a.mm_dtype = prec.npass, prec.mm_dtype
     if lazy is not None and lazy._val is None:
-        if src16 is None or w_frag is None or prec.npass != 1 or not lib().stedm_conv_rs_ok(C.byref(a)):
+        if src16 is None or (w_frag is None and w_frag16 is None) or prec.npass != 1 or not lib().stedm_conv_rs_ok(C.byref(a)):
             w_hi, w_lo = lazy.get()
             a.w_hi, a.w_lo = _ptr(w_hi), (_ptr(w_lo) if prec.npass == 3 else None)
     elif mode == CONV_UP_SUBPIXEL:

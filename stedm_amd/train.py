@@ -142,6 +142,7 @@ class UNetTrainer:
         w = self._w4(conv).contiguous()
         co_f, ci_f, ks = w.shape[0], w.shape[1], w.shape[-1]
         taps = ks * ks
+        frag16 = None
         if pad_cin or pad_cout:    # first / last convolution (7 and 4 channels): padded copy (layout shuffle), generic kernels
             wt = w.flip(2, 3).transpose(0, 1).contiguous()
             full = torch.zeros((pad_cout or wt.shape[0], pad_cin or wt.shape[1]) + tuple(wt.shape[2:]), dtype=torch.float32, device=wt.device)
@@ -153,11 +154,16 @@ class UNetTrainer:
             want_frag = self.m.conv_path == "dma" and bp.npass == 1 and ((ks == 3 and co_f % 16 == 0) or (ks == 1 and co_f % 64 == 0))
             args = (w, taps, ci_f * taps, True, ci_f, co_f, ks, bp)
             if want_frag:   # the planes are only read when a problem falls to the LDS-operand kernels: packed on first need
-                frag = ops.pack_conv_weight_strided(*args, want_hi=False, want_frag=True)[2]
+                # the dgrad conv contracts over the forward's OUTPUT channels: the 16x16x32 MFMA kind takes it from 256 of them on
+                m16 = ks == 3 and self.m._m16 and co_f % 32 == 0 and co_f >= 256
+                if m16:
+                    frag, frag16 = None, ops.pack_conv_weight_frag16(w, bp, sn=taps, sc=ci_f * taps, flip=True, cout=ci_f, cin=co_f, ks=3)
+                else:
+                    frag = ops.pack_conv_weight_strided(*args, want_hi=False, want_frag=True)[2]
                 hi, lo = ops.LazyPlanes(lambda: ops.pack_conv_weight_strided(*args, want_hi=True, want_frag=False)[:2]), None
             else:
                 hi, lo, frag = ops.pack_conv_weight_strided(*args, want_hi=True, want_frag=False)
-        self._dpacks[key] = (hi, lo, frag, ks)
+        self._dpacks[key] = (hi, lo, frag, ks, frag16)
         return self._dpacks[key]
 
     def _cus(self) -> int:
@@ -172,8 +178,9 @@ class UNetTrainer:
 
     def _dgrad(self, conv, dy16, out: torch.Tensor, accumulate: bool = False, pad_cin: int = 0, pad_cout: int = 0) -> torch.Tensor:
         """out (+)= conv(dy16, flipped filter); dy16 planes are at the resolution of `out`"""
-        hi, lo, frag, ks = self._dpack(conv, pad_cin, pad_cout)
-        ops.conv_igemm(None, hi, lo, out, prec=self.bprec, ks=ks, src16=dy16, w_frag=frag, res=out if accumulate else None, ws=self._ws(out.numel()))
+        hi, lo, frag, ks, frag16 = self._dpack(conv, pad_cin, pad_cout)
+        ops.conv_igemm(None, hi, lo, out, prec=self.bprec, ks=ks, src16=dy16, w_frag=frag, w_frag16=frag16, res=out if accumulate else None,
+                       ws=self._ws(out.numel()))
         return out
 
     def _wgrad(self, src16, dy16, dy_f32: Optional[torch.Tensor], wparam: nn.Parameter, ks: int, mode: int) -> None:

@@ -293,9 +293,14 @@ class UNetModel(nn.Module):
             k1 = tuple(w4.shape[2:]) == (1, 1) and conv.in_channels % 64 == 0
             frag16 = None
             if self.conv_path == "dma" and prec.npass == 1 and (k3 or k1):
-                frag = ops.pack_conv_weight_frag(w4, prec)   # register-streamed weights
-                if (k3 or k1) and conv.in_channels % 32 == 0 and self._m16:
-                    frag16 = ops.pack_conv_weight_frag16(w4, prec)    # the same, in the 16x16x32 MFMA kind's fragment order
+                # register-streamed weights, packed in the fragment order of the MFMA shape the dispatcher will pick: 16x16x32 for a 3x3 from
+                # 256 input channels on (conv_rs.inc RS_3X3M), 32x32x16 otherwise; a 1x1 (skip_connection, qkv, proj_out) gets both: fused
+                # into an RS_3X3M launch it is read in the 16x16x32 order, on its own in the other
+                m16 = self._m16 and conv.in_channels % 32 == 0 and (k1 or conv.in_channels >= 256)
+                if not (m16 and k3):
+                    frag = ops.pack_conv_weight_frag(w4, prec)
+                if m16:
+                    frag16 = ops.pack_conv_weight_frag16(w4, prec)
                 # the [cout][tap][cin] planes are read only by the LDS-operand kernels: packed on first need
                 hi = ops.LazyPlanes(lambda w=conv.weight: ops.pack_conv_weight(w.float(), prec))
             else:
@@ -450,7 +455,7 @@ class UNetModel(nn.Module):
             fused = self._consts.get(fuse_key)
             kw = dict(prec=prec, src16=h16, bias=pk2.bias, w_frag=pk2.frag, chan_stats=self._cs_new(out), ws=ws, out16=o16, w_frag16=pk2.frag16)
             if fused is None:
-                fused = bool(pk2.frag is not None and ps.frag is not None and
+                fused = bool((pk2.frag is not None or pk2.frag16 is not None) and ps.frag is not None and
                              ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias, ps.frag16), query_fused=True, **kw))
                 self._consts[fuse_key] = fused
             if fused:

@@ -323,8 +323,10 @@ class VQModelInterface(nn.Module):
             ok = (ks == 3 and conv.in_channels % 16 == 0) or (ks == 1 and conv.in_channels % 64 == 0)
             frag16 = None
             if prec.npass == 1 and ok and conv.stride == (1, 1):
-                frag = ops.pack_conv_weight_frag(w4, prec)
-                if conv.in_channels % 32 == 0:
+                m16 = conv.in_channels % 32 == 0 and (ks == 1 or conv.in_channels >= 256)    # the MFMA shape the dispatcher picks (conv_rs.inc)
+                if not (m16 and ks == 3):
+                    frag = ops.pack_conv_weight_frag(w4, prec)
+                if m16:
                     frag16 = ops.pack_conv_weight_frag16(w4, prec)     # 16x16x32 MFMA kind of the register-streamed kernel
                 hi = ops.LazyPlanes(lambda w=w4: ops.pack_conv_weight(w, prec))
             else:
@@ -392,7 +394,7 @@ class VQModelInterface(nn.Module):
         kw = dict(prec=self.precision, src16=h16, bias=pk2.bias, w_frag=pk2.frag, chan_stats=self._cs_new(out), ws=self._ws(out.numel()),
                   w_frag16=pk2.frag16)
         if fused is None:
-            fused = bool(pk2.frag is not None and ps.frag is not None and
+            fused = bool((pk2.frag is not None or pk2.frag16 is not None) and ps.frag is not None and
                          ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias, ps.frag16), query_fused=True, **kw))
             self._packed[fkey] = fused
         if fused:
