@@ -57,3 +57,74 @@ def all_reduce_buckets(flat: torch.Tensor, bucket_elems: int, group=None) -> int
     for w in works:
         w.wait()
     return world
+
+
+class BucketSchedule:
+    """Gradient buckets of a flat arena for an all-reduce that overlaps the backward pass (what DistributedDataParallel's reducer does
+    for the reference, train_diff.py:75): the arena is cut at PARAMETER boundaries into runs of about `bucket_elems` elements; parameters
+    report completion in whatever order the backward produces them; a bucket fires — once — when its last parameter completes. The same
+    cuts serve the non-overlapped path, so both issue identical collectives (bitwise-equal sums for any world size).
+    `tail_from`: parameters from this index on (gradients filled after the backward, e.g. the cond stage's) form a last bucket of their own."""
+
+    def __init__(self, offsets, sizes, bucket_elems: int, tail_from: Optional[int] = None, align: int = 1, total: Optional[int] = None):
+        """align: a bucket may only end where the next parameter starts at a multiple of `align` elements (vector kernels work on the
+        slices); total: the arena's padded length (the last bucket runs to it)."""
+        assert len(offsets) == len(sizes) and bucket_elems > 0
+        n = len(sizes)
+        tail_from = n if tail_from is None else tail_from
+        self.bounds: List[Tuple[int, int]] = []
+        self.param_bucket: List[int] = [0] * n
+        lo, acc, first = None, 0, 0
+        for i in range(n):
+            if lo is None:
+                lo, first = offsets[i], i
+            self.param_bucket[i] = len(self.bounds)
+            acc += sizes[i]
+            last = i == n - 1
+            end = offsets[i] + sizes[i]
+            aligned = last or offsets[i + 1] % align == 0
+            if last or (aligned and ((acc >= bucket_elems and i < tail_from) or i + 1 == tail_from)):
+                self.bounds.append((lo, (total if (last and total is not None) else (end if last else offsets[i + 1]))))
+                lo, acc = None, 0
+        self.count = [0] * len(self.bounds)
+        for b in self.param_bucket:
+            self.count[b] += 1
+        self.reset()
+
+    def reset(self) -> None:
+        self.left = list(self.count)
+        self.seen = [False] * len(self.param_bucket)
+        self.fired = [False] * len(self.bounds)
+
+    def done(self, param_index: int) -> Optional[int]:
+        """mark one parameter complete; returns its bucket's index when that completes the bucket"""
+        if self.seen[param_index]:
+            return None
+        self.seen[param_index] = True
+        b = self.param_bucket[param_index]
+        self.left[b] -= 1
+        if self.left[b] == 0 and not self.fired[b]:
+            self.fired[b] = True
+            return b
+        return None
+
+    def pending(self) -> List[int]:
+        """buckets that have not fired (to be flushed after the backward)"""
+        out = [b for b, f in enumerate(self.fired) if not f]
+        for b in out:
+            self.fired[b] = True
+        return out
+
+
+def all_reduce_bounds(flat: torch.Tensor, bounds, group=None) -> int:
+    """In-place SUM all-reduce of flat[lo:hi] for every (lo, hi) of `bounds` (views, no copies); returns the world size."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    world = dist.get_world_size(group)
+    if world == 1:
+        return 1
+    works = [dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True) for lo, hi in bounds]
+    for w in works:
+        w.wait()
+    return world

@@ -55,6 +55,9 @@ class UNetTrainer:
         self._dpacks: Dict[int, tuple] = {}
         self._opt = None
         self._ema = None
+        self._touched: Optional[list] = None
+        self.bucket_mb = 256            # gradient all-reduce bucket (xGMI rings are per-link bound: few, large collectives)
+        self.overlap_all_reduce = os.environ.get("STEDM_NO_OVERLAP") is None
         self.G: Dict[int, torch.Tensor] = {}
 
     # ------------------------------------------------------------------------------------------------ helpers
@@ -107,25 +110,34 @@ class UNetTrainer:
         seen = {id(p) for p in emb_w}
         order = emb_w + [p for p in m.parameters() if id(p) not in seen] + self.extra_params
         self._n_unet_params = len(order) - len(self.extra_params)
-        total = (sum(p.numel() for p in order) + 3) // 4 * 4
-        self.grad_arena = torch.zeros((total,), dtype=torch.float32, device=order[0].device)
-        off = 0
-        self._arena_off = []
-        for p in order:
-            p.grad = self.grad_arena[off:off + p.numel()].view(p.shape)
-            self._arena_off.append(off)
+        offs, off = [], 0
+        for i, p in enumerate(order):
+            if i == self._n_unet_params:
+                off = (off + 3) // 4 * 4          # the cond stage's gradients form a bucket of their own: vector-aligned start
+            offs.append(off)
             off += p.numel()
+        total = (off + 3) // 4 * 4
+        self.grad_arena = torch.zeros((total,), dtype=torch.float32, device=order[0].device)
+        self._arena_off = offs
+        for p, o in zip(order, offs):
+            p.grad = self.grad_arena[o:o + p.numel()].view(p.shape)
         ted = m.model_channels * 4
         self._dWcat = self.grad_arena[:m._emb_ntot * ted].view(m._emb_ntot, ted)
         self._arena_params = order
         self._int_views = [p.grad for p in order]
         self._pub_arena = None
+        from .parallel import BucketSchedule
+        self._pidx = {id(p): i for i, p in enumerate(order)}
+        self._sched = BucketSchedule(self._arena_off, [p.numel() for p in order], self.bucket_mb * (1 << 20) // 4, tail_from=self._n_unet_params,
+                                     align=4, total=total)
 
     def _param_grad(self, p: nn.Parameter) -> torch.Tensor:
         if getattr(self, "grad_arena", None) is None:
             self._alloc_grads()
         elif p.grad is None:          # e.g. after optimizer.zero_grad(set_to_none=True): the arena stays, the views come back
             self.internal_grads()
+        if self._touched is not None:
+            self._touched.append(p)
         return p.grad
 
     def _w4(self, conv) -> torch.Tensor:
@@ -282,19 +294,33 @@ class UNetTrainer:
 
     # ------------------------------------------------------------------------------------------------ backward
     @torch.no_grad()
-    def backward(self, d_eps: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def backward(self, d_eps: torch.Tensor, on_bucket=None) -> Tuple[torch.Tensor, torch.Tensor]:
         """d_eps [B,out,H,W] = dL/d(eps prediction). Fills `.grad` of every parameter; returns (dL/dx [B,in,H,W] over the
-        concatenated [x | c_concat] input, dL/dcontext [B, 4*model_channels])."""
+        concatenated [x | c_concat] input, dL/dcontext [B, 4*model_channels]). on_bucket(b): called as soon as every gradient of
+        bucket b of the arena (self._sched.bounds[b]) is final — the walk runs from the output to the input, so the arena's buckets
+        complete back to front and their all-reduce overlaps the rest of the backward."""
         m = self.m
         self.G = {}
         self._dpacks = {}
         self.internal_grads()
+        if on_bucket is not None:
+            self._sched.reset()
         B = d_eps.shape[0]
         ted = m.model_channels * 4
         self.dE = self._buf("dE", (B, m._emb_ntot))
         self.dEs = None
         dx_in = None
+        def flush():
+            if on_bucket is not None:
+                for p in self._touched:
+                    b = self._sched.done(self._pidx[id(p)])
+                    if b is not None:
+                        on_bucket(b)
+                self._touched = []
+
+        self._touched = [] if on_bucket is not None else None
         for rec in reversed(self.tape):
+            flush()           # a record's gradients are final once the NEXT record starts (emb_layers biases are copies made inside the record)
             kind = rec[0]
             if kind == "conv_out":
                 self._conv_out_bwd(rec[1], d_eps.float().contiguous())
@@ -311,6 +337,8 @@ class UNetTrainer:
             else:
                 raise RuntimeError(kind)
         dctx = self._emb_bwd(B, ted)
+        flush()
+        self._touched = None
         self._grads_ready = True
         return dx_in, dctx
 
@@ -494,13 +522,13 @@ class UNetTrainer:
 
     # ------------------------------------------------------------------------------------------------ loss + optimizer
     @torch.no_grad()
-    def loss_and_backward(self, x, c_concat, t, context, target) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    def loss_and_backward(self, x, c_concat, t, context, target, on_bucket=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """L1 loss of ddpm.py:1030-1040 on the eps prediction, then the full backward. -> (loss [1] device tensor, dx, dcontext)"""
         pred = self.forward(x, c_concat, t, context)
         loss = self._buf("loss", (1,))
         dpred = self._buf(f"dpred.{tuple(pred.shape)}", tuple(pred.shape))
         ops.l1_loss(pred, target.float().contiguous(), dpred, self._buf("loss.ws", (1024,), torch.float64), loss)
-        dx, dctx = self.backward(dpred)
+        dx, dctx = self.backward(dpred, on_bucket=on_bucket)
         return loss, dx, dctx
 
     def _chunks(self, params, dev):
@@ -552,8 +580,8 @@ class UNetTrainer:
         """Data-parallel training (train_diff.py runs Lightning DDP): sum the gradient arena over the ranks in a few large buckets
         (xGMI rings are per-link bound: few, large collectives); the 1/world average is folded into the optimizer kernel.
         Returns the world size."""
-        from .parallel import all_reduce_buckets
-        world = all_reduce_buckets(self.grad_arena, bucket_mb * (1 << 20) // 4, group)
+        from .parallel import all_reduce_bounds
+        world = all_reduce_bounds(self.grad_arena, self._sched.bounds, group)
         self._grad_scale = 1.0 / world
         return world
 
@@ -703,18 +731,50 @@ class UNetTrainer:
         optimizer on the mean of the accumulated gradients (Lightning divides the loss by the accumulation count); LitEma's update
         runs after every micro-batch. after_backward(dx, dcontext): fills the gradients of `extra_params` (cond stage)."""
         import torch.distributed as dist
-        loss, dx, dctx = self.loss_and_backward(x, c_concat, t, context, target)
+        k = self.accumulate_grad_batches
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        last = self._micro + 1 >= k
+        works = []
+        on_bucket = None
+        if multi and last and self.overlap_all_reduce and getattr(self, "grad_arena", None) is not None:
+            # the collective of a bucket starts the moment the backward has produced its last gradient (the all-reduce then runs beside
+            # the remaining dgrad / wgrad kernels); with accumulation the bucket is first folded into the running mean
+            def on_bucket(b):
+                lo, hi = self._sched.bounds[b]
+                if b == len(self._sched.bounds) - 1 and self.extra_params:
+                    return                      # the cond stage's gradients arrive after the backward: reduced below
+                src = self.grad_arena
+                if k > 1:
+                    ops.axpby(self.grad_arena[lo:hi], self._acc_arena[lo:hi], 1.0 / k, 1.0 if self._micro > 0 else 0.0)
+                    src = self._acc_arena
+                works.append(dist.all_reduce(src[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True))
+        if k > 1 and getattr(self, "_acc_arena", None) is None and getattr(self, "grad_arena", None) is not None:
+            self._acc_arena = torch.empty_like(self.grad_arena)
+        loss, dx, dctx = self.loss_and_backward(x, c_concat, t, context, target, on_bucket=on_bucket)
         if after_backward is not None:
             after_backward(dx, dctx)
-        k = self.accumulate_grad_batches
+        if k > 1 and getattr(self, "_acc_arena", None) is None:
+            self._acc_arena = torch.empty_like(self.grad_arena)
+        if on_bucket is not None:
+            nb = len(self._sched.bounds)
+            rest = [b for b in range(nb) if not self._sched.fired[b] or (b == nb - 1 and self.extra_params)]
+            for b in rest:                       # buckets that did not complete inside the backward (the cond stage's tail)
+                lo, hi = self._sched.bounds[b]
+                src = self.grad_arena
+                if k > 1:
+                    ops.axpby(self.grad_arena[lo:hi], self._acc_arena[lo:hi], 1.0 / k, 1.0 if self._micro > 0 else 0.0)
+                    src = self._acc_arena
+                works.append(dist.all_reduce(src[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True))
+            for w in works:
+                w.wait()
+            self._grad_scale = 1.0 / dist.get_world_size(group)
+            if k > 1:
+                ops.axpby(self._acc_arena, self.grad_arena, 1.0, 0.0)
+                self._micro = 0
+            self.optimizer_step()
+            return loss
         if k > 1:
-            if self._micro == 0:
-                self._acc_arena = getattr(self, "_acc_arena", None)
-                if self._acc_arena is None:
-                    self._acc_arena = torch.empty_like(self.grad_arena)
-                ops.axpby(self.grad_arena, self._acc_arena, 1.0 / k, 0.0)
-            else:
-                ops.axpby(self.grad_arena, self._acc_arena, 1.0 / k, 1.0)
+            ops.axpby(self.grad_arena, self._acc_arena, 1.0 / k, 1.0 if self._micro > 0 else 0.0)
             self._micro += 1
             if self._micro < k:
                 self._grads_ready = False
@@ -722,7 +782,7 @@ class UNetTrainer:
                 return loss
             ops.axpby(self._acc_arena, self.grad_arena, 1.0, 0.0)      # the optimizer table points at the gradient arena
             self._micro = 0
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if multi:
             self.all_reduce_grads(group)
         self.optimizer_step()
         return loss

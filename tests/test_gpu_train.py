@@ -313,7 +313,7 @@ def test_unet_backward_odd_shapes_vs_oracle(dev, B, H, W):
             assert float((p.grad.cpu() - grads[n]).norm()) / gn < 1e-3, n
 
 
-def _ddp_worker(rank, world, port, q):
+def _ddp_worker(rank, world, port, q, overlap=True, bucket_mb=256):
     import os
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -323,6 +323,7 @@ def _ddp_worker(rank, world, port, q):
     dev = torch.device("cuda:0")
     m = build(TINY, 6, dev)
     tr = UNetTrainer(m, lr=1e-3, weight_decay=0.0)
+    tr.overlap_all_reduce, tr.bucket_mb = overlap, bucket_mb
     x, ctx, target = _inputs("tiny", TINY, 2, 16, 6, dev)
     t = torch.tensor([951, 21], device=dev)
     sl = slice(rank, rank + 1)                       # each rank trains on its own sample
@@ -361,6 +362,37 @@ def test_two_rank_data_parallel_step_equals_gradient_accumulation(dev):
     worst = max(float(np.abs(got[n] - ref[n].numpy()).max()) for n in ref)
     print(f"two-rank data-parallel step vs gradient accumulation: max |dw| = {worst:.2e} (lr 1e-3)")
     assert worst < 2e-5
+
+
+def test_overlapped_gradient_all_reduce_equals_the_plain_one_bitwise(dev):
+    """two ranks on the device arena: buckets (1 MB here, so that the tiny U-Net has several) all-reduced the moment the backward has
+    produced their last gradient vs the same buckets reduced after the backward: identical weights, bit for bit; and the first
+    bucket to fire is the arena's LAST (the backward walks from the output layers to the input)."""
+    import os
+    import torch.multiprocessing as mp
+    ctxm = mp.get_context("spawn")
+    res = []
+    for overlap in (True, False):
+        q = ctxm.Queue()
+        port = 36500 + (os.getpid() % 2000) + (1 if overlap else 0)
+        procs = [ctxm.Process(target=_ddp_worker, args=(r, 2, port, q, overlap, 1)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res.append(q.get(timeout=300))
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    for n in res[0]:
+        assert np.array_equal(res[0][n], res[1][n]), n
+    from stedm_amd.train import UNetTrainer
+    m = build(TINY, 6, dev)
+    tr = UNetTrainer(m)
+    tr.bucket_mb = 1
+    x, ctx, target = _inputs("tiny", TINY, 2, 16, 6, dev)
+    fired = []
+    tr.loss_and_backward(x[:, :4].contiguous(), x[:, 4:].contiguous(), torch.tensor([951, 21], device=dev), ctx, target, on_bucket=fired.append)
+    nb = len(tr._sched.bounds)
+    assert nb >= 3 and sorted(fired) == list(range(nb)) and fired[0] == nb - 1 and fired[-1] == 0
 
 
 @pytest.mark.parametrize("B,T,heads,ch", [(2, 64, 4, 32), (2, 256, 4, 32), (1, 1024, 2, 64), (3, 100, 2, 16)])

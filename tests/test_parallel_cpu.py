@@ -116,3 +116,70 @@ def test_bench_gpus_flag_launches_the_ranks_itself():
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     r, line = _bench(["--gpus", "1"], {"STEDM_BENCH_DRY": "1", "WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and line is None and "WORLD_SIZE=2" in r.stderr
+
+
+def test_bucket_schedule_cuts_and_firing():
+    """buckets are cut at parameter boundaries on vector-aligned offsets, cover the padded arena exactly once, the tail parameters
+    (gradients that arrive after the backward) get a bucket of their own, and a bucket fires exactly once, when its last parameter completes"""
+    import random
+    rnd = random.Random(3)
+    sizes = [rnd.choice([4, 8, 12, 36, 100, 128, 1152, 6]) for _ in range(60)] + [6, 2]
+    offs, o = [], 0
+    for i, sz in enumerate(sizes):
+        if i == 60:
+            o = (o + 3) // 4 * 4
+        offs.append(o); o += sz
+    total = (o + 3) // 4 * 4
+    s = par.BucketSchedule(offs, sizes, 2000, tail_from=60, align=4, total=total)
+    assert s.bounds[0][0] == 0 and s.bounds[-1][1] == total and s.bounds[-1][0] == offs[60]
+    for (a, b), (c, d) in zip(s.bounds, s.bounds[1:]):
+        assert b == c and c % 4 == 0 and a < b
+    assert all(s.bounds[s.param_bucket[i]][0] <= offs[i] and offs[i] + sizes[i] <= s.bounds[s.param_bucket[i]][1] for i in range(len(sizes)))
+    order = list(range(len(sizes)))[::-1]
+    rnd.shuffle(order)
+    fired = [b for i in order if (b := s.done(i)) is not None]
+    assert sorted(fired) == list(range(len(s.bounds))) and s.pending() == [] and s.done(order[0]) is None
+
+
+def _overlap_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    sizes = [4 * k for k in (3, 50, 7, 200, 1, 90, 33, 64, 5, 120)]
+    offs = [sum(sizes[:i]) for i in range(len(sizes))]
+    sched = par.BucketSchedule(offs, sizes, 600, align=4, total=sum(sizes))
+    grads = torch.randn(sum(sizes), generator=g)
+    plain = grads.clone()
+    par.all_reduce_bounds(plain, sched.bounds)                    # after the "backward", bucket by bucket
+    over = grads.clone()
+    works = []
+    for i in reversed(range(len(sizes))):                         # the backward walks the parameters back to front
+        b = sched.done(i)
+        if b is not None:
+            lo, hi = sched.bounds[b]
+            works.append(dist.all_reduce(over[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+    for w in works:
+        w.wait()
+    if rank == 0:
+        q.put((plain.numpy(), over.numpy(), len(works), len(sched.bounds)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_overlapped_buckets_equal_the_plain_bucketed_all_reduce():
+    """world_size 2 over gloo: collectives issued per bucket as soon as the bucket is complete (overlapping the rest of the backward)
+    give bitwise the sums of the same buckets reduced after the backward"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    plain, over, nworks, nb = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert nworks == nb and nb >= 3
+    assert (plain == over).all()
