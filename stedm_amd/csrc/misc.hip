@@ -103,24 +103,28 @@ extern "C" int stedm_pack_conv_weight_up(const float* w, void* w_hi, void* w_lo,
 // One block = one (128-row tile tn, 16-channel chunk, 64-row half): the 64 x 16 x taps source values go through LDS so that both the
 // gather from the source (runs along its contiguous index: (ci, tap) for an OIHW filter, (n, tap) for the transposed forms) and the
 // 16-B fragment stores are coalesced.
-template <typename T, int taps>
+// M16: the fragment order of the 16x16x32 MFMA kind (stedm_pack_conv_weight_frag16): blocks of 32 rows x 32 channels,
+//   out[tn][chunk32][tap][c][lane][e] = W[n = tn*128 + c*16 + (lane&15)][ci = chunk*32 + kofs(lane>>4) + e][tap], kofs(g) = 16 (g&1) + 8 (g>>1) for a
+//   3x3 (plane, piece), 8 g for a 1x1.
+template <typename T, int taps, bool M16 = false>
 __global__ void __launch_bounds__(256) pack_conv_weight_frag_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, long total,
                                                                     long sn, long sc, int flip) {
   typedef T V8 __attribute__((ext_vector_type(8)));
-  __shared__ float tile[64][16 * taps + 1];
-  const int nch = cin / 16;
-  const int half = blockIdx.x & 1;
-  const int chunk = (blockIdx.x >> 1) % nch, tn = (blockIdx.x >> 1) / nch;
-  const int n0 = tn * 128 + half * 64, ci0 = chunk * 16;
-  const int per = 64 * 16 * taps;
+  constexpr int NR = M16 ? 32 : 64, KC = M16 ? 32 : 16, NSUB = 128 / NR;     // rows and channels per block, blocks per 128-row tile
+  __shared__ float tile[NR][KC * taps + 1];
+  const int nch = cin / KC;
+  const int half = blockIdx.x % NSUB;
+  const int chunk = (blockIdx.x / NSUB) % nch, tn = (blockIdx.x / NSUB) / nch;
+  const int n0 = tn * 128 + half * NR, ci0 = chunk * KC;
+  const int per = NR * KC * taps;
   const bool n_fast = sn <= sc;       // which source index is contiguous
   // 16-B loads along the contiguous source run when the layout allows it (rows inside the matrix, 16-B aligned runs): the pack is a
   // pure stream, its speed is the bytes in flight
-  const bool vec = n0 + 64 <= cout && (n_fast ? (sn == taps && (sc * 4) % 16 == 0) : (sc == taps && (sn * 4) % 16 == 0)) &&
-                   ((reinterpret_cast<uintptr_t>(w) & 15) == 0) && ((n_fast ? 64 : 16) * taps) % 4 == 0;
+  const bool vec = n0 + NR <= cout && (n_fast ? (sn == taps && (sc * 4) % 16 == 0) : (sc == taps && (sn * 4) % 16 == 0)) &&
+                   ((reinterpret_cast<uintptr_t>(w) & 15) == 0) && ((n_fast ? NR : KC) * taps) % 4 == 0;
   if (vec) {
-    const int run = (n_fast ? 64 : 16) * taps;          // contiguous floats per outer index (ci for n_fast, n otherwise)
-    const int nouter = n_fast ? 16 : 64;
+    const int run = (n_fast ? NR : KC) * taps;          // contiguous floats per outer index (ci for n_fast, n otherwise)
+    const int nouter = n_fast ? KC : NR;
     for (int v4 = threadIdx.x; v4 < nouter * (run / 4); v4 += 256) {
       const int o = v4 / (run / 4), r0 = (v4 - o * (run / 4)) * 4;
       const float* src = n_fast ? w + (long)n0 * sn + (long)(ci0 + o) * sc + r0 : w + (long)(n0 + o) * sn + (long)ci0 * sc + r0;
@@ -137,21 +141,23 @@ __global__ void __launch_bounds__(256) pack_conv_weight_frag_kernel(const float*
   } else
   for (int idx = threadIdx.x; idx < per; idx += 256) {
     int row, cil, tap;
-    if (n_fast) { cil = idx / (64 * taps); const int r = idx - cil * 64 * taps; row = r / taps; tap = r - row * taps; }
-    else { row = idx / (16 * taps); const int r = idx - row * 16 * taps; cil = r / taps; tap = r - cil * taps; }
+    if (n_fast) { cil = idx / (NR * taps); const int r = idx - cil * NR * taps; row = r / taps; tap = r - row * taps; }
+    else { row = idx / (KC * taps); const int r = idx - row * KC * taps; cil = r / taps; tap = r - cil * taps; }
     const int n = n0 + row;
     tile[row][cil * taps + tap] = n < cout ? w[(long)n * sn + (long)(ci0 + cil) * sc + (flip ? taps - 1 - tap : tap)] : 0.f;
   }
   __syncthreads();
-  // stores: (tap, q&1, lane) -> one 16-B vector of 8 consecutive channels
+  // stores: (tap, fragment of the block, lane) -> one 16-B vector of 8 consecutive channels
   for (int v = threadIdx.x; v < taps * 2 * 64; v += 256) {
     const int lane = v & 63, ql = (v >> 6) & 1, tap = v >> 7;
-    const int row = ql * 32 + (lane & 31), c8 = (lane >> 5) * 8;
+    int row, c8;
+    if (M16) { const int g = lane >> 4; row = ql * 16 + (lane & 15); c8 = taps == 9 ? (g & 1) * 16 + (g >> 1) * 8 : g * 8; }
+    else { row = ql * 32 + (lane & 31); c8 = (lane >> 5) * 8; }
     V8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (T)tile[row][(c8 + e) * taps + tap];
     const int q = half * 2 + ql;
-    *reinterpret_cast<V8*>(out + ((((long)tn * nch + chunk) * taps + tap) * 4 + q) * 512 + lane * 8) = o;
+    *reinterpret_cast<V8*>(out + ((((long)tn * nch + chunk) * taps + tap) * (M16 ? 8 : 4) + q) * 512 + lane * 8) = o;
   }
 }
 
@@ -240,34 +246,20 @@ extern "C" int stedm_pack_conv_weight_up_frag(const float* w, void* out, int cou
   return 0;
 }
 
-// Fragment order of the 16x16x32 MFMA kind (conv_rs.inc RS_3X3M), see stedm_pack_conv_weight_frag16 in the header
-template <typename T>
-__global__ void pack_conv_weight_frag16_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, long total, long sn, long sc, int flip,
-                                               int taps) {
-  const int nch = cin / 32;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int e = (int)(i & 7);
-    const int lane = (int)((i >> 3) & 63);
-    const int c = (int)((i >> 9) & 7);
-    long r = i >> 12;
-    const int tap = (int)(r % taps); r /= taps;
-    const int chunk = (int)(r % nch);
-    const int tn = (int)(r / nch);
-    const int g = lane >> 4;
-    const int n = tn * 128 + c * 16 + (lane & 15);
-    const int ci = chunk * 32 + (taps == 9 ? (g & 1) * 16 + (g >> 1) * 8 : g * 8) + e;
-    out[i] = n < cout ? (T)w[(long)n * sn + (long)ci * sc + (flip ? taps - 1 - tap : tap)] : (T)0.f;
-  }
-}
-
 extern "C" int stedm_pack_conv_weight_frag16(const float* w, long sn, long sc, int flip, void* out, int cout, int cin, int ks, int mm_dtype, void* stream) {
   STEDM_CHECK_ARG(w && out && cin % 32 == 0 && cout > 0 && (ks == 1 || ks == 3), "pack_conv_weight_frag16: bad args (cin %% 32, ks 1 or 3)");
-  const int taps = ks * ks;
   STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "pack_conv_weight_frag16: bad mm_dtype %d", mm_dtype);
+  const int taps = ks * ks;
   const long total = (long)((cout + 127) / 128) * (cin / 32) * taps * 8 * 64 * 8;
-  const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-  if (mm_dtype == STEDM_F16) pack_conv_weight_frag16_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(w, (_Float16*)out, cout, cin, total, sn, sc, flip, taps);
-  else pack_conv_weight_frag16_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(w, (__bf16*)out, cout, cin, total, sn, sc, flip, taps);
+  const int grid = ((cout + 127) / 128) * (cin / 32) * 4;
+  hipStream_t st = as_stream(stream);
+  if (mm_dtype == STEDM_F16) {
+    if (taps == 9) pack_conv_weight_frag_kernel<_Float16, 9, true><<<grid, 256, 0, st>>>(w, (_Float16*)out, cout, cin, total, sn, sc, flip);
+    else pack_conv_weight_frag_kernel<_Float16, 1, true><<<grid, 256, 0, st>>>(w, (_Float16*)out, cout, cin, total, sn, sc, flip);
+  } else {
+    if (taps == 9) pack_conv_weight_frag_kernel<__bf16, 9, true><<<grid, 256, 0, st>>>(w, (__bf16*)out, cout, cin, total, sn, sc, flip);
+    else pack_conv_weight_frag_kernel<__bf16, 1, true><<<grid, 256, 0, st>>>(w, (__bf16*)out, cout, cin, total, sn, sc, flip);
+  }
   STEDM_LAUNCH_CHECK();
   return 0;
 }

@@ -497,6 +497,8 @@ class UNetTrainer:
         S = ops.silu(emb, self._buf("emb.S", (B, ted)))
         self._param_grad(m._emb_layout[0][0].emb_layers[1].weight)
         ops.gemm_f32(self.dE, True, S, False, self._dWcat)       # the emb_layers weight gradients are row blocks of this matrix
+        if self._touched is not None:
+            self._touched.extend(rb.emb_layers[1].weight for rb, _ in m._emb_layout)
         gws = self._buf("emb.gws", (64 * B * ted,))
         dS = ops.gemm_f32(self.dE, False, c["emb_w"], False, self._buf("emb.dS", (B, ted)), ws=gws)    # dE @ Wcat: few rows, long K -> split-K
         demb = ops.silu(emb, self._buf("emb.demb", (B, ted)), dy=dS)
