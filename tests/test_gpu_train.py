@@ -392,7 +392,8 @@ def test_overlapped_gradient_all_reduce_equals_the_plain_one_bitwise(dev):
     fired = []
     tr.loss_and_backward(x[:, :4].contiguous(), x[:, 4:].contiguous(), torch.tensor([951, 21], device=dev), ctx, target, on_bucket=fired.append)
     nb = len(tr._sched.bounds)
-    assert nb >= 3 and sorted(fired) == list(range(nb)) and fired[0] == nb - 1 and fired[-1] == 0
+    assert nb >= 3 and sorted(fired) == list(range(nb)) and fired[0] == nb - 1       # each bucket once; the arena's end (output layers) first
+    assert fired.index(0) > fired.index(nb - 2)                                        # the embedding Linears at the arena's start complete late
 
 
 @pytest.mark.parametrize("B,T,heads,ch", [(2, 64, 4, 32), (2, 256, 4, 32), (1, 1024, 2, 64), (3, 100, 2, 16)])
