@@ -15,6 +15,7 @@ struct ConvParams {
   stedm_conv_args a;
   int M, Hout, Wout, HWout, Cin, taps;
   int whole, nsamp, trows;  // tile geometry
+  int wsplit;               // 1: image rows are WIDER than the tile (Wout % tile == 0): a tile is a run of one row, PW = tile + 2 (conv_rs only)
   int PRs, PW, NP;          // patch rows per sample, patch cols, patch positions
   int tiles_m, tiles_n;
   unsigned mg_hw, mg_w, mg_pw, mg_prpw;   // ceil(2^32 / d) for d = HWout, Wout, PW, PRs*PW: n / d == umulhi(n, mg) while n * d < 2^32
@@ -56,7 +57,7 @@ struct MM<__bf16> {
 namespace stedm {
 // Fills the tile geometry of `p` for an M-tile of `bm` output pixels. Returns false (with the error set) when the
 // spatial shape cannot be tiled that way.
-bool conv_geometry(ConvParams& p, int bm);
+bool conv_geometry(ConvParams& p, int bm, bool allow_wsplit = false);
 // v2 (warp-specialised) launcher; returns -1 when v2 does not support this problem (caller falls back to v1).
 int conv_launch_ws(ConvParams& p, hipStream_t st);
 // v3 (LDS-DMA operands from 16-bit activation planes); 0 ok, > 0 error (message set).

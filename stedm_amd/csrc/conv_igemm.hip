@@ -285,10 +285,11 @@ static int launch(const ConvParams& p, hipStream_t st) {
   return 0;
 }
 
-bool stedm::conv_geometry(ConvParams& p, int bm) {
+bool stedm::conv_geometry(ConvParams& p, int bm, bool allow_wsplit) {
   const stedm_conv_args& a = p.a;
   p.tiles_n = (a.cout + BN - 1) / BN;
   p.tiles_m = (p.M + bm - 1) / bm;
+  p.wsplit = 0;
   if (a.ks == 1) {
     p.whole = 0; p.nsamp = 1; p.trows = 0; p.PRs = 1; p.PW = bm; p.NP = bm;
     return true;
@@ -297,6 +298,9 @@ bool stedm::conv_geometry(ConvParams& p, int bm) {
     if (bm % p.HWout != 0) { set_error("conv_igemm: Hout*Wout=%d must divide %d", p.HWout, bm); return false; }
     p.whole = 1; p.nsamp = bm / p.HWout; p.trows = p.Hout;
     p.tiles_m = (a.B + p.nsamp - 1) / p.nsamp;
+  } else if (allow_wsplit && p.Wout > bm && p.Wout % bm == 0 && (a.mode == STEDM_CONV_S1 || a.mode == STEDM_CONV_UP_SUBPIXEL || a.mode == STEDM_CONV_S2D)) {
+    // rows wider than the tile (the 512-pixel rows of the first stage's decoder): a tile is a run of `bm` pixels of ONE row
+    p.whole = 0; p.nsamp = 1; p.trows = 1; p.wsplit = 1;
   } else {
     if (bm % p.Wout != 0 || p.HWout % bm != 0) {
       set_error("conv_igemm: unsupported spatial shape %dx%d (need Wout | %d and %d | Hout*Wout)", p.Hout, p.Wout, bm, bm);
@@ -307,7 +311,7 @@ bool stedm::conv_geometry(ConvParams& p, int bm) {
   if (a.mode == STEDM_CONV_S1 || a.mode == STEDM_CONV_UP_SUBPIXEL || a.mode == STEDM_CONV_S2D) p.PRs = p.trows + 2;
   else if (a.mode == STEDM_CONV_DOWN) p.PRs = 2 * p.trows + 1;
   else p.PRs = (p.trows + 1) / 2 + 2;
-  p.PW = a.Win + 2;
+  p.PW = (p.wsplit ? bm : a.Win) + 2;
   p.NP = p.nsamp * p.PRs * p.PW;
   return true;
 }

@@ -323,11 +323,11 @@ class VQModelInterface(nn.Module):
             ok = (ks == 3 and conv.in_channels % 16 == 0) or (ks == 1 and conv.in_channels % 64 == 0)
             frag16 = None
             if prec.npass == 1 and ok and conv.stride == (1, 1):
-                m16 = conv.in_channels % 32 == 0 and (ks == 1 or conv.in_channels >= 256)    # the MFMA shape the dispatcher picks (conv_rs.inc)
-                if not (m16 and ks == 3):
-                    frag = ops.pack_conv_weight_frag(w4, prec)
-                if m16:
-                    frag16 = ops.pack_conv_weight_frag16(w4, prec)     # 16x16x32 MFMA kind of the register-streamed kernel
+                # both fragment orders (the stage is frozen: packed once): the 16x16x32 MFMA kind takes a 3x3 from 256 input channels on
+                # unless its two-plane chunk ring does not fit LDS (rows of 256+ pixels), where the 32x32x16 kind runs
+                frag = ops.pack_conv_weight_frag(w4, prec)
+                if conv.in_channels % 32 == 0:
+                    frag16 = ops.pack_conv_weight_frag16(w4, prec)
                 hi = ops.LazyPlanes(lambda w=w4: ops.pack_conv_weight(w, prec))
             else:
                 hi, lo = ops.pack_conv_weight(w4, prec)
@@ -399,7 +399,9 @@ class VQModelInterface(nn.Module):
             self._packed[fkey] = fused
         if fused:
             return ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias, ps.frag16), **kw)
-        self._conv(ps, x16, out, ks=1, stats=False)
+        M = B * H * W        # the unfused 1x1 as one long "image" (per-pixel work: no sample structure needed, any H*W admitted)
+        flat = lambda t: None if t is None else t.view(1, 1, M, t.shape[-1])
+        self._conv(ps, (flat(x16[0]), flat(x16[1])), flat(out), ks=1, stats=False)
         return ops.conv_igemm(None, pk2.hi, pk2.lo, out, res=out, **kw)
 
     def _attn(self, tag, ab: AttnBlock, x):

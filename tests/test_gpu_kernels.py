@@ -513,6 +513,15 @@ def test_conv_fused_skip(dev, prec, tol, B, H, W, cin, cb, cout, emb, m16):
         assert torch.allclose(cs[:, k, :, 0].double(), sl.sum(1), rtol=1e-4, atol=2e-3)
 
 
+@pytest.mark.parametrize("prec,tol", PRECS[1:])
+@pytest.mark.parametrize("B,H,W,cin,cout,mode,m16", [(1, 8, 512, 128, 128, "s1", False), (2, 4, 1024, 64, 96, "s1", False), (1, 6, 512, 256, 128, "s1", True),
+                                                       (1, 4, 256, 256, 256, "s1", True), (1, 4, 256, 256, 128, "up2", False), (1, 2, 512, 64, 64, "up2", False)])
+def test_conv_rows_wider_than_the_tile(dev, prec, tol, B, H, W, cin, cout, mode, m16):
+    """image rows of 256 .. 1024 pixels (the first stage's decoder at 256^2 / 512^2): a 256-pixel tile is a run of ONE row, its patch
+    3 x 258 positions (conv_geometry wsplit) — 3x3 and the sub-pixel upsample on the register-streamed kernel, against F.conv2d."""
+    _conv_dma_case(dev, prec, tol, B, H, W, cin, cout, mode, 3, use_emb=(mode == "s1"), use_res=True, frag=True, m16=m16)
+
+
 def test_conv_fused_skip_rejected_when_unsupported(dev):
     """a fusion the kernel cannot run is reported by the query and refused by the call (never silently dropped)."""
     from stedm_amd import ops

@@ -152,3 +152,25 @@ def test_predict_step_with_first_stage_end_to_end(dev):
     diff = np.abs(img.astype(np.int32) - ref8.astype(np.int32))
     assert diff.max() <= 1 and (diff > 0).mean() < 0.02          # truncating cast: a float 1e-5 apart may land on the other side of an integer
     assert np.array_equal(seg, torch.argmax(lb["segmentation"], dim=-1).cpu().numpy().astype(np.uint8))
+
+
+def test_decoder_at_256_pixel_rows_vs_oracle(dev):
+    """the shipped vq-f4 architecture decoding a 64^2 latent to a 256^2 image: its last level runs on 256-pixel rows (one tile per row),
+    the level before on 128 — against the oracle's decoder (summary of the output)."""
+    from oracle import vq as ovq
+    cfg = ovq.VQConfig()
+    m = build(dict(DD_F4, resolution=256), dev)
+    P = prng.fill_state_dict(ovq.shapes(cfg), 15)
+    z = prng.normal(15, "vq.w256.z", (1, 3, 64, 64))
+    m._prepare(); m._cs = {}
+    y = m._decoder(z.to(dev))
+    ref = ovq.decoder(P, cfg, z)
+    assert tuple(y.shape) == (1, 3, 256, 256)
+    err = rel(y, ref)
+    print(f"[VQ f4 decoder 64^2 -> 256^2, parity] rel err vs oracle {err:.3e}")
+    assert err < 1e-3
+    m.set_precision("bf16"); m._prepare(); m._cs = {}
+    y2 = m._decoder(z.to(dev))
+    l2 = float((y2.double().cpu() - ref.double()).norm() / ref.double().norm())
+    print(f"[VQ f4 decoder 64^2 -> 256^2, bf16] rel-L2 vs oracle {l2:.3e}")
+    assert l2 < 0.1
