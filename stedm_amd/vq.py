@@ -346,6 +346,9 @@ class VQModelInterface(nn.Module):
                 hi, lo = ops.pack_conv_weight_up(w, prec)
                 frag = ops.pack_conv_weight_up_frag(w, prec) if prec.npass == 1 and m.conv.in_channels % 32 == 0 else None
                 self._packed[id(m.conv)] = _Packed(hi, lo, m.conv.bias.detach().float().contiguous(), frag)
+                pack(m.conv)                                   # the plain 3x3 form, for inputs too wide for the sub-pixel kernel's LDS ring
+                self._packed[("plain", id(m.conv))] = self._packed.pop(id(m.conv))
+                self._packed[id(m.conv)] = _Packed(hi, lo, m.conv.bias.detach().float().contiguous(), frag)
             elif isinstance(m, Downsample):
                 # bottom/right-padded stride-2 conv as a 2x2 conv over space-to-depth planes (register-streamed kernel, single product);
                 # the 3-product parity mode runs it as hi*hi + lo*hi + hi*lo with the residual weights packed beside
@@ -451,7 +454,16 @@ class VQModelInterface(nn.Module):
         B, H, W, C = x.shape
         pk = self._packed[id(up.conv)]
         out = self._buf(tag + ".out", (B, 2 * H, 2 * W, C))
-        return ops.conv_igemm(None, pk.hi, pk.lo, out, prec=self.precision, mode=CONV_UP_SUBPIXEL, src16=self._norm16(None, 0, x, kind="up16"),
+        src16 = self._norm16(None, 0, x, kind="up16")
+        if W >= 256:
+            # input rows of 256+ pixels (the 512^2 level of the shipped config): the sub-pixel kernel's two-plane chunk ring does not fit
+            # LDS there; the nearest-x2 plane is materialised in 16 bits (a layout copy) and the plain 3x3 runs on it (9/4 of the MACs)
+            up16 = self._planes((B, 2 * H, 2 * W, C), "upx2")
+            for s16, d16 in zip(src16, up16):
+                if s16 is not None:
+                    d16.view(B, H, 2, W, 2, C).copy_(s16.view(B, H, 1, W, 1, C).expand(B, H, 2, W, 2, C))
+            return self._conv(self._packed[("plain", id(up.conv))], up16, out)
+        return ops.conv_igemm(None, pk.hi, pk.lo, out, prec=self.precision, mode=CONV_UP_SUBPIXEL, src16=src16,
                               bias=pk.bias, w_frag=pk.frag, chan_stats=self._cs_new(out, 4 * ops.gn_chan_nslab(H * W)))
 
     def _down(self, tag, dn: Downsample, x):
