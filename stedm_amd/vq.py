@@ -208,10 +208,10 @@ class VectorQuantizer(nn.Module):
 
 
 class _Packed:
-    __slots__ = ("hi", "lo", "bias", "frag", "extra", "frag16")
+    __slots__ = ("hi", "lo", "bias", "frag", "extra", "frag16", "extra_src")
 
-    def __init__(self, hi, lo, bias, frag=None, extra=None, frag16=None):
-        self.hi, self.lo, self.bias, self.frag, self.extra, self.frag16 = hi, lo, bias, frag, extra, frag16
+    def __init__(self, hi, lo, bias, frag=None, extra=None, frag16=None, extra_src=None):
+        self.hi, self.lo, self.bias, self.frag, self.extra, self.frag16, self.extra_src = hi, lo, bias, frag, extra, frag16, extra_src
 
 
 class VQModelInterface(nn.Module):
@@ -331,7 +331,8 @@ class VQModelInterface(nn.Module):
                 hi = ops.LazyPlanes(lambda w=w4: ops.pack_conv_weight(w, prec))
             else:
                 hi, lo = ops.pack_conv_weight(w4, prec)
-            self._packed[id(conv)] = _Packed(hi, lo, None if conv.bias is None else conv.bias.detach().float().contiguous(), frag, None, frag16)
+            self._packed[id(conv)] = _Packed(hi, lo, None if conv.bias is None else conv.bias.detach().float().contiguous(), frag, None, frag16,
+                                             extra_src=w4 if (prec.npass == 3 and ks == 3) else None)
 
         for m in self.modules():
             if isinstance(m, ResnetBlock):
@@ -369,7 +370,27 @@ class VQModelInterface(nn.Module):
         self._pack_key = key
 
     # ------------------------------------------------------------------------------------------------ block runners (NHWC fp32)
+    def _wide3(self, pk, src16, out, res, stats):
+        """3x3 on rows of 256+ pixels in the 3-product parity mode: only the register-streamed kernel tiles such rows and it is a
+        single-product kernel, so the three products run as three launches over the hi / lo planes (lo*hi + hi*lo + hi*hi, fp32
+        accumulation through `res`), with the weight's hi part and residual packed in fragment order on first use"""
+        prec = self.precision
+        one = Precision(prec.mm_dtype, 1)
+        if pk.extra is None:
+            w = pk.extra_src
+            wh = w.to(torch.float16 if prec.mm_dtype == 0 else torch.bfloat16).float()
+            pk.extra = (ops.pack_conv_weight_frag(wh, one), ops.pack_conv_weight_frag((w - wh).contiguous(), one))
+        fh, fl = pk.extra
+        lazy = lambda: ops.LazyPlanes(lambda: (_ for _ in ()).throw(StedmHipError("wide 3-product conv: the register-streamed kernel refused the shape")))
+        ws = self._ws(out.numel())
+        ops.conv_igemm(None, lazy(), None, out, prec=one, src16=(src16[1], None), w_frag=fh, res=res, ws=ws)
+        ops.conv_igemm(None, lazy(), None, out, prec=one, src16=(src16[0], None), w_frag=fl, res=out, ws=ws)
+        return ops.conv_igemm(None, lazy(), None, out, prec=one, src16=(src16[0], None), w_frag=fh, bias=pk.bias, res=out, ws=ws,
+                              chan_stats=self._cs_new(out) if stats else None)
+
     def _conv(self, pk, src16, out, ks=3, res=None, stats=True, **kw):
+        if self.precision.npass == 3 and ks == 3 and out is not None and src16[0].shape[2] >= 256 and not kw:
+            return self._wide3(pk, src16, out, res, stats)
         nel = out.numel() if out is not None else src16[0].numel() // src16[0].shape[-1] * kw["out16"][0].shape[-1]
         return ops.conv_igemm(None, pk.hi, pk.lo, out, prec=self.precision, ks=ks, src16=src16, bias=pk.bias, res=res, w_frag=pk.frag,
                               chan_stats=self._cs_new(out) if (stats and out is not None) else None, ws=self._ws(nel),
@@ -405,6 +426,8 @@ class VQModelInterface(nn.Module):
         M = B * H * W        # the unfused 1x1 as one long "image" (per-pixel work: no sample structure needed, any H*W admitted)
         flat = lambda t: None if t is None else t.view(1, 1, M, t.shape[-1])
         self._conv(ps, (flat(x16[0]), flat(x16[1])), flat(out), ks=1, stats=False)
+        if self.precision.npass == 3 and W >= 256:
+            return self._wide3(pk2, h16, out, out, True)
         return ops.conv_igemm(None, pk2.hi, pk2.lo, out, res=out, **kw)
 
     def _attn(self, tag, ab: AttnBlock, x):
