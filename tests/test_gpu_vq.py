@@ -174,3 +174,24 @@ def test_decoder_at_256_pixel_rows_vs_oracle(dev):
     l2 = float((y2.double().cpu() - ref.double()).norm() / ref.double().norm())
     print(f"[VQ f4 decoder 64^2 -> 256^2, bf16] rel-L2 vs oracle {l2:.3e}")
     assert l2 < 0.1
+
+
+def test_decoder_reference_native_512_vs_oracle(dev):
+    """the reference's own size: vq-f4.yaml decoding a 128^2 x 3 latent to a 512^2 image (conf/diffusion/ldm_based.yaml image_size 128,
+    conf/data patch_size 512): 16 384-token middle attention, 512-pixel rows at the last level (two tiles per row), the 256 -> 512 upsample
+    through the materialised plane. One CPU oracle decode (~1.3 TFLOP); parity mode < 1e-3, bf16 reported."""
+    from oracle import vq as ovq
+    cfg = ovq.VQConfig()
+    m = build(dict(DD_F4, resolution=512), dev)
+    P = prng.fill_state_dict(ovq.shapes(cfg), 15)
+    z = prng.normal(15, "vq.w512.z", (1, 3, 128, 128))
+    ref = ovq.decoder(P, cfg, z)
+    m._prepare(); m._cs = {}
+    y = m._decoder(z.to(dev))
+    assert tuple(y.shape) == (1, 3, 512, 512)
+    err = rel(y, ref)
+    m.set_precision("bf16"); m._prepare(); m._cs = {}
+    y2 = m._decoder(z.to(dev))
+    l2 = float((y2.double().cpu() - ref.double()).norm() / ref.double().norm())
+    print(f"[VQ f4 decoder 128^2 -> 512^2] parity rel err vs oracle {err:.3e}; bf16 rel-L2 {l2:.3e}")
+    assert err < 1e-3 and l2 < 0.1
