@@ -600,8 +600,18 @@ class S_ZSS_DM(LatentDiffusion):
             self._agg_block = st.sViT(image_size=img, num_classes=512, ns=ns, **a)
         else:
             if embedder is None:
-                raise NotImplementedError(f"style_agg={name(agg_cfg)!r} needs the torchvision {encoder!r} embedder (third-party, not "
-                                          "part of this package): pass it as S_ZSS_DM(..., embedder=module)")
+                # s_zss_dm.py:19-20: `torchvision.models.get_model(encoder)` with its head replaced by Linear(768, 512). torchvision is a
+                # third-party dependency of the reference (environment.yml:32); when it is installed the embedder is built exactly like
+                # that and runs on PyTorch-ROCm's own kernels (its arithmetic is torchvision's: parity unpinned) — the HIP
+                # path accelerates the aggregation and everything downstream. Without torchvision: pass a module, or use style_agg=svit.
+                try:
+                    import torchvision
+                except ImportError as e:
+                    raise NotImplementedError(f"style_agg={name(agg_cfg)!r} needs the torchvision {encoder!r} embedder (third-party, not part "
+                                              "of this package, not installed here): install torchvision, pass a module as "
+                                              "S_ZSS_DM(..., embedder=module), or use style_agg=svit") from e
+                embedder = torchvision.models.get_model(encoder)
+                embedder.head = torch.nn.Linear(768, 512)
             cls = {"linear": st.Agg_Linear, "max": st.Agg_Max, "mean": st.Agg_Mean}.get(name(agg_cfg))
             if cls is None:
                 raise Exception("Unkown aggregation function!")
