@@ -71,10 +71,13 @@ __global__ void __launch_bounds__(256) qkv_pack_fp8_kernel(const float* __restri
     sv[tl][d] = v.x * sv_; sv[tl][d + 1] = v.y * sv_; sv[tl][d + 2] = v.z * sv_; sv[tl][d + 3] = v.w * sv_;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 64 * 16; i += 256) {          // one thread = 4 consecutive tokens of a channel
+  for (int i = threadIdx.x; i < 64 * 16; i += 256) {          // one thread = 4 consecutive positions of a channel
     const int d = i >> 4, tl = (i & 15) * 4;
+    // V^T keys permuted inside every group of 16 (order 0-3, 8-11, 4-7, 12-15: the k order of the accumulator-as-operand tile), so that a
+    // lane's 8 values are one contiguous 8-B read: the 4 positions of this thread hold 4 consecutive keys starting at kq
+    const int p16 = tl & 15, kq = (tl & ~15) | ((p16 & 3) | ((p16 & 4) << 1) | ((p16 & 8) >> 1));
     const long o = ((long)bh * 64 + d) * Tp + t0 + tl;
-    *reinterpret_cast<unsigned*>(v8 + o) = pack4_fp8(sv[tl][d], sv[tl + 1][d], sv[tl + 2][d], sv[tl + 3][d]);
+    *reinterpret_cast<unsigned*>(v8 + o) = pack4_fp8(sv[kq][d], sv[kq + 1][d], sv[kq + 2][d], sv[kq + 3][d]);
   }
 }
 
@@ -192,10 +195,7 @@ __global__ void __launch_bounds__(256, 2) lsa_flash_fp8_kernel(Flash8Args a) {
         const long pf = (long)(((unsigned long)phi << 32) | plo);
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
-          const int base = (d * 32 + r) * RS + sub * 32 + s2 * 16 + h * 4;
-          const unsigned v0 = *reinterpret_cast<const unsigned*>(sV + base);
-          const unsigned v1 = *reinterpret_cast<const unsigned*>(sV + base + 8);
-          const long vf = (long)(((unsigned long)v1 << 32) | v0);
+          const long vf = *reinterpret_cast<const long*>(sV + (d * 32 + r) * RS + sub * 32 + s2 * 16 + h * 8);
           o[d] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vf, pf, o[d], 0, 0, 0);
         }
       }
