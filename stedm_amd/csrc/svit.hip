@@ -292,7 +292,7 @@ template <typename T, int NPASS>
 __global__ void __launch_bounds__(256, 2) lsa_flash_kernel(FlashArgs a) {
   using V8 = typename MM<T>::V8;
   constexpr int NPL = NPASS == 3 ? 2 : 1;
-  constexpr int KT = 128;                         // keys per staged tile (two 64-key halves per pair of barriers)
+  constexpr int KT = 64;                          // keys per staged tile (128: two 64-key halves per pair of barriers — measured slower)
   constexpr int RSK = 72;                         // K rows: 64 channels + 8 pad (144 B: a ds_read_b128 group's 16 rows hit 16 distinct slots)
   constexpr int RSV = KT + 8;                     // V^T rows: 128 keys + 8 pad (272 B)
   constexpr int KTILE = KT * RSK, VTILE = 64 * RSV;
@@ -325,26 +325,31 @@ __global__ void __launch_bounds__(256, 2) lsa_flash_kernel(FlashArgs a) {
   float m_run = -INFINITY, l_run = 0.f;
   const int qidx = q0 + r;
 
-  const int ntiles = a.Tp / KT;                   // Tp is a multiple of 128; keys >= T are masked below (their K / V^T rows are zero)
+  const int ntiles = (a.T + KT - 1) / KT;         // keys >= T of the last tile are masked below (their K / V^T rows are zero; Tp % 128 == 0)
   // K / V^T tiles travel global -> registers -> LDS with the loads of tile kt + 1 issued BEFORE the MFMAs of tile kt (async-stage
   // split, cdna_hip_programming.md T14). Per thread and plane: 4 x 16 B of K (128 rows x 128 B) and 4 x 16 B of V^T (64 rows x 256 B).
   // (named registers, macro-expanded: an array captured by a lambda went to scratch)
   uint4 kr0, kr1, kr2, kr3, vr0, vr1, vr2, vr3, lr0, lr1, lr2, lr3, wr0, wr1, wr2, wr3;
+  constexpr int VP = KT / 8, VR = 256 / VP;       // 16-B pieces per V^T row, V^T rows per pass of the block
   const int krow = tid >> 3, kc = tid & 7;        // K: row krow + 32 i, 16-B piece kc
-  const int vrow = tid >> 4, vc = tid & 15;       // V^T: row vrow + 16 i, 16-B piece vc
+  const int vrow = tid / VP, vc = tid % VP;       // V^T: row vrow + VR i, 16-B piece vc
 #define LSA_FETCH(KTI)                                                                                                  \
   {                                                                                                                     \
     const long kb_ = ((long)bh * a.Tp + (long)(KTI) * KT + krow) * 64 + kc * 8;                                         \
     const long vb_ = ((long)bh * 64 + vrow) * a.Tp + (long)(KTI) * KT + vc * 8;                                         \
     kr0 = *reinterpret_cast<const uint4*>(kg[0] + kb_);            kr1 = *reinterpret_cast<const uint4*>(kg[0] + kb_ + 32 * 64);   \
-    kr2 = *reinterpret_cast<const uint4*>(kg[0] + kb_ + 64 * 64);  kr3 = *reinterpret_cast<const uint4*>(kg[0] + kb_ + 96 * 64);   \
-    vr0 = *reinterpret_cast<const uint4*>(vg[0] + vb_);                        vr1 = *reinterpret_cast<const uint4*>(vg[0] + vb_ + 16l * a.Tp); \
-    vr2 = *reinterpret_cast<const uint4*>(vg[0] + vb_ + 32l * a.Tp);           vr3 = *reinterpret_cast<const uint4*>(vg[0] + vb_ + 48l * a.Tp); \
+    vr0 = *reinterpret_cast<const uint4*>(vg[0] + vb_);            vr1 = *reinterpret_cast<const uint4*>(vg[0] + vb_ + (long)VR * a.Tp); \
+    if (KT == 128) {                                                                                                    \
+      kr2 = *reinterpret_cast<const uint4*>(kg[0] + kb_ + 64 * 64);  kr3 = *reinterpret_cast<const uint4*>(kg[0] + kb_ + 96 * 64); \
+      vr2 = *reinterpret_cast<const uint4*>(vg[0] + vb_ + 2l * VR * a.Tp);  vr3 = *reinterpret_cast<const uint4*>(vg[0] + vb_ + 3l * VR * a.Tp); \
+    }                                                                                                                   \
     if (NPASS == 3) {                                                                                                   \
       lr0 = *reinterpret_cast<const uint4*>(kg[1] + kb_);            lr1 = *reinterpret_cast<const uint4*>(kg[1] + kb_ + 32 * 64); \
-      lr2 = *reinterpret_cast<const uint4*>(kg[1] + kb_ + 64 * 64);  lr3 = *reinterpret_cast<const uint4*>(kg[1] + kb_ + 96 * 64); \
-      wr0 = *reinterpret_cast<const uint4*>(vg[1] + vb_);                      wr1 = *reinterpret_cast<const uint4*>(vg[1] + vb_ + 16l * a.Tp); \
-      wr2 = *reinterpret_cast<const uint4*>(vg[1] + vb_ + 32l * a.Tp);         wr3 = *reinterpret_cast<const uint4*>(vg[1] + vb_ + 48l * a.Tp); \
+      wr0 = *reinterpret_cast<const uint4*>(vg[1] + vb_);            wr1 = *reinterpret_cast<const uint4*>(vg[1] + vb_ + (long)VR * a.Tp); \
+      if (KT == 128) {                                                                                                  \
+        lr2 = *reinterpret_cast<const uint4*>(kg[1] + kb_ + 64 * 64);  lr3 = *reinterpret_cast<const uint4*>(kg[1] + kb_ + 96 * 64); \
+        wr2 = *reinterpret_cast<const uint4*>(vg[1] + vb_ + 2l * VR * a.Tp);  wr3 = *reinterpret_cast<const uint4*>(vg[1] + vb_ + 3l * VR * a.Tp); \
+      }                                                                                                                 \
     }                                                                                                                   \
   }
   LSA_FETCH(0)
@@ -353,23 +358,23 @@ __global__ void __launch_bounds__(256, 2) lsa_flash_kernel(FlashArgs a) {
     {
       T* dk = &sK[0][krow * RSK + kc * 8];
       *reinterpret_cast<uint4*>(dk) = kr0; *reinterpret_cast<uint4*>(dk + 32 * RSK) = kr1;
-      *reinterpret_cast<uint4*>(dk + 64 * RSK) = kr2; *reinterpret_cast<uint4*>(dk + 96 * RSK) = kr3;
+      if (KT == 128) { *reinterpret_cast<uint4*>(dk + 64 * RSK) = kr2; *reinterpret_cast<uint4*>(dk + 96 * RSK) = kr3; }
       T* dv = &sV[0][vrow * RSV + vc * 8];
-      *reinterpret_cast<uint4*>(dv) = vr0; *reinterpret_cast<uint4*>(dv + 16 * RSV) = vr1;
-      *reinterpret_cast<uint4*>(dv + 32 * RSV) = vr2; *reinterpret_cast<uint4*>(dv + 48 * RSV) = vr3;
+      *reinterpret_cast<uint4*>(dv) = vr0; *reinterpret_cast<uint4*>(dv + VR * RSV) = vr1;
+      if (KT == 128) { *reinterpret_cast<uint4*>(dv + 2 * VR * RSV) = vr2; *reinterpret_cast<uint4*>(dv + 3 * VR * RSV) = vr3; }
       if (NPASS == 3) {
         T* ek = &sK[NPL - 1][krow * RSK + kc * 8];
         *reinterpret_cast<uint4*>(ek) = lr0; *reinterpret_cast<uint4*>(ek + 32 * RSK) = lr1;
-        *reinterpret_cast<uint4*>(ek + 64 * RSK) = lr2; *reinterpret_cast<uint4*>(ek + 96 * RSK) = lr3;
+        if (KT == 128) { *reinterpret_cast<uint4*>(ek + 64 * RSK) = lr2; *reinterpret_cast<uint4*>(ek + 96 * RSK) = lr3; }
         T* ev = &sV[NPL - 1][vrow * RSV + vc * 8];
-        *reinterpret_cast<uint4*>(ev) = wr0; *reinterpret_cast<uint4*>(ev + 16 * RSV) = wr1;
-        *reinterpret_cast<uint4*>(ev + 32 * RSV) = wr2; *reinterpret_cast<uint4*>(ev + 48 * RSV) = wr3;
+        *reinterpret_cast<uint4*>(ev) = wr0; *reinterpret_cast<uint4*>(ev + VR * RSV) = wr1;
+        if (KT == 128) { *reinterpret_cast<uint4*>(ev + 2 * VR * RSV) = wr2; *reinterpret_cast<uint4*>(ev + 3 * VR * RSV) = wr3; }
       }
     }
     __syncthreads();
     if (kt + 1 < ntiles) LSA_FETCH(kt + 1)
-#pragma unroll 1
-    for (int hk = 0; hk < 2; ++hk) {
+#pragma unroll
+    for (int hk = 0; hk < KT / 64; ++hk) {
       const int k0 = kt * KT + hk * 64;           // first key of this 64-key half
       if (k0 >= a.T) break;                        // wave-uniform: nothing but padding left
       // ---- S^T tiles (2 x 32 keys) x 32 queries
