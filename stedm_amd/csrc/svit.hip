@@ -224,10 +224,7 @@ extern "C" int stedm_ln_apply16(const float* x, const float* gamma, const float*
 }
 
 // ------------------------------------------------------------------------------------------------ qkv pack
-// qkv fp32 [B][T][3*H*64] -> q16/k16 [B*H][Tp][64] (rows >= T zero), vT16 [B*H][64][Tp] (cols >= T zero).
-// V^T's keys are stored PERMUTED inside every group of 16: position p holds key p ^ (((p >> 2) & 1) ^ ((p >> 3) & 1) ? 12 : 0), i.e. the
-// order 0-3, 8-11, 4-7, 12-15 — the k order in which lsa_flash's accumulator tile P serves as the next MFMA's operand (slot j of lane
-// half h is key 8 (j >> 2) + 4 h + (j & 3)): a lane's 8 V^T elements are then ONE contiguous 16-B LDS read.
+// qkv fp32 [B][T][3*H*64] -> q16/k16 [B*H][Tp][64] (rows >= T zero), vT16 [B*H][64][Tp] (cols >= T zero)
 template <typename T>
 __global__ void __launch_bounds__(256) qkv_pack_kernel(const float* __restrict__ qkv, float qscale, T* __restrict__ qh,
                                                        T* __restrict__ ql, T* __restrict__ kh, T* __restrict__ kl,
@@ -253,8 +250,7 @@ __global__ void __launch_bounds__(256) qkv_pack_kernel(const float* __restrict__
   __syncthreads();
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
     const int d = i >> 6, tl = i & 63;
-    const int p16 = tl & 15, key = (tl & ~15) | ((p16 & 3) | ((p16 & 4) << 1) | ((p16 & 8) >> 1));   // position -> key: swap bits 2 and 3
-    const float v = sv[key][d];
+    const float v = sv[tl][d];
     const long o = ((long)bh * 64 + d) * Tp + t0 + tl;
     const T v16 = (T)v;
     vh[o] = v16;
@@ -291,16 +287,16 @@ struct FlashArgs {
 template <typename T, int NPASS>
 __global__ void __launch_bounds__(256, 2) lsa_flash_kernel(FlashArgs a) {
   using V8 = typename MM<T>::V8;
+  typedef T V4t __attribute__((ext_vector_type(4)));
   constexpr int NPL = NPASS == 3 ? 2 : 1;
-  constexpr int KT = 64;                          // keys per staged tile (128: two 64-key halves per pair of barriers — measured slower)
-  constexpr int RSK = 72;                         // K rows: 64 channels + 8 pad (144 B: a ds_read_b128 group's 16 rows hit 16 distinct slots)
-  constexpr int RSV = KT + 8;                     // V^T rows: 128 keys + 8 pad (272 B)
-  constexpr int KTILE = KT * RSK, VTILE = 64 * RSV;
-  constexpr int KV_BYTES = NPL * (KTILE + VTILE) * (int)sizeof(T);
+  constexpr int RS = 72;                          // LDS row stride in elements (64 + 8 pad -> 144 B)
+  // one LDS block: K and V^T tiles during the loop, the O^T transpose buffer afterwards
+  constexpr int TILE = 64 * RS;
+  constexpr int KV_BYTES = 2 * NPL * TILE * (int)sizeof(T);
   constexpr int O_BYTES = 4 * 32 * 65 * (int)sizeof(float);
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[KV_BYTES > O_BYTES ? KV_BYTES : O_BYTES];
-  T (*sK)[KTILE] = reinterpret_cast<T (*)[KTILE]>(lds_raw);
-  T (*sV)[VTILE] = reinterpret_cast<T (*)[VTILE]>(lds_raw + NPL * KTILE * sizeof(T));
+  T (*sK)[TILE] = reinterpret_cast<T (*)[TILE]>(lds_raw);
+  T (*sV)[TILE] = reinterpret_cast<T (*)[TILE]>(lds_raw + NPL * TILE * sizeof(T));
   float (*sO)[32][65] = reinterpret_cast<float (*)[32][65]>(lds_raw);
   const int bh = blockIdx.x, b = bh / a.H, hd = bh % a.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -325,145 +321,136 @@ __global__ void __launch_bounds__(256, 2) lsa_flash_kernel(FlashArgs a) {
   float m_run = -INFINITY, l_run = 0.f;
   const int qidx = q0 + r;
 
-  const int ntiles = (a.T + KT - 1) / KT;         // keys >= T of the last tile are masked below (their K / V^T rows are zero; Tp % 128 == 0)
+  const int ntiles = (a.T + 63) / 64;
   // K / V^T tiles travel global -> registers -> LDS with the loads of tile kt + 1 issued BEFORE the MFMAs of tile kt (async-stage
-  // split, cdna_hip_programming.md T14). Per thread and plane: 4 x 16 B of K (128 rows x 128 B) and 4 x 16 B of V^T (64 rows x 256 B).
+  // split, cdna_hip_programming.md T14): their latency hides behind the tile's compute instead of sitting between two barriers
   // (named registers, macro-expanded: an array captured by a lambda went to scratch)
-  uint4 kr0, kr1, kr2, kr3, vr0, vr1, vr2, vr3, lr0, lr1, lr2, lr3, wr0, wr1, wr2, wr3;
-  constexpr int VP = KT / 8, VR = 256 / VP;       // 16-B pieces per V^T row, V^T rows per pass of the block
-  const int krow = tid >> 3, kc = tid & 7;        // K: row krow + 32 i, 16-B piece kc
-  const int vrow = tid / VP, vc = tid % VP;       // V^T: row vrow + VR i, 16-B piece vc
-#define LSA_FETCH(KTI)                                                                                                  \
+  uint4 kr0h, kr1h, vr0h, vr1h, kr0l, kr1l, vr0l, vr1l;
+  const int frow0 = tid >> 3, frow1 = (tid + 256) >> 3, fc = tid & 7;
+#define LSA_FETCH(KT)                                                                                                   \
   {                                                                                                                     \
-    const long kb_ = ((long)bh * a.Tp + (long)(KTI) * KT + krow) * 64 + kc * 8;                                         \
-    const long vb_ = ((long)bh * 64 + vrow) * a.Tp + (long)(KTI) * KT + vc * 8;                                         \
-    kr0 = *reinterpret_cast<const uint4*>(kg[0] + kb_);            kr1 = *reinterpret_cast<const uint4*>(kg[0] + kb_ + 32 * 64);   \
-    vr0 = *reinterpret_cast<const uint4*>(vg[0] + vb_);            vr1 = *reinterpret_cast<const uint4*>(vg[0] + vb_ + (long)VR * a.Tp); \
-    if (KT == 128) {                                                                                                    \
-      kr2 = *reinterpret_cast<const uint4*>(kg[0] + kb_ + 64 * 64);  kr3 = *reinterpret_cast<const uint4*>(kg[0] + kb_ + 96 * 64); \
-      vr2 = *reinterpret_cast<const uint4*>(vg[0] + vb_ + 2l * VR * a.Tp);  vr3 = *reinterpret_cast<const uint4*>(vg[0] + vb_ + 3l * VR * a.Tp); \
-    }                                                                                                                   \
+    const long kb_ = ((long)bh * a.Tp + (KT) * 64) * 64 + fc * 8;                                                       \
+    const long vb_ = (long)bh * 64 * a.Tp + (KT) * 64 + fc * 8;                                                         \
+    kr0h = *reinterpret_cast<const uint4*>(kg[0] + kb_ + frow0 * 64);                                                   \
+    kr1h = *reinterpret_cast<const uint4*>(kg[0] + kb_ + frow1 * 64);                                                   \
+    vr0h = *reinterpret_cast<const uint4*>(vg[0] + vb_ + (long)frow0 * a.Tp);                                           \
+    vr1h = *reinterpret_cast<const uint4*>(vg[0] + vb_ + (long)frow1 * a.Tp);                                           \
     if (NPASS == 3) {                                                                                                   \
-      lr0 = *reinterpret_cast<const uint4*>(kg[1] + kb_);            lr1 = *reinterpret_cast<const uint4*>(kg[1] + kb_ + 32 * 64); \
-      wr0 = *reinterpret_cast<const uint4*>(vg[1] + vb_);            wr1 = *reinterpret_cast<const uint4*>(vg[1] + vb_ + (long)VR * a.Tp); \
-      if (KT == 128) {                                                                                                  \
-        lr2 = *reinterpret_cast<const uint4*>(kg[1] + kb_ + 64 * 64);  lr3 = *reinterpret_cast<const uint4*>(kg[1] + kb_ + 96 * 64); \
-        wr2 = *reinterpret_cast<const uint4*>(vg[1] + vb_ + 2l * VR * a.Tp);  wr3 = *reinterpret_cast<const uint4*>(vg[1] + vb_ + 3l * VR * a.Tp); \
-      }                                                                                                                 \
+      kr0l = *reinterpret_cast<const uint4*>(kg[1] + kb_ + frow0 * 64);                                                 \
+      kr1l = *reinterpret_cast<const uint4*>(kg[1] + kb_ + frow1 * 64);                                                 \
+      vr0l = *reinterpret_cast<const uint4*>(vg[1] + vb_ + (long)frow0 * a.Tp);                                         \
+      vr1l = *reinterpret_cast<const uint4*>(vg[1] + vb_ + (long)frow1 * a.Tp);                                         \
     }                                                                                                                   \
   }
   LSA_FETCH(0)
   for (int kt = 0; kt < ntiles; ++kt) {
     __syncthreads();   // every wave is done reading the previous tile
-    {
-      T* dk = &sK[0][krow * RSK + kc * 8];
-      *reinterpret_cast<uint4*>(dk) = kr0; *reinterpret_cast<uint4*>(dk + 32 * RSK) = kr1;
-      if (KT == 128) { *reinterpret_cast<uint4*>(dk + 64 * RSK) = kr2; *reinterpret_cast<uint4*>(dk + 96 * RSK) = kr3; }
-      T* dv = &sV[0][vrow * RSV + vc * 8];
-      *reinterpret_cast<uint4*>(dv) = vr0; *reinterpret_cast<uint4*>(dv + VR * RSV) = vr1;
-      if (KT == 128) { *reinterpret_cast<uint4*>(dv + 2 * VR * RSV) = vr2; *reinterpret_cast<uint4*>(dv + 3 * VR * RSV) = vr3; }
-      if (NPASS == 3) {
-        T* ek = &sK[NPL - 1][krow * RSK + kc * 8];
-        *reinterpret_cast<uint4*>(ek) = lr0; *reinterpret_cast<uint4*>(ek + 32 * RSK) = lr1;
-        if (KT == 128) { *reinterpret_cast<uint4*>(ek + 64 * RSK) = lr2; *reinterpret_cast<uint4*>(ek + 96 * RSK) = lr3; }
-        T* ev = &sV[NPL - 1][vrow * RSV + vc * 8];
-        *reinterpret_cast<uint4*>(ev) = wr0; *reinterpret_cast<uint4*>(ev + VR * RSV) = wr1;
-        if (KT == 128) { *reinterpret_cast<uint4*>(ev + 2 * VR * RSV) = wr2; *reinterpret_cast<uint4*>(ev + 3 * VR * RSV) = wr3; }
-      }
+    *reinterpret_cast<uint4*>(&sK[0][frow0 * RS + fc * 8]) = kr0h;
+    *reinterpret_cast<uint4*>(&sK[0][frow1 * RS + fc * 8]) = kr1h;
+    *reinterpret_cast<uint4*>(&sV[0][frow0 * RS + fc * 8]) = vr0h;
+    *reinterpret_cast<uint4*>(&sV[0][frow1 * RS + fc * 8]) = vr1h;
+    if (NPASS == 3) {
+      *reinterpret_cast<uint4*>(&sK[NPL - 1][frow0 * RS + fc * 8]) = kr0l;
+      *reinterpret_cast<uint4*>(&sK[NPL - 1][frow1 * RS + fc * 8]) = kr1l;
+      *reinterpret_cast<uint4*>(&sV[NPL - 1][frow0 * RS + fc * 8]) = vr0l;
+      *reinterpret_cast<uint4*>(&sV[NPL - 1][frow1 * RS + fc * 8]) = vr1l;
     }
     __syncthreads();
     if (kt + 1 < ntiles) LSA_FETCH(kt + 1)
+    // ---- S^T tiles (2 x 32 keys) x 32 queries
+    f32x16 s[2];
 #pragma unroll
-    for (int hk = 0; hk < KT / 64; ++hk) {
-      const int k0 = kt * KT + hk * 64;           // first key of this 64-key half
-      if (k0 >= a.T) break;                        // wave-uniform: nothing but padding left
-      // ---- S^T tiles (2 x 32 keys) x 32 queries
-      f32x16 s[2];
+    for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
+      for (int e = 0; e < 16; ++e) s[sub][e] = 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) s[sub][e] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const V8 kf = *reinterpret_cast<const V8*>(&sK[0][(hk * 64 + sub * 32 + r) * RSK + ks * 16 + h * 8]);
-          if (NPASS == 3) {
-            const V8 kfl = *reinterpret_cast<const V8*>(&sK[NPL - 1][(hk * 64 + sub * 32 + r) * RSK + ks * 16 + h * 8]);
-            s[sub] = MM<T>::mfma(kfl, qf[0][ks], s[sub]);
-            s[sub] = MM<T>::mfma(kf, qf[NPL - 1][ks], s[sub]);
-          }
-          s[sub] = MM<T>::mfma(kf, qf[0][ks], s[sub]);
+      for (int ks = 0; ks < 4; ++ks) {
+        const V8 kf = *reinterpret_cast<const V8*>(&sK[0][(sub * 32 + r) * RS + ks * 16 + h * 8]);
+        if (NPASS == 3) {
+          const V8 kfl = *reinterpret_cast<const V8*>(&sK[NPL - 1][(sub * 32 + r) * RS + ks * 16 + h * 8]);
+          s[sub] = MM<T>::mfma(kfl, qf[0][ks], s[sub]);
+          s[sub] = MM<T>::mfma(kf, qf[NPL - 1][ks], s[sub]);
         }
+        s[sub] = MM<T>::mfma(kf, qf[0][ks], s[sub]);
       }
-      // ---- mask (diagonal: a token never attends to itself, vit_set.py:58-60; padding keys) + online softmax. The logits arrive in
-      // the log2 domain (qkv_pack folds log2(e) into q), so the exponential is the hardware exp2; the masks only touch the one half
-      // that holds this wave's own keys and the halves past T (wave-uniform branches); the running output is rescaled only when some
-      // lane's maximum actually moved.
-      if ((q0 >> 6) == (k0 >> 6)) {
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-          for (int e = 0; e < 16; ++e)
-            if (k0 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h == qidx) s[sub][e] = -FLT_MAX;
-      }
-      if (k0 + 64 > a.T) {
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-          for (int e = 0; e < 16; ++e)
-            if (k0 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= a.T) s[sub][e] = -INFINITY;
-      }
-      float mx = s[0][0];
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[sub][e]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      float rs = 0.f;
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float pv = __builtin_amdgcn_exp2f(s[sub][e] - m_new);
-          s[sub][e] = pv;
-          rs += pv;
-        }
-      rs += __shfl_xor(rs, 32, 64);
-      l_run = l_run * alpha + rs;
-      m_run = m_new;
-      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
-      }
-      // ---- O^T += V^T P^T (V^T's keys are stored in the operand's k order: one 16-B read per fragment)
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          V8 ph, pl8;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float pv = s[sub][8 * s2 + j];
-            const T hv = (T)pv;
-            ph[j] = hv;
-            if (NPASS == 3) pl8[j] = (T)(pv - (float)hv);
-          }
-#pragma unroll
-          for (int d = 0; d < 2; ++d) {
-            const int base = (d * 32 + r) * RSV + hk * 64 + sub * 32 + s2 * 16 + h * 8;
-            const V8 vf = *reinterpret_cast<const V8*>(&sV[0][base]);
-            if (NPASS == 3) {
-              const V8 vfl = *reinterpret_cast<const V8*>(&sV[NPL - 1][base]);
-              o[d] = MM<T>::mfma(vfl, ph, o[d]);
-              o[d] = MM<T>::mfma(vf, pl8, o[d]);
-            }
-            o[d] = MM<T>::mfma(vf, ph, o[d]);
-          }
-        }
     }
+    // ---- mask (diagonal: a token never attends to itself, vit_set.py:58-60; padding keys) + online softmax. The logits arrive in
+    // the log2 domain (qkv_pack folds log2(e) into q), so the exponential is the hardware exp2; the masks only touch the one tile
+    // that holds this wave's own keys and the tiles past T (wave-uniform branches); the running output is rescaled only when some
+    // lane's maximum actually moved.
+    if ((q0 >> 6) == kt) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (kt * 64 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h == qidx) s[sub][e] = -FLT_MAX;
+    }
+    if (kt * 64 + 64 > a.T) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (kt * 64 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= a.T) s[sub][e] = -INFINITY;
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[sub][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = __builtin_amdgcn_exp2f(s[sub][e] - m_new);
+        s[sub][e] = pv;
+        rs += pv;
+      }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+    }
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        V8 ph, pl8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float pv = s[sub][8 * s2 + j];
+          const T hv = (T)pv;
+          ph[j] = hv;
+          if (NPASS == 3) pl8[j] = (T)(pv - (float)hv);
+        }
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          // A fragment of V^T: row = d*32 + r, keys 32*sub + 16*s2 + {4h .. 4h+3} and {8 + 4h .. 8 + 4h + 3}
+          const int base = (d * 32 + r) * RS + sub * 32 + s2 * 16 + h * 4;
+          V8 vf, vfl;
+          const V4t v0 = *reinterpret_cast<const V4t*>(&sV[0][base]);
+          const V4t v1 = *reinterpret_cast<const V4t*>(&sV[0][base + 8]);
+          vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
+          vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+          if (NPASS == 3) {
+            const V4t w0 = *reinterpret_cast<const V4t*>(&sV[NPL - 1][base]);
+            const V4t w1 = *reinterpret_cast<const V4t*>(&sV[NPL - 1][base + 8]);
+            vfl[0] = w0[0]; vfl[1] = w0[1]; vfl[2] = w0[2]; vfl[3] = w0[3];
+            vfl[4] = w1[0]; vfl[5] = w1[1]; vfl[6] = w1[2]; vfl[7] = w1[3];
+            o[d] = MM<T>::mfma(vfl, ph, o[d]);
+            o[d] = MM<T>::mfma(vf, pl8, o[d]);
+          }
+          o[d] = MM<T>::mfma(vf, ph, o[d]);
+        }
+      }
   }
 #undef LSA_FETCH
   // ---- epilogue: O^T / l through LDS so that every token row is written contiguously (token-major [B][T][H*64])
