@@ -298,6 +298,33 @@ int stedm_agg_reduce(const float* feats, float* out, int B, int n, int F, int mo
 int stedm_spatial_rescale(const float* x, const float* w, float* out, int B, int cin, int cout, int H, int W,
                           int n_stages, void* stream);
 
+/* ---- Swin-Transformer-V2 style embedder ---------------------------------------------------------
+ * Replaces the non-GEMM pieces of torchvision's swin_v2_t (torchvision==0.18.1, third party; call sites networks/s_zss_dm.py:19-20,
+ * networks/agg_blocks.py:28,49,70); every Linear / the patch Conv2d runs through stedm_conv_igemm (1x1). Parity unpinned (oracle/swin.py).
+ * features[0][0] Conv2d(3, 96, 4, 4) as a GEMM: img [N][3][H][W] with element strides (sn, sc, sh, sw) -> 16-bit operand rows
+ * [N*(H/4)*(W/4)][64], column k = c*16 + ky*4 + kx (the flattened OIHW weight), columns 48..63 zero. */
+int stedm_swin_patch16(const float* img, long sn, long sc, long sh, long sw, int N, int H, int W, void* out_hi, void* out_lo,
+                       int mm_dtype, void* stream);
+/* out = res + LayerNorm(y) over rows of `dim` (SwinTransformerBlockV2's post-norm residual x + norm(f(x)); res NULL: plain LayerNorm);
+ * fp32 rows (out, may be NULL) and / or 16-bit operand planes (out_hi / out_lo, may be NULL). res may alias out. */
+int stedm_swin_ln(const float* y, const float* gamma, const float* beta, float eps, const float* res, float* out, void* out_hi,
+                  void* out_lo, long rows, int dim, int mm_dtype, void* stream);
+/* torchvision shifted_window_attention with ShiftedWindowAttentionV2's cosine logits, 8 x 8 windows, head dim 32:
+ * qkv [N*H*W][3C] fp32 in token order (bias included, k bias zeroed) -> softmax(normalize(q) normalize(k)^T * scale[h] + rpb + mask) v
+ * as the 16-bit plane [N*H*W][C] `proj` consumes. Cyclic shift, window partition, F.pad rows (q = bias_q, k = 0, v = bias_v) and their
+ * inverses are index arithmetic. bias_kzero [3C]; scale [heads] = exp(min(logit_scale, log 100)); rpbT [heads][key][query] =
+ * 16 sigmoid(cpb_mlp(relative_coords_table))[relative_position_index]. A side no larger than the window is not shifted. */
+int stedm_swin_window_attn(const float* qkv, const float* bias_kzero, const float* scale, const float* rpbT, void* out_hi, void* out_lo,
+                           int N, int H, int W, int C, int heads, int shift, int mm_dtype, void* stream);
+/* PatchMergingV2's input: x [N][H][W][C] fp32 -> 16-bit operand rows [N*ceil(H/2)*ceil(W/2)][4C] = [x(0,0) | x(1,0) | x(0,1) | x(1,1)]
+ * (zero beyond an odd side). */
+int stedm_swin_merge16(const float* x, int N, int H, int W, int C, void* out_hi, void* out_lo, int mm_dtype, void* stream);
+/* ShiftedWindowAttentionV2.get_relative_position_bias: cpb [ntab][heads] = cpb_mlp(relative_coords_table) (two stedm_linear calls),
+ * index [64*64] int64 = relative_position_index (query-major) -> rpbT [heads][key][query] = 16 sigmoid(cpb[index]). */
+int stedm_swin_rpb(const float* cpb, const long* index, float* rpbT, int heads, int ntab, void* stream);
+/* AdaptiveAvgPool2d(1) over the tokens: x [N][T][C] -> out [N][C]. */
+int stedm_swin_token_mean(const float* x, float* out, int N, int T, int C, void* stream);
+
 /* ---- training step: backward of the U-Net, loss, optimizer -------------------------------------
  * Replaces torch.autograd over UNetModel.forward (openaimodel.py:761-806) inside LatentDiffusion.p_losses (ddpm.py:1015-1048),
  * torch.optim.AdamW (ldm_diffusion.py:224-234) and LitEma.forward (ema.py:25-44). The convolution contractions of the backward

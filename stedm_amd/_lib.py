@@ -87,6 +87,12 @@ SIGNATURES = {
     "stedm_geglu16": (_I, [_P, _P, _P, C.c_long, _I, _I, _P]),
     "stedm_agg_reduce": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "stedm_spatial_rescale": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "stedm_swin_patch16": (_I, [_P, C.c_long, C.c_long, C.c_long, C.c_long, _I, _I, _I, _P, _P, _I, _P]),
+    "stedm_swin_ln": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, C.c_long, _I, _I, _P]),
+    "stedm_swin_window_attn": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "stedm_swin_merge16": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "stedm_swin_rpb": (_I, [_P, _P, _P, _I, _I, _P]),
+    "stedm_swin_token_mean": (_I, [_P, _P, _I, _I, _I, _P]),
     "stedm_pack_conv_weight_strided": (_I, [_P, C.c_long, C.c_long, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "stedm_gn_fold": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P]),
     "stedm_gn_bwd": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P]),

@@ -575,8 +575,8 @@ class S_ZSS_DM(LatentDiffusion):
     dict {"c_concat": [layout], "c_crossattn": [style]}.
 
     `encoder` names the torchvision embedder of the mean/max/linear aggregators in the reference ("swin_v2_t", third-party,
-    SURVEY.md §8c); here it must be supplied as a module through `embedder=` for those modes. `style_agg: svit` and
-    `style_sampling: none` need no embedder."""
+    SURVEY.md §8c): the Swin-V2 family is built on the HIP kernels (stedm_amd/swin.py); any other embedder can be supplied as a module
+    through `embedder=`. `style_agg: svit` and `style_sampling: none` need no embedder."""
 
     def __init__(self, encoder, sampling_cfg, agg_cfg, cfg, *args, embedder: Optional[nn.Module] = None, **kwargs):
         super().__init__(*args, **kwargs)
@@ -600,17 +600,11 @@ class S_ZSS_DM(LatentDiffusion):
             self._agg_block = st.sViT(image_size=img, num_classes=512, ns=ns, **a)
         else:
             if embedder is None:
-                # s_zss_dm.py:19-20: `torchvision.models.get_model(encoder)` with its head replaced by Linear(768, 512). torchvision is a
-                # third-party dependency of the reference (environment.yml:32); when it is installed the embedder is built exactly like
-                # that and runs on PyTorch-ROCm's own kernels (its arithmetic is torchvision's: parity unpinned) — the HIP
-                # path accelerates the aggregation and everything downstream. Without torchvision: pass a module, or use style_agg=svit.
-                try:
-                    import torchvision
-                except ImportError as e:
-                    raise NotImplementedError(f"style_agg={name(agg_cfg)!r} needs the torchvision {encoder!r} embedder (third-party, not part "
-                                              "of this package, not installed here): install torchvision, pass a module as "
-                                              "S_ZSS_DM(..., embedder=module), or use style_agg=svit") from e
-                embedder = torchvision.models.get_model(encoder)
+                # s_zss_dm.py:19-20: `torchvision.models.get_model(encoder)` with its head replaced by Linear(768, 512). The HIP-backed
+                # Swin-V2 (stedm_amd/swin.py) keeps torchvision's state-dict names, so a torchvision checkpoint loads into it; its arithmetic
+                # is torchvision's published algorithm (third-party: parity unpinned). Other encoders: pass `embedder=`.
+                from .swin import get_model
+                embedder = get_model(encoder)
                 embedder.head = torch.nn.Linear(768, 512)
             cls = {"linear": st.Agg_Linear, "max": st.Agg_Max, "mean": st.Agg_Mean}.get(name(agg_cfg))
             if cls is None:

@@ -491,6 +491,54 @@ def agg_reduce(feats, out, n: int, mode: int):
     return out
 
 
+# ------------------------------------------------------------------------------------------- Swin-V2 embedder (non-GEMM pieces)
+def swin_patch16(img: torch.Tensor, hi: torch.Tensor, lo: Optional[torch.Tensor], prec: Precision) -> None:
+    """img [N, 3, H, W] fp32, ANY strides (the '(b n) c h w' view of NHWC style images is read in place) -> rows [N*H/4*W/4, 64]."""
+    assert img.dtype == torch.float32 and img.is_cuda and img.dim() == 4 and img.shape[1] == 3
+    N, _, H, W = img.shape
+    sn, sc, sh, sw = img.stride()
+    check(lib().stedm_swin_patch16(img.data_ptr(), sn, sc, sh, sw, N, H, W, hi.data_ptr(), _ptr(lo), prec.mm_dtype, _stream()), "stedm_swin_patch16")
+
+
+def swin_ln(y: torch.Tensor, gamma, beta, eps: float, res: Optional[torch.Tensor], out: Optional[torch.Tensor], hi: Optional[torch.Tensor],
+            lo: Optional[torch.Tensor], prec: Precision) -> None:
+    """out = res + LayerNorm(y) as fp32 rows and / or 16-bit operand planes."""
+    _chk(y, name="y")
+    dim = y.shape[-1]
+    check(lib().stedm_swin_ln(y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), _ptr(res), _ptr(out), _ptr(hi), _ptr(lo),
+                              y.numel() // dim, dim, prec.mm_dtype, _stream()), "stedm_swin_ln")
+
+
+def swin_window_attn(qkv: torch.Tensor, bias_kzero: torch.Tensor, scale: torch.Tensor, rpbT: torch.Tensor, hi: torch.Tensor,
+                     lo: Optional[torch.Tensor], N: int, H: int, W: int, heads: int, shift: int, prec: Precision) -> None:
+    _chk(qkv, name="qkv")
+    C = qkv.shape[-1] // 3
+    check(lib().stedm_swin_window_attn(qkv.data_ptr(), bias_kzero.data_ptr(), scale.data_ptr(), rpbT.data_ptr(), hi.data_ptr(), _ptr(lo),
+                                       N, H, W, C, heads, shift, prec.mm_dtype, _stream()), "stedm_swin_window_attn")
+
+
+def swin_merge16(x: torch.Tensor, hi: torch.Tensor, lo: Optional[torch.Tensor], prec: Precision) -> None:
+    _chk(x, name="x")
+    N, H, W, C = x.shape
+    check(lib().stedm_swin_merge16(x.data_ptr(), N, H, W, C, hi.data_ptr(), _ptr(lo), prec.mm_dtype, _stream()), "stedm_swin_merge16")
+
+
+def swin_rpb(cpb: torch.Tensor, index: torch.Tensor, heads: int) -> torch.Tensor:
+    """cpb [ntab, heads] fp32, index [4096] int64 -> rpbT [heads, 64, 64] (key-major) = 16 sigmoid(cpb[index])."""
+    _chk(cpb, name="cpb")
+    assert index.dtype == torch.int64 and index.numel() == 4096 and index.is_cuda
+    out = torch.empty((heads, 64, 64), dtype=torch.float32, device=cpb.device)
+    check(lib().stedm_swin_rpb(cpb.data_ptr(), index.data_ptr(), out.data_ptr(), heads, cpb.shape[0], _stream()), "stedm_swin_rpb")
+    return out
+
+
+def swin_token_mean(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    _chk(x, name="x")
+    N, T, C = x.shape
+    check(lib().stedm_swin_token_mean(x.data_ptr(), out.data_ptr(), N, T, C, _stream()), "stedm_swin_token_mean")
+    return out
+
+
 def spatial_rescale(x, w, out, n_stages: int):
     _chk(x, name="x")
     B, cin, H, W = x.shape

@@ -5,8 +5,8 @@
   SpatialRescaler                                      ldm/modules/encoders/modules.py:104-133
 
 torch.nn modules are parameter containers; `forward` launches HIP kernels through the C ABI.
-The swin_v2_t embedder of Agg_* is third-party torchvision code (parity unpinned): it stays a
-caller-supplied nn.Module; only the set aggregation after it runs here.
+The embedder of Agg_* is any nn.Module mapping [(b n), 3, h, w] -> [(b n), f]; the reference's swin_v2_t is built on the HIP kernels in
+stedm_amd/swin.py (third-party torchvision arithmetic, SURVEY.md §8c: parity unpinned).
 """
 from __future__ import annotations
 
@@ -212,6 +212,14 @@ class sViT(nn.Module):
 
 
 # ---------------------------------------------------------------------------------------------------- agg blocks
+class _AggBase(nn.Module):
+    def set_precision(self, precision):
+        """MFMA operand mode of a HIP-backed embedder (stedm_amd.swin); a foreign embedder keeps its own arithmetic."""
+        emb = getattr(self, "_embedder", None)
+        if emb is not None and hasattr(emb, "set_precision"):
+            emb.set_precision(precision)
+
+
 def _embed(embedder: nn.Module, style_imgs: torch.Tensor) -> torch.Tensor:
     """'b n h w c -> (b n) c h w' then the caller's embedder -> [(b n), f] (agg_blocks.py:26-28)."""
     b, n, h, w, c = style_imgs.shape
@@ -219,7 +227,7 @@ def _embed(embedder: nn.Module, style_imgs: torch.Tensor) -> torch.Tensor:
     return embedder(x).float().contiguous()
 
 
-class Agg_Linear(nn.Module):
+class Agg_Linear(_AggBase):
     """agg_blocks.py:6-33."""
 
     def __init__(self, sampling_cfg, embedder):
@@ -240,7 +248,7 @@ class Agg_Linear(nn.Module):
         return ops.linear(h, ops.transpose(l2.weight.float()), l2.bias, torch.empty((b, 512), device=f.device), act_in=0, act_out=2)
 
 
-class Agg_Max(nn.Module):
+class Agg_Max(_AggBase):
     """agg_blocks.py:36-54."""
 
     def __init__(self, sampling_cfg, embedder):
@@ -256,7 +264,7 @@ class Agg_Max(nn.Module):
         return ops.agg_reduce(f, torch.empty((b, f.shape[-1]), device=f.device), n, 1)
 
 
-class Agg_Mean(nn.Module):
+class Agg_Mean(_AggBase):
     """agg_blocks.py:57-75."""
 
     def __init__(self, sampling_cfg, embedder):
@@ -272,7 +280,7 @@ class Agg_Mean(nn.Module):
         return ops.agg_reduce(f, torch.empty((b, f.shape[-1]), device=f.device), n, 0)
 
 
-class Agg_None(nn.Module):
+class Agg_None(_AggBase):
     """agg_blocks.py:78-86."""
 
     def __init__(self, sampling_cfg, embedder):

@@ -1,0 +1,184 @@
+"""GPU tier (-m gpu): Swin-Transformer-V2 style embedder — the HIP-backed `stedm_amd.swin.SwinTransformerV2` against the
+CPU oracle `oracle/swin.py` (restated torchvision algorithm; PARITY UNPINNED: torchvision is absent, see the oracle's header).
+Edge cases follow torchvision's own: feature maps that are not multiples of the window (F.pad rows take part as keys), a side the window
+covers (no shift along it), odd sides in PatchMergingV2."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from stedm_amd.utils import prng
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a = a.double().cpu(); b = torch.as_tensor(np.asarray(b)).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max()) / (float(b.std()) + 1e-12)
+
+
+def fill_swin_(m, seed=11):
+    """PRNG recipe for the Swin containers: LayerNorm affine 1 + 0.1 N / 0.1 N, logit_scale log(10) + 0.3 N, biases 0.05 N (the key third of
+    qkv.bias too: the forward must zero it), weights N(0, 1/sqrt(fan_in))."""
+    for mod_name, mod in m.named_modules():
+        for pn, p in mod.named_parameters(recurse=False):
+            name = f"{mod_name}.{pn}" if mod_name else pn
+            if isinstance(mod, nn.LayerNorm):
+                p.copy_(prng.normal(seed, name, p.shape, std=0.1, mean=1.0 if pn == "weight" else 0.0))
+            elif pn == "logit_scale":
+                p.copy_(prng.normal(seed, name, p.shape, std=0.3, mean=math.log(10.0)))
+            elif p.dim() >= 2:
+                p.copy_(prng.normal(seed, name, p.shape, std=1.0 / math.sqrt(int(np.prod(p.shape[1:])))))
+            else:
+                p.copy_(prng.normal(seed, name, p.shape, std=0.05))
+    return m
+
+
+def make_swin(dev, precision="parity", classes=512, **kw):
+    from stedm_amd.swin import swin_v2_t
+    m = swin_v2_t(num_classes=classes, precision=precision, **kw).eval()
+    fill_swin_(m)
+    params = {k: v.clone() for k, v in m.state_dict().items()}
+    return m.to(dev), params
+
+
+def test_swin_rpb_and_buffers_match_oracle(dev):
+    from oracle import swin as osw
+    from stedm_amd import ops
+    from stedm_amd.swin import ShiftedWindowAttentionV2
+    at = ShiftedWindowAttentionV2(96, [8, 8], [4, 4], 3)
+    assert torch.equal(at.relative_position_index.view(64, 64), osw.relative_position_index())
+    assert torch.allclose(at.relative_coords_table.view(-1, 2), osw.relative_coords_table(), atol=0, rtol=0)
+    fill_swin_(at, 3)
+    p = {k: v.clone() for k, v in at.state_dict().items()}
+    want = osw.position_bias(p, "", 3)                                   # [heads, query, key]
+    at = at.to(dev)
+    l0, l2 = at.cpb_mlp[0], at.cpb_mlp[2]
+    table = at.relative_coords_table.reshape(-1, 2).contiguous()
+    h1 = ops.linear(table, ops.transpose(l0.weight), l0.bias, torch.empty((225, 512), device=dev), act_out=2)
+    cpb = ops.linear(h1, ops.transpose(l2.weight), None, torch.empty((225, 3), device=dev))
+    got = ops.swin_rpb(cpb, at.relative_position_index, 3).transpose(1, 2)
+    assert float((got.cpu() - want).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("H,W,shift", [(16, 16, 0), (16, 16, 4), (12, 20, 4), (8, 24, 4), (4, 4, 4), (24, 8, 4), (9, 17, 4)])
+def test_swin_window_attention_kernel_vs_oracle(dev, H, W, shift):
+    """cosine window attention incl. roll, partition, F.pad rows, mask of a partly shifted map; `proj` is the identity here."""
+    from oracle import swin as osw
+    from stedm_amd import ops
+    from stedm_amd.ops import Precision
+    from stedm_amd.swin import ShiftedWindowAttentionV2
+    heads, C, N = 3, 96, 2
+    at = fill_swin_(ShiftedWindowAttentionV2(C, [8, 8], [shift, shift], heads), 5)
+    p = {k: v.clone() for k, v in at.state_dict().items()}
+    p["proj.weight"], p["proj.bias"] = torch.eye(C), torch.zeros(C)
+    x = prng.normal(5, f"swin.attn.{H}.{W}", (N, H, W, C))
+    want = osw.window_attention(x, p, "", heads, shift)
+    bz = p["qkv.bias"].clone(); bz[C:2 * C] = 0
+    qkv = F.linear(x, p["qkv.weight"], bz).reshape(N * H * W, 3 * C).contiguous().to(dev)
+    rpbT = osw.position_bias(p, "", heads).transpose(1, 2).contiguous().to(dev)
+    scale = torch.clamp(p["logit_scale"].reshape(-1), max=math.log(100.0)).exp().to(dev)
+    prec = Precision.parse("parity")
+    hi = torch.zeros((N * H * W, C), dtype=torch.int16, device=dev)
+    lo = torch.zeros_like(hi)
+    ops.swin_window_attn(qkv, bz.to(dev), scale, rpbT, hi, lo, N, H, W, heads, shift, prec)
+    got = (hi.view(torch.float16).float() + lo.view(torch.float16).float()).view(N, H, W, C)
+    err = rel(got, want)
+    print(f"[swin window attention {H}x{W} shift {shift}] {err:.2e}")
+    assert err < 2e-5
+
+
+def test_swin_gather_kernels_vs_torch(dev):
+    from stedm_amd import ops
+    from stedm_amd.ops import Precision
+    prec = Precision.parse("parity")
+    f16 = lambda hi, lo: hi.view(torch.float16).float() + lo.view(torch.float16).float()
+    # patch rows from a permuted NHWC view (what Agg_* hands over)
+    img = prng.uniform(3, "swin.img", (2, 24, 40, 3)).to(dev)
+    x = img.permute(0, 3, 1, 2)
+    hi = torch.empty((2 * 6 * 10, 64), dtype=torch.int16, device=dev); lo = torch.empty_like(hi)
+    ops.swin_patch16(x, hi, lo, prec)
+    want = F.unfold(x.contiguous(), kernel_size=4, stride=4).transpose(1, 2).reshape(-1, 48)      # (c, ky, kx) columns, row-major patches
+    got = f16(hi, lo)
+    assert float((got[:, :48] - want).abs().max()) < 1e-6 and float(got[:, 48:].abs().max()) == 0.0
+    # 2x2 merge with odd sides
+    t = prng.normal(3, "swin.merge", (2, 5, 7, 32)).to(dev)
+    hi = torch.empty((2 * 3 * 4, 128), dtype=torch.int16, device=dev); lo = torch.empty_like(hi)
+    ops.swin_merge16(t, hi, lo, prec)
+    tp = F.pad(t, (0, 0, 0, 1, 0, 1))
+    want = torch.cat([tp[:, 0::2, 0::2], tp[:, 1::2, 0::2], tp[:, 0::2, 1::2], tp[:, 1::2, 1::2]], -1).reshape(-1, 128)
+    assert float((f16(hi, lo) - want).abs().max()) < 1e-6
+    # residual LayerNorm (in place) + planes, token mean
+    y = prng.normal(3, "swin.ln.y", (50, 96)).to(dev); r = prng.normal(3, "swin.ln.r", (50, 96)).to(dev)
+    g = prng.normal(3, "swin.ln.g", (96,), 0.1, 1.0).to(dev); b = prng.normal(3, "swin.ln.b", (96,), 0.1).to(dev)
+    want = r + F.layer_norm(y, (96,), g, b, 1e-5)
+    out = r.clone(); hi = torch.empty((50, 96), dtype=torch.int16, device=dev); lo = torch.empty_like(hi)
+    ops.swin_ln(y, g, b, 1e-5, out, out, hi, lo, prec)
+    assert float((out - want).abs().max()) < 1e-5 and float((f16(hi, lo) - out).abs().max()) < 1e-6
+    tm = ops.swin_token_mean(want.view(2, 25, 96).contiguous(), torch.empty((2, 96), device=dev))
+    assert float((tm - want.view(2, 25, 96).mean(1)).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("tag,N,H,W", [("256", 2, 256, 256), ("ragged", 2, 144, 208), ("512", 1, 512, 512)])
+def test_swin_v2_t_vs_oracle(dev, tag, N, H, W):
+    """Whole embedder with the reference's head (Linear(768, 512), s_zss_dm.py:20), parity mode, at 1e-3. 512 x 512 is the reference's patch
+    size (all four stages shifted); 256: the last stage is one window (no shift); ragged: padded windows and odd merges."""
+    from oracle import swin as osw
+    m, params = make_swin(dev)
+    x = prng.uniform(11, f"swin.img.{tag}", (N, H, W, 3))
+    want = osw.swin_v2_forward(params, x.permute(0, 3, 1, 2).contiguous())
+    got = m(x.to(dev).permute(0, 3, 1, 2))            # the strided '(b n) c h w' view of NHWC images
+    err = rel(got, want)
+    print(f"[swin_v2_t {tag}] parity-mode max|diff|/std vs CPU oracle: {err:.3e}")
+    assert err < 1e-3
+
+
+@pytest.mark.parametrize("precision,tol", [("f16", 2e-2), ("bf16", 1e-1)])
+def test_swin_fast_modes_reported(dev, precision, tol):
+    from oracle import swin as osw
+    m, params = make_swin(dev, precision)
+    x = prng.uniform(11, "swin.img.256", (2, 256, 256, 3))
+    want = osw.swin_v2_forward(params, x.permute(0, 3, 1, 2).contiguous())
+    err = rel(m(x.to(dev).permute(0, 3, 1, 2)), want)
+    print(f"[swin_v2_t 256 {precision}] max|diff|/std vs CPU oracle: {err:.3e}")
+    assert err < tol
+
+
+def test_swin_chunking(dev):
+    """images are independent: any chunking gives the same rows (to rounding: the small-batch Linear / split-K forms sum in another order)."""
+    m, _ = make_swin(dev, chunk_images=2)
+    x = prng.uniform(11, "swin.img.chunk", (5, 3, 64, 64)).to(dev)
+    a = m(x).clone()
+    m.chunk_images = 8
+    assert rel(a, m(x).cpu()) < 1e-5
+
+
+def test_agg_blocks_with_hip_embedder(dev):
+    """agg_blocks.py:24-75 end to end on the HIP embedder: '(b n) c h w' -> swin -> mean / max / MLP."""
+    from types import SimpleNamespace
+    from oracle import swin as osw
+    from stedm_amd.style import Agg_Linear, Agg_Max, Agg_Mean
+    emb, params = make_swin(dev)
+    imgs = prng.uniform(11, "swin.agg.img", (2, 3, 128, 128, 3))
+    f = osw.swin_v2_forward(params, imgs.reshape(6, 128, 128, 3).permute(0, 3, 1, 2).contiguous()).view(2, 3, 512)
+    cfg = SimpleNamespace(name="mp", num_patches=3)
+    assert rel(Agg_Mean(cfg, emb)(imgs.to(dev)), f.mean(1)) < 1e-3
+    assert rel(Agg_Max(cfg, emb)(imgs.to(dev)), f.max(1)[0]) < 1e-3
+    lin = Agg_Linear(cfg, emb)
+    prng.fill_module_(lin._linear_block, seed=13)
+    lb = lin._linear_block
+    want = F.relu(F.linear(F.relu(F.linear(F.relu(f.reshape(2, -1)), lb[1].weight, lb[1].bias)), lb[3].weight, lb[3].bias))
+    lin = lin.to(dev)
+    assert rel(lin(imgs.to(dev)), want) < 1e-3

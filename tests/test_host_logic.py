@@ -116,3 +116,87 @@ def test_first_stage_config_is_built_or_refused_never_dropped():
     zm.train()
     with pytest.raises(StedmHipError):
         zm.get_input(batch, "image")
+
+
+def test_swin_state_dict_names_and_size():
+    """torchvision's swin_v2_t: 28 351 570 parameters with the 1000-class head (its published model card); names as its state dict."""
+    from stedm_amd.swin import swin_v2_t, get_model
+    m = swin_v2_t()
+    assert sum(p.numel() for p in m.parameters()) == 28_351_570
+    sd = m.state_dict()
+    for k in ("features.0.0.weight", "features.0.2.bias", "features.1.1.attn.qkv.bias", "features.1.0.attn.logit_scale", "features.1.0.attn.cpb_mlp.0.bias",
+              "features.1.0.attn.cpb_mlp.2.weight", "features.1.0.attn.relative_coords_table", "features.1.0.attn.relative_position_index",
+              "features.5.5.mlp.3.weight", "features.2.reduction.weight", "features.6.norm.bias", "features.7.1.norm2.weight", "norm.weight", "head.bias"):
+        assert k in sd, k
+    assert not any(".stochastic_depth." in k or k.startswith("permute") for k in sd)
+    assert sum(p.numel() for p in get_model("swin_v2_s").parameters()) == 49_737_442
+    assert sum(p.numel() for p in get_model("swin_v2_b").parameters()) == 87_930_848
+
+
+def test_default_style_agg_builds_the_hip_swin_embedder():
+    """conf/config_diff.yaml:16 `style_agg: linear` (and README's `mean`) with style_sampling mp: S_ZSS_DM builds swin_v2_t with the
+    Linear(768, 512) head (networks/s_zss_dm.py:19-20) on the HIP-backed containers, no torchvision needed; oracle tables agree."""
+    from oracle import swin as osw
+    from stedm_amd.latent_diffusion import S_ZSS_DM
+    from stedm_amd.swin import SwinTransformerV2
+    from stedm_amd.unet import UNetModel
+    tiny = dict(image_size=16, in_channels=7, model_channels=32, out_channels=4, num_res_blocks=1, attention_resolutions=[32], channel_mult=[1, 2],
+                num_heads=4)
+    from types import SimpleNamespace
+    mp = SimpleNamespace(name="mp", num_patches=4)
+    zm = S_ZSS_DM("swin_v2_t", mp, SimpleNamespace(name="linear"), {"data": {"patch_size": 512}}, UNetModel(**tiny),
+                  conditioning_key="hybrid", image_size=16, channels=4, cond_stage_key="segmentation")
+    emb = zm.agg_block.embedder
+    assert isinstance(emb, SwinTransformerV2) and tuple(emb.head.weight.shape) == (512, 768)
+    assert "agg_block.embedder.features.5.3.attn.cpb_mlp.2.weight" in zm.state_dict() and "agg_block.linear_block.1.weight" in zm.state_dict()
+    at = emb.features[1][1].attn
+    assert at.shift_size == [4, 4] and emb.features[1][0].attn.shift_size == [0, 0]
+    assert torch.equal(at.relative_position_index.view(64, 64), osw.relative_position_index())
+    assert torch.equal(at.relative_coords_table.view(-1, 2), osw.relative_coords_table())
+    assert float(at.qkv.bias[96:192].abs().max()) == 0.0
+    import pytest
+    with pytest.raises(NotImplementedError):
+        S_ZSS_DM("resnet50", mp, SimpleNamespace(name="mean"), {"data": {"patch_size": 512}}, UNetModel(**tiny),
+                 conditioning_key="hybrid", image_size=16, channels=4, cond_stage_key="segmentation")
+
+
+def test_oracle_swin_window_attention_matches_per_window_bruteforce():
+    """The oracle's roll / reshape / mask form against a literal per-token loop over one shifted, padded map."""
+    import math
+    import torch.nn.functional as F
+    from oracle import swin as osw
+    from stedm_amd.swin import ShiftedWindowAttentionV2
+    torch.manual_seed(0)
+    C, heads, H, W, shift = 64, 2, 12, 20, 4
+    at = ShiftedWindowAttentionV2(C, [8, 8], [shift, shift], heads)
+    p = {k: v.clone() for k, v in at.state_dict().items()}
+    p["qkv.weight"] = torch.randn(3 * C, C) / 8
+    p["qkv.bias"] = torch.randn(3 * C) * 0.1
+    p["proj.weight"], p["proj.bias"] = torch.eye(C), torch.zeros(C)
+    p["cpb_mlp.0.weight"], p["cpb_mlp.0.bias"], p["cpb_mlp.2.weight"] = torch.randn(512, 2), torch.randn(512) * 0.1, torch.randn(heads, 512) / 22
+    x = torch.randn(1, H, W, C)
+    want = osw.window_attention(x, p, "", heads, shift)
+    pH, pW = 16, 24
+    bz = p["qkv.bias"].clone(); bz[C:2 * C] = 0
+    xp = F.pad(x, (0, 0, 0, pW - W, 0, pH - H))
+    qkv = F.linear(xp, p["qkv.weight"], bz)[0]                       # [pH, pW, 3C], pad rows = bias
+    bias = osw.position_bias(p, "", heads)
+    scale = torch.clamp(p["logit_scale"], max=math.log(100.0)).exp().reshape(-1)
+    region = lambda v, n: 0 if v < n - 8 else (1 if v < n - shift else 2)
+    got = torch.zeros(H, W, C)
+    for wy in range(pH // 8):
+        for wx in range(pW // 8):
+            toks = [((wy * 8 + i // 8), (wx * 8 + i % 8)) for i in range(64)]            # rolled-frame positions
+            src = [((ys + shift) % pH, (xs + shift) % pW) for ys, xs in toks]
+            ids = [region(ys, pH) * 3 + region(xs, pW) for ys, xs in toks]
+            for hd in range(heads):
+                sl = slice(hd * 32, hd * 32 + 32)
+                q = torch.stack([qkv[y, x_, :C][sl] for y, x_ in src]); k = torch.stack([qkv[y, x_, C:2 * C][sl] for y, x_ in src])
+                v = torch.stack([qkv[y, x_, 2 * C:][sl] for y, x_ in src])
+                a = F.normalize(q, dim=-1) @ F.normalize(k, dim=-1).T * scale[hd] + bias[hd]
+                m = torch.tensor([[0.0 if ids[i] == ids[j] else -100.0 for j in range(64)] for i in range(64)])
+                o = F.softmax(a + m, dim=-1) @ v
+                for i, (y, x_) in enumerate(src):
+                    if y < H and x_ < W:
+                        got[y, x_, sl] = o[i]
+    assert float((got - want[0]).abs().max()) < 1e-5
