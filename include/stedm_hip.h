@@ -309,19 +309,20 @@ int stedm_swin_patch16(const float* img, long sn, long sc, long sh, long sw, int
  * fp32 rows (out, may be NULL) and / or 16-bit operand planes (out_hi / out_lo, may be NULL). res may alias out. */
 int stedm_swin_ln(const float* y, const float* gamma, const float* beta, float eps, const float* res, float* out, void* out_hi,
                   void* out_lo, long rows, int dim, int mm_dtype, void* stream);
-/* torchvision shifted_window_attention with ShiftedWindowAttentionV2's cosine logits, 8 x 8 windows, head dim 32:
- * qkv [N*H*W][3C] fp32 in token order (bias included, k bias zeroed) -> softmax(normalize(q) normalize(k)^T * scale[h] + rpb + mask) v
- * as the 16-bit plane [N*H*W][C] `proj` consumes. Cyclic shift, window partition, F.pad rows (q = bias_q, k = 0, v = bias_v) and their
- * inverses are index arithmetic. bias_kzero [3C]; scale [heads] = exp(min(logit_scale, log 100)); rpbT [heads][key][query] =
- * 16 sigmoid(cpb_mlp(relative_coords_table))[relative_position_index]. A side no larger than the window is not shifted. */
-int stedm_swin_window_attn(const float* qkv, const float* bias_kzero, const float* scale, const float* rpbT, void* out_hi, void* out_lo,
-                           int N, int H, int W, int C, int heads, int shift, int mm_dtype, void* stream);
+/* torchvision shifted_window_attention with ShiftedWindowAttentionV2's cosine logits, 8 x 8 windows, head dim 32, on MFMA (npass 1: single
+ * product; 3: hi/lo split products, the parity mode): qkv [N*H*W][3C] fp32 in token order (bias included, k bias zeroed) ->
+ * softmax(normalize(q) normalize(k)^T * scale[h] + rpb + mask) v as the 16-bit plane(s) [N*H*W][C] `proj` consumes. Cyclic shift, window
+ * partition, F.pad rows (q = bias_q, k = 0, v = bias_v) and their inverses are index arithmetic; normalisation, logits and softmax are fp32.
+ * bias_kzero [3C]; scale [heads] = exp(min(logit_scale, log 100)); rpb [heads][query][key] = 16 sigmoid(cpb_mlp(relative_coords_table))
+ * [relative_position_index]. A side no larger than the window is not shifted. */
+int stedm_swin_window_attn(const float* qkv, const float* bias_kzero, const float* scale, const float* rpb, void* out_hi, void* out_lo,
+                           int N, int H, int W, int C, int heads, int shift, int npass, int mm_dtype, void* stream);
 /* PatchMergingV2's input: x [N][H][W][C] fp32 -> 16-bit operand rows [N*ceil(H/2)*ceil(W/2)][4C] = [x(0,0) | x(1,0) | x(0,1) | x(1,1)]
  * (zero beyond an odd side). */
 int stedm_swin_merge16(const float* x, int N, int H, int W, int C, void* out_hi, void* out_lo, int mm_dtype, void* stream);
 /* ShiftedWindowAttentionV2.get_relative_position_bias: cpb [ntab][heads] = cpb_mlp(relative_coords_table) (two stedm_linear calls),
- * index [64*64] int64 = relative_position_index (query-major) -> rpbT [heads][key][query] = 16 sigmoid(cpb[index]). */
-int stedm_swin_rpb(const float* cpb, const long* index, float* rpbT, int heads, int ntab, void* stream);
+ * index [64*64] int64 = relative_position_index (query-major) -> rpb [heads][query][key] = 16 sigmoid(cpb[index]). */
+int stedm_swin_rpb(const float* cpb, const long* index, float* rpb, int heads, int ntab, void* stream);
 /* AdaptiveAvgPool2d(1) over the tokens: x [N][T][C] -> out [N][C]. */
 int stedm_swin_token_mean(const float* x, float* out, int N, int T, int C, void* stream);
 

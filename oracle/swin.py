@@ -46,7 +46,7 @@ def relative_position_index(ws: int = WS) -> torch.Tensor:
 
 def position_bias(p: Params, pre: str, heads: int) -> torch.Tensor:
     """16 sigmoid(cpb_mlp(table))[index] -> [heads, ws^2, ws^2]. The table / index are recomputed (they are constants of the layer)."""
-    t = relative_coords_table()
+    t = relative_coords_table().to(p[pre + "cpb_mlp.0.weight"].dtype)
     h = F.relu(F.linear(t, p[pre + "cpb_mlp.0.weight"], p[pre + "cpb_mlp.0.bias"]))
     cpb = F.linear(h, p[pre + "cpb_mlp.2.weight"])                    # [(2ws-1)^2, heads]
     idx = relative_position_index()

@@ -7,15 +7,16 @@
 //                       (k = c*16 + ky*4 + kx, the OIHW order of the conv weight; columns 48..63 zero), any input strides
 //   swin_ln           : out = res + LayerNorm(y) (post-norm residual of SwinTransformerBlockV2; res NULL: the plain LayerNorms of
 //                       features[0][2], PatchMergingV2.norm and the final norm) as fp32 rows and / or 16-bit operand planes
-//   swin_window_attn  : shifted_window_attention with cosine logits (ShiftedWindowAttentionV2): cyclic shift + window partition as index
-//                       arithmetic, F.normalize(q) . F.normalize(k) * exp(min(logit_scale, log 100)) + 16 sigmoid(cpb) + shift mask,
-//                       softmax, P V, written back at the tokens' own positions as the 16-bit plane `proj` consumes. Windows that hang
-//                       over the feature map (F.pad) see zero rows: q = q_bias, k = 0, v = v_bias, exactly as the padded Linear gives.
+//   swin_window_attn  : shifted_window_attention with cosine logits (ShiftedWindowAttentionV2) on MFMA, one wave per (window, head): cyclic
+//                       shift + window partition as index arithmetic, F.normalize(q) . F.normalize(k) * exp(min(logit_scale, log 100)) +
+//                       16 sigmoid(cpb) + shift mask, softmax, P V, written back at the tokens' own positions as the 16-bit plane `proj`
+//                       consumes. Windows that hang over the feature map (F.pad) see zero rows: q = q_bias, k = 0, v = v_bias, exactly as
+//                       the padded Linear gives.
 //   swin_merge16      : PatchMergingV2's 2x2 neighbourhood concat [x(0,0) | x(1,0) | x(0,1) | x(1,1)] -> 16-bit operand rows [tok][4C]
 //   swin_token_mean   : AdaptiveAvgPool2d(1) over the tokens of an image
 #include <float.h>
 
-#include "common.hpp"
+#include "conv_common.hpp"
 using namespace stedm;
 
 namespace {
@@ -68,110 +69,238 @@ __global__ void __launch_bounds__(256) swin_ln_kernel(const float* __restrict__ 
   }
 }
 
+// A product that is split into hi / lo planes goes through this first: hipcc otherwise folds `(T)(x * y)` into v_fma_mixlo_f16 (ONE rounding)
+// where it rematerialises the hi part and keeps mul + cvt (two roundings) where it stores it; near a tie the stored hi and the hi its lo
+// was taken against then differ by an fp16 ulp.
+__device__ __forceinline__ float rounded(float v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 struct SwinAttnArgs {
   const float* qkv;     // [N*H*W][3C]  ('(three heads d)' columns, bias included)
   const float* bias;    // [3C] the Linear's bias with the k third zeroed (pad rows)
   const float* scale;   // [heads] exp(min(logit_scale, log 100))
-  const float* rpbT;    // [heads][64 keys][64 queries] 16 * sigmoid(cpb_mlp(table))[index], key-major so that a wave reads rows
+  const float* rpb;     // [heads][64 queries][64 keys] 16 * sigmoid(cpb_mlp(table))[index]
   void* hi;             // [N*H*W][C]
   void* lo;
-  int H, W, C, heads, shift_h, shift_w, padH, padW;
+  int H, W, C, heads, shift_h, shift_w, padH, padW, nprob;
 };
 
-// one wave per (window, head): lane = query token of the 8 x 8 window, head dim 32
-template <typename T>
-__global__ void __launch_bounds__(64) swin_window_attn_kernel(const SwinAttnArgs a) {
-  __shared__ __attribute__((aligned(16))) float sk[64][32];
-  __shared__ __attribute__((aligned(16))) float sv[64][32];
-  __shared__ int sid[64];
-  const int lane = threadIdx.x;
-  const int nwx = a.padW >> 3;
-  const int wy = blockIdx.x / nwx, wx = blockIdx.x % nwx;
-  const int h = blockIdx.y;
-  const long n = blockIdx.z;
-  const int ys = wy * 8 + (lane >> 3), xs = wx * 8 + (lane & 7);        // position in the shifted (rolled) frame
-  int y = ys + a.shift_h; if (y >= a.padH) y -= a.padH;                  // torch.roll(x, -shift): rolled[ys] = x[(ys + shift) % pad]
-  int x = xs + a.shift_w; if (x >= a.padW) x -= a.padW;
-  const bool valid = y < a.H && x < a.W;
-  const long tok = (n * a.H + y) * a.W + x;
-  const int C = a.C, c0 = h * 32;
-  float q[32], o[32];
+// One wave per (window, head), 4 per block: the 64 x 64 x 32 attention of an 8 x 8 window on the wave's MFMAs (the form of attn64_mfma_kernel,
+// attn.hip). The wave gathers its 64 token rows (coalesced: 8 lanes x 16 B per row), L2-normalises q and k in fp32, rounds to the MFMA type
+// (NPASS 3: hi + lo planes, products hi.hi + hi.lo + lo.hi) and keeps q, k [64][32] and V^T [32][64] in LDS.
+//   S^T = K Q^T (keys on the rows: a query's softmax is a reduction over the lane's registers plus one cross-half exchange), logits =
+//   S^T * scale + bias (+ -100 across shift regions), P = exp(. - max) stays in the accumulators and is the B operand of O^T = V^T P as it
+//   lies: k-slot j of k-step (it, u) of lane half h is key (j&3) + 8(2u + (j>>2)) + 4h + 32 it, and V^T is read in that order.
+template <typename T, int NPASS>
+__global__ void __launch_bounds__(256) swin_window_attn_kernel(const SwinAttnArgs a) {
+  using V8 = typename MM<T>::V8;
+  typedef T V4T __attribute__((ext_vector_type(4)));
+  constexpr int QS = 40, VS = 72;                       // row strides in elements (80 B / 144 B: 16-B resp. 8-B aligned rows, skewed banks)
+  constexpr int PLANE = 2 * 64 * QS + 32 * VS;
+  constexpr int NPL = NPASS == 3 ? 2 : 1;
+  // split-product mode: operands are scaled by exact powers of two before the hi / lo split so that the lo parts (2^-12 of the value) stay
+  // above fp16's normal range — normalised q, k entries are ~0.2 and P <= 1, whose lo parts would be subnormal; folded back into the
+  // logits scale and the softmax normalisation
+  constexpr float QKS = NPASS == 3 ? 64.f : 1.f, PS = NPASS == 3 ? 1024.f : 1.f, VSC = NPASS == 3 ? 64.f : 1.f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T* sq = reinterpret_cast<T*>(smem_) + wave * NPL * PLANE;
+  T* sk = sq + 64 * QS;
+  T* sv = sk + 64 * QS;
+  int* sid = reinterpret_cast<int*>(reinterpret_cast<T*>(smem_) + 4 * NPL * PLANE) + wave * 64;
+  int prob = blockIdx.x * 4 + wave;
+  const bool live = prob < a.nprob;
+  if (!live) prob = a.nprob - 1;
+  const int nwx = a.padW >> 3, nW = nwx * (a.padH >> 3);
+  const int win = prob % nW, hd = (prob / nW) % a.heads;
+  const long n = prob / (nW * a.heads);
+  const int wy = win / nwx, wx = win % nwx;
+  const int C = a.C, c0 = hd * 32;
+  const bool masked = (a.shift_h | a.shift_w) != 0;
+  // token t of the window (row t >> 3, column t & 7 of the rolled frame) -> source token (torch.roll(x, -shift): rolled[ys] = x[(ys + shift) % pad])
+  auto source = [&](int t, long& tok) {
+    int y = wy * 8 + (t >> 3) + a.shift_h; if (y >= a.padH) y -= a.padH;
+    int x = wx * 8 + (t & 7) + a.shift_w; if (x >= a.padW) x -= a.padW;
+    tok = (n * a.H + y) * a.W + x;
+    return y < a.H && x < a.W;
+  };
   {
-    const float* pq = valid ? a.qkv + tok * (3L * C) + c0 : a.bias + c0;
-    const float* pk = pq + C;
-    const float* pv = pq + 2 * C;
-    float kk[32];
-    float nq = 0.f, nk = 0.f;
+    const int sub = lane & 7, tg = lane >> 3;
 #pragma unroll
-    for (int d = 0; d < 32; d += 4) {
-      const float4 q4 = *reinterpret_cast<const float4*>(pq + d);
-      const float4 k4 = *reinterpret_cast<const float4*>(pk + d);
-      const float4 v4 = *reinterpret_cast<const float4*>(pv + d);
-      q[d] = q4.x; q[d + 1] = q4.y; q[d + 2] = q4.z; q[d + 3] = q4.w;
-      kk[d] = k4.x; kk[d + 1] = k4.y; kk[d + 2] = k4.z; kk[d + 3] = k4.w;
-      *reinterpret_cast<float4*>(&sv[lane][d]) = v4;
+    for (int i = 0; i < 8; ++i) {
+      const int t = 8 * i + tg;
+      long tok;
+      const bool valid = source(t, tok);
+      const float* pq = (valid ? a.qkv + tok * (3L * C) : a.bias) + c0 + 4 * sub;      // F.pad rows: the Linear of a zero row is its bias
+      const float4 q4 = *reinterpret_cast<const float4*>(pq);
+      const float4 k4 = *reinterpret_cast<const float4*>(pq + C);
+      const float4 v4 = *reinterpret_cast<const float4*>(pq + 2 * C);
+      float nq = q4.x * q4.x + q4.y * q4.y + q4.z * q4.z + q4.w * q4.w;
+      float nk = k4.x * k4.x + k4.y * k4.y + k4.z * k4.z + k4.w * k4.w;
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) { nq += __shfl_xor(nq, o, 64); nk += __shfl_xor(nk, o, 64); }
+      // F.normalize(p=2, eps=1e-12): v / max(||v||, eps)
+      const float rq = QKS / fmaxf(sqrtf(nq), 1e-12f), rk = QKS / fmaxf(sqrtf(nk), 1e-12f);
+      float qf[4] = {q4.x * rq, q4.y * rq, q4.z * rq, q4.w * rq};
+      float kf[4] = {k4.x * rk, k4.y * rk, k4.z * rk, k4.w * rk};
+      float vf[4] = {v4.x * VSC, v4.y * VSC, v4.z * VSC, v4.w * VSC};
+      if (NPASS == 3) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { qf[u] = rounded(qf[u]); kf[u] = rounded(kf[u]); vf[u] = rounded(vf[u]); }
+      }
+      V4T qh, kh, ql, kl;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        qh[u] = (T)qf[u]; kh[u] = (T)kf[u];
+        ql[u] = (T)(qf[u] - (float)qh[u]); kl[u] = (T)(kf[u] - (float)kh[u]);
+        const T vh = (T)vf[u];
+        sv[(4 * sub + u) * VS + t] = vh;
+        if (NPASS == 3) sv[PLANE + (4 * sub + u) * VS + t] = (T)(vf[u] - (float)vh);
+      }
+      *reinterpret_cast<V4T*>(sq + t * QS + 4 * sub) = qh;
+      *reinterpret_cast<V4T*>(sk + t * QS + 4 * sub) = kh;
+      if (NPASS == 3) {
+        *reinterpret_cast<V4T*>(sq + PLANE + t * QS + 4 * sub) = ql;
+        *reinterpret_cast<V4T*>(sk + PLANE + t * QS + 4 * sub) = kl;
+      }
+      if (masked && sub == 0) {
+        // shift-mask regions of the rolled frame: [0, pad-8) / [pad-8, pad-shift) / [pad-shift, pad) per side (an unshifted side is one
+        // region: torchvision's third slice [-0:] then covers, and overwrites, the whole side)
+        const int ys = wy * 8 + i, xs = wx * 8 + tg;
+        const int ih = !a.shift_h ? 0 : (ys < a.padH - 8 ? 0 : (ys < a.padH - a.shift_h ? 1 : 2));
+        const int iw = !a.shift_w ? 0 : (xs < a.padW - 8 ? 0 : (xs < a.padW - a.shift_w ? 1 : 2));
+        sid[t] = ih * 3 + iw;
+      }
     }
-#pragma unroll
-    for (int d = 0; d < 32; ++d) { nq += q[d] * q[d]; nk += kk[d] * kk[d]; }
-    // F.normalize(p=2, eps=1e-12): v / max(||v||, eps)
-    const float rq = 1.0f / fmaxf(sqrtf(nq), 1e-12f), rk = 1.0f / fmaxf(sqrtf(nk), 1e-12f);
-#pragma unroll
-    for (int d = 0; d < 32; ++d) { q[d] *= rq; kk[d] *= rk; }
-#pragma unroll
-    for (int d = 0; d < 32; d += 4) *reinterpret_cast<float4*>(&sk[lane][d]) = make_float4(kk[d], kk[d + 1], kk[d + 2], kk[d + 3]);
   }
-  // shift mask regions of the rolled frame: rows [0, pad-ws) / [pad-ws, pad-shift) / [pad-shift, pad), same for columns
-  int rid = 0;
-  if (a.shift_h | a.shift_w) {
-    // (an unshifted side is one region: torchvision's third slice [-0:] then covers, and overwrites, the whole side)
-    const int ih = !a.shift_h ? 0 : (ys < a.padH - 8 ? 0 : (ys < a.padH - a.shift_h ? 1 : 2));
-    const int iw = !a.shift_w ? 0 : (xs < a.padW - 8 ? 0 : (xs < a.padW - a.shift_w ? 1 : 2));
-    rid = ih * 3 + iw;
-  }
-  sid[lane] = rid;
   __syncthreads();
-  const float sc = a.scale[h];
-  const float* rp = a.rpbT + (long)h * 4096 + lane;
-  float s[64];
-  float mx = -FLT_MAX;
+  const int r = lane & 31, h = lane >> 5;
+  f32x16 st[2][2];
 #pragma unroll
-  for (int j = 0; j < 64; ++j) {
-    float acc = 0.f;
+  for (int it = 0; it < 2; ++it)
 #pragma unroll
-    for (int d = 0; d < 32; d += 4) {
-      const float4 k4 = *reinterpret_cast<const float4*>(&sk[j][d]);
-      acc += q[d] * k4.x; acc += q[d + 1] * k4.y; acc += q[d + 2] * k4.z; acc += q[d + 3] * k4.w;
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[it][jt][e] = 0.f;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    V8 ka[2], qb[2], kal[2], qbl[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      ka[it] = *reinterpret_cast<const V8*>(sk + (32 * it + r) * QS + 16 * s + 8 * h);
+      qb[it] = *reinterpret_cast<const V8*>(sq + (32 * it + r) * QS + 16 * s + 8 * h);
+      if (NPASS == 3) {
+        kal[it] = *reinterpret_cast<const V8*>(sk + PLANE + (32 * it + r) * QS + 16 * s + 8 * h);
+        qbl[it] = *reinterpret_cast<const V8*>(sq + PLANE + (32 * it + r) * QS + 16 * s + 8 * h);
+      }
     }
-    float v = acc * sc + rp[j * 64];
-    if (sid[j] != rid) v += -100.0f;
-    s[j] = v;
-    mx = fmaxf(mx, v);
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        st[it][jt] = MM<T>::mfma(ka[it], qb[jt], st[it][jt]);
+        if (NPASS == 3) {
+          st[it][jt] = MM<T>::mfma(ka[it], qbl[jt], st[it][jt]);
+          st[it][jt] = MM<T>::mfma(kal[it], qb[jt], st[it][jt]);
+        }
+      }
   }
-  float sum = 0.f;
+  // logits of query column q = 32 jt + r over keys (e&3) + 8(e>>2) + 4h + 32 it; softmax: 32 values here, 32 in lane ^ 32
+  const float sc = a.scale[hd] * (1.0f / (QKS * QKS));
+  float inv[2];
 #pragma unroll
-  for (int d = 0; d < 32; ++d) o[d] = 0.f;
+  for (int jt = 0; jt < 2; ++jt) {
+    const int q = 32 * jt + r;
+    const float* rp = a.rpb + ((long)hd * 64 + q) * 64 + 4 * h;
+    const int rq = masked ? sid[q] : 0;
+    float m = -FLT_MAX;
 #pragma unroll
-  for (int j = 0; j < 64; ++j) {
-    const float pj = __expf(s[j] - mx);
-    sum += pj;
+    for (int it = 0; it < 2; ++it)
 #pragma unroll
-    for (int d = 0; d < 32; d += 4) {
-      const float4 v4 = *reinterpret_cast<const float4*>(&sv[j][d]);
-      o[d] += pj * v4.x; o[d + 1] += pj * v4.y; o[d + 2] += pj * v4.z; o[d + 3] += pj * v4.w;
+      for (int eq = 0; eq < 4; ++eq) {
+        const float4 b4 = *reinterpret_cast<const float4*>(rp + 32 * it + 8 * eq);
+        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float v = st[it][jt][4 * eq + k] * sc + bb[k];
+          if (masked && sid[32 * it + 8 * eq + 4 * h + k] != rq) v += -100.0f;
+          st[it][jt][4 * eq + k] = v;
+          m = fmaxf(m, v);
+        }
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = __expf(st[it][jt][e] - m);
+        st[it][jt][e] = pv;
+        sum += pv;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    inv[jt] = 1.0f / (sum * (PS * VSC));
+  }
+  // O^T[d][q] = sum_k V[k][d] P[k][q]
+  f32x16 ot[2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ot[jt][e] = 0.f;
+#pragma unroll
+  for (int it = 0; it < 2; ++it)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      V8 pb[2], pbl[2];
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float pv = NPASS == 3 ? rounded(st[it][jt][8 * u + j] * PS) : st[it][jt][8 * u + j];
+          pb[jt][j] = (T)pv;
+          if (NPASS == 3) pbl[jt][j] = (T)(pv - (float)pb[jt][j]);
+        }
+      const T* vrow = sv + r * VS + 32 * it + 16 * u + 4 * h;      // keys (j&3) + 8(2u + (j>>2)) + 4h + 32 it of channel r
+      const V4T v0 = *reinterpret_cast<const V4T*>(vrow), v1 = *reinterpret_cast<const V4T*>(vrow + 8);
+      V8 va, val;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { va[j] = v0[j]; va[4 + j] = v1[j]; }
+      if (NPASS == 3) {
+        const V4T l0 = *reinterpret_cast<const V4T*>(vrow + PLANE), l1 = *reinterpret_cast<const V4T*>(vrow + PLANE + 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { val[j] = l0[j]; val[4 + j] = l1[j]; }
+      }
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        ot[jt] = MM<T>::mfma(va, pb[jt], ot[jt]);
+        if (NPASS == 3) {
+          ot[jt] = MM<T>::mfma(va, pbl[jt], ot[jt]);
+          ot[jt] = MM<T>::mfma(val, pb[jt], ot[jt]);
+        }
+      }
     }
-  }
-  if (!valid) return;
-  const float inv = 1.0f / sum;
-  T* ph = reinterpret_cast<T*>(a.hi) + tok * C + c0;
-  T* pl = a.lo ? reinterpret_cast<T*>(a.lo) + tok * C + c0 : nullptr;
-  typedef T V8 __attribute__((ext_vector_type(8)));
+  if (!live) return;
+  // lane (query 32 jt + r) holds channels (e&3) + 8(e>>2) + 4h: 4 consecutive channels per e-quad -> 8-B stores at the token's own row
 #pragma unroll
-  for (int d = 0; d < 32; d += 8) {
-    V8 h8, l8;
+  for (int jt = 0; jt < 2; ++jt) {
+    long tok;
+    if (!source(32 * jt + r, tok)) continue;
+    T* ph = reinterpret_cast<T*>(a.hi) + tok * C + c0 + 4 * h;
+    T* pl = a.lo ? reinterpret_cast<T*>(a.lo) + tok * C + c0 + 4 * h : nullptr;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { const float v = o[d + u] * inv; h8[u] = (T)v; l8[u] = (T)(v - (float)h8[u]); }
-    *reinterpret_cast<V8*>(ph + d) = h8;
-    if (pl) *reinterpret_cast<V8*>(pl + d) = l8;
+    for (int eq = 0; eq < 4; ++eq) {
+      V4T vh, vl;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float v = NPASS == 3 ? rounded(ot[jt][eq * 4 + k] * inv[jt]) : ot[jt][eq * 4 + k] * inv[jt];
+        vh[k] = (T)v;
+        vl[k] = (T)(v - (float)vh[k]);
+      }
+      *reinterpret_cast<V4T*>(ph + 8 * eq) = vh;
+      if (pl) *reinterpret_cast<V4T*>(pl + 8 * eq) = vl;
+    }
   }
 }
 
@@ -201,13 +330,13 @@ __global__ void __launch_bounds__(256) swin_merge16_kernel(const float* __restri
   if (lo) *reinterpret_cast<V4*>(lo + o) = l4;
 }
 
-// rpbT[h][key j][query i] = 16 sigmoid(cpb[index[i * 64 + j]][h]) (ShiftedWindowAttentionV2.get_relative_position_bias)
+// rpb[h][query i][key j] = 16 sigmoid(cpb[index[i * 64 + j]][h]) (ShiftedWindowAttentionV2.get_relative_position_bias)
 __global__ void __launch_bounds__(256) swin_rpb_kernel(const float* __restrict__ cpb, const long* __restrict__ index, float* __restrict__ out,
                                                        int heads, int ntab) {
   const int i = blockIdx.x * 256 + threadIdx.x;   // over heads * 4096
   if (i >= heads * 4096) return;
-  const int h = i >> 12, j = (i >> 6) & 63, q = i & 63;
-  long e = index[q * 64 + j];
+  const int h = i >> 12;
+  long e = index[i & 4095];
   e = e < 0 ? 0 : (e >= ntab ? ntab - 1 : e);
   out[i] = 16.0f / (1.0f + __expf(-cpb[e * heads + h]));
 }
@@ -254,22 +383,35 @@ extern "C" int stedm_swin_ln(const float* y, const float* gamma, const float* be
   return 0;
 }
 
-extern "C" int stedm_swin_window_attn(const float* qkv, const float* bias_kzero, const float* scale, const float* rpbT, void* out_hi, void* out_lo,
-                                      int N, int H, int W, int C, int heads, int shift, int mm_dtype, void* stream) {
-  STEDM_CHECK_ARG(qkv && bias_kzero && scale && rpbT && out_hi && N > 0 && H > 0 && W > 0, "swin_window_attn: bad args");
+extern "C" int stedm_swin_window_attn(const float* qkv, const float* bias_kzero, const float* scale, const float* rpb, void* out_hi, void* out_lo,
+                                      int N, int H, int W, int C, int heads, int shift, int npass, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(qkv && bias_kzero && scale && rpb && out_hi && N > 0 && H > 0 && W > 0, "swin_window_attn: bad args");
   STEDM_CHECK_ARG(heads > 0 && C == heads * 32, "swin_window_attn: head dim must be 32 (C=%d heads=%d): swin_v2_t/s/b", C, heads);
   STEDM_CHECK_ARG(shift >= 0 && shift < 8, "swin_window_attn: shift %d outside the 8 x 8 window", shift);
-  STEDM_CHECK_ARG(N <= 65535 && heads <= 65535, "swin_window_attn: grid limits (N=%d)", N);
+  STEDM_CHECK_ARG((npass == 1 || npass == 3) && (npass == 1 || out_lo), "swin_window_attn: npass must be 1 or 3 (3 writes out_lo)");
   SwinAttnArgs a;
-  a.qkv = qkv; a.bias = bias_kzero; a.scale = scale; a.rpbT = rpbT; a.hi = out_hi; a.lo = out_lo;
+  a.qkv = qkv; a.bias = bias_kzero; a.scale = scale; a.rpb = rpb; a.hi = out_hi; a.lo = npass == 3 ? out_lo : nullptr;
   a.H = H; a.W = W; a.C = C; a.heads = heads;
   a.padH = (H + 7) / 8 * 8; a.padW = (W + 7) / 8 * 8;
   // "if window size is larger than feature size, there is no need to shift window" (torchvision shifted_window_attention)
   a.shift_h = 8 >= a.padH ? 0 : shift;
   a.shift_w = 8 >= a.padW ? 0 : shift;
-  const dim3 grid((a.padH / 8) * (a.padW / 8), heads, N);
-  if (mm_dtype == STEDM_F16) swin_window_attn_kernel<_Float16><<<grid, 64, 0, as_stream(stream)>>>(a);
-  else swin_window_attn_kernel<__bf16><<<grid, 64, 0, as_stream(stream)>>>(a);
+  const long nprob = (long)N * (a.padH / 8) * (a.padW / 8) * heads;
+  STEDM_CHECK_ARG(nprob < (1L << 31), "swin_window_attn: too many windows (%ld)", nprob);
+  a.nprob = (int)nprob;
+  const unsigned grid = (unsigned)((nprob + 3) / 4);
+  constexpr int kPlaneBytes = (2 * 64 * 40 + 32 * 72) * 2;
+  const size_t lds = (size_t)4 * (npass == 3 ? 2 : 1) * kPlaneBytes + 4 * 64 * sizeof(int);
+  hipStream_t st = as_stream(stream);
+#define LAUNCH_SWIN_ATTN(TT, NP)                                                                                                          \
+  {                                                                                                                                       \
+    if (lds > 64 * 1024)                                                                                                                  \
+      STEDM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(swin_window_attn_kernel<TT, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    swin_window_attn_kernel<TT, NP><<<grid, 256, lds, st>>>(a);                                                                           \
+  }
+  if (mm_dtype == STEDM_F16) { if (npass == 3) LAUNCH_SWIN_ATTN(_Float16, 3) else LAUNCH_SWIN_ATTN(_Float16, 1) }
+  else { if (npass == 3) LAUNCH_SWIN_ATTN(__bf16, 3) else LAUNCH_SWIN_ATTN(__bf16, 1) }
+#undef LAUNCH_SWIN_ATTN
   STEDM_LAUNCH_CHECK();
   return 0;
 }
@@ -294,9 +436,9 @@ extern "C" int stedm_swin_token_mean(const float* x, float* out, int N, int T, i
   return 0;
 }
 
-extern "C" int stedm_swin_rpb(const float* cpb, const long* index, float* rpbT, int heads, int ntab, void* stream) {
-  STEDM_CHECK_ARG(cpb && index && rpbT && heads > 0 && ntab > 0, "swin_rpb: bad args");
-  swin_rpb_kernel<<<(heads * 4096 + 255) / 256, 256, 0, as_stream(stream)>>>(cpb, index, rpbT, heads, ntab);
+extern "C" int stedm_swin_rpb(const float* cpb, const long* index, float* rpb, int heads, int ntab, void* stream) {
+  STEDM_CHECK_ARG(cpb && index && rpb && heads > 0 && ntab > 0, "swin_rpb: bad args");
+  swin_rpb_kernel<<<(heads * 4096 + 255) / 256, 256, 0, as_stream(stream)>>>(cpb, index, rpb, heads, ntab);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

@@ -509,12 +509,13 @@ def swin_ln(y: torch.Tensor, gamma, beta, eps: float, res: Optional[torch.Tensor
                               y.numel() // dim, dim, prec.mm_dtype, _stream()), "stedm_swin_ln")
 
 
-def swin_window_attn(qkv: torch.Tensor, bias_kzero: torch.Tensor, scale: torch.Tensor, rpbT: torch.Tensor, hi: torch.Tensor,
+def swin_window_attn(qkv: torch.Tensor, bias_kzero: torch.Tensor, scale: torch.Tensor, rpb: torch.Tensor, hi: torch.Tensor,
                      lo: Optional[torch.Tensor], N: int, H: int, W: int, heads: int, shift: int, prec: Precision) -> None:
+    """rpb [heads, 64 queries, 64 keys]."""
     _chk(qkv, name="qkv")
     C = qkv.shape[-1] // 3
-    check(lib().stedm_swin_window_attn(qkv.data_ptr(), bias_kzero.data_ptr(), scale.data_ptr(), rpbT.data_ptr(), hi.data_ptr(), _ptr(lo),
-                                       N, H, W, C, heads, shift, prec.mm_dtype, _stream()), "stedm_swin_window_attn")
+    check(lib().stedm_swin_window_attn(qkv.data_ptr(), bias_kzero.data_ptr(), scale.data_ptr(), rpb.data_ptr(), hi.data_ptr(), _ptr(lo),
+                                       N, H, W, C, heads, shift, prec.npass, prec.mm_dtype, _stream()), "stedm_swin_window_attn")
 
 
 def swin_merge16(x: torch.Tensor, hi: torch.Tensor, lo: Optional[torch.Tensor], prec: Precision) -> None:
@@ -524,7 +525,7 @@ def swin_merge16(x: torch.Tensor, hi: torch.Tensor, lo: Optional[torch.Tensor], 
 
 
 def swin_rpb(cpb: torch.Tensor, index: torch.Tensor, heads: int) -> torch.Tensor:
-    """cpb [ntab, heads] fp32, index [4096] int64 -> rpbT [heads, 64, 64] (key-major) = 16 sigmoid(cpb[index])."""
+    """cpb [ntab, heads] fp32, index [4096] int64 (query-major) -> rpb [heads, 64 queries, 64 keys] = 16 sigmoid(cpb[index])."""
     _chk(cpb, name="cpb")
     assert index.dtype == torch.int64 and index.numel() == 4096 and index.is_cuda
     out = torch.empty((heads, 64, 64), dtype=torch.float32, device=cpb.device)

@@ -69,7 +69,7 @@ def test_swin_rpb_and_buffers_match_oracle(dev):
     table = at.relative_coords_table.reshape(-1, 2).contiguous()
     h1 = ops.linear(table, ops.transpose(l0.weight), l0.bias, torch.empty((225, 512), device=dev), act_out=2)
     cpb = ops.linear(h1, ops.transpose(l2.weight), None, torch.empty((225, 3), device=dev))
-    got = ops.swin_rpb(cpb, at.relative_position_index, 3).transpose(1, 2)
+    got = ops.swin_rpb(cpb, at.relative_position_index, 3)
     assert float((got.cpu() - want).abs().max()) < 2e-5
 
 
@@ -88,12 +88,12 @@ def test_swin_window_attention_kernel_vs_oracle(dev, H, W, shift):
     want = osw.window_attention(x, p, "", heads, shift)
     bz = p["qkv.bias"].clone(); bz[C:2 * C] = 0
     qkv = F.linear(x, p["qkv.weight"], bz).reshape(N * H * W, 3 * C).contiguous().to(dev)
-    rpbT = osw.position_bias(p, "", heads).transpose(1, 2).contiguous().to(dev)
+    rpb = osw.position_bias(p, "", heads).contiguous().to(dev)
     scale = torch.clamp(p["logit_scale"].reshape(-1), max=math.log(100.0)).exp().to(dev)
     prec = Precision.parse("parity")
     hi = torch.zeros((N * H * W, C), dtype=torch.int16, device=dev)
     lo = torch.zeros_like(hi)
-    ops.swin_window_attn(qkv, bz.to(dev), scale, rpbT, hi, lo, N, H, W, heads, shift, prec)
+    ops.swin_window_attn(qkv, bz.to(dev), scale, rpb, hi, lo, N, H, W, heads, shift, prec)
     got = (hi.view(torch.float16).float() + lo.view(torch.float16).float()).view(N, H, W, C)
     err = rel(got, want)
     print(f"[swin window attention {H}x{W} shift {shift}] {err:.2e}")
