@@ -306,9 +306,10 @@ int stedm_spatial_rescale(const float* x, const float* w, float* out, int B, int
 int stedm_swin_patch16(const float* img, long sn, long sc, long sh, long sw, int N, int H, int W, void* out_hi, void* out_lo,
                        int mm_dtype, void* stream);
 /* out = res + LayerNorm(y) over rows of `dim` (SwinTransformerBlockV2's post-norm residual x + norm(f(x)); res NULL: plain LayerNorm);
- * fp32 rows (out, may be NULL) and / or 16-bit operand planes (out_hi / out_lo, may be NULL). res may alias out. */
+ * fp32 rows (out, may be NULL) and / or 16-bit operand planes (out_hi / out_lo, may be NULL) of row stride ld16 >= dim elements (columns
+ * dim..ld16-1 are not written: a caller that pads K to the GEMM kernel's 64-channel chunks zeroes them once). res may alias out. dim <= 768. */
 int stedm_swin_ln(const float* y, const float* gamma, const float* beta, float eps, const float* res, float* out, void* out_hi,
-                  void* out_lo, long rows, int dim, int mm_dtype, void* stream);
+                  void* out_lo, long rows, int dim, int ld16, int mm_dtype, void* stream);
 /* torchvision shifted_window_attention with ShiftedWindowAttentionV2's cosine logits, 8 x 8 windows, head dim 32, on MFMA (npass 1: single
  * product; 3: hi/lo split products, the parity mode): qkv [N*H*W][3C] fp32 in token order (bias included, k bias zeroed) ->
  * softmax(normalize(q) normalize(k)^T * scale[h] + rpb + mask) v as the 16-bit plane(s) [N*H*W][C] `proj` consumes. Cyclic shift, window
@@ -316,7 +317,7 @@ int stedm_swin_ln(const float* y, const float* gamma, const float* beta, float e
  * bias_kzero [3C]; scale [heads] = exp(min(logit_scale, log 100)); rpb [heads][query][key] = 16 sigmoid(cpb_mlp(relative_coords_table))
  * [relative_position_index]. A side no larger than the window is not shifted. */
 int stedm_swin_window_attn(const float* qkv, const float* bias_kzero, const float* scale, const float* rpb, void* out_hi, void* out_lo,
-                           int N, int H, int W, int C, int heads, int shift, int npass, int mm_dtype, void* stream);
+                           int ld16, int N, int H, int W, int C, int heads, int shift, int npass, int mm_dtype, void* stream);
 /* PatchMergingV2's input: x [N][H][W][C] fp32 -> 16-bit operand rows [N*ceil(H/2)*ceil(W/2)][4C] = [x(0,0) | x(1,0) | x(0,1) | x(1,1)]
  * (zero beyond an odd side). */
 int stedm_swin_merge16(const float* x, int N, int H, int W, int C, void* out_hi, void* out_lo, int mm_dtype, void* stream);

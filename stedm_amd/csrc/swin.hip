@@ -42,39 +42,59 @@ __global__ void __launch_bounds__(256) swin_patch16_kernel(const float* __restri
   if (lo) lo[i] = (T)(v - (float)h);
 }
 
-// one wave per row
-template <typename T>
-__global__ void __launch_bounds__(256) swin_ln_kernel(const float* __restrict__ y, const float* __restrict__ g, const float* __restrict__ bt,
-                                                      float eps, const float* __restrict__ res, float* __restrict__ out, T* __restrict__ hi,
-                                                      T* __restrict__ lo, long rows, int dim) {
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int lane = threadIdx.x & 63;
-  const float* py = y + row * dim;
-  float s1 = 0.f;
-  for (int k = lane; k < dim; k += 64) s1 += py[k];
-  const float mean = wave_sum(s1) / dim;
-  float s2 = 0.f;
-  for (int k = lane; k < dim; k += 64) { const float d = py[k] - mean; s2 += d * d; }
-  const float rstd = 1.0f / sqrtf(wave_sum(s2) / dim + eps);
-  for (int k = lane; k < dim; k += 64) {
-    float v = (py[k] - mean) * rstd * g[k] + bt[k];
-    if (res) v += res[row * dim + k];
-    if (out) out[row * dim + k] = v;
-    if (hi) {
-      const T h = (T)v;
-      hi[row * dim + k] = h;
-      if (lo) lo[row * dim + k] = (T)(v - (float)h);
-    }
-  }
-}
-
 // A product that is split into hi / lo planes goes through this first: hipcc otherwise folds `(T)(x * y)` into v_fma_mixlo_f16 (ONE rounding)
 // where it rematerialises the hi part and keeps mul + cvt (two roundings) where it stores it; near a tie the stored hi and the hi its lo
 // was taken against then differ by an fp16 ulp.
 __device__ __forceinline__ float rounded(float v) {
   asm volatile("" : "+v"(v));
   return v;
+}
+
+// LPR lanes per row (32: two rows per wave for dim <= 192; 64 above), the row lives in registers (dim <= 12 * LPR): one global read per element
+template <typename T, int LPR>
+__global__ void __launch_bounds__(256) swin_ln_kernel(const float* __restrict__ y, const float* __restrict__ g, const float* __restrict__ bt,
+                                                      float eps, const float* __restrict__ res, float* __restrict__ out, T* __restrict__ hi,
+                                                      T* __restrict__ lo, long rows, int dim, int ld16) {
+  constexpr int RPB = 256 / LPR, NVMAX = 12;
+  const long row = (long)blockIdx.x * RPB + threadIdx.x / LPR;
+  if (row >= rows) return;
+  const int l = threadIdx.x % LPR;
+  const float* py = y + row * dim;
+  float v[NVMAX];
+  float s1 = 0.f;
+#pragma unroll
+  for (int j = 0; j < NVMAX; ++j) {
+    const int k = l + j * LPR;
+    v[j] = k < dim ? py[k] : 0.f;
+    s1 += v[j];
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+  const float mean = s1 / dim;
+  float s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < NVMAX; ++j) {
+    const float d = l + j * LPR < dim ? v[j] - mean : 0.f;
+    s2 += d * d;
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+  const float rstd = 1.0f / sqrtf(s2 / dim + eps);
+#pragma unroll
+  for (int j = 0; j < NVMAX; ++j) {
+    const int k = l + j * LPR;
+    if (k < dim) {
+      float w = (v[j] - mean) * rstd * g[k] + bt[k];
+      if (res) w += res[row * dim + k];
+      w = rounded(w);
+      if (out) out[row * dim + k] = w;
+      if (hi) {
+        const T h = (T)w;
+        hi[row * ld16 + k] = h;
+        if (lo) lo[row * ld16 + k] = (T)(w - (float)h);
+      }
+    }
+  }
 }
 
 struct SwinAttnArgs {
@@ -84,7 +104,7 @@ struct SwinAttnArgs {
   const float* rpb;     // [heads][64 queries][64 keys] 16 * sigmoid(cpb_mlp(table))[index]
   void* hi;             // [N*H*W][C]
   void* lo;
-  int H, W, C, heads, shift_h, shift_w, padH, padW, nprob;
+  int H, W, C, ld16, heads, shift_h, shift_w, padH, padW, nprob;
 };
 
 // One wave per (window, head), 4 per block: the 64 x 64 x 32 attention of an 8 x 8 window on the wave's MFMAs (the form of attn64_mfma_kernel,
@@ -287,8 +307,8 @@ __global__ void __launch_bounds__(256) swin_window_attn_kernel(const SwinAttnArg
   for (int jt = 0; jt < 2; ++jt) {
     long tok;
     if (!source(32 * jt + r, tok)) continue;
-    T* ph = reinterpret_cast<T*>(a.hi) + tok * C + c0 + 4 * h;
-    T* pl = a.lo ? reinterpret_cast<T*>(a.lo) + tok * C + c0 + 4 * h : nullptr;
+    T* ph = reinterpret_cast<T*>(a.hi) + tok * a.ld16 + c0 + 4 * h;
+    T* pl = a.lo ? reinterpret_cast<T*>(a.lo) + tok * a.ld16 + c0 + 4 * h : nullptr;
 #pragma unroll
     for (int eq = 0; eq < 4; ++eq) {
       V4T vh, vl;
@@ -371,27 +391,33 @@ extern "C" int stedm_swin_patch16(const float* img, long sn, long sc, long sh, l
 }
 
 extern "C" int stedm_swin_ln(const float* y, const float* gamma, const float* beta, float eps, const float* res, float* out, void* out_hi,
-                             void* out_lo, long rows, int dim, int mm_dtype, void* stream) {
+                             void* out_lo, long rows, int dim, int ld16, int mm_dtype, void* stream) {
   STEDM_CHECK_ARG(y && gamma && beta && (out || out_hi) && rows > 0 && dim > 0, "swin_ln: bad args");
   STEDM_CHECK_ARG(!out_lo || out_hi, "swin_ln: out_lo without out_hi");
-  const unsigned grid = (unsigned)((rows + 3) / 4);
-  if (mm_dtype == STEDM_F16)
-    swin_ln_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(y, gamma, beta, eps, res, out, (_Float16*)out_hi, (_Float16*)out_lo, rows, dim);
-  else
-    swin_ln_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(y, gamma, beta, eps, res, out, (__bf16*)out_hi, (__bf16*)out_lo, rows, dim);
+  STEDM_CHECK_ARG(dim <= 768, "swin_ln: rows of up to 768 channels (dim=%d)", dim);
+  STEDM_CHECK_ARG(!out_hi || ld16 >= dim, "swin_ln: ld16 %d < dim %d", ld16, dim);
+  hipStream_t st = as_stream(stream);
+#define LAUNCH_SWIN_LN(TT)                                                                                                                        \
+  {                                                                                                                                               \
+    if (dim <= 192) swin_ln_kernel<TT, 32><<<(unsigned)((rows + 7) / 8), 256, 0, st>>>(y, gamma, beta, eps, res, out, (TT*)out_hi, (TT*)out_lo, rows, dim, ld16); \
+    else swin_ln_kernel<TT, 64><<<(unsigned)((rows + 3) / 4), 256, 0, st>>>(y, gamma, beta, eps, res, out, (TT*)out_hi, (TT*)out_lo, rows, dim, ld16);          \
+  }
+  if (mm_dtype == STEDM_F16) LAUNCH_SWIN_LN(_Float16) else LAUNCH_SWIN_LN(__bf16)
+#undef LAUNCH_SWIN_LN
   STEDM_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int stedm_swin_window_attn(const float* qkv, const float* bias_kzero, const float* scale, const float* rpb, void* out_hi, void* out_lo,
-                                      int N, int H, int W, int C, int heads, int shift, int npass, int mm_dtype, void* stream) {
+                                      int ld16, int N, int H, int W, int C, int heads, int shift, int npass, int mm_dtype, void* stream) {
   STEDM_CHECK_ARG(qkv && bias_kzero && scale && rpb && out_hi && N > 0 && H > 0 && W > 0, "swin_window_attn: bad args");
   STEDM_CHECK_ARG(heads > 0 && C == heads * 32, "swin_window_attn: head dim must be 32 (C=%d heads=%d): swin_v2_t/s/b", C, heads);
   STEDM_CHECK_ARG(shift >= 0 && shift < 8, "swin_window_attn: shift %d outside the 8 x 8 window", shift);
+  STEDM_CHECK_ARG(ld16 >= C && ld16 % 4 == 0, "swin_window_attn: ld16 %d (C=%d)", ld16, C);
   STEDM_CHECK_ARG((npass == 1 || npass == 3) && (npass == 1 || out_lo), "swin_window_attn: npass must be 1 or 3 (3 writes out_lo)");
   SwinAttnArgs a;
   a.qkv = qkv; a.bias = bias_kzero; a.scale = scale; a.rpb = rpb; a.hi = out_hi; a.lo = npass == 3 ? out_lo : nullptr;
-  a.H = H; a.W = W; a.C = C; a.heads = heads;
+  a.H = H; a.W = W; a.C = C; a.ld16 = ld16; a.heads = heads;
   a.padH = (H + 7) / 8 * 8; a.padW = (W + 7) / 8 * 8;
   // "if window size is larger than feature size, there is no need to shift window" (torchvision shifted_window_attention)
   a.shift_h = 8 >= a.padH ? 0 : shift;

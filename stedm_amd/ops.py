@@ -502,20 +502,20 @@ def swin_patch16(img: torch.Tensor, hi: torch.Tensor, lo: Optional[torch.Tensor]
 
 def swin_ln(y: torch.Tensor, gamma, beta, eps: float, res: Optional[torch.Tensor], out: Optional[torch.Tensor], hi: Optional[torch.Tensor],
             lo: Optional[torch.Tensor], prec: Precision) -> None:
-    """out = res + LayerNorm(y) as fp32 rows and / or 16-bit operand planes."""
+    """out = res + LayerNorm(y) as fp32 rows and / or 16-bit operand planes (row stride hi.shape[-1] >= dim; pad columns are left alone)."""
     _chk(y, name="y")
     dim = y.shape[-1]
     check(lib().stedm_swin_ln(y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), _ptr(res), _ptr(out), _ptr(hi), _ptr(lo),
-                              y.numel() // dim, dim, prec.mm_dtype, _stream()), "stedm_swin_ln")
+                              y.numel() // dim, dim, dim if hi is None else hi.shape[-1], prec.mm_dtype, _stream()), "stedm_swin_ln")
 
 
 def swin_window_attn(qkv: torch.Tensor, bias_kzero: torch.Tensor, scale: torch.Tensor, rpb: torch.Tensor, hi: torch.Tensor,
                      lo: Optional[torch.Tensor], N: int, H: int, W: int, heads: int, shift: int, prec: Precision) -> None:
-    """rpb [heads, 64 queries, 64 keys]."""
+    """rpb [heads, 64 queries, 64 keys]; hi / lo [N*H*W, ld16 >= C]."""
     _chk(qkv, name="qkv")
     C = qkv.shape[-1] // 3
     check(lib().stedm_swin_window_attn(qkv.data_ptr(), bias_kzero.data_ptr(), scale.data_ptr(), rpb.data_ptr(), hi.data_ptr(), _ptr(lo),
-                                       N, H, W, C, heads, shift, prec.npass, prec.mm_dtype, _stream()), "stedm_swin_window_attn")
+                                       hi.shape[-1], N, H, W, C, heads, shift, prec.npass, prec.mm_dtype, _stream()), "stedm_swin_window_attn")
 
 
 def swin_merge16(x: torch.Tensor, hi: torch.Tensor, lo: Optional[torch.Tensor], prec: Precision) -> None:

@@ -131,8 +131,19 @@ class SwinTransformerV2(nn.Module):
         return t
 
     def _planes(self, name, shape):
+        """16-bit operand planes [rows, K]; K is padded to the GEMM kernels' 64-channel chunks (zero columns, written once here: the producers
+        only touch the first `dim` columns) — the register-streamed 1x1 kernel needs K % 64 == 0, and stage 1 of swin_v2_t has K = 96."""
         i16 = torch.int16
-        return (self._buf(name + ".hi", shape, i16), self._buf(name + ".lo", shape, i16) if self.precision.npass == 3 else None)
+        rows, k = shape
+        kp = (k + 63) // 64 * 64
+        def mk(nm):
+            key = (nm, (rows, kp), i16)
+            t = self._bufs.get(key)
+            if t is None:
+                t = torch.zeros((rows, kp), dtype=i16, device=self.norm.weight.device)
+                self._bufs[key] = t
+            return t
+        return (mk(name + ".hi"), mk(name + ".lo") if self.precision.npass == 3 else None)
 
     def _stages(self):
         """[(blocks, merge or None)] in order."""
@@ -154,9 +165,10 @@ class SwinTransformerV2(nn.Module):
             return
         prec = self.precision
 
-        def pack(w, kpad=None):   # Linear [N][K] -> packed 1x1 conv operands (+ fragment order for the register-streamed kernel)
+        def pack(w):   # Linear [N][K] -> packed 1x1 conv operands (+ fragment order for the register-streamed kernel)
             w = w.detach().float()
-            if kpad is not None and kpad > w.shape[1]:
+            kpad = (w.shape[1] + 63) // 64 * 64          # zero columns up to the 64-channel chunk (the operand planes are padded alike)
+            if kpad > w.shape[1]:
                 w = torch.cat([w, w.new_zeros(w.shape[0], kpad - w.shape[1])], dim=1)
             w4 = w.contiguous().unsqueeze(-1).unsqueeze(-1)
             hi, lo = ops.pack_conv_weight(w4, prec)
@@ -165,7 +177,7 @@ class SwinTransformerV2(nn.Module):
 
         P: Dict = {}
         conv = self.features[0][0]
-        P["pe"] = pack(conv.weight.reshape(conv.out_channels, -1), kpad=64)      # OIHW flattened: k = c*16 + ky*4 + kx
+        P["pe"] = pack(conv.weight.reshape(conv.out_channels, -1))      # OIHW flattened: k = c*16 + ky*4 + kx
         for s, (blocks, merge) in enumerate(self._stages()):
             for i, blk in enumerate(blocks):
                 at = blk.attn
