@@ -224,12 +224,13 @@ def cpu_baseline_train():
 
 
 def csrc_fingerprint():
-    """sha1 over the kernel sources: a profile-derived figure (roofline.traffic) is only reported for the binary it was taken on"""
+    """sha1 over the convolution kernels' sources (conv*.hip / .inc / .hpp + common.hpp: what the roofline's kernel is compiled from): a
+    profile-derived figure (roofline.traffic) is only reported for the kernels it was taken on"""
     import hashlib
     h = hashlib.sha1()
     d = os.path.join(ROOT, "stedm_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".inc", ".hpp")):
+        if f.endswith((".hip", ".inc", ".hpp")) and (f.startswith("conv") or f == "common.hpp"):
             h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
