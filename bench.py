@@ -19,6 +19,7 @@ launcher, the process group, the barriers, the max-over-ranks timing and the all
 """
 from __future__ import annotations
 
+from types import SimpleNamespace
 import argparse
 import json
 import os
@@ -484,7 +485,23 @@ def main():
                                    "decode_seconds": round(t2 - t1, 4), "images_per_s": round(B / (t2 - t0), 1),
                                    "decode_what": "decode_first_stage (VQ-f4 architecture: quantise over 8192 codes, post_quant_conv, Decoder 32^2 -> 128^2, "
                                                   "55 M parameters) + uint8 / class-map epilogue: predict_step end to end, images/s over the whole step"}
-            del zm, batch
+            # the default aggregator of the reference's config (conf/config_diff.yaml:16 style_agg: linear): Swin-V2-T over the same B x 4 style
+            # images + the Agg_Linear MLP (networks/agg_blocks.py:24-33) — the style encoding that replaces the sViT's in predict_step
+            zs = S_ZSS_DM("swin_v2_t", SimpleNamespace(name="mp", num_patches=4), SimpleNamespace(name="linear"), {"data": {"patch_size": 512}}, unet,
+                          linear_start=0.0015, linear_end=0.0205, image_size=32, channels=4, conditioning_key="hybrid", loss_type="l1",
+                          cond_stage_key="segmentation")
+            prng.fill_module_(zs.agg_block.linear_block, seed=54)
+            zs = zs.to(dev).eval()
+            zs.agg_block.set_precision(args.precision)
+            zs.agg_block(batch["style_imgs"])
+            torch.cuda.synchronize(); t3 = time.perf_counter()
+            sv = zs.agg_block(batch["style_imgs"])
+            torch.cuda.synchronize(); t4 = time.perf_counter()
+            assert tuple(sv.shape) == (B, 512) and bool(torch.isfinite(sv).all())
+            out["sampling_run"]["swin_linear_style_seconds"] = round(t4 - t3, 4)
+            out["sampling_run"]["swin_linear_what"] = (f"Agg_Linear over swin_v2_t (stedm_amd/swin.py, trunc-normal weights) on {B} x 4 style images of 512^2: "
+                                                       f"{4 * B / (t4 - t3):.0f} images/s, 47.4 GFLOP per image")
+            del zm, zs, batch
         if not args.no_train_leg and world == 1:
             # BASELINE config 2: one training step (forward + L1 + backward + AdamW/EMA) on the same U-Net and batch
             from stedm_amd.train import UNetTrainer
