@@ -327,6 +327,14 @@ int stedm_swin_rpb(const float* cpb, const long* index, float* rpb, int heads, i
 /* AdaptiveAvgPool2d(1) over the tokens: x [N][T][C] -> out [N][C]. */
 int stedm_swin_token_mean(const float* x, float* out, int N, int T, int C, void* stream);
 
+/* Several fragment-order packs (stedm_pack_conv_weight_frag / _frag16 / the fragment part of _strided) in ONE launch: the training step
+ * re-packs every convolution's weights after each optimizer step (forward order + flipped / transposed dgrad order, ~130 tensors), and the
+ * individual packs were launch-bound. descs: DEVICE array of nd records
+ *   { const float* w; void* out; long sn, sc; int cout, cin, taps (9 | 1), flip, m16 (0: 32x32x16 order, 1: 16x16x32 order), blk0; }   (56 bytes)
+ * blk0 = first block of the tensor, ascending; its block count is ceil(cout/128) * (cin/16) * 2 (m16: ceil(cout/128) * (cin/32) * 4);
+ * total_blocks = their sum. Outputs are bit-identical to the single-tensor entry points. */
+int stedm_pack_frag_multi(const void* descs, int nd, int total_blocks, int mm_dtype, void* stream);
+
 /* ---- training step: backward of the U-Net, loss, optimizer -------------------------------------
  * Replaces torch.autograd over UNetModel.forward (openaimodel.py:761-806) inside LatentDiffusion.p_losses (ddpm.py:1015-1048),
  * torch.optim.AdamW (ldm_diffusion.py:224-234) and LitEma.forward (ema.py:25-44). The convolution contractions of the backward

@@ -106,15 +106,20 @@ extern "C" int stedm_pack_conv_weight_up(const float* w, void* w_hi, void* w_lo,
 // M16: the fragment order of the 16x16x32 MFMA kind (stedm_pack_conv_weight_frag16): blocks of 32 rows x 32 channels,
 //   out[tn][chunk32][tap][c][lane][e] = W[n = tn*128 + c*16 + (lane&15)][ci = chunk*32 + kofs(lane>>4) + e][tap], kofs(g) = 16 (g&1) + 8 (g>>1) for a
 //   3x3 (plane, piece), 8 g for a 1x1.
-template <typename T, int taps, bool M16 = false>
-__global__ void __launch_bounds__(256) pack_conv_weight_frag_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, long total,
-                                                                    long sn, long sc, int flip) {
+constexpr int kPackTileFloats = 64 * (16 * 9 + 1);     // the largest tile of the four (taps, M16) forms: 64 rows x (16 x 9 + 1)
+
+// block `bid` of one tensor's pack; `traw`: kPackTileFloats floats of LDS
+template <typename T, int taps, bool M16>
+__device__ __forceinline__ void pack_frag_block(const float* __restrict__ w, T* __restrict__ out, const int cout, const int cin, const long sn,
+                                                const long sc, const int flip, const int bid, float* traw) {
   typedef T V8 __attribute__((ext_vector_type(8)));
   constexpr int NR = M16 ? 32 : 64, KC = M16 ? 32 : 16, NSUB = 128 / NR;     // rows and channels per block, blocks per 128-row tile
-  __shared__ float tile[NR][KC * taps + 1];
+  constexpr int PITCH = KC * taps + 1;
+  static_assert(NR * PITCH <= kPackTileFloats, "pack tile");
+  float (*tile)[PITCH] = reinterpret_cast<float (*)[PITCH]>(traw);
   const int nch = cin / KC;
-  const int half = blockIdx.x % NSUB;
-  const int chunk = (blockIdx.x / NSUB) % nch, tn = (blockIdx.x / NSUB) / nch;
+  const int half = bid % NSUB;
+  const int chunk = (bid / NSUB) % nch, tn = (bid / NSUB) / nch;
   const int n0 = tn * 128 + half * NR, ci0 = chunk * KC;
   const int per = NR * KC * taps;
   const bool n_fast = sn <= sc;       // which source index is contiguous
@@ -159,6 +164,52 @@ __global__ void __launch_bounds__(256) pack_conv_weight_frag_kernel(const float*
     const int q = half * 2 + ql;
     *reinterpret_cast<V8*>(out + ((((long)tn * nch + chunk) * taps + tap) * (M16 ? 8 : 4) + q) * 512 + lane * 8) = o;
   }
+}
+
+template <typename T, int taps, bool M16 = false>
+__global__ void __launch_bounds__(256) pack_conv_weight_frag_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, long total,
+                                                                    long sn, long sc, int flip) {
+  __shared__ float traw[kPackTileFloats];
+  pack_frag_block<T, taps, M16>(w, out, cout, cin, sn, sc, flip, blockIdx.x, traw);
+}
+
+// Many tensors in ONE launch (the training step re-packs every convolution's weights after each optimizer step: ~130 packs of a few
+// microseconds each were launch-bound). descs[i].blk0 = first block of tensor i (ascending); a block finds its tensor by binary search.
+struct PackDesc {
+  const float* w;
+  void* out;
+  long sn, sc;
+  int cout, cin, taps, flip, m16, blk0;
+};
+static_assert(sizeof(PackDesc) == 56, "PackDesc layout is part of the ABI (stedm_pack_frag_multi)");
+
+template <typename T>
+__global__ void __launch_bounds__(256) pack_frag_multi_kernel(const PackDesc* __restrict__ descs, const int nd) {
+  __shared__ float traw[kPackTileFloats];
+  int lo = 0, hi = nd - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackDesc d = descs[lo];
+  const int bid = blockIdx.x - d.blk0;
+  T* out = reinterpret_cast<T*>(d.out);
+  if (d.m16) {
+    if (d.taps == 9) pack_frag_block<T, 9, true>(d.w, out, d.cout, d.cin, d.sn, d.sc, d.flip, bid, traw);
+    else pack_frag_block<T, 1, true>(d.w, out, d.cout, d.cin, d.sn, d.sc, d.flip, bid, traw);
+  } else {
+    if (d.taps == 9) pack_frag_block<T, 9, false>(d.w, out, d.cout, d.cin, d.sn, d.sc, d.flip, bid, traw);
+    else pack_frag_block<T, 1, false>(d.w, out, d.cout, d.cin, d.sn, d.sc, d.flip, bid, traw);
+  }
+}
+
+extern "C" int stedm_pack_frag_multi(const void* descs, int nd, int total_blocks, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(descs && nd > 0 && total_blocks > 0, "pack_frag_multi: bad args");
+  STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "pack_frag_multi: bad mm_dtype %d", mm_dtype);
+  if (mm_dtype == STEDM_F16) pack_frag_multi_kernel<_Float16><<<total_blocks, 256, 0, as_stream(stream)>>>(reinterpret_cast<const PackDesc*>(descs), nd);
+  else pack_frag_multi_kernel<__bf16><<<total_blocks, 256, 0, as_stream(stream)>>>(reinterpret_cast<const PackDesc*>(descs), nd);
+  STEDM_LAUNCH_CHECK();
+  return 0;
 }
 
 static void launch_pack_frag(const float* w, void* out, int cout, int cin, int taps, long total, long sn, long sc, int flip, int mm_dtype, int grid,

@@ -245,8 +245,60 @@ class LazyPlanes:
     def get(self):
         if self._val is None:
             self._val = self._fn()
-            self._fn = None
         return self._val
+
+    def reset(self):
+        """the source weights changed: pack again on the next need"""
+        self._val = None
+
+
+class PackPlan:
+    """The fragment-order weight packs of a module set, recorded as they first happen and re-run later as ONE launch
+    (stedm_pack_frag_multi) into the same output tensors: after an optimizer step every convolution's packs are stale, and ~130 separate
+    packs of a few microseconds each are launch-bound. Valid while the source tensors keep their storage (the caller keys on data_ptr)."""
+
+    def __init__(self, prec: Precision):
+        self.prec = prec
+        self.items = []          # (w tensor (kept alive), sn, sc, flip, cout, cin, taps, m16, out)
+        self._table = None
+        self._blocks = 0
+
+    def frag(self, w: torch.Tensor, sn: int, sc: int, flip: bool, cout: int, cin: int, ks: int, m16: bool) -> torch.Tensor:
+        """Pack now (single-tensor launch) and remember the problem. w: fp32 tensor whose element (n, ci, tap) is flat[n*sn + ci*sc + tap']."""
+        _chk(w, name="w")
+        taps = ks * ks
+        if m16:
+            assert cin % 32 == 0
+            out = torch.empty(((cout + 127) // 128, cin // 32, taps, 8, 64, 8), dtype=torch.int16, device=w.device)
+            check(lib().stedm_pack_conv_weight_frag16(w.data_ptr(), sn, sc, int(flip), out.data_ptr(), cout, cin, ks, self.prec.mm_dtype, _stream()),
+                  "stedm_pack_conv_weight_frag16")
+        else:
+            assert cin % 16 == 0
+            out = torch.empty(((cout + 127) // 128, cin // 16, taps, 4, 64, 8), dtype=torch.int16, device=w.device)
+            check(lib().stedm_pack_conv_weight_strided(w.data_ptr(), sn, sc, int(flip), None, None, out.data_ptr(), cout, cin, ks, self.prec.mm_dtype,
+                                                       _stream()), "stedm_pack_conv_weight_strided")
+        self.items.append((w, sn, sc, int(flip), cout, cin, taps, int(m16), out))
+        self._table = None
+        return out
+
+    def frag_oihw(self, w4: torch.Tensor, m16: bool) -> torch.Tensor:
+        """plain OIHW filter [cout, cin, ks, ks]"""
+        cout, cin, ks, _ = w4.shape
+        return self.frag(w4, cin * ks * ks, ks * ks, False, cout, cin, ks, m16)
+
+    def run(self) -> None:
+        """all recorded packs again, one launch"""
+        if not self.items:
+            return
+        if self._table is None:
+            import struct
+            rec, blk = [], 0
+            for (w, sn, sc, flip, cout, cin, taps, m16, out) in self.items:
+                rec.append(struct.pack("<QQqqiiiiii", w.data_ptr(), out.data_ptr(), sn, sc, cout, cin, taps, flip, m16, blk))
+                blk += ((cout + 127) // 128) * ((cin // 32) * 4 if m16 else (cin // 16) * 2)
+            self._table = torch.frombuffer(bytearray(b"".join(rec)), dtype=torch.uint8).to(self.items[0][0].device)
+            self._blocks = blk
+        check(lib().stedm_pack_frag_multi(self._table.data_ptr(), len(self.items), self._blocks, self.prec.mm_dtype, _stream()), "stedm_pack_frag_multi")
 
 
 def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[torch.Tensor], out: torch.Tensor, *, prec: Precision,

@@ -53,6 +53,8 @@ class UNetTrainer:
         self.ema_updates = 0
         self._grads_ready = False
         self._dpacks: Dict[int, tuple] = {}
+        self._dpacks_step: Dict[int, tuple] = {}
+        self._dplan, self._dplan_key = None, None
         self._opt = None
         self._ema = None
         self._touched: Optional[list] = None
@@ -148,10 +150,13 @@ class UNetTrainer:
         """weights of the dgrad convolution: filter flipped and transposed (layout shuffle), packed like forward weights"""
         key = id(conv)
         hit = self._dpacks.get(key)
+        if hit is None:
+            hit = self._dpacks_step.get(key)
         if hit is not None:
             return hit
         bp = self.bprec
         w = self._w4(conv).contiguous()
+        in_place = w.data_ptr() == conv.weight.data_ptr()     # the plan re-reads the parameter's own storage on later steps
         co_f, ci_f, ks = w.shape[0], w.shape[1], w.shape[-1]
         taps = ks * ks
         frag16 = None
@@ -169,14 +174,20 @@ class UNetTrainer:
                 # the dgrad conv contracts over the forward's OUTPUT channels: the 16x16x32 MFMA kind takes it from 256 of them on
                 m16 = ks == 3 and self.m._m16 and co_f % 32 == 0 and co_f >= 256
                 if m16:
-                    frag, frag16 = None, ops.pack_conv_weight_frag16(w, bp, sn=taps, sc=ci_f * taps, flip=True, cout=ci_f, cin=co_f, ks=3)
+                    frag = None
+                    frag16 = (self._dplan.frag(w, taps, ci_f * taps, True, ci_f, co_f, 3, True) if in_place else
+                              ops.pack_conv_weight_frag16(w, bp, sn=taps, sc=ci_f * taps, flip=True, cout=ci_f, cin=co_f, ks=3))
                 else:
-                    frag = ops.pack_conv_weight_strided(*args, want_hi=False, want_frag=True)[2]
+                    frag = (self._dplan.frag(w, taps, ci_f * taps, True, ci_f, co_f, ks, False) if in_place else
+                            ops.pack_conv_weight_strided(*args, want_hi=False, want_frag=True)[2])
                 hi, lo = ops.LazyPlanes(lambda: ops.pack_conv_weight_strided(*args, want_hi=True, want_frag=False)[:2]), None
+                if in_place:      # kept across steps: the plan refreshes the fragments in one launch, the lazy planes are reset
+                    self._dpacks[key] = (hi, lo, frag, ks, frag16)
+                    return self._dpacks[key]
             else:
                 hi, lo, frag = ops.pack_conv_weight_strided(*args, want_hi=True, want_frag=False)
-        self._dpacks[key] = (hi, lo, frag, ks, frag16)
-        return self._dpacks[key]
+        self._dpacks_step[key] = (hi, lo, frag, ks, frag16)
+        return self._dpacks_step[key]
 
     def _cus(self) -> int:
         if not hasattr(self, "_ncus"):
@@ -301,7 +312,18 @@ class UNetTrainer:
         complete back to front and their all-reduce overlaps the rest of the backward."""
         m = self.m
         self.G = {}
-        self._dpacks = {}
+        # dgrad weight packs: the fragment-order ones recorded by the last backward run again as ONE launch when the parameters kept their
+        # storage (ops.PackPlan); everything else is packed when first needed, as before
+        dkey = (self.bprec, m.conv_path, m._m16, tuple(p.data_ptr() for p in m.parameters()))
+        self._dpacks_step = {}
+        if getattr(self, "_dplan", None) is not None and self._dplan_key == dkey:
+            self._dplan.run()
+            for ent in self._dpacks.values():
+                if isinstance(ent[0], ops.LazyPlanes):
+                    ent[0].reset()
+        else:
+            self._dpacks = {}
+            self._dplan, self._dplan_key = ops.PackPlan(self.bprec), dkey
         self.internal_grads()
         if on_bucket is not None:
             self._sched.reset()

@@ -246,8 +246,8 @@ class UNetModel(nn.Module):
         self.invalidate()
 
     def invalidate(self) -> None:
-        """Drop packed weights (call after changing parameters in place without bumping their version)."""
-        self._packed.clear()
+        """The parameters' VALUES changed (e.g. in place through raw pointers, without a version bump): the next forward packs again — as one
+        multi-tensor launch into the same buffers when the storage is still the same (_prepare), from scratch otherwise."""
         self._style_cache.clear()
         self._consts.clear()
         self._pack_key = None
@@ -276,19 +276,38 @@ class UNetModel(nn.Module):
         dev = params[0].device
         if dev.type != "cuda":
             raise StedmHipError("UNetModel.forward needs its parameters on the GPU; there is no CPU fallback")
-        key = (self.precision, dev, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        ptrs = tuple(p.data_ptr() for p in params)
+        key = (self.precision, dev, tuple(p._version for p in params), ptrs)
         if key == self._pack_key:
             return
-        self._packed.clear()
+        prec = self.precision
+        # Same storage, new values (an optimizer step): the fragment-order packs recorded last time run again as ONE launch into the same
+        # tensors (ops.PackPlan); the few other packs below are redone as before. Anything else: pack from scratch and record.
+        ptr_key = (prec, dev, ptrs, self.conv_path, self._m16)
+        plan = getattr(self, "_plan", None)
+        replay = plan is not None and self._plan_key == ptr_key and len(self._packed) > 0
+        if not replay:
+            self._packed.clear()
+            plan = self._plan = ops.PackPlan(prec)
+            self._plan_key = ptr_key
         self._consts.clear()
         self._style_cache.clear()
-        prec = self.precision
 
         def pack(conv):
+            if replay:
+                pk = self._packed[id(conv)]
+                if isinstance(pk.hi, ops.LazyPlanes):
+                    pk.hi.reset()
+                else:
+                    pk.hi, pk.lo = ops.pack_conv_weight(conv.weight.float(), prec)
+                return
             hi = lo = frag = None
-            w4 = conv.weight.float()
+            w4 = conv.weight.detach().float()
             if w4.dim() == 3:     # Conv1d qkv / proj_out of the AttentionBlock
                 w4 = w4.unsqueeze(-1)
+            in_place = w4.is_contiguous() and w4.data_ptr() == conv.weight.data_ptr()    # the plan re-reads the parameter's own storage
+            if not in_place:
+                self._plan_key = None
             k3 = tuple(w4.shape[2:]) == (3, 3) and conv.stride == (1, 1) and conv.in_channels % 16 == 0
             k1 = tuple(w4.shape[2:]) == (1, 1) and conv.in_channels % 64 == 0
             frag16 = None
@@ -298,9 +317,9 @@ class UNetModel(nn.Module):
                 # into an RS_3X3M launch it is read in the 16x16x32 order, on its own in the other
                 m16 = self._m16 and conv.in_channels % 32 == 0 and (k1 or conv.in_channels >= 256)
                 if not (m16 and k3):
-                    frag = ops.pack_conv_weight_frag(w4, prec)
+                    frag = plan.frag_oihw(w4, False) if in_place else ops.pack_conv_weight_frag(w4, prec)
                 if m16:
-                    frag16 = ops.pack_conv_weight_frag16(w4, prec)
+                    frag16 = plan.frag_oihw(w4, True) if in_place else ops.pack_conv_weight_frag16(w4, prec)
                 # the [cout][tap][cin] planes are read only by the LDS-operand kernels: packed on first need
                 hi = ops.LazyPlanes(lambda w=conv.weight: ops.pack_conv_weight(w.float(), prec))
             else:
@@ -330,6 +349,8 @@ class UNetModel(nn.Module):
                 pack(m.proj_out)
             elif type(m).__name__ == "SpatialTransformer":
                 self._packed[id(m)] = m.pack(prec)
+        if replay:
+            plan.run()
         c = self._consts
         half = self.model_channels // 2
         # host-built frequency table (util.py:162-164 builds it on the CPU in fp32)
