@@ -72,6 +72,32 @@ def test_batch64_cfg_rows_vs_cpu_oracle(dev, oracle_ns32):
     assert out["bf16"][0] < 1.5e-2 and out["bf16"][1] < 8e-2
 
 
+def test_config5_latent64_batch64_cfg_rows_vs_cpu_oracle(dev, oracle_ns32):
+    """BASELINE config 5's per-GPU share (CATCH 512^2 images: 64x64x4 latents, 512 / 8 = 64 per GPU; its ns = 8 fp8 style encoder is
+    covered in tests/test_gpu_style.py): the same U-Net on 4x the pixels — 64-pixel rows, attention over 256 tokens, other tile
+    geometries and split-K choices than at 32^2. Two rows of the CFG pass against the CPU oracle on those samples."""
+    from oracle import unet as ou
+    cfg, plan, P = oracle_ns32
+    B = 64
+    x = prng.normal(5, "c5.x", (B, 4, 64, 64)); cc = prng.normal(5, "c5.cc", (B, 3, 64, 64))
+    ctx_c = prng.normal(5, "c5.ctx", (B, 512)); ctx_u = prng.normal(5, "c5.ctxu", (B, 512))
+    rows = [0, 63]
+    t2 = torch.full((2,), 500, dtype=torch.long)
+    xc2 = torch.cat([x[rows], cc[rows]], 1)
+    ref = torch.cat([ou.unet_forward(P, cfg, xc2, t2, ctx_c[rows], plan=plan), ou.unet_forward(P, cfg, xc2, t2, ctx_u[rows], plan=plan)])
+    m = build(dev, "parity")
+    t = torch.full((B,), 500, dtype=torch.long, device=dev)
+    out = {}
+    for precision in ("parity", "f16", "bf16"):
+        m.set_precision(precision)
+        ec, eu = m.forward_cfg(x.to(dev), cc.to(dev), t, ctx_c.to(dev), ctx_u.to(dev), uniform_t=True)
+        out[precision] = dev2(torch.cat([ec[rows], eu[rows]]), ref)
+        print(f"[NS32 U-Net on 64x64x4 latents, B=64 CFG, rows {rows}, {precision}] vs CPU oracle: rel-L2 {out[precision][0]:.3e}, max/std {out[precision][1]:.3e}")
+    assert out["parity"][0] < 1e-3 and out["parity"][1] < 1e-3
+    assert out["f16"][0] < 1e-3 and out["f16"][1] < 1e-2
+    assert out["bf16"][0] < 1.5e-2 and out["bf16"][1] < 8e-2
+
+
 def test_config1_batch1_ddim20_cfg_loop_vs_cpu_oracle(dev, oracle_ns32):
     """BASELINE config 1: NS32, batch 1, DDIM 20 steps, cfg 1.5 (rescale 0.7), eta 0, through LatentDiffusion.sample_log with the
     hipGraph replay — every step on the 16-way split-K kernels — against oracle.ddim.ddim_sample with the oracle U-Net (40 CPU
