@@ -315,8 +315,9 @@ int stedm_swin_ln(const float* y, const float* gamma, const float* beta, float e
  * softmax(normalize(q) normalize(k)^T * scale[h] + rpb + mask) v as the 16-bit plane(s) [N*H*W][C] `proj` consumes. Cyclic shift, window
  * partition, F.pad rows (q = bias_q, k = 0, v = bias_v) and their inverses are index arithmetic; normalisation, logits and softmax are fp32.
  * bias_kzero [3C]; scale [heads] = exp(min(logit_scale, log 100)); rpb [heads][query][key] = 16 sigmoid(cpb_mlp(relative_coords_table))
- * [relative_position_index]. A side no larger than the window is not shifted. */
-int stedm_swin_window_attn(const float* qkv, const float* bias_kzero, const float* scale, const float* rpb, void* out_hi, void* out_lo,
+ * [relative_position_index]. A side no larger than the window is not shifted. qkv16 (single-product modes; then qkv is NULL): the same rows as
+ * 16-bit values of type mm_dtype — the qkv GEMM's out16 — which halves the largest stream of stage 1. */
+int stedm_swin_window_attn(const float* qkv, const void* qkv16, const float* bias_kzero, const float* scale, const float* rpb, void* out_hi, void* out_lo,
                            int ld16, int N, int H, int W, int C, int heads, int shift, int npass, int mm_dtype, void* stream);
 /* PatchMergingV2's input: x [N][H][W][C] fp32 -> 16-bit operand rows [N*ceil(H/2)*ceil(W/2)][4C] = [x(0,0) | x(1,0) | x(0,1) | x(1,1)]
  * (zero beyond an odd side). */

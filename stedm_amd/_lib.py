@@ -90,7 +90,7 @@ SIGNATURES = {
     "stedm_pack_frag_multi": (_I, [_P, _I, _I, _I, _P]),
     "stedm_swin_patch16": (_I, [_P, C.c_long, C.c_long, C.c_long, C.c_long, _I, _I, _I, _P, _P, _I, _P]),
     "stedm_swin_ln": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, C.c_long, _I, _I, _I, _P]),
-    "stedm_swin_window_attn": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "stedm_swin_window_attn": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "stedm_swin_merge16": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P]),
     "stedm_swin_rpb": (_I, [_P, _P, _P, _I, _I, _P]),
     "stedm_swin_token_mean": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -38,6 +38,21 @@ __device__ __forceinline__ float silu_f(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
 }
 
+// exact (erf) GELU of nn.GELU's default: 0.5 v (1 + erf(v / sqrt 2)). erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7): a rational
+// argument, a degree-5 polynomial and one hardware exp — a third of libm erff's instructions, which made the GEMM epilogues that apply it
+// (fc1 of the ViT / Swin MLPs) compute-bound. The complement y = 1 - erf(|x|) is used directly on the negative side, so the tail keeps
+// its relative accuracy.
+__device__ __forceinline__ float gelu_erf_f(float v) {
+  const float x = fabsf(v) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float y = p * t * __expf(-x * x);          // 1 - erf(|x|)
+  return 0.5f * v * (v >= 0.f ? 2.0f - y : y);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

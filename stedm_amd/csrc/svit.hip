@@ -682,7 +682,7 @@ __global__ void __launch_bounds__(256) geglu16_kernel(const float* __restrict__ 
     const float xs[4] = {x.x, x.y, x.z, x.w}, ts[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float v = xs[j] * (0.5f * ts[j] * (1.0f + erff(ts[j] * 0.70710678118654752f)));
+      const float v = xs[j] * gelu_erf_f(ts[j]);
       const T h = (T)v;
       hi[row * I + q * 4 + j] = h;
       if (lo) lo[row * I + q * 4 + j] = (T)(v - (float)h);

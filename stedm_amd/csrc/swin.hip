@@ -98,7 +98,8 @@ __global__ void __launch_bounds__(256) swin_ln_kernel(const float* __restrict__ 
 }
 
 struct SwinAttnArgs {
-  const float* qkv;     // [N*H*W][3C]  ('(three heads d)' columns, bias included)
+  const float* qkv;     // [N*H*W][3C]  ('(three heads d)' columns, bias included); NULL with IN16
+  const void* qkv16;    // the same rows as 16-bit values of the MFMA type (the qkv GEMM's 16-bit output: half the bytes of the largest stream)
   const float* bias;    // [3C] the Linear's bias with the k third zeroed (pad rows)
   const float* scale;   // [heads] exp(min(logit_scale, log 100))
   const float* rpb;     // [heads][64 queries][64 keys] 16 * sigmoid(cpb_mlp(table))[index]
@@ -113,7 +114,7 @@ struct SwinAttnArgs {
 //   S^T = K Q^T (keys on the rows: a query's softmax is a reduction over the lane's registers plus one cross-half exchange), logits =
 //   S^T * scale + bias (+ -100 across shift regions), P = exp(. - max) stays in the accumulators and is the B operand of O^T = V^T P as it
 //   lies: k-slot j of k-step (it, u) of lane half h is key (j&3) + 8(2u + (j>>2)) + 4h + 32 it, and V^T is read in that order.
-template <typename T, int NPASS>
+template <typename T, int NPASS, bool IN16 = false>
 __global__ void __launch_bounds__(256) swin_window_attn_kernel(const SwinAttnArgs a) {
   using V8 = typename MM<T>::V8;
   typedef T V4T __attribute__((ext_vector_type(4)));
@@ -153,10 +154,19 @@ __global__ void __launch_bounds__(256) swin_window_attn_kernel(const SwinAttnArg
       const int t = 8 * i + tg;
       long tok;
       const bool valid = source(t, tok);
-      const float* pq = (valid ? a.qkv + tok * (3L * C) : a.bias) + c0 + 4 * sub;      // F.pad rows: the Linear of a zero row is its bias
-      const float4 q4 = *reinterpret_cast<const float4*>(pq);
-      const float4 k4 = *reinterpret_cast<const float4*>(pq + C);
-      const float4 v4 = *reinterpret_cast<const float4*>(pq + 2 * C);
+      float4 q4, k4, v4;
+      if (IN16 && valid) {
+        const T* p16 = reinterpret_cast<const T*>(a.qkv16) + tok * (3L * C) + c0 + 4 * sub;
+        const V4T qv = *reinterpret_cast<const V4T*>(p16), kv = *reinterpret_cast<const V4T*>(p16 + C), vv = *reinterpret_cast<const V4T*>(p16 + 2 * C);
+        q4 = make_float4((float)qv[0], (float)qv[1], (float)qv[2], (float)qv[3]);
+        k4 = make_float4((float)kv[0], (float)kv[1], (float)kv[2], (float)kv[3]);
+        v4 = make_float4((float)vv[0], (float)vv[1], (float)vv[2], (float)vv[3]);
+      } else {
+        const float* pq = ((valid && !IN16) ? a.qkv + tok * (3L * C) : a.bias) + c0 + 4 * sub;      // F.pad rows: the Linear of a zero row is its bias
+        q4 = *reinterpret_cast<const float4*>(pq);
+        k4 = *reinterpret_cast<const float4*>(pq + C);
+        v4 = *reinterpret_cast<const float4*>(pq + 2 * C);
+      }
       float nq = q4.x * q4.x + q4.y * q4.y + q4.z * q4.z + q4.w * q4.w;
       float nk = k4.x * k4.x + k4.y * k4.y + k4.z * k4.z + k4.w * k4.w;
 #pragma unroll
@@ -408,15 +418,16 @@ extern "C" int stedm_swin_ln(const float* y, const float* gamma, const float* be
   return 0;
 }
 
-extern "C" int stedm_swin_window_attn(const float* qkv, const float* bias_kzero, const float* scale, const float* rpb, void* out_hi, void* out_lo,
+extern "C" int stedm_swin_window_attn(const float* qkv, const void* qkv16, const float* bias_kzero, const float* scale, const float* rpb, void* out_hi, void* out_lo,
                                       int ld16, int N, int H, int W, int C, int heads, int shift, int npass, int mm_dtype, void* stream) {
-  STEDM_CHECK_ARG(qkv && bias_kzero && scale && rpb && out_hi && N > 0 && H > 0 && W > 0, "swin_window_attn: bad args");
+  STEDM_CHECK_ARG((qkv || qkv16) && bias_kzero && scale && rpb && out_hi && N > 0 && H > 0 && W > 0, "swin_window_attn: bad args");
+  STEDM_CHECK_ARG(!qkv16 || (npass == 1 && !qkv), "swin_window_attn: the 16-bit qkv input belongs to the single-product modes (and excludes the fp32 one)");
   STEDM_CHECK_ARG(heads > 0 && C == heads * 32, "swin_window_attn: head dim must be 32 (C=%d heads=%d): swin_v2_t/s/b", C, heads);
   STEDM_CHECK_ARG(shift >= 0 && shift < 8, "swin_window_attn: shift %d outside the 8 x 8 window", shift);
   STEDM_CHECK_ARG(ld16 >= C && ld16 % 4 == 0, "swin_window_attn: ld16 %d (C=%d)", ld16, C);
   STEDM_CHECK_ARG((npass == 1 || npass == 3) && (npass == 1 || out_lo), "swin_window_attn: npass must be 1 or 3 (3 writes out_lo)");
   SwinAttnArgs a;
-  a.qkv = qkv; a.bias = bias_kzero; a.scale = scale; a.rpb = rpb; a.hi = out_hi; a.lo = npass == 3 ? out_lo : nullptr;
+  a.qkv = qkv; a.qkv16 = qkv16; a.bias = bias_kzero; a.scale = scale; a.rpb = rpb; a.hi = out_hi; a.lo = npass == 3 ? out_lo : nullptr;
   a.H = H; a.W = W; a.C = C; a.ld16 = ld16; a.heads = heads;
   a.padH = (H + 7) / 8 * 8; a.padW = (W + 7) / 8 * 8;
   // "if window size is larger than feature size, there is no need to shift window" (torchvision shifted_window_attention)
@@ -435,7 +446,10 @@ extern "C" int stedm_swin_window_attn(const float* qkv, const float* bias_kzero,
       STEDM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(swin_window_attn_kernel<TT, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     swin_window_attn_kernel<TT, NP><<<grid, 256, lds, st>>>(a);                                                                           \
   }
-  if (mm_dtype == STEDM_F16) { if (npass == 3) LAUNCH_SWIN_ATTN(_Float16, 3) else LAUNCH_SWIN_ATTN(_Float16, 1) }
+  if (qkv16) {
+    if (mm_dtype == STEDM_F16) swin_window_attn_kernel<_Float16, 1, true><<<grid, 256, lds, st>>>(a);
+    else swin_window_attn_kernel<__bf16, 1, true><<<grid, 256, lds, st>>>(a);
+  } else if (mm_dtype == STEDM_F16) { if (npass == 3) LAUNCH_SWIN_ATTN(_Float16, 3) else LAUNCH_SWIN_ATTN(_Float16, 1) }
   else { if (npass == 3) LAUNCH_SWIN_ATTN(__bf16, 3) else LAUNCH_SWIN_ATTN(__bf16, 1) }
 #undef LAUNCH_SWIN_ATTN
   STEDM_LAUNCH_CHECK();

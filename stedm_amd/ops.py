@@ -563,11 +563,14 @@ def swin_ln(y: torch.Tensor, gamma, beta, eps: float, res: Optional[torch.Tensor
 
 def swin_window_attn(qkv: torch.Tensor, bias_kzero: torch.Tensor, scale: torch.Tensor, rpb: torch.Tensor, hi: torch.Tensor,
                      lo: Optional[torch.Tensor], N: int, H: int, W: int, heads: int, shift: int, prec: Precision) -> None:
-    """rpb [heads, 64 queries, 64 keys]; hi / lo [N*H*W, ld16 >= C]."""
-    _chk(qkv, name="qkv")
+    """rpb [heads, 64 queries, 64 keys]; hi / lo [N*H*W, ld16 >= C]. qkv: fp32 rows, or (single-product modes) int16 rows holding the
+    qkv GEMM's 16-bit output."""
     C = qkv.shape[-1] // 3
-    check(lib().stedm_swin_window_attn(qkv.data_ptr(), bias_kzero.data_ptr(), scale.data_ptr(), rpb.data_ptr(), hi.data_ptr(), _ptr(lo),
-                                       hi.shape[-1], N, H, W, C, heads, shift, prec.npass, prec.mm_dtype, _stream()), "stedm_swin_window_attn")
+    is16 = qkv.dtype == torch.int16
+    _chk(qkv, torch.int16 if is16 else torch.float32, "qkv")
+    check(lib().stedm_swin_window_attn(None if is16 else qkv.data_ptr(), qkv.data_ptr() if is16 else None, bias_kzero.data_ptr(), scale.data_ptr(),
+                                       rpb.data_ptr(), hi.data_ptr(), _ptr(lo), hi.shape[-1], N, H, W, C, heads, shift, prec.npass, prec.mm_dtype,
+                                       _stream()), "stedm_swin_window_attn")
 
 
 def swin_merge16(x: torch.Tensor, hi: torch.Tensor, lo: Optional[torch.Tensor], prec: Precision) -> None:

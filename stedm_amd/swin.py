@@ -240,13 +240,19 @@ class SwinTransformerV2(nn.Module):
         ops.swin_ln(y, ln0.weight, ln0.bias, ln0.eps, None, xc, x16[0], x16[1], prec)
         for s, (blocks, merge) in enumerate(self._stages()):
             heads = self.heads[s]
-            qkv = self._buf(f"qkv{s}", (M, 3 * dim))
+            # single-product modes: the attention's operands are rounded to 16 bits anyway, so the qkv GEMM writes its 16-bit output only
+            # (stage 1's fp32 qkv tensor was the largest stream of the model: 18.9 MB per image and block)
+            q16 = prec.npass == 1
+            qkv = self._buf(f"qkv16.{s}", (M, 3 * dim), torch.int16) if q16 else self._buf(f"qkv{s}", (M, 3 * dim))
             att = self._planes(f"att{s}", (M, dim))
             y = self._buf(f"y{s}", (M, dim))
             for i, blk in enumerate(blocks):
                 nm = f"{s}.{i}"
                 at = blk.attn
-                self._gemm(x16, P["qkv" + nm], M, bias=P["qkvb" + nm], out=qkv)
+                if q16:
+                    self._gemm(x16, P["qkv" + nm], M, bias=P["qkvb" + nm], out16=(qkv, None))
+                else:
+                    self._gemm(x16, P["qkv" + nm], M, bias=P["qkvb" + nm], out=qkv)
                 ops.swin_window_attn(qkv, P["qkvb" + nm], P["scale" + nm], P["rpb" + nm], att[0], att[1], N, H, W, heads, at.shift_size[0], prec)
                 self._gemm(att, P["proj" + nm], M, bias=at.proj.bias, out=y)
                 ops.swin_ln(y, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, xc, xc, x16[0], x16[1], prec)     # x = x + norm1(attn(x))
