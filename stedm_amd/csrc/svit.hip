@@ -289,9 +289,13 @@ __global__ void __launch_bounds__(256, 2) lsa_flash_kernel(FlashArgs a) {
   using V8 = typename MM<T>::V8;
   typedef T V4t __attribute__((ext_vector_type(4)));
   constexpr int NPL = NPASS == 3 ? 2 : 1;
-  constexpr int RS = 72;                          // LDS row stride in elements (64 + 8 pad -> 144 B)
+  constexpr int RS = 72;                          // K rows: LDS stride in elements (64 + 8 pad -> 144 B: conflict-free ds_read_b128 fragments)
+  // V^T rows are read 8 B per lane by 32 consecutive rows (ds_read_b64: lane groups {0-31}, {32-63}): 144 B = 36 dwords repeats its bank
+  // pair every 16 rows (2-way conflicts on every read, a third of the LDS cycles of the kernel: SQ_LDS_BANK_CONFLICT); 152 B = 38 dwords
+  // gives 32 distinct pairs. Rows are then only 8-B aligned: the tile is stored with 8-B writes.
+  constexpr int RSV = 76;
   // one LDS block: K and V^T tiles during the loop, the O^T transpose buffer afterwards
-  constexpr int TILE = 64 * RS;
+  constexpr int TILE = 64 * RSV;
   constexpr int KV_BYTES = 2 * NPL * TILE * (int)sizeof(T);
   constexpr int O_BYTES = 4 * 32 * 65 * (int)sizeof(float);
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[KV_BYTES > O_BYTES ? KV_BYTES : O_BYTES];
@@ -347,13 +351,17 @@ __global__ void __launch_bounds__(256, 2) lsa_flash_kernel(FlashArgs a) {
     __syncthreads();   // every wave is done reading the previous tile
     *reinterpret_cast<uint4*>(&sK[0][frow0 * RS + fc * 8]) = kr0h;
     *reinterpret_cast<uint4*>(&sK[0][frow1 * RS + fc * 8]) = kr1h;
-    *reinterpret_cast<uint4*>(&sV[0][frow0 * RS + fc * 8]) = vr0h;
-    *reinterpret_cast<uint4*>(&sV[0][frow1 * RS + fc * 8]) = vr1h;
+    *reinterpret_cast<uint2*>(&sV[0][frow0 * RSV + fc * 8]) = make_uint2(vr0h.x, vr0h.y);
+    *reinterpret_cast<uint2*>(&sV[0][frow0 * RSV + fc * 8 + 4]) = make_uint2(vr0h.z, vr0h.w);
+    *reinterpret_cast<uint2*>(&sV[0][frow1 * RSV + fc * 8]) = make_uint2(vr1h.x, vr1h.y);
+    *reinterpret_cast<uint2*>(&sV[0][frow1 * RSV + fc * 8 + 4]) = make_uint2(vr1h.z, vr1h.w);
     if (NPASS == 3) {
       *reinterpret_cast<uint4*>(&sK[NPL - 1][frow0 * RS + fc * 8]) = kr0l;
       *reinterpret_cast<uint4*>(&sK[NPL - 1][frow1 * RS + fc * 8]) = kr1l;
-      *reinterpret_cast<uint4*>(&sV[NPL - 1][frow0 * RS + fc * 8]) = vr0l;
-      *reinterpret_cast<uint4*>(&sV[NPL - 1][frow1 * RS + fc * 8]) = vr1l;
+      *reinterpret_cast<uint2*>(&sV[NPL - 1][frow0 * RSV + fc * 8]) = make_uint2(vr0l.x, vr0l.y);
+      *reinterpret_cast<uint2*>(&sV[NPL - 1][frow0 * RSV + fc * 8 + 4]) = make_uint2(vr0l.z, vr0l.w);
+      *reinterpret_cast<uint2*>(&sV[NPL - 1][frow1 * RSV + fc * 8]) = make_uint2(vr1l.x, vr1l.y);
+      *reinterpret_cast<uint2*>(&sV[NPL - 1][frow1 * RSV + fc * 8 + 4]) = make_uint2(vr1l.z, vr1l.w);
     }
     __syncthreads();
     if (kt + 1 < ntiles) LSA_FETCH(kt + 1)
@@ -434,7 +442,7 @@ __global__ void __launch_bounds__(256, 2) lsa_flash_kernel(FlashArgs a) {
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
           // A fragment of V^T: row = d*32 + r, keys 32*sub + 16*s2 + {4h .. 4h+3} and {8 + 4h .. 8 + 4h + 3}
-          const int base = (d * 32 + r) * RS + sub * 32 + s2 * 16 + h * 4;
+          const int base = (d * 32 + r) * RSV + sub * 32 + s2 * 16 + h * 4;
           V8 vf, vfl;
           const V4t v0 = *reinterpret_cast<const V4t*>(&sV[0][base]);
           const V4t v1 = *reinterpret_cast<const V4t*>(&sV[0][base + 8]);
