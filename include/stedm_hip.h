@@ -300,7 +300,7 @@ int stedm_spatial_rescale(const float* x, const float* w, float* out, int B, int
 
 /* ---- Swin-Transformer-V2 style embedder ---------------------------------------------------------
  * Replaces the non-GEMM pieces of torchvision's swin_v2_t (torchvision==0.18.1, third party; call sites networks/s_zss_dm.py:19-20,
- * networks/agg_blocks.py:28,49,70); every Linear / the patch Conv2d runs through stedm_conv_igemm (1x1). Parity unpinned (oracle/swin.py).
+ * networks/agg_blocks.py:28,49,70); every Linear / the patch Conv2d runs through stedm_conv_igemm (1x1). Parity unpinned.
  * features[0][0] Conv2d(3, 96, 4, 4) as a GEMM: img [N][3][H][W] with element strides (sn, sc, sh, sw) -> 16-bit operand rows
  * [N*(H/4)*(W/4)][64], column k = c*16 + ky*4 + kx (the flattened OIHW weight), columns 48..63 zero. */
 int stedm_swin_patch16(const float* img, long sn, long sc, long sh, long sw, int N, int H, int W, void* out_hi, void* out_lo,

@@ -1,7 +1,7 @@
 // Swin-Transformer-V2 style embedder: the pieces of torchvision's `swin_v2_t` (pinned torchvision==0.18.1,
 // call sites networks/s_zss_dm.py:19-20, networks/agg_blocks.py:28,49,70) that are not GEMMs. torchvision is a third-party dependency
 // absent from /root/reference: the kernels restate its published algorithm (Liu et al., "Swin Transformer V2", and the layer
-// definitions of torchvision.models.swin_transformer) — parity unpinned, see oracle/swin.py.
+// definitions of torchvision.models.swin_transformer) — parity unpinned.
 //
 //   swin_patch16      : features[0][0] Conv2d(3, 96, 4, stride 4) as a GEMM: 4x4x3 patch gather -> 16-bit operand rows [tok][64]
 //                       (k = c*16 + ky*4 + kx, the OIHW order of the conv weight; columns 48..63 zero), any input strides

@@ -2,7 +2,7 @@
 
 The reference builds `torchvision.models.get_model("swin_v2_t")` and swaps its head for `Linear(768, 512)` (networks/s_zss_dm.py:19-20);
 the Agg_* blocks call it on '(b n) c h w' images (networks/agg_blocks.py:28,49,70). torchvision (pinned 0.18.1) is third-party and not
-under /root/reference: this file restates the published architecture (parity unpinned, oracle/swin.py) with torchvision's state-dict
+under /root/reference: this file restates the published architecture (parity unpinned: DESIGN.md §2) with torchvision's state-dict
 names, so a torchvision checkpoint of swin_v2_t / swin_v2_s / swin_v2_b loads with `load_state_dict`:
 
   features.0.{0 Conv2d(3, C, 4, 4) | 2 LayerNorm}         features.{1,3,5,7}.<i>.{norm1, attn.{qkv, proj, logit_scale, cpb_mlp.0, cpb_mlp.2,
