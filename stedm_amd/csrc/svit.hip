@@ -11,9 +11,14 @@
 //   spatial_rescale  : SpatialRescaler (encoders/modules.py:123-130): n x bilinear 1/2 (== 2x2 box mean for even sizes)
 //                      then bias-free 1x1 conv
 #include <float.h>
+#include <stdlib.h>
 
 #include "conv_common.hpp"
 using namespace stedm;
+
+#define GLDS16(gptr, lptr)                                                                                  \
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gptr),                   \
+                                   (void __attribute__((address_space(3)))*)(lptr), 16, 0, 0)
 
 // ------------------------------------------------------------------------------------------------ patch embed
 struct PatchArgs {
@@ -486,6 +491,178 @@ __global__ void __launch_bounds__(256, 2) lsa_flash_kernel(FlashArgs a) {
   }
 }
 
+// Single-product form whose K / V^T tiles travel global -> LDS by DMA (global_load_lds_dwordx4) into a ring of three tiles, two tiles ahead
+// of the MFMAs, with ONE barrier per tile. Compile-time timing ablations of the kernel above (B = 8, random operands) put its 737 us at
+// 417 us of MFMA + softmax work plus 320 us added by the tile staging (global -> registers -> ds_write, two barriers per tile), which the
+// three resident blocks did not hide. Here a tile costs each wave four DMA instructions (1 KiB each, no VGPRs, no ds_write) and one counted
+// vmcnt wait; measured +3 % on the sViT forward (the kernel is insensitive to its staging, occupancy and barrier count: DESIGN.md §6.2).
+// A DMA instruction writes its 64 x 16 B linearly, so rows are unpadded (128 B) and the 16-B pieces are XOR-swizzled through
+// the SOURCE address: physical piece p of row w holds logical piece p ^ ((w >> 1) & 7) — conflict-free ds_read_b128 K fragments, 2-way
+// on the 8-B V^T reads (as the padded layout had before its stride fix: measured 1 %).
+template <typename T, int NBUF>
+__global__ void __launch_bounds__(256, NBUF == 2 ? 4 : 3) lsa_flash_dma_kernel(FlashArgs a) {
+  using V8 = typename MM<T>::V8;
+  typedef T V4t __attribute__((ext_vector_type(4)));
+  constexpr int TILE_B = 16384;          // K 8 KiB | V^T 8 KiB
+  constexpr int O_BYTES = 4 * 32 * 65 * (int)sizeof(float);
+  constexpr int LDS_B = NBUF * TILE_B > O_BYTES ? NBUF * TILE_B : O_BYTES;       // the epilogue's transpose buffer overlays the ring
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[LDS_B];
+  float (*sO)[32][65] = reinterpret_cast<float (*)[32][65]>(ring);
+  const int bh = blockIdx.x, b = bh / a.H, hd = bh % a.H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.y * 128 + wave * 32;
+  const T* qg = reinterpret_cast<const T*>(a.qh);
+  const T* kg = reinterpret_cast<const T*>(a.kh);
+  const T* vg = reinterpret_cast<const T*>(a.vh);
+
+  V8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const V8*>(qg + ((long)bh * a.Tp + q0 + r) * 64 + ks * 16 + h * 8);
+
+  // DMA sources of this wave: chunks 2 wave, 2 wave + 1 of the K tile (rows 16 wave .. 16 wave + 15) and of the V^T tile; lane l of a chunk
+  // fills physical piece l & 7 of row 8 c + (l >> 3)
+  // (uniform 64-bit base + 32-bit lane offset: the compiler keeps the base in scalar registers)
+  const T* const kbase = kg + (long)bh * a.Tp * 64;
+  const T* const vbase = vg + (long)bh * 64 * a.Tp;
+  unsigned koff[2], voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 8 * (2 * wave + i) + (lane >> 3);
+    const int q = (lane & 7) ^ ((row >> 1) & 7);
+    koff[i] = row * 64 + q * 8;                    // + kt * 64 * 64 per tile
+    voff[i] = row * a.Tp + q * 8;                  // + kt * 64 per tile
+  }
+  auto issue = [&](int kt) {
+    unsigned char* dst = ring + (kt % NBUF) * TILE_B + (2 * wave) * 1024;
+    const T* kt_k = kbase + (long)kt * 4096;
+    const T* kt_v = vbase + (long)kt * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      GLDS16(kt_k + koff[i], dst + i * 1024);
+      GLDS16(kt_v + voff[i], dst + 8192 + i * 1024);
+    }
+  };
+
+  f32x16 o[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int qidx = q0 + r;
+  const int ntiles = (a.T + 63) / 64;
+  // fragment byte offsets inside a tile buffer: row * 128 + ((piece ^ f(row)) << 4), f(row) = (row >> 1) & 7. The piece index of a fragment
+  // is (compile-time even part) ^ (lane's h or 0), so each offset is a per-lane base XOR a compile-time constant: 4 registers, not 16
+  unsigned kb[2], vb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = i * 32 + r;
+    kb[i] = row * 128 + ((h ^ ((row >> 1) & 7)) << 4);              // K: piece 2 ks + h     -> kb[sub] ^ (ks << 5)
+    vb[i] = 8192 + row * 128 + (((row >> 1) & 7) << 4) + 8 * h;     // V^T: piece 4 sub + 2 s2 (+ 1) -> vb[d] ^ ((4 sub + 2 s2) << 4) (^ 16)
+  }
+
+  issue(0);
+  if (NBUF == 3 && ntiles > 1) issue(1);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    // this wave's share of tile kt has landed (NBUF 3: its 4 newest DMAs belong to tile kt + 1, when there is one)
+    if (NBUF == 3 && kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // tile kt is complete in LDS; every wave is done with tile kt - 1, whose buffer takes the next tile fetched
+    if (kt + NBUF - 1 < ntiles) issue(kt + NBUF - 1);
+    const unsigned char* tb = ring + (kt % NBUF) * TILE_B;
+    // ---- S^T tiles (2 x 32 keys) x 32 queries
+    f32x16 s[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[sub][e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const V8 kf = *reinterpret_cast<const V8*>(tb + (kb[sub] ^ (unsigned)(ks << 5)));
+        s[sub] = MM<T>::mfma(kf, qf[ks], s[sub]);
+      }
+    }
+    if ((q0 >> 6) == kt) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (kt * 64 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h == qidx) s[sub][e] = -FLT_MAX;
+    }
+    if (kt * 64 + 64 > a.T) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (kt * 64 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= a.T) s[sub][e] = -INFINITY;
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[sub][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = __builtin_amdgcn_exp2f(s[sub][e] - m_new);
+        s[sub][e] = pv;
+        rs += pv;
+      }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+    }
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        V8 ph;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ph[j] = (T)s[sub][8 * s2 + j];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          // A fragment of V^T: row = d*32 + r, keys 32*sub + 16*s2 + {4h .. 4h+3} and {8 + 4h .. 8 + 4h + 3}
+          const unsigned vo = vb[d] ^ (unsigned)((4 * sub + 2 * s2) << 4);
+          const V4t v0 = *reinterpret_cast<const V4t*>(tb + vo);
+          const V4t v1 = *reinterpret_cast<const V4t*>(tb + (vo ^ 16u));
+          V8 vf;
+          vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
+          vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+          o[d] = MM<T>::mfma(vf, ph, o[d]);
+        }
+      }
+  }
+  // ---- epilogue: O^T / l through LDS so that every token row is written contiguously (token-major [B][T][H*64])
+  __syncthreads();   // all waves are done with the ring: it is reused for the transpose
+  const float inv = 1.0f / l_run;
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sO[wave][r][d * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] = o[d][e] * inv;
+  __syncthreads();
+  {
+    const int row = lane >> 1, half = lane & 1;
+    const int t = q0 + row;
+    if (t < a.T) {
+      T* oh = reinterpret_cast<T*>(a.oh) + ((long)b * a.T + t) * (a.H * 64) + hd * 64 + half * 32;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) oh[j] = (T)sO[wave][row][half * 32 + j];
+    }
+  }
+}
+
 extern "C" int stedm_lsa_flash(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi,
                                const void* vt_lo, void* out_hi, void* out_lo, int B, int T, int Tp, int heads, int npass,
                                int mm_dtype, void* stream) {
@@ -495,6 +672,14 @@ extern "C" int stedm_lsa_flash(const void* q_hi, const void* q_lo, const void* k
   FlashArgs a{q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out_hi, npass == 3 ? out_lo : nullptr, T, Tp, heads};
   dim3 grid(B * heads, Tp / 128);
   hipStream_t st = as_stream(stream);
+  static const bool dma_off = getenv("STEDM_LSA_NODMA") != nullptr;      // A/B: the register-staged form for the single-product modes too
+  if (npass == 1 && !dma_off) {
+    // (a two-tile ring at four waves per SIMD measured 1-5 % slower than three tiles at three waves)
+    if (mm_dtype == STEDM_F16) lsa_flash_dma_kernel<_Float16, 3><<<grid, 256, 0, st>>>(a);
+    else lsa_flash_dma_kernel<__bf16, 3><<<grid, 256, 0, st>>>(a);
+    STEDM_LAUNCH_CHECK();
+    return 0;
+  }
   if (mm_dtype == STEDM_F16) {
     if (npass == 3) lsa_flash_kernel<_Float16, 3><<<grid, 256, 0, st>>>(a);
     else lsa_flash_kernel<_Float16, 1><<<grid, 256, 0, st>>>(a);
