@@ -1,4 +1,4 @@
-// Shared definitions of the implicit-GEMM convolution kernels (v1: conv_igemm.hip, v2: conv_igemm_ws.hip).
+// Shared definitions of the implicit-GEMM convolution kernels.
 #pragma once
 #include "common.hpp"
 
@@ -58,8 +58,6 @@ namespace stedm {
 // Fills the tile geometry of `p` for an M-tile of `bm` output pixels. Returns false (with the error set) when the
 // spatial shape cannot be tiled that way.
 bool conv_geometry(ConvParams& p, int bm, bool allow_wsplit = false);
-// v2 (warp-specialised) launcher; returns -1 when v2 does not support this problem (caller falls back to v1).
-int conv_launch_ws(ConvParams& p, hipStream_t st);
 // v3 (LDS-DMA operands from 16-bit activation planes); 0 ok, > 0 error (message set).
 int conv_launch_dma(ConvParams& p, hipStream_t st, bool dry = false);
 }  // namespace stedm

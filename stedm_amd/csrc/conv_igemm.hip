@@ -405,14 +405,7 @@ static int conv_dispatch(ConvParams& p, void* stream) {
     if (rc == 0 || !a.src1) return rc;
     // otherwise fall through to the fused fp32-source kernels
   }
-  // v2 (warp-specialised, 256/128 x 128 tiles) when it supports the problem; v1 otherwise
-  static const bool force_v1 = getenv("STEDM_CONV_V1") != nullptr;
-  static const int dbg = getenv("STEDM_CONV_DBG") ? atoi(getenv("STEDM_CONV_DBG")) : 0;
-  p.dbg = dbg;
-  if (!force_v1) {
-    const int rc = conv_launch_ws(p, st);
-    if (rc >= 0) return rc;
-  }
+  // fp32-source form (GroupNorm folded into the patch loader): the parity mode's stride-2 convs and the opt-in "fused" path
   const int bkc = (a.npass == 1 && p.Cin % 64 == 0 && (a.c2 == 0 || a.c1 % 64 == 0)) ? 64 : 32;
   if (!conv_geometry(p, BM)) return 1;
   const bool f16 = a.mm_dtype == STEDM_F16;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of stedm_conv_igemm on the NS32 layer shapes (B=64 encoder / B=128 CFG decoder).
-Prints TFLOP/s per shape; STEDM_CONV_V1=1 forces the v1 kernel."""
+Prints TFLOP/s per shape."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
