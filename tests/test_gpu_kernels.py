@@ -685,3 +685,49 @@ def test_conv_dma_up_subpixel(dev, prec, tol, B, H, W, c, cout):
 @pytest.mark.parametrize("B,H,W,cin,cout", [(2, 8, 8, 192, 128), (3, 4, 4, 128, 384), (1, 10, 10, 64, 64), (32, 8, 8, 256, 128)])
 def test_conv_dma_1x1(dev, prec, tol, B, H, W, cin, cout):
     _conv_dma_case(dev, prec, tol, B, H, W, cin, cout, "s1", 1, use_emb=False)
+
+
+def test_pack_frag_multi_equals_single_packs(dev):
+    """ops.PackPlan: the recorded fragment-order packs (forward order, flipped / transposed dgrad order, both MFMA fragment orders, 3x3 and
+    1x1, a cout that is not a multiple of 128) re-run as ONE launch give bit-identical outputs, also after the weights changed."""
+    from stedm_amd import ops
+    from stedm_amd.ops import Precision
+    for mode in ("bf16", "f16"):
+        prec = Precision.parse(mode)
+        plan = ops.PackPlan(prec)
+        ws, outs, refs = [], [], []
+        for i, (co, ci, ks) in enumerate([(128, 128, 3), (192, 64, 3), (512, 256, 3), (64, 128, 1), (320, 64, 1)]):
+            w = torch.randn(co, ci, ks, ks, device=dev)
+            ws.append(w)
+            taps = ks * ks
+            outs.append(plan.frag_oihw(w, False))                                              # forward, 32x32x16 order
+            if ci % 32 == 0:
+                outs.append(plan.frag_oihw(w, True))                                           # forward, 16x16x32 order
+            if co % 16 == 0:
+                outs.append(plan.frag(w, taps, ci * taps, True, ci, co, ks, False))            # dgrad: flipped, transposed
+            if ks == 3 and co % 32 == 0:
+                outs.append(plan.frag(w, taps, ci * taps, True, ci, co, 3, True))
+
+        def single():
+            r = []
+            for w in ws:
+                co, ci, ks, _ = w.shape
+                taps = ks * ks
+                r.append(ops.pack_conv_weight_frag(w, prec))
+                if ci % 32 == 0:
+                    r.append(ops.pack_conv_weight_frag16(w, prec))
+                if co % 16 == 0:
+                    r.append(ops.pack_conv_weight_strided(w, taps, ci * taps, True, ci, co, ks, prec, want_hi=False, want_frag=True)[2])
+                if ks == 3 and co % 32 == 0:
+                    r.append(ops.pack_conv_weight_frag16(w, prec, sn=taps, sc=ci * taps, flip=True, cout=ci, cin=co, ks=3))
+            return r
+
+        for a, b in zip(outs, single()):
+            assert torch.equal(a, b)
+        for w in ws:                      # an "optimizer step": same storage, new values
+            w.mul_(0.5).add_(0.1)
+        for o in outs:
+            o.zero_()
+        plan.run()
+        for a, b in zip(outs, single()):
+            assert a.shape == b.shape and torch.equal(a, b)
