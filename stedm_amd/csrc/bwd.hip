@@ -243,6 +243,22 @@ __global__ void __launch_bounds__(256) wgrad_to_oihw_kernel(const float* __restr
                                                             int cout_ld, int accumulate, int nsplit) {
   __shared__ float tile[9 * 16][33];
   const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 16;
+  if ((cout_ld & 3) == 0 && co0 + 32 <= cout && (reinterpret_cast<uintptr_t>(dw) & 15) == 0) {
+    // 16-B loads along co (8 lanes cover a 128-B run): a quarter of the load instructions, four times the bytes in flight per lane
+    for (int e = threadIdx.x; e < taps * 16 * 8; e += 256) {
+      const int c4 = e & 7, r = e >> 3;               // r = tap * 16 + ci_local
+      const int tap = r >> 4, cil = r & 15;
+      const int ci = ci0 + cil;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ci < cin)
+#pragma unroll 4
+        for (int z = 0; z < nsplit; ++z) {            // split-K partials, fixed order
+          const float4 w = *reinterpret_cast<const float4*>(dw + (((long)z * taps + tap) * cin_ld + ci) * cout_ld + co0 + c4 * 4);
+          v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+      tile[r][c4 * 4] = v.x; tile[r][c4 * 4 + 1] = v.y; tile[r][c4 * 4 + 2] = v.z; tile[r][c4 * 4 + 3] = v.w;
+    }
+  } else
   for (int e = threadIdx.x; e < taps * 16 * 32; e += 256) {
     const int col = e & 31, r = e >> 5;               // r = tap * 16 + ci_local
     const int tap = r >> 4, cil = r & 15;
