@@ -58,7 +58,9 @@ struct GnBwdArgs {
   void* o_hi; void* o_lo;   // optional 16-bit planes of dx (operand of the producer convolution's dgrad / wgrad)
 };
 
-// grid (B, 256-pixel slabs, blocks of 64 channel quads)
+// grid (B, kGnBwdSlab-pixel slabs, blocks of 64 channel quads). 64-pixel slabs: with 256 the grid of a 16x16 x 512-channel tensor at batch 64
+// was 128 blocks (half the chip idle, 64 dependent pixel steps per thread)
+constexpr int kGnBwdSlab = 64;
 __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(GnBwdArgs a) {
   __shared__ float cpart[256 * 8];
   const int b = blockIdx.x, slab = blockIdx.y, nslab = gridDim.y;
@@ -66,7 +68,7 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(GnBwdArgs a) {
   const int qb0 = blockIdx.z * 64, QB = min(64, Q - qb0);
   const int npl = 256 / QB, tq = t % QB, tp = t / QB;
   const int c = (qb0 + tq) * 4;
-  const int px0 = min(a.HW, slab * 256), px1 = min(a.HW, px0 + 256);
+  const int px0 = min(a.HW, slab * kGnBwdSlab), px1 = min(a.HW, px0 + kGnBwdSlab);
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   if (tp < npl) {
     float mean[4], rstd[4], ga[4], be[4];
@@ -689,7 +691,7 @@ extern "C" int stedm_gn_bwd(const float* x1, int c1, const float* x2, int c2, co
   STEDM_CHECK_ARG((x2 != nullptr) == (c2 > 0) && (c2 == 0 || dx2), "gn_bwd: x2/c2/dx2 mismatch");
   STEDM_CHECK_ARG(C % 4 == 0 && c1 % 4 == 0 && groups > 0 && groups <= 64 && C % groups == 0 && C * 8 <= 65536, "gn_bwd: channel constraints");
   STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "gn_bwd: bad mm_dtype");
-  const int nslab = (HW + 255) / 256, Q = C / 4;
+  const int nslab = (HW + kGnBwdSlab - 1) / kGnBwdSlab, Q = C / 4;
   // workspace: part [B][nslab][C][2] | bc [B][C][2] | gm [B][groups][2]
   float* part = ws;
   float* bc = part + (long)B * nslab * C * 2;
@@ -707,7 +709,7 @@ extern "C" int stedm_gn_bwd(const float* x1, int c1, const float* x2, int c2, co
 }
 
 extern "C" long stedm_gn_bwd_ws_floats(int B, int HW, int C, int groups) {
-  return (long)B * ((HW + 255) / 256) * C * 2 + (long)B * C * 2 + (long)B * groups * 2;
+  return (long)B * ((HW + kGnBwdSlab - 1) / kGnBwdSlab) * C * 2 + (long)B * C * 2 + (long)B * groups * 2;
 }
 
 extern "C" int stedm_im2col_t16(const void* src16, void* dst16, int B, int Hs, int Ws, int C, int ks, int mode, long Ppad, void* stream) {
