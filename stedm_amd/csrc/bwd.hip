@@ -305,7 +305,21 @@ __global__ void __launch_bounds__(256) chan_sum_fold_kernel(const float* __restr
   const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
   float tot = 0.f;
   if (c < C) {
-    for (int b = bl; b < B; b += 4) {
+    // four samples per step: their loads are independent and in flight together (the kernel is pure load latency); same summation order
+    int b = bl;
+    for (; b + 12 < B; b += 16) {
+      float u[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < nslab; ++k) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] += cs[(((long)(b + 4 * i) * nslab + k) * C + c) * 2];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (per_sample) per_sample[(long)(b + 4 * i) * ld + c] = u[i];
+        tot += u[i];
+      }
+    }
+    for (; b < B; b += 4) {
       float u = 0.f;
       for (int k = 0; k < nslab; ++k) u += cs[(((long)b * nslab + k) * C + c) * 2];
       if (per_sample) per_sample[(long)b * ld + c] = u;
