@@ -633,8 +633,21 @@ extern "C" int stedm_gn_apply16c(const float* x1, int c1, const float* cs1, int 
   STEDM_CHECK_ARG(raw_hi || !raw_lo, "gn_apply16c: raw_lo without raw_hi");
   STEDM_CHECK_ARG(nslab1 > 0 && (x2 == nullptr || nslab2 > 0), "gn_apply16c: nslab1 / nslab2 must be the slot counts of cs1 / cs2");
   GnApplyCArgs a{x1, x2, cs1, cs2, c1, c2, x2_bmod, groups, HW, act, nslab1, x2 ? nslab2 : 0, gamma, beta, eps, out_hi, out_lo, raw_hi, raw_lo};
-  static const int slab_kb = getenv("STEDM_GN_SLAB_KB") ? atoi(getenv("STEDM_GN_SLAB_KB")) : 32;
-  int slab = (slab_kb * 256 + C - 1) / C;   // pixels per block: slab_kb KiB of fp32 input
+  // Pixels per block. Every block folds the group statistics and builds its per-channel table first, a cost that grows with C, so wide
+  // tensors want long runs (128 KiB of fp32 input: 21 pixels of the 1536-channel decoder concat; at a fixed 32 KiB that shape ran at 4.3
+  // TB/s, now 5.3) — as long as the grid keeps >= 768 blocks (3 per CU), which the 64-pixel samples of the 8x8 level need (12 pixels per
+  // block there: 3.1 -> 3.9 TB/s); narrow tensors are indifferent (tools/bench_gn.py). STEDM_GN_SLAB_KB fixes the run length for A/B runs.
+  static const int slab_kb = getenv("STEDM_GN_SLAB_KB") ? atoi(getenv("STEDM_GN_SLAB_KB")) : 0;
+  int slab;
+  if (slab_kb > 0) slab = (slab_kb * 256 + C - 1) / C;
+  else {
+    const int want = (128 * 256 + C - 1) / C;                                   // 128 KiB of fp32 input
+    int per_sample = (HW + want - 1) / want;                                    // blocks per sample at that run length
+    const int need = (768 + B - 1) / B;                                         // ... and for 768 blocks in all
+    if (per_sample < need) per_sample = need;
+    if (per_sample > HW) per_sample = HW;
+    slab = (HW + per_sample - 1) / per_sample;
+  }
   if (slab < 1) slab = 1;
   if (slab > HW) slab = HW;
   dim3 grid(B, (HW + slab - 1) / slab);
