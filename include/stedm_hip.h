@@ -263,8 +263,9 @@ int stedm_ln_apply16(const float* x, const float* gamma, const float* beta, floa
                      long rows, int dim, int mm_dtype, void* stream);
 /* to_qkv output [B][T][3*heads*64] ('(h d)' per chunk, vit_set.py:53-54) -> q/k [B*heads][Tp][64] (q scaled by
  * qscale = exp(temperature) * log2(e): stedm_lsa_flash works in the log2 domain, vit_set.py:56; rows >= T zero) and
- * V^T [B*heads][64][Tp]; Tp multiple of 128. */
-int stedm_qkv_pack(const float* qkv, float qscale, void* q_hi, void* q_lo, void* k_hi, void* k_lo, void* vt_hi,
+ * V^T [B*heads][64][Tp]; Tp multiple of 128. qkv: fp32 rows, or (qkv_is16, single-product modes) the 16-bit plane of type mm_dtype that the
+ * to_qkv GEMM wrote as its out16. */
+int stedm_qkv_pack(const void* qkv, int qkv_is16, float qscale, void* q_hi, void* q_lo, void* k_hi, void* k_lo, void* vt_hi,
                    void* vt_lo, int B, int T, int Tp, int heads, int mm_dtype, void* stream);
 /* LSA attention vit_set.py:56-66: softmax over keys of q.k with the DIAGONAL masked to -FLT_MAX, times v; flash-style
  * on MFMA (head dim 64). q.k must be log2(e) times the reference's logits (see stedm_qkv_pack): p = exp2(s - max).

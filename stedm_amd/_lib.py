@@ -78,7 +78,7 @@ SIGNATURES = {
     "stedm_svit_patch_ln16": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _I, _P]),
     "stedm_svit_tok_place": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "stedm_ln_apply16": (_I, [_P, _P, _P, _F, _P, _P, C.c_long, _I, _I, _P]),
-    "stedm_qkv_pack": (_I, [_P, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "stedm_qkv_pack": (_I, [_P, _I, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "stedm_lsa_flash": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "stedm_qkv_amax": (_I, [_P, _F, C.c_long, _I, _P, _P]),
     "stedm_qkv_pack_fp8": (_I, [_P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -230,7 +230,9 @@ extern "C" int stedm_ln_apply16(const float* x, const float* gamma, const float*
 
 // ------------------------------------------------------------------------------------------------ qkv pack
 // qkv fp32 [B][T][3*H*64] -> q16/k16 [B*H][Tp][64] (rows >= T zero), vT16 [B*H][64][Tp] (cols >= T zero)
-template <typename T>
+// IN16: qkv arrives as the 16-bit plane the to_qkv GEMM's epilogue wrote (single-product modes: same operand rounding for k and v, one
+// more rounding of the scaled q; half the bytes of the encoder's largest activation both ways)
+template <typename T, bool IN16 = false>
 __global__ void __launch_bounds__(256) qkv_pack_kernel(const float* __restrict__ qkv, float qscale, T* __restrict__ qh,
                                                        T* __restrict__ ql, T* __restrict__ kh, T* __restrict__ kl,
                                                        T* __restrict__ vh, T* __restrict__ vl, int Tn, int Tp, int H) {
@@ -243,8 +245,14 @@ __global__ void __launch_bounds__(256) qkv_pack_kernel(const float* __restrict__
     const int t = t0 + tl;
     float q = 0.f, k = 0.f, v = 0.f;
     if (t < Tn) {
-      const float* p = qkv + ((long)b * Tn + t) * (3 * HD) + hd * 64 + d;
-      q = p[0] * qscale; k = p[HD]; v = p[2 * HD];
+      const long off = ((long)b * Tn + t) * (3 * HD) + hd * 64 + d;
+      if (IN16) {
+        const T* p = reinterpret_cast<const T*>(qkv) + off;
+        q = (float)p[0] * qscale; k = (float)p[HD]; v = (float)p[2 * HD];
+      } else {
+        const float* p = qkv + off;
+        q = p[0] * qscale; k = p[HD]; v = p[2 * HD];
+      }
     }
     const long o = ((long)bh * Tp + t) * 64 + d;
     const T q16 = (T)q, k16 = (T)k;
@@ -263,16 +271,27 @@ __global__ void __launch_bounds__(256) qkv_pack_kernel(const float* __restrict__
   }
 }
 
-extern "C" int stedm_qkv_pack(const float* qkv, float qscale, void* q_hi, void* q_lo, void* k_hi, void* k_lo, void* vt_hi,
+extern "C" int stedm_qkv_pack(const void* qkv, int qkv_is16, float qscale, void* q_hi, void* q_lo, void* k_hi, void* k_lo, void* vt_hi,
                               void* vt_lo, int B, int T, int Tp, int heads, int mm_dtype, void* stream) {
   STEDM_CHECK_ARG(qkv && q_hi && k_hi && vt_hi, "qkv_pack: null pointer");
   STEDM_CHECK_ARG(Tp % 128 == 0 && Tp >= T, "qkv_pack: Tp must be a multiple of 128 and >= T");
+  STEDM_CHECK_ARG(!qkv_is16 || (!q_lo && !k_lo && !vt_lo), "qkv_pack: a 16-bit qkv input belongs to the single-product modes (no lo planes)");
   dim3 grid(B * heads, Tp / 64);
+  if (qkv_is16) {
+    const float* qp = reinterpret_cast<const float*>(qkv);
+    if (mm_dtype == STEDM_F16)
+      qkv_pack_kernel<_Float16, true><<<grid, 256, 0, as_stream(stream)>>>(qp, qscale, (_Float16*)q_hi, nullptr, (_Float16*)k_hi, nullptr, (_Float16*)vt_hi, nullptr, T, Tp, heads);
+    else
+      qkv_pack_kernel<__bf16, true><<<grid, 256, 0, as_stream(stream)>>>(qp, qscale, (__bf16*)q_hi, nullptr, (__bf16*)k_hi, nullptr, (__bf16*)vt_hi, nullptr, T, Tp, heads);
+    STEDM_LAUNCH_CHECK();
+    return 0;
+  }
+  const float* qkvf = reinterpret_cast<const float*>(qkv);
   if (mm_dtype == STEDM_F16)
-    qkv_pack_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(qkv, qscale, (_Float16*)q_hi, (_Float16*)q_lo, (_Float16*)k_hi,
+    qkv_pack_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(qkvf, qscale, (_Float16*)q_hi, (_Float16*)q_lo, (_Float16*)k_hi,
                                                                   (_Float16*)k_lo, (_Float16*)vt_hi, (_Float16*)vt_lo, T, Tp, heads);
   else
-    qkv_pack_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(qkv, qscale, (__bf16*)q_hi, (__bf16*)q_lo, (__bf16*)k_hi, (__bf16*)k_lo,
+    qkv_pack_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(qkvf, qscale, (__bf16*)q_hi, (__bf16*)q_lo, (__bf16*)k_hi, (__bf16*)k_lo,
                                                                 (__bf16*)vt_hi, (__bf16*)vt_lo, T, Tp, heads);
   STEDM_LAUNCH_CHECK();
   return 0;

@@ -496,7 +496,7 @@ def ln_apply16(x, gamma, beta, eps, hi, lo, prec: Precision):
 
 def qkv_pack(qkv, qscale: float, q, k, vt, B: int, T: int, Tp: int, heads: int, prec: Precision):
     """q, k, vt: (hi, lo) tuples of int16 tensors [B*heads, Tp, 64] / [B*heads, 64, Tp]."""
-    check(lib().stedm_qkv_pack(qkv.data_ptr(), float(qscale), q[0].data_ptr(), _ptr(q[1]), k[0].data_ptr(), _ptr(k[1]),
+    check(lib().stedm_qkv_pack(qkv.data_ptr(), int(qkv.dtype == torch.int16), float(qscale), q[0].data_ptr(), _ptr(q[1]), k[0].data_ptr(), _ptr(k[1]),
                                vt[0].data_ptr(), _ptr(vt[1]), B, T, Tp, heads, prec.mm_dtype, _stream()), "stedm_qkv_pack")
 
 

@@ -182,14 +182,19 @@ class sViT(nn.Module):
         self._gemm(pe16, P["pe"], B * n, dim, bias=tp[2].bias, out=tok)
         ops.svit_tok_place(tok, self.pos_embedding, self.cls_token, x)
         ln = (self._buf("ln.hi", (M, dim), i16), self._buf("ln.lo", (M, dim), i16) if lo_ok else None)
-        qkv = self._buf("qkv", (M, 3 * heads * 64))
+        # single-product modes without the fp8 attention: to_qkv writes its 16-bit output only (the attention's operands are 16-bit anyway)
+        q16 = prec.npass == 1 and not prec.attn_fp8
+        qkv = self._buf("qkv16", (M, 3 * heads * 64), i16) if q16 else self._buf("qkv", (M, 3 * heads * 64))
         mk = lambda nm, shp: (self._buf(nm + ".hi", shp, i16, zero=True), self._buf(nm + ".lo", shp, i16, zero=True) if lo_ok else None)
         q, k, vt = mk("q", (B * heads, Tp, 64)), mk("k", (B * heads, Tp, 64)), mk("vt", (B * heads, 64, Tp))
         att = (self._buf("att.hi", (M, heads * 64), i16), self._buf("att.lo", (M, heads * 64), i16) if lo_ok else None)
         for l, (attn, ff) in enumerate(self.transformer.layers):
             mlp = ff.fn.net[0].out_features
             ops.ln_apply16(x, attn.norm.weight, attn.norm.bias, attn.norm.eps, ln[0], ln[1], prec)
-            self._gemm(ln, P[f"qkv{l}"], M, 3 * heads * 64, out=qkv)
+            if q16:
+                self._gemm(ln, P[f"qkv{l}"], M, 3 * heads * 64, out16=(qkv, None))
+            else:
+                self._gemm(ln, P[f"qkv{l}"], M, 3 * heads * 64, out=qkv)
             if prec.attn_fp8:     # e4m3 operands with per-tensor scales (BASELINE config 5)
                 amax = self._buf("amax", (4,))
                 q8, k8, v8 = (self._buf(nm, shp, torch.uint8) for nm, shp in (("q8", (B * heads, Tp, 64)), ("k8", (B * heads, Tp, 64)), ("vt8", (B * heads, 64, Tp))))
