@@ -230,9 +230,7 @@ extern "C" int stedm_ln_apply16(const float* x, const float* gamma, const float*
 
 // ------------------------------------------------------------------------------------------------ qkv pack
 // qkv fp32 [B][T][3*H*64] -> q16/k16 [B*H][Tp][64] (rows >= T zero), vT16 [B*H][64][Tp] (cols >= T zero)
-// IN16: qkv arrives as the 16-bit plane the to_qkv GEMM's epilogue wrote (single-product modes: same operand rounding for k and v, one
-// more rounding of the scaled q; half the bytes of the encoder's largest activation both ways)
-template <typename T, bool IN16 = false>
+template <typename T>
 __global__ void __launch_bounds__(256) qkv_pack_kernel(const float* __restrict__ qkv, float qscale, T* __restrict__ qh,
                                                        T* __restrict__ ql, T* __restrict__ kh, T* __restrict__ kl,
                                                        T* __restrict__ vh, T* __restrict__ vl, int Tn, int Tp, int H) {
@@ -245,14 +243,8 @@ __global__ void __launch_bounds__(256) qkv_pack_kernel(const float* __restrict__
     const int t = t0 + tl;
     float q = 0.f, k = 0.f, v = 0.f;
     if (t < Tn) {
-      const long off = ((long)b * Tn + t) * (3 * HD) + hd * 64 + d;
-      if (IN16) {
-        const T* p = reinterpret_cast<const T*>(qkv) + off;
-        q = (float)p[0] * qscale; k = (float)p[HD]; v = (float)p[2 * HD];
-      } else {
-        const float* p = qkv + off;
-        q = p[0] * qscale; k = p[HD]; v = p[2 * HD];
-      }
+      const float* p = qkv + ((long)b * Tn + t) * (3 * HD) + hd * 64 + d;
+      q = p[0] * qscale; k = p[HD]; v = p[2 * HD];
     }
     const long o = ((long)bh * Tp + t) * 64 + d;
     const T q16 = (T)q, k16 = (T)k;
@@ -271,6 +263,55 @@ __global__ void __launch_bounds__(256) qkv_pack_kernel(const float* __restrict__
   }
 }
 
+// qkv arrives as the 16-bit plane the to_qkv GEMM's epilogue wrote (single-product modes: same operand rounding for k and v, one more
+// rounding of the scaled q; half the bytes of the encoder's largest activation both ways), with 16-B accesses on both sides (the scalar form above moves 2 B per lane and store): block = (sample-head, 64
+// tokens); q, k: 4 threads per token, 16 channels each; V^T through an LDS tile of the MFMA type, 8 tokens per 16-B store.
+template <typename T>
+__global__ void __launch_bounds__(256) qkv_pack16_kernel(const T* __restrict__ qkv, float qscale, T* __restrict__ qh, T* __restrict__ kh,
+                                                         T* __restrict__ vh, int Tn, int Tp, int H) {
+  typedef T V8 __attribute__((ext_vector_type(8)));
+  __shared__ __attribute__((aligned(16))) T sv[64][72];      // [token][channel], 144-B rows
+  const int bh = blockIdx.x, b = bh / H, hd = bh % H;
+  const int t0 = blockIdx.y * 64;
+  const int HD = H * 64;
+  const int tl = threadIdx.x >> 2, part = threadIdx.x & 3;   // token of the tile, 16-channel part
+  const int t = t0 + tl;
+  V8 q[2], k[2], v[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { q[i][u] = (T)0.f; k[i][u] = (T)0.f; v[i][u] = (T)0.f; }
+  if (t < Tn) {
+    const T* p = qkv + ((long)b * Tn + t) * (3 * HD) + hd * 64 + part * 16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const V8 qr = *reinterpret_cast<const V8*>(p + 8 * i);
+      k[i] = *reinterpret_cast<const V8*>(p + HD + 8 * i);
+      v[i] = *reinterpret_cast<const V8*>(p + 2 * HD + 8 * i);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[i][u] = (T)((float)qr[u] * qscale);
+    }
+  }
+  const long o = ((long)bh * Tp + t) * 64 + part * 16;       // t < Tp always (Tp is a multiple of the 64-token tile); rows >= Tn are zero
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    *reinterpret_cast<V8*>(qh + o + 8 * i) = q[i];
+    *reinterpret_cast<V8*>(kh + o + 8 * i) = k[i];
+    *reinterpret_cast<V8*>(&sv[tl][part * 16 + 8 * i]) = v[i];
+  }
+  __syncthreads();
+  // V^T [bh][64 channels][Tp]: thread = (channel, 8-token chunk), 512 items
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int item = threadIdx.x + 256 * it;
+    const int d = item >> 3, ch = item & 7;
+    V8 w;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w[u] = sv[ch * 8 + u][d];
+    *reinterpret_cast<V8*>(vh + ((long)bh * 64 + d) * Tp + t0 + ch * 8) = w;
+  }
+}
+
 extern "C" int stedm_qkv_pack(const void* qkv, int qkv_is16, float qscale, void* q_hi, void* q_lo, void* k_hi, void* k_lo, void* vt_hi,
                               void* vt_lo, int B, int T, int Tp, int heads, int mm_dtype, void* stream) {
   STEDM_CHECK_ARG(qkv && q_hi && k_hi && vt_hi, "qkv_pack: null pointer");
@@ -278,11 +319,10 @@ extern "C" int stedm_qkv_pack(const void* qkv, int qkv_is16, float qscale, void*
   STEDM_CHECK_ARG(!qkv_is16 || (!q_lo && !k_lo && !vt_lo), "qkv_pack: a 16-bit qkv input belongs to the single-product modes (no lo planes)");
   dim3 grid(B * heads, Tp / 64);
   if (qkv_is16) {
-    const float* qp = reinterpret_cast<const float*>(qkv);
     if (mm_dtype == STEDM_F16)
-      qkv_pack_kernel<_Float16, true><<<grid, 256, 0, as_stream(stream)>>>(qp, qscale, (_Float16*)q_hi, nullptr, (_Float16*)k_hi, nullptr, (_Float16*)vt_hi, nullptr, T, Tp, heads);
+      qkv_pack16_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>((const _Float16*)qkv, qscale, (_Float16*)q_hi, (_Float16*)k_hi, (_Float16*)vt_hi, T, Tp, heads);
     else
-      qkv_pack_kernel<__bf16, true><<<grid, 256, 0, as_stream(stream)>>>(qp, qscale, (__bf16*)q_hi, nullptr, (__bf16*)k_hi, nullptr, (__bf16*)vt_hi, nullptr, T, Tp, heads);
+      qkv_pack16_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>((const __bf16*)qkv, qscale, (__bf16*)q_hi, (__bf16*)k_hi, (__bf16*)vt_hi, T, Tp, heads);
     STEDM_LAUNCH_CHECK();
     return 0;
   }
