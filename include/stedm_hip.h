@@ -371,6 +371,11 @@ int stedm_wgrad_to_oihw(const float* dw, float* grad, int cout, int cin, int tap
 int stedm_wgrad3x3_plan(int B, int H, int W, int Cin, int Cout, int* ksplit);
 int stedm_wgrad3x3(const void* x16, const void* dy16, float* part, int B, int H, int W, int Cin, int Cout, int mm_dtype,
                    void* stream);
+/* The same for a 1x1 convolution (skip_connection, attention qkv / proj_out): x16 [P][Cin], dy16 [P][Cout] (bf16, P = B*H*W pixels) ->
+ * part [ksplit][Cin][Cout] fp32 partials (then stedm_wgrad_to_oihw with taps = 1, nsplit = ksplit). stedm_wgrad1x1_plan returns 1 when the
+ * shape is supported (P %% 64 == 0, Cin %% 128 == 0, Cout %% 128 == 0) and the split it will use. */
+int stedm_wgrad1x1_plan(long P, int Cin, int Cout, int* ksplit);
+int stedm_wgrad1x1(const void* x16, const void* dy16, float* part, long P, int Cin, int Cout, int mm_dtype, void* stream);
 /* chan partials cs [B][nslab][C][2] -> per-sample channel sums per_sample[b*ld + c] (NULL: skip) and their batch total
  * total[c] (bias gradients; the per-sample sums are the gradient of the emb_layers output, openaimodel.py:277-280). */
 int stedm_chan_sum_fold(const float* cs, int B, int nslab, int C, float* per_sample, long ld, float* total, int accumulate,

@@ -170,6 +170,96 @@ __global__ void __launch_bounds__(512) wgrad3x3_kernel(WgradArgs a) {
   }
 }
 
+// ---- the same for a 1x1 convolution (skip_connection, attention qkv / proj_out): dW[ci][co] = sum over pixels p of X[p][ci] * dY[p][co].
+// No patch geometry: the planes are flat [P][C] and a unit is 64 consecutive pixels. With one tap the accumulators are small, so a workgroup
+// owns 128 (ci) x 128 (co) — every wave 32 x 64 — which halves the re-reads of X against the 128 x 64 block of the 3x3 kernel; the loop is
+// bound by the operand stream (32 KB per unit and workgroup for 64 MFMAs), not by the MFMA pipe. Replaces stedm_im2col_t16 (two 16-bit
+// transposes through HBM) + the dY^T fragment pack + the 1x1-kind GEMM of the GEMM form.
+struct Wgrad1Args {
+  const uint16_t* x16;    // [P][Cin]
+  const uint16_t* dy16;   // [P][Cout]
+  float* part;            // [ksplit][Cin][Cout]
+  int Cin, Cout, nunits, ksplit, tiles_n;    // tiles_n = Cout / 128
+};
+
+constexpr int W1_S = 320;                 // row pitch of both LDS images: 128 channels = 256 B + 64 B pad (see WG_XS)
+constexpr int W1_BUF = 64 * W1_S;
+
+__global__ void __launch_bounds__(512) wgrad1x1_kernel(Wgrad1Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sX = smem;                  // [2][W1_BUF]
+  unsigned char* sY = smem + 2 * W1_BUF;     // [2][W1_BUF]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 3, wn = wave >> 2;   // 8 waves: 32 input channels x 64 output channels each
+  const int ntile = (a.Cin / 128) * a.tiles_n;
+  const int tile = blockIdx.x % ntile, kz = blockIdx.x / ntile;
+  const int ci0 = (tile / a.tiles_n) * 128, co0 = (tile % a.tiles_n) * 128;
+  const int per = (a.nunits + a.ksplit - 1) / a.ksplit;
+  const int u0 = kz * per, u1 = min(a.nunits, u0 + per);
+
+  // staging registers: four 16-B chunks per thread and unit (named, macro-expanded: arrays captured by the lambdas went to scratch)
+  uint4 rx0, rx1, ry0, ry1;
+  const int srow0 = tid >> 4, srow1 = (tid + 512) >> 4, sch = tid & 15;
+#define W1_LOAD(U)                                                                                      \
+  {                                                                                                     \
+    const long p0_ = (long)(U) * 64 + srow0, p1_ = (long)(U) * 64 + srow1;                              \
+    rx0 = *reinterpret_cast<const uint4*>(a.x16 + p0_ * a.Cin + ci0 + sch * 8);                         \
+    rx1 = *reinterpret_cast<const uint4*>(a.x16 + p1_ * a.Cin + ci0 + sch * 8);                         \
+    ry0 = *reinterpret_cast<const uint4*>(a.dy16 + p0_ * a.Cout + co0 + sch * 8);                       \
+    ry1 = *reinterpret_cast<const uint4*>(a.dy16 + p1_ * a.Cout + co0 + sch * 8);                       \
+  }
+#define W1_STORE(BUF)                                                                                   \
+  {                                                                                                     \
+    *reinterpret_cast<uint4*>(sX + (BUF) * W1_BUF + srow0 * W1_S + sch * 16) = rx0;                     \
+    *reinterpret_cast<uint4*>(sX + (BUF) * W1_BUF + srow1 * W1_S + sch * 16) = rx1;                     \
+    *reinterpret_cast<uint4*>(sY + (BUF) * W1_BUF + srow0 * W1_S + sch * 16) = ry0;                     \
+    *reinterpret_cast<uint4*>(sY + (BUF) * W1_BUF + srow1 * W1_S + sch * 16) = ry1;                     \
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  // transposed-read constants as in wgrad3x3_kernel: group g = lane >> 4 (h = g >> 1 selects k 8h..8h+7, g & 1 the 16-column half),
+  // lane 4q + p of the group addresses row q, columns 4p..4p+3 of the 4 x 16 block
+  const int g = lane >> 4, h = g >> 1, q = (lane & 15) >> 2, p = lane & 3;
+  const int colA = (wm * 32 + 16 * (g & 1)) * 2 + 8 * p;
+  const int colB = (wn * 64 + 16 * (g & 1)) * 2 + 8 * p;
+  auto compute_unit = [&](int buf) {
+    const unsigned char* px = sX + buf * W1_BUF;
+    const unsigned char* py = sY + buf * W1_BUF;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int k_lo = 16 * s + 8 * h + q, k_hi = k_lo + 4;
+      const bf16x8 af = tr_pair(px, k_lo * W1_S + colA, k_hi * W1_S + colA);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bf16x8 bf = tr_pair(py, k_lo * W1_S + colB + j * 64, k_hi * W1_S + colB + j * 64);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[j], 0, 0, 0);
+      }
+    }
+  };
+  if (u0 < u1) { W1_LOAD(u0) W1_STORE(0) }
+  __syncthreads();
+  for (int u = u0; u < u1; ++u) {
+    const int buf = (u - u0) & 1;
+    if (u + 1 < u1) W1_LOAD(u + 1)
+    compute_unit(buf);
+    if (u + 1 < u1) W1_STORE(buf ^ 1)
+    __syncthreads();
+  }
+#undef W1_LOAD
+#undef W1_STORE
+  // ---- partial dW[kz][ci][co]
+  const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float* dst = a.part + ((long)kz * a.Cin + ci0 + wm * 32) * a.Cout + co0 + wn * 64 + j * 32 + col;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dst[(long)((e & 3) + 8 * (e >> 2) + 4 * hh) * a.Cout] = acc[j][e];
+  }
+}
+
 }  // namespace
 
 // 1 when stedm_wgrad3x3 supports the shape, and the split it would use in *ksplit (for sizing `part`: ksplit * 9 * Cin * Cout floats)
@@ -222,6 +312,43 @@ extern "C" int stedm_wgrad3x3(const void* x16, const void* dy16, float* part, in
   else if (W == 16) wgrad3x3_kernel<16><<<grid, 512, lds, st>>>(a);
   else if (W == 32) wgrad3x3_kernel<32><<<grid, 512, lds, st>>>(a);
   else wgrad3x3_kernel<64><<<grid, 512, lds, st>>>(a);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+// 1 when stedm_wgrad1x1 supports the shape (P %% 64 == 0, Cin %% 128 == 0, Cout %% 128 == 0), and the split it would use in *ksplit
+// (for sizing `part`: ksplit * Cin * Cout floats)
+extern "C" int stedm_wgrad1x1_plan(long P, int Cin, int Cout, int* ksplit) {
+  if (ksplit) *ksplit = 0;
+  if (P <= 0 || P % 64 != 0 || Cin % 128 != 0 || Cout % 128 != 0 || P * (Cin > Cout ? Cin : Cout) >= (1L << 31)) return 0;
+  static int cus = 0;
+  if (cus == 0) { cus = stedm_device_cus(); if (cus <= 0) cus = 256; }
+  const int tiles = (Cin / 128) * (Cout / 128), nunits = (int)(P / 64);
+  int ks = (2 * cus + tiles - 1) / tiles;        // two workgroups (80 KB of LDS each) are resident per CU
+  if (ks > 32) ks = 32;
+  if (ks > nunits / 4) ks = nunits / 4;          // >= 4 units per slice
+  if (ks < 1) ks = 1;
+  const int per = (nunits + ks - 1) / ks;
+  ks = (nunits + per - 1) / per;                 // no empty slices
+  if (ksplit) *ksplit = ks;
+  return 1;
+}
+
+extern "C" int stedm_wgrad1x1(const void* x16, const void* dy16, float* part, long P, int Cin, int Cout, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(x16 && dy16 && part, "wgrad1x1: null pointer");
+  STEDM_CHECK_ARG(mm_dtype == STEDM_BF16, "wgrad1x1: bf16 operands only (the backward pass's operand format)");
+  int ks = 0;
+  STEDM_CHECK_ARG(stedm_wgrad1x1_plan(P, Cin, Cout, &ks) == 1, "wgrad1x1: unsupported shape (P %% 64 == 0, Cin %% 128 == 0, Cout %% 128 == 0)");
+  Wgrad1Args a;
+  a.x16 = (const uint16_t*)x16; a.dy16 = (const uint16_t*)dy16; a.part = part;
+  a.Cin = Cin; a.Cout = Cout; a.nunits = (int)(P / 64); a.ksplit = ks; a.tiles_n = Cout / 128;
+  const size_t lds = 4 * W1_BUF;
+  static bool attr = false;
+  if (!attr) {
+    STEDM_HIP_TRY(hipFuncSetAttribute((const void*)wgrad1x1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  wgrad1x1_kernel<<<(Cin / 128) * a.tiles_n * ks, 512, lds, as_stream(stream)>>>(a);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

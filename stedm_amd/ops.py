@@ -722,6 +722,21 @@ def wgrad3x3(x16: torch.Tensor, dy16: torch.Tensor, part: torch.Tensor, prec: Pr
     check(lib().stedm_wgrad3x3(x16.data_ptr(), dy16.data_ptr(), part.data_ptr(), B, H, W, cin, cout, prec.mm_dtype, _stream()), "stedm_wgrad3x3")
 
 
+def wgrad1x1_plan(P: int, cin: int, cout: int) -> int:
+    """split count of the direct 1x1 weight-gradient kernel for this shape, 0 when the shape is not supported"""
+    ks = C.c_int(0)
+    return ks.value if lib().stedm_wgrad1x1_plan(P, cin, cout, C.byref(ks)) else 0
+
+
+def wgrad1x1(x16: torch.Tensor, dy16: torch.Tensor, part: torch.Tensor, prec: Precision) -> None:
+    """x16 [..., cin], dy16 [..., cout] bf16 planes over the same pixels -> part [ksplit, cin, cout] fp32 partial weight gradients"""
+    cin, cout = x16.shape[-1], dy16.shape[-1]
+    P = x16.numel() // cin
+    assert x16.dtype == torch.int16 and dy16.dtype == torch.int16 and dy16.numel() // cout == P and part.dtype == torch.float32
+    assert x16.is_contiguous() and dy16.is_contiguous() and part.numel() >= wgrad1x1_plan(P, cin, cout) * cin * cout
+    check(lib().stedm_wgrad1x1(x16.data_ptr(), dy16.data_ptr(), part.data_ptr(), P, cin, cout, prec.mm_dtype, _stream()), "stedm_wgrad1x1")
+
+
 def chan_sum_fold(cs: torch.Tensor, per_sample: Optional[torch.Tensor], ld: int, total: Optional[torch.Tensor], accumulate: bool) -> None:
     B, nslab, Cc, _ = cs.shape
     check(lib().stedm_chan_sum_fold(cs.data_ptr(), B, nslab, Cc, _ptr(per_sample), ld, _ptr(total), int(accumulate), _stream()), "stedm_chan_sum_fold")

@@ -60,6 +60,7 @@ class UNetTrainer:
         self._touched: Optional[list] = None
         self.bucket_mb = 256            # gradient all-reduce bucket (xGMI rings are per-link bound: few, large collectives)
         self.overlap_all_reduce = os.environ.get("STEDM_NO_OVERLAP") is None
+        self.direct_wgrad1 = os.environ.get("STEDM_WGRAD1X1_GEMM") is None      # A/B: the 1x1 convolutions' weight gradients in the GEMM form
         self.G: Dict[int, torch.Tensor] = {}
 
     # ------------------------------------------------------------------------------------------------ helpers
@@ -216,6 +217,13 @@ class UNetTrainer:
             if nsplit > 0:    # direct kernel: both operands straight from the NHWC planes, transposed in the LDS reads
                 part = self._buf("wg.part", (nsplit * 9 * Cs * co,))
                 ops.wgrad3x3(src16[0], dy16[0], part, bp)
+                ops.wgrad_to_oihw(part, self._param_grad(wparam), Cs, co, False, nsplit)
+                return
+        if ks == 1 and mode == 0 and bp.npass == 1 and self.m.conv_path == "dma" and self.direct_wgrad and self.direct_wgrad1 and src16[0].is_contiguous() and dy16[0].is_contiguous():
+            nsplit = ops.wgrad1x1_plan(B * Hs * Ws, Cs, co)
+            if nsplit > 0:    # direct kernel for the 1x1 convolutions: flat [P][C] planes, no transposes through HBM
+                part = self._buf("wg.part1", (nsplit * Cs * co,))
+                ops.wgrad1x1(src16[0], dy16[0], part, bp)
                 ops.wgrad_to_oihw(part, self._param_grad(wparam), Cs, co, False, nsplit)
                 return
         # GEMM form. Its contraction length K = (samples) * Ho * Wo is bounded by the conv kernels' zero page (65 536): larger problems go in

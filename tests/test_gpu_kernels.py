@@ -731,3 +731,25 @@ def test_pack_frag_multi_equals_single_packs(dev):
         plan.run()
         for a, b in zip(outs, single()):
             assert a.shape == b.shape and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("P,cin,cout", [(64 * 64, 128, 128), (64 * 256, 1536, 512), (4096, 1024, 3072), (64 * 1024, 256, 128)])
+def test_wgrad1x1_direct_vs_einsum(dev, P, cin, cout):
+    """direct weight gradient of a 1x1 convolution from the flat bf16 planes (split-K partials folded by wgrad_to_oihw) against the fp32
+    contraction over the same bf16-rounded operands."""
+    from stedm_amd import ops
+    from stedm_amd.ops import Precision
+    prec = Precision.parse("bf16")
+    x = torch.randn(P, cin, device=dev).to(torch.bfloat16)
+    dy = (torch.randn(P, cout, device=dev) * 0.1).to(torch.bfloat16)
+    ns = ops.wgrad1x1_plan(P, cin, cout)
+    assert ns > 0
+    part = torch.empty(ns * cin * cout, device=dev)
+    ops.wgrad1x1(x.view(torch.int16), dy.view(torch.int16), part, prec)
+    grad = torch.empty(cout, cin, 1, 1, device=dev)
+    ops.wgrad_to_oihw(part, grad, cin, cout, False, ns)
+    want = dy.float().T @ x.float()
+    err = float((grad.view(cout, cin) - want).abs().max() / want.std())
+    print(f"[wgrad1x1 P={P} {cin}->{cout}, {ns} slices] max|diff|/std {err:.2e}")
+    assert err < 1e-4
+    assert ops.wgrad1x1_plan(P, 96, cout) == 0 and ops.wgrad1x1_plan(P + 1, cin, cout) == 0
