@@ -97,10 +97,18 @@ __global__ void __launch_bounds__(256, 2) lsa_flash_fp8_kernel(Flash8Args a) {
   unsigned char* sK = lds_raw;
   unsigned char* sV = lds_raw + TILE;
   float (*sO)[32][65] = reinterpret_cast<float (*)[32][65]>(lds_raw);
-  const int bh = blockIdx.x, b = bh / a.H, hd = bh % a.H;
+  // XCD-aware block -> (sample-head, query tile): the blocks of one sample-head all run on one XCD (block id mod 8), so its K / V^T stay in
+  // that XCD's L2 (see lsa_flash_dma_kernel, svit.hip)
+  int bh, qtile;
+  {
+    const int nbh = gridDim.x, nq = gridDim.y, L = blockIdx.x + nbh * blockIdx.y;      // dispatch order of the 2-D grid
+    if ((nbh & 7) == 0) { const int x = L & 7, j = L >> 3; bh = x + 8 * (j / nq); qtile = j % nq; }
+    else { bh = blockIdx.x; qtile = blockIdx.y; }
+  }
+  const int b = bh / a.H, hd = bh % a.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int q0 = blockIdx.y * 128 + wave * 32;
+  const int q0 = qtile * 128 + wave * 32;
   const float s_logit = (fmaxf(a.amax[0], 1e-20f) / 448.0f) * (fmaxf(a.amax[1], 1e-20f) / 448.0f);   // fp8 q.k -> log2-domain logit
   const float s_out = (fmaxf(a.amax[2], 1e-20f) / 448.0f) / 256.0f;                                   // (256 P) (448 / amax_v v) -> P v
 

@@ -366,10 +366,17 @@ __global__ void __launch_bounds__(256, 2) lsa_flash_kernel(FlashArgs a) {
   T (*sK)[TILE] = reinterpret_cast<T (*)[TILE]>(lds_raw);
   T (*sV)[TILE] = reinterpret_cast<T (*)[TILE]>(lds_raw + NPL * TILE * sizeof(T));
   float (*sO)[32][65] = reinterpret_cast<float (*)[32][65]>(lds_raw);
-  const int bh = blockIdx.x, b = bh / a.H, hd = bh % a.H;
+  // XCD-aware block -> (sample-head, query tile): see lsa_flash_dma_kernel
+  int bh, qtile;
+  {
+    const int nbh = gridDim.x, nq = gridDim.y, L = blockIdx.x + nbh * blockIdx.y;      // dispatch order of the 2-D grid
+    if ((nbh & 7) == 0) { const int x = L & 7, j = L >> 3; bh = x + 8 * (j / nq); qtile = j % nq; }
+    else { bh = blockIdx.x; qtile = blockIdx.y; }
+  }
+  const int b = bh / a.H, hd = bh % a.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int q0 = blockIdx.y * 128 + wave * 32;
+  const int q0 = qtile * 128 + wave * 32;
   const T* qg[2] = {reinterpret_cast<const T*>(a.qh), reinterpret_cast<const T*>(a.ql)};
   const T* kg[2] = {reinterpret_cast<const T*>(a.kh), reinterpret_cast<const T*>(a.kl)};
   const T* vg[2] = {reinterpret_cast<const T*>(a.vh), reinterpret_cast<const T*>(a.vl)};
@@ -567,10 +574,19 @@ __global__ void __launch_bounds__(256, NBUF == 2 ? 4 : 3) lsa_flash_dma_kernel(F
   constexpr int LDS_B = NBUF * TILE_B > O_BYTES ? NBUF * TILE_B : O_BYTES;       // the epilogue's transpose buffer overlays the ring
   __shared__ __attribute__((aligned(1024))) unsigned char ring[LDS_B];
   float (*sO)[32][65] = reinterpret_cast<float (*)[32][65]>(ring);
-  const int bh = blockIdx.x, b = bh / a.H, hd = bh % a.H;
+  // Block -> (sample-head, 128-query tile), XCD-aware: workgroups go to the 8 XCDs round-robin (block id mod 8), and each XCD has its own 4 MB
+  // L2. With the sample-head on the fast grid axis every XCD streams the K / V^T of ALL heads (104 MB at B = 8: far beyond L2, so every tile
+  // came from the fabric: 3.4 GB per call); here the blocks of one sample-head all run on one XCD and the ~3 heads resident there fit its L2.
+  int bh, qtile;
+  {
+    const int nq = a.Tp / 128, nbh = gridDim.x / nq, L = blockIdx.x;
+    if ((nbh & 7) == 0) { const int x = L & 7, j = L >> 3; bh = x + 8 * (j / nq); qtile = j % nq; }
+    else { bh = L % nbh; qtile = L / nbh; }
+  }
+  const int b = bh / a.H, hd = bh % a.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int q0 = blockIdx.y * 128 + wave * 32;
+  const int q0 = qtile * 128 + wave * 32;
   const T* qg = reinterpret_cast<const T*>(a.qh);
   const T* kg = reinterpret_cast<const T*>(a.kh);
   const T* vg = reinterpret_cast<const T*>(a.vh);
@@ -734,8 +750,9 @@ extern "C" int stedm_lsa_flash(const void* q_hi, const void* q_lo, const void* k
   static const bool dma_off = getenv("STEDM_LSA_NODMA") != nullptr;      // A/B: the register-staged form for the single-product modes too
   if (npass == 1 && !dma_off) {
     // (a two-tile ring at four waves per SIMD measured 1-5 % slower than three tiles at three waves)
-    if (mm_dtype == STEDM_F16) lsa_flash_dma_kernel<_Float16, 3><<<grid, 256, 0, st>>>(a);
-    else lsa_flash_dma_kernel<__bf16, 3><<<grid, 256, 0, st>>>(a);
+    const dim3 grid1(B * heads * (Tp / 128));
+    if (mm_dtype == STEDM_F16) lsa_flash_dma_kernel<_Float16, 3><<<grid1, 256, 0, st>>>(a);
+    else lsa_flash_dma_kernel<__bf16, 3><<<grid1, 256, 0, st>>>(a);
     STEDM_LAUNCH_CHECK();
     return 0;
   }
