@@ -203,6 +203,47 @@ def cpu_baseline(seconds_budget=15.0, gpu_eval=None):
     return out, deviation
 
 
+def config1_leg(ld, dev, precision):
+    """BASELINE config 1 (the reference's own CPU-runnable case): NS32, batch 1, DDIM-20 + CFG 1.5 — the whole loop on the HIP path
+    (hipGraph replay through sample_log) beside the CPU oracle's loop on this host's cores, and the deviation of the final latent."""
+    from oracle import ddim as od
+    from oracle import unet as ou
+    from stedm_amd.utils import prng
+    cores = int(os.environ.get("STEDM_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
+    torch.set_num_threads(cores)
+    cfg = ou.UNetConfig()
+    plan = ou.build_plan(cfg)
+    P = prng.fill_state_dict(plan.shapes, 0)
+    xT = prng.normal(1, "c1.xT", (1, 4, 32, 32))
+    cc = (prng.normal(2, "c1.layout", (1, 3, 32, 32)) > 0).float()
+    ctx, ctx_u = prng.normal(3, "c1.ctx", (1, 512)), prng.normal(4, "c1.ctxu", (1, 512))
+
+    def apply_model(x, t, c):
+        return ou.unet_forward(P, cfg, torch.cat([x, c["c_concat"][0]], 1), t, c["c_crossattn"][0], plan=plan)
+
+    t0 = time.perf_counter()
+    ref = od.ddim_sample(apply_model, od.Schedule(), xT, {"c_concat": [cc], "c_crossattn": [ctx]}, 20, 0.0,
+                         uncond={"c_concat": [cc], "c_crossattn": [ctx_u]}, scale=1.5)
+    cpu_s = time.perf_counter() - t0
+    unet = ld.model.diffusion_model
+    cond = {"c_concat": [cc.to(dev)], "c_crossattn": [ctx.to(dev)]}
+    unc = {"c_concat": [cc.to(dev)], "c_crossattn": [ctx_u.to(dev)]}
+    res = {}
+    for mode in dict.fromkeys([precision, "parity"]):
+        unet.set_precision(mode)
+        run = lambda: ld.sample_log(cond, 1, True, 20, eta=0.0, x_T=xT.to(dev), unconditional_conditioning=unc, unconditional_guidance_scale=1.5,
+                                    log_every_t=1000)[0]
+        run()
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        s = run()
+        torch.cuda.synchronize()
+        res[unet.precision.label] = {"seconds": round(time.perf_counter() - t1, 5),
+                                     "rel_l2_vs_cpu_oracle": float((s.double().cpu() - ref.double()).norm() / ref.double().norm())}
+    unet.set_precision(precision)
+    return {"what": "NS32, batch 1, DDIM-20 + CFG 1.5 (rescale 0.7): the whole sampling loop, final latent compared with the CPU oracle's loop",
+            "gpu": res, "cpu_oracle_seconds": round(cpu_s, 2), "cpu_cores": cores}
+
+
 def cpu_baseline_train():
     """The CPU oracle's training-step arithmetic (forward + L1 + reverse-mode gradients by autograd over the fixture-pinned
     restatement; no optimizer) on this host's cores, one bounded sample."""
@@ -551,6 +592,7 @@ def main():
                 return res
 
             out["cpu_baseline"], dev_rep = cpu_baseline(gpu_eval=gpu_eval)
+            out["config1_loop"] = config1_leg(ld, dev, args.precision)      # (after gpu_eval: it restores the PRNG weights the oracle holds)
             out["deviation_vs_cpu_oracle"] = dev_rep
             if dev_rep and out["dtype"] in dev_rep:
                 out["headline_rel_l2_vs_oracle"] = round(dev_rep[out["dtype"]]["rel_l2"], 6)
