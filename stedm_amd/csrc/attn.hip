@@ -288,10 +288,129 @@ __global__ void __launch_bounds__(256) attn64_mfma_kernel(const void* __restrict
   }
 }
 
+// T = 64 n tokens (the middle block at 64x64 latents: 256; at 128x128: 1024), single-product modes, 16-bit qkv plane in: one wave per
+// (sample, head, 32-query block), key tiles of 64 with the online softmax of a flash kernel around the products of attn64_mfma_kernel above
+// (running maximum / sum per query in fp32, O^T rescaled only when a maximum moved). 32 queries per wave: with 64 the CH = 128 form needed
+// 512 registers and scratch. Replaces the fp32 VALU kernel (1.23 ms per CFG pass of 64 latents of 64x64) for these sizes.
+template <typename T, int CH>
+__global__ void __launch_bounds__(256) attn_mfma_tiles_kernel(const T* __restrict__ qkv16, T* __restrict__ out, int nprob, int heads, int Tn, float scale2) {
+  using V8 = typename MM<T>::V8;
+  typedef T V4T __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int prob = blockIdx.x * 4 + wave;
+  if (prob >= nprob) return;
+  const int nqb = Tn >> 5, nkt = Tn >> 6;
+  const int qb = prob % nqb, bh = prob / nqb;
+  const int b = bh / heads, hd = bh % heads;
+  const int C3 = heads * 3 * CH, C = heads * CH;
+  const T* base16 = qkv16 + (long)b * Tn * C3 + hd * 3 * CH;
+  const int r = lane & 31, h = lane >> 5;
+  auto frag8 = [&](long off) { return *reinterpret_cast<const V8*>(base16 + off); };
+
+  V8 qf[CH / 16];      // the wave's 32 queries, all k-steps
+#pragma unroll
+  for (int s = 0; s < CH / 16; ++s) qf[s] = frag8((long)(qb * 32 + r) * C3 + 16 * s + 8 * h);
+  f32x16 ot[CH / 32];
+#pragma unroll
+  for (int dt = 0; dt < CH / 32; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ot[dt][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll 1
+  for (int kt = 0; kt < nkt; ++kt) {
+    f32x16 st[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[it][e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < CH / 16; ++s) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const V8 ka = frag8((long)(kt * 64 + 32 * it + r) * C3 + CH + 16 * s + 8 * h);
+        st[it] = MM<T>::mfma(ka, qf[s], st[it]);
+      }
+    }
+    // online softmax over the keys of query column r: 32 values of this tile in this lane, 32 in lane ^ 32
+    float m = -INFINITY;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) m = fmaxf(m, st[it][e]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float m_new = fmaxf(m_run, m);
+    const float alpha = __expf((m_run - m_new) * scale2);
+    float sum = 0.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = __expf((st[it][e] - m_new) * scale2);
+        st[it][e] = pv;
+        sum += pv;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    l_run = l_run * alpha + sum;
+    m_run = m_new;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+#pragma unroll
+      for (int dt = 0; dt < CH / 32; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ot[dt][e] *= alpha;
+    }
+    // O^T[d][q] += sum_k V[k][d] P[k][q] over this tile's keys
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        V8 pb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pb[j] = (T)st[it][8 * u + j];
+#pragma unroll
+        for (int dt = 0; dt < CH / 32; ++dt) {
+          V8 va;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int key = kt * 64 + (j & 3) + 8 * (2 * u + (j >> 2)) + 4 * h + 32 * it;
+            va[j] = base16[(long)key * C3 + 2 * CH + 32 * dt + r];
+          }
+          ot[dt] = MM<T>::mfma(va, pb, ot[dt]);
+        }
+      }
+  }
+  // lane (query r) holds channels d = 32 dt + (e&3) + 8(e>>2) + 4h: 4 consecutive channels per e-quad -> 8-B stores
+  const float inv = 1.0f / l_run;
+  T* orow = out + ((long)b * Tn + qb * 32 + r) * C + hd * CH;
+#pragma unroll
+  for (int dt = 0; dt < CH / 32; ++dt)
+#pragma unroll
+    for (int eq = 0; eq < 4; ++eq) {
+      V4T v;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = (T)(ot[dt][eq * 4 + k] * inv);
+      *reinterpret_cast<V4T*>(orow + 32 * dt + 8 * eq + 4 * h) = v;
+    }
+}
+
 extern "C" int stedm_attn_legacy16(const void* qkv, int qkv_is16, void* out16, int B, int T, int heads, int ch, int mm_dtype, void* stream) {
   STEDM_CHECK_ARG(qkv && out16 && B > 0 && heads > 0, "attn_legacy16: bad args");
-  STEDM_CHECK_ARG(T == 64 && (ch == 128 || ch == 64 || ch == 32), "attn_legacy16: covers T == 64 and ch in {32, 64, 128} (T=%d ch=%d)", T, ch);
+  STEDM_CHECK_ARG(T > 0 && T % 64 == 0 && T <= 4096 && (ch == 128 || ch == 64 || ch == 32) && (T == 64 || (qkv_is16 && ch != 32)),
+                  "attn_legacy16: covers T == 64 (ch in {32, 64, 128}) and, from the 16-bit qkv plane, T = 64 n <= 4096 with ch in {64, 128} (T=%d ch=%d)", T, ch);
   STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "attn_legacy16: bad mm_dtype");
+  if (T != 64) {
+    const int np = B * heads * (T / 32), g = (np + 3) / 4;
+    const float sc2 = 1.0f / sqrtf((float)ch);
+    hipStream_t s_ = as_stream(stream);
+    if (mm_dtype == STEDM_F16) {
+      if (ch == 128) attn_mfma_tiles_kernel<_Float16, 128><<<g, 256, 0, s_>>>((const _Float16*)qkv, (_Float16*)out16, np, heads, T, sc2);
+      else attn_mfma_tiles_kernel<_Float16, 64><<<g, 256, 0, s_>>>((const _Float16*)qkv, (_Float16*)out16, np, heads, T, sc2);
+    } else {
+      if (ch == 128) attn_mfma_tiles_kernel<__bf16, 128><<<g, 256, 0, s_>>>((const __bf16*)qkv, (__bf16*)out16, np, heads, T, sc2);
+      else attn_mfma_tiles_kernel<__bf16, 64><<<g, 256, 0, s_>>>((const __bf16*)qkv, (__bf16*)out16, np, heads, T, sc2);
+    }
+    STEDM_LAUNCH_CHECK();
+    return 0;
+  }
   const int nprob = B * heads, grid = (nprob + 3) / 4;
   const float scale2 = 1.0f / sqrtf((float)ch);
   hipStream_t st = as_stream(stream);

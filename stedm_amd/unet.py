@@ -510,8 +510,9 @@ class UNetModel(nn.Module):
         pp = self._packed[id(ab.proj_out)]
         out = self._buf(tag + ".out", (B, H, W, Cc))
         ch = Cc // ab.num_heads
-        if dma and prec.npass == 1 and H * W == 64 and ch in (32, 64, 128) and self._tape is None:
-            # 64 tokens: the qkv conv writes its result as a 16-bit plane, the whole attention of a (sample, head) runs on one wave's
+        if dma and prec.npass == 1 and self._tape is None and ((H * W == 64 and ch in (32, 64, 128)) or
+                                                                 ((H * W) % 64 == 0 and H * W <= 4096 and ch in (64, 128))):
+            # 64 tokens (64 n tokens: key tiles with an online softmax around the same products): the qkv conv writes its result as a 16-bit plane, the whole attention of a (sample, head) runs on one wave's
             # MFMAs and is written as proj_out's 16-bit operand plane (same operand rounding as everywhere in these modes)
             qkv16 = self._planes(B, H, W, 3 * Cc, "qkv16")
             ops.conv_igemm(None, pq.hi, pq.lo, None, prec=prec, ks=1, src16=self._norm16(ab.norm, 0, x), bias=pq.bias, w_frag=pq.frag,

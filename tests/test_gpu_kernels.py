@@ -250,6 +250,27 @@ def test_attn_legacy16_mfma(dev, prec, tol, B, heads, ch):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("prec,tol", [("f16", 1.5e-2), ("bf16", 1e-1)])      # (max error over more keys per query than at T = 64; reported modes)
+@pytest.mark.parametrize("B,T,heads,ch", [(2, 256, 8, 128), (1, 1024, 8, 128), (3, 128, 4, 64), (66, 256, 8, 128)])
+def test_attn_legacy16_mfma_key_tiles(dev, prec, tol, B, T, heads, ch):
+    """the middle block's attention at larger latents (T = 256 at 64x64, 1024 at 128x128): MFMA products with an online softmax over
+    64-key tiles, from the 16-bit qkv plane, against the fp32 oracle."""
+    from oracle import unet as ou
+    from stedm_amd import ops
+    pr = ops.Precision.parse(prec)
+    qkv = prng.normal(7, f"a16t.qkv.{T}", (B, heads * 3 * ch, T)) * 1.5
+    ref = ou.qkv_attention_legacy(qkv, heads)                       # [B, C, T]
+    qd = qkv.permute(0, 2, 1).contiguous().to(dev)
+    q16 = torch.empty(qd.shape, dtype=torch.int16, device=dev)
+    ops.gn_apply16(qd.view(B, 1, T, -1), None, q16.view(B, 1, T, -1), None, pr)
+    out = torch.empty((B, T, heads * ch), dtype=torch.int16, device=dev)
+    ops.attn_legacy16(q16, out, heads, pr)
+    got = _as_float(out, pr).permute(0, 2, 1)
+    err = rel_err(got, ref)
+    print(f"[attention T={T} B={B} {heads}x{ch} {prec}] {err:.2e}")
+    assert err < tol
+
+
 # ------------------------------------------------------------------------------------------------ DDIM
 @pytest.mark.parametrize("B,C,H,W,cfg,eta", [(2, 4, 32, 32, True, 0.0), (3, 3, 16, 16, True, 1.0), (2, 4, 8, 8, False, 1.0),
                                              (1, 3, 128, 128, True, 0.0), (2, 4, 12, 24, True, 0.5)])
