@@ -227,7 +227,9 @@ int stedm_attn_legacy(const float* qkv, float* out, int B, int T, int heads, int
 /* The same for T == 64 tokens and ch in {32, 64, 128} on MFMA (single-product modes): q, k, v and the softmax weights are rounded
  * to the 16-bit operand type, logits / softmax / normalisation stay fp32; writes the 16-bit operand plane [B][64][heads*ch] that
  * proj_out's 1x1 reads (no fp32 intermediate). qkv_is16: qkv is itself the 16-bit plane written by the qkv convolution's epilogue
- * (stedm_conv_args.out16_hi) instead of fp32 - the same rounding, half the bytes. */
+ * (stedm_conv_args.out16_hi) instead of fp32 - the same rounding, half the bytes.
+ * Also T = 64 n <= 4096 tokens with ch in {64, 128} and qkv_is16 = 1 (the middle block at 64x64 / 128x128 latents): 64-key tiles with
+ * an online softmax around the same products. Any other shape returns an error (the caller uses stedm_attn_legacy). */
 int stedm_attn_legacy16(const void* qkv, int qkv_is16, void* out16, int B, int T, int heads, int ch, int mm_dtype, void* stream);
 
 /* ---- DDIM update with rescaled classifier-free guidance ----------------------------------- */

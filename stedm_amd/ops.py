@@ -614,8 +614,8 @@ def attn_legacy(qkv: torch.Tensor, out: torch.Tensor, heads: int) -> torch.Tenso
 
 
 def attn_legacy16(qkv: torch.Tensor, out16: torch.Tensor, heads: int, prec: Precision) -> torch.Tensor:
-    """qkv [B,64,heads*3*ch] (fp32, or the int16 plane a conv epilogue wrote) -> out16 [B,64,heads*ch] 16-bit operand plane
-    (MFMA form, single-product modes)."""
+    """qkv [B,T,heads*3*ch] (fp32, or the int16 plane a conv epilogue wrote) -> out16 [B,T,heads*ch] 16-bit operand plane
+    (MFMA form, single-product modes). T = 64 with ch in {32, 64, 128}; T = 64 n <= 4096 with ch in {64, 128} from the int16 plane."""
     is16 = qkv.dtype == torch.int16
     _chk(qkv, torch.int16 if is16 else torch.float32, name="qkv")
     B, T, C3 = qkv.shape
