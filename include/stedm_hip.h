@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STEDM_ABI_VERSION 2
+#define STEDM_ABI_VERSION 3
 
 #define STEDM_F16 0
 #define STEDM_BF16 1
@@ -78,6 +78,11 @@ int stedm_space_to_depth16(const float* x, int C, int B, int H, int W, void* out
  * Element (n, ci, tap) is read at w[n*sn + ci*sc + tap'] with tap' = flip ? taps - 1 - tap : tap (sn = cin*taps, sc = taps, flip = 0
  * for a plain OIHW filter). */
 int stedm_pack_conv_weight_frag16(const float* w, long sn, long sc, int flip, void* out, int cout, int cin, int ks, int mm_dtype, void* stream);
+/* The 3x3 form for the 3-product mode (npass = 3): out = [2][total] 16-bit elements, the fragment stream of hi = round(w) followed by the
+ * stream of lo = round(w - hi), total = ceil(cout / 128) * (cin / 32) * 9 * 4096. Passed as stedm_conv_args.w_frag16 with npass = 3, the plain
+ * stride-1 3x3 problems from 128 input channels run on the register-streamed kernel (three MFMAs per fragment pair); w_hi / w_lo must still be
+ * given: every other problem takes the LDS-operand kernels as before. */
+int stedm_pack_conv_weight_frag16_hl(const float* w, long sn, long sc, int flip, void* out, int cout, int cin, int mm_dtype, void* stream);
 int stedm_pack_conv_weight_s2d_frag(const float* w_oihw, void* out, int cout, int cin, int mm_dtype, int pad_br, void* stream);
 /* [rows][cols] fp32 -> [cols][rows] fp32 (Linear weights are consumed K-major). */
 int stedm_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
@@ -168,7 +173,8 @@ typedef struct stedm_conv_args {
   float* ws;
   int64_t ws_floats;
   int32_t chan_nslab; /* slot count of chan_stats (see there) */
-  const void* w_frag16; /* optional: the 3x3 weights in the fragment order of v_mfma_f32_16x16x32 (stedm_pack_conv_weight_frag16; cin %% 32 == 0).
+  const void* w_frag16; /* optional: the 3x3 weights in the fragment order of v_mfma_f32_16x16x32 (stedm_pack_conv_weight_frag16; cin %% 32 == 0;
+                         * npass = 3: the hi + lo streams of stedm_pack_conv_weight_frag16_hl).
                          * When given, the plain 3x3 stride-1 single-product problems of the register-streamed kernel run on that MFMA
                          * shape (same tiles, same LDS image; the chip holds a higher clock on it on real data) */
   const void* w_frag_b16; /* with w_frag16 and the fused skip_connection: the 1x1 weights from stedm_pack_conv_weight_frag16(ks = 1) */

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STEDM_HIP_LIB") or os.path.join(_HERE, "libstedm_hip.so")     # STEDM_HIP_LIB: A/B timing of another build
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 F16, BF16 = 0, 1
 CONV_S1, CONV_DOWN, CONV_UP, CONV_UP_SUBPIXEL, CONV_S2D = 0, 1, 2, 3, 4
 
@@ -51,6 +51,7 @@ SIGNATURES = {
     "stedm_pack_conv_weight_frag": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "stedm_pack_conv_weight_up_frag": (_I, [_P, _P, _I, _I, _I, _P]),
     "stedm_pack_conv_weight_frag16": (_I, [_P, C.c_long, C.c_long, _I, _P, _I, _I, _I, _I, _P]),
+    "stedm_pack_conv_weight_frag16_hl": (_I, [_P, C.c_long, C.c_long, _I, _P, _I, _I, _I, _P]),
     "stedm_pack_conv_weight_s2d_frag": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "stedm_space_to_depth16": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P]),
     "stedm_transpose_f32": (_I, [_P, _P, _I, _I, _P]),

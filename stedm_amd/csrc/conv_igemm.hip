@@ -329,9 +329,10 @@ extern "C" int stedm_conv_fused_skip_ok(const stedm_conv_args* args) {
 }
 
 // Would the register-streamed kernel (fragment-order weights, conv_rs.inc) run this problem? Then w_hi / w_lo are never read and the
-// caller may skip packing them (pass any non-NULL w_hi). Same decision path as stedm_conv_igemm, nothing is launched.
+// caller may skip packing them (pass any non-NULL w_hi). Same decision path as stedm_conv_igemm, nothing is launched. (npass = 3: with the
+// hi + lo streams in w_frag16.)
 extern "C" int stedm_conv_rs_ok(const stedm_conv_args* args) {
-  if (!args || !args->src16_hi || (!args->w_frag && !args->w_frag16) || args->npass != 1) return 0;
+  if (!args || !args->src16_hi || (!args->w_frag && !args->w_frag16) || (args->npass != 1 && !args->w_frag16)) return 0;
   ConvParams p;
   memset(&p, 0, sizeof(p));
   p.a = *args;

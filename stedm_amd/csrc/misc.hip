@@ -111,7 +111,7 @@ constexpr int kPackTileFloats = 64 * (16 * 9 + 1);     // the largest tile of th
 // block `bid` of one tensor's pack; `traw`: kPackTileFloats floats of LDS
 template <typename T, int taps, bool M16>
 __device__ __forceinline__ void pack_frag_block(const float* __restrict__ w, T* __restrict__ out, const int cout, const int cin, const long sn,
-                                                const long sc, const int flip, const int bid, float* traw) {
+                                                const long sc, const int flip, const int bid, float* traw, T* __restrict__ out_lo = nullptr) {
   typedef T V8 __attribute__((ext_vector_type(8)));
   constexpr int NR = M16 ? 32 : 64, KC = M16 ? 32 : 16, NSUB = 128 / NR;     // rows and channels per block, blocks per 128-row tile
   constexpr int PITCH = KC * taps + 1;
@@ -162,15 +162,22 @@ __device__ __forceinline__ void pack_frag_block(const float* __restrict__ w, T* 
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (T)tile[row][(c8 + e) * taps + tap];
     const int q = half * 2 + ql;
-    *reinterpret_cast<V8*>(out + ((((long)tn * nch + chunk) * taps + tap) * (M16 ? 8 : 4) + q) * 512 + lane * 8) = o;
+    const long at = ((((long)tn * nch + chunk) * taps + tap) * (M16 ? 8 : 4) + q) * 512 + lane * 8;
+    *reinterpret_cast<V8*>(out + at) = o;
+    if (out_lo) {     // 3-product mode: the second stream holds w - hi
+      V8 l;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) l[e] = (T)(tile[row][(c8 + e) * taps + tap] - (float)o[e]);
+      *reinterpret_cast<V8*>(out_lo + at) = l;
+    }
   }
 }
 
 template <typename T, int taps, bool M16 = false>
 __global__ void __launch_bounds__(256) pack_conv_weight_frag_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, long total,
-                                                                    long sn, long sc, int flip) {
+                                                                    long sn, long sc, int flip, T* __restrict__ out_lo = nullptr) {
   __shared__ float traw[kPackTileFloats];
-  pack_frag_block<T, taps, M16>(w, out, cout, cin, sn, sc, flip, blockIdx.x, traw);
+  pack_frag_block<T, taps, M16>(w, out, cout, cin, sn, sc, flip, blockIdx.x, traw, out_lo);
 }
 
 // Many tensors in ONE launch (the training step re-packs every convolution's weights after each optimizer step: ~130 packs of a few
@@ -311,6 +318,21 @@ extern "C" int stedm_pack_conv_weight_frag16(const float* w, long sn, long sc, i
     if (taps == 9) pack_conv_weight_frag_kernel<__bf16, 9, true><<<grid, 256, 0, st>>>(w, (__bf16*)out, cout, cin, total, sn, sc, flip);
     else pack_conv_weight_frag_kernel<__bf16, 1, true><<<grid, 256, 0, st>>>(w, (__bf16*)out, cout, cin, total, sn, sc, flip);
   }
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+// hi and lo fragment streams of the 3-product mode: out = [2][total] elements, total = ceil(cout / 128) * (cin / 32) * 9 * 8 * 512
+extern "C" int stedm_pack_conv_weight_frag16_hl(const float* w, long sn, long sc, int flip, void* out, int cout, int cin, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(w && out && cin % 32 == 0 && cout > 0, "pack_conv_weight_frag16_hl: bad args (cin %% 32)");
+  STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "pack_conv_weight_frag16_hl: bad mm_dtype %d", mm_dtype);
+  const long total = (long)((cout + 127) / 128) * (cin / 32) * 9 * 8 * 64 * 8;
+  const int grid = ((cout + 127) / 128) * (cin / 32) * 4;
+  hipStream_t st = as_stream(stream);
+  if (mm_dtype == STEDM_F16)
+    pack_conv_weight_frag_kernel<_Float16, 9, true><<<grid, 256, 0, st>>>(w, (_Float16*)out, cout, cin, total, sn, sc, flip, (_Float16*)out + total);
+  else
+    pack_conv_weight_frag_kernel<__bf16, 9, true><<<grid, 256, 0, st>>>(w, (__bf16*)out, cout, cin, total, sn, sc, flip, (__bf16*)out + total);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

@@ -112,6 +112,12 @@ def pack_conv_weight_frag16(w: torch.Tensor, prec: Precision, sn: Optional[int] 
         sn, sc = cin * ks * ks, ks * ks
     _chk(w, name="conv weight")
     assert cin % 32 == 0
+    if prec.npass == 3:      # 3-product mode: [2] = the hi stream, then the lo stream (3x3 only)
+        assert ks == 3
+        out = torch.empty((2, (cout + 127) // 128, cin // 32, 9, 8, 64, 8), dtype=torch.int16, device=w.device)
+        check(lib().stedm_pack_conv_weight_frag16_hl(w.data_ptr(), sn, sc, int(flip), out.data_ptr(), cout, cin, prec.mm_dtype, _stream()),
+              "stedm_pack_conv_weight_frag16_hl")
+        return out
     out = torch.empty(((cout + 127) // 128, cin // 32, ks * ks, 8, 64, 8), dtype=torch.int16, device=w.device)
     check(lib().stedm_pack_conv_weight_frag16(w.data_ptr(), sn, sc, int(flip), out.data_ptr(), cout, cin, ks, prec.mm_dtype, _stream()),
           "stedm_pack_conv_weight_frag16")
@@ -309,7 +315,7 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
                src16: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None, act_out: int = 0,
                out16: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None, w_frag: Optional[torch.Tensor] = None,
                chan_stats: Optional[torch.Tensor] = None,
-               skip: Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = None, query_fused: bool = False,
+               skip: Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = None, query_fused: bool = False, query_rs: bool = False,
                ws: Optional[torch.Tensor] = None, pad_br: bool = False, w_frag16: Optional[torch.Tensor] = None):
     """src1 [B,Hin,Win,c1] NHWC fp32 (fused path) and/or src16 = (hi, lo) 16-bit NHWC planes [B,Hin,Win,Cin] from
     gn_apply16 (DMA path) -> out [B,Hout,Wout,cout] NHWC fp32 (see stedm_conv_igemm)."""
@@ -318,7 +324,7 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
     a = ConvArgs()
     a.act_out = act_out
     a.pad_br = int(pad_br)
-    a.w_frag16 = _ptr(w_frag16) if prec.npass == 1 else None
+    a.w_frag16 = _ptr(w_frag16)      # npass 3: the hi + lo streams of pack_conv_weight_frag16 in that mode
     a.w_frag = _ptr(w_frag) if prec.npass == 1 else None
     a.chan_stats = _ptr(chan_stats)
     a.chan_nslab = 0 if chan_stats is None else chan_stats.shape[1]
@@ -375,6 +381,8 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
         assert w_hi.shape == (a.cout, ks * ks, a.c1 + a.c2), (w_hi.shape, a.cout, ks, a.c1, a.c2)
     if query_fused:     # capability query only: would this (fused) problem run as one kernel?
         return bool(lib().stedm_conv_fused_skip_ok(C.byref(a)))
+    if query_rs:        # capability query only: would the register-streamed kernel run this problem?
+        return bool(lib().stedm_conv_rs_ok(C.byref(a)))
     check(lib().stedm_conv_igemm(C.byref(a), _stream()), "stedm_conv_igemm")
     return out
 

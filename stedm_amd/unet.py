@@ -300,6 +300,8 @@ class UNetModel(nn.Module):
                     pk.hi.reset()
                 else:
                     pk.hi, pk.lo = ops.pack_conv_weight(conv.weight.float(), prec)
+                    if pk.frag16 is not None:     # 3-product mode: the hi + lo fragment streams
+                        pk.frag16 = ops.pack_conv_weight_frag16(conv.weight.detach().float(), prec)
                 return
             hi = lo = frag = None
             w4 = conv.weight.detach().float()
@@ -324,6 +326,10 @@ class UNetModel(nn.Module):
                 hi = ops.LazyPlanes(lambda w=conv.weight: ops.pack_conv_weight(w.float(), prec))
             else:
                 hi, lo = ops.pack_conv_weight(conv.weight.float(), prec)
+                if self.conv_path == "dma" and prec.npass == 3 and k3 and self._m16 and conv.in_channels % 32 == 0 and conv.in_channels >= 128:
+                    # 3-product mode on the register-streamed kernel (conv_rs.inc P3): hi + lo fragment streams; the planes above stay for
+                    # the problems it does not take
+                    frag16 = ops.pack_conv_weight_frag16(w4, prec)
             self._packed[id(conv)] = _Packed(hi, lo, None if conv.bias is None else conv.bias.detach().float().contiguous(), frag, frag16)
 
         for m in self.modules():

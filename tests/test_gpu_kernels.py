@@ -400,7 +400,7 @@ def test_conv_epilogue_chan_stats(dev, prec, B, H, W, cin, cout):
     assert torch.equal(cs, cs2)   # no atomics anywhere: bitwise reproducible
 
 
-def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_emb=True, use_res=True, seed=12, frag=False, ws=False, m16=False):
+def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_emb=True, use_res=True, seed=12, frag=False, ws=False, m16=False, want_rs=None):
     from stedm_amd import ops
     from stedm_amd._lib import CONV_DOWN, CONV_S1, CONV_UP, CONV_UP_SUBPIXEL
     prec = ops.Precision.parse(prec_name)
@@ -427,12 +427,15 @@ def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_em
     out = torch.full((B, Ho, Wo, cout), float("nan"), device=dev)
     # stride-2 patches can exceed LDS in the DMA kernel: pass the fp32 source too so the dispatcher may fall back
     src1 = nhwc(a).to(dev) if mode == "down" else None
-    ops.conv_igemm(src1, whi, wlo, out, prec=prec, ks=ks, mode=m, src16=(hi16, lo16), bias=bias.to(dev),
-                   emb=None if emb is None else emb.to(dev), emb_offset=8, emb_bstride=0 if emb is None else emb.shape[1],
-                   res=None if res is None else nhwc(res).to(dev),
-                   w_frag=None if not frag else (ops.pack_conv_weight_up_frag(w.to(dev), prec) if mode == "up2" else ops.pack_conv_weight_frag(w.to(dev), prec)),
-                   ws=torch.empty(16 * out.numel(), device=dev) if ws else None,
-                   w_frag16=ops.pack_conv_weight_frag16(w.to(dev), prec) if m16 else None)
+    kw = dict(prec=prec, ks=ks, mode=m, src16=(hi16, lo16), bias=bias.to(dev),
+              emb=None if emb is None else emb.to(dev), emb_offset=8, emb_bstride=0 if emb is None else emb.shape[1],
+              res=None if res is None else nhwc(res).to(dev),
+              w_frag=None if not frag else (ops.pack_conv_weight_up_frag(w.to(dev), prec) if mode == "up2" else ops.pack_conv_weight_frag(w.to(dev), prec)),
+              ws=torch.empty(16 * out.numel(), device=dev) if ws else None,
+              w_frag16=ops.pack_conv_weight_frag16(w.to(dev), prec) if m16 else None)
+    if want_rs is not None:     # the register-streamed kernel must (not) be the one that runs
+        assert ops.conv_igemm(src1, whi, wlo, out, query_rs=True, **kw) == want_rs
+    ops.conv_igemm(src1, whi, wlo, out, **kw)
     torch.cuda.synchronize()
     err = rel_err(nchw(out), ref)
     assert err < tol, f"{prec_name}: rel err {err:.3e} >= {tol}"
@@ -469,6 +472,19 @@ def test_conv_3x3_mfma16x16x32_kind(dev, prec, tol, B, H, W, cin, cout, emb, res
     large-K shapes, and the split-K form of small grids — against F.conv2d. (Below 256 input channels the dispatcher keeps the
     32x32x16 form — the last case — which is faster there.)"""
     _conv_dma_case(dev, prec, tol, B, H, W, cin, cout, "s1", 3, use_emb=emb, use_res=res, frag=True, ws=ws, m16=True)
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,emb,res,ws", [
+    (50, 32, 32, 256, 96, True, True, False), (200, 16, 16, 288, 128, True, False, False), (801, 8, 8, 256, 32, False, True, False),
+    (12, 64, 64, 128, 32, True, True, False), (64, 32, 32, 128, 160, True, True, False), (400, 8, 8, 320, 256, True, True, False),
+    (128, 8, 8, 1024, 1024, True, True, False), (64, 16, 16, 1536, 512, False, False, False), (64, 8, 8, 2048, 1024, True, False, True),
+    (2, 8, 8, 1024, 1024, False, True, True), (1, 32, 32, 384, 128, True, True, True), (100, 16, 16, 160, 256, True, True, False)])
+def test_conv_3x3_three_products_register_streamed(dev, B, H, W, cin, cout, emb, res, ws):
+    """the 3-product (hi / lo split) mode on the register-streamed 16x16x32 kind (conv_rs.inc P3: hi + lo images in a 3-buffer chunk
+    ring, hi + lo fragment streams of stedm_pack_conv_weight_frag16_hl, lo.hi + hi.lo + hi.hi per fragment pair): full and ragged
+    grids, whole-sample tiles, odd and even chunk counts, the split-K form — against F.conv2d at the parity tolerance; the capability
+    query confirms which kernel runs."""
+    _conv_dma_case(dev, "parity", PRECS[0][1], B, H, W, cin, cout, "s1", 3, use_emb=emb, use_res=res, ws=ws, m16=True, want_rs=True)
 
 
 @pytest.mark.parametrize("prec,tol", PRECS[1:])

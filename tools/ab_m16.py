@@ -4,6 +4,7 @@ v_mfma_f32_32x32x16 vs RS_3X3M on v_mfma_f32_16x16x32, interleaved rounds on ran
 28), per layer shape of the NS32 denoising step and for the whole hipGraph-replayed step.
 
     python tools/ab_m16.py [bf16|f16] [rounds]
+    python tools/ab_m16.py parity [rounds]     3-product mode: LDS-operand kernel vs the register-streamed 16x16x32 kind (conv_rs.inc P3)
 """
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,14 +30,15 @@ def main():
         x = torch.randn(B, H, W, cin, device=dev)
         w = torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
         h16 = torch.empty(B, H, W, cin, dtype=torch.int16, device=dev)
-        ops.gn_apply16(x, None, h16, None, prec)
-        hi, _ = ops.pack_conv_weight(w, prec)
-        wf, wf16 = ops.pack_conv_weight_frag(w, prec), ops.pack_conv_weight_frag16(w, prec)
+        l16 = torch.empty_like(h16) if prec.npass == 3 else None
+        ops.gn_apply16(x, None, h16, l16, prec)
+        hi, lo = ops.pack_conv_weight(w, prec)
+        wf, wf16 = (ops.pack_conv_weight_frag(w, prec) if prec.npass == 1 else None), ops.pack_conv_weight_frag16(w, prec)
         out = torch.empty(B, H, W, cout, device=dev)
         bias = torch.randn(cout, device=dev)
         ws = torch.empty(16 * out.numel(), device=dev) if out.numel() <= (1 << 20) else torch.empty(2 * out.numel(), device=dev)
         cs = torch.empty(B, (H * W + 255) // 256, cout, 2, device=dev)
-        runs = [lambda f16=f16: ops.conv_igemm(None, hi, None, out, prec=prec, src16=(h16, None), bias=bias, w_frag=wf, w_frag16=f16, ws=ws, chan_stats=cs)
+        runs = [lambda f16=f16: ops.conv_igemm(None, hi, lo, out, prec=prec, src16=(h16, l16), bias=bias, w_frag=wf, w_frag16=f16, ws=ws, chan_stats=cs)
                 for f16 in (None, wf16)]
         for r in runs:
             for _ in range(3): r()
@@ -50,7 +52,7 @@ def main():
                 e1.record(); torch.cuda.synchronize()
                 ts[k].append(e0.elapsed_time(e1) / 5 * 1e3)
         m = [float(np.median(t)) for t in ts]
-        fl = 2.0 * B * H * W * cout * cin * 9
+        fl = 2.0 * B * H * W * cout * cin * 9 * prec.npass      # executed products
         tot[0] += m[0]; tot[1] += m[1]
         print(f"{name:24s} {m[0]:12.1f} {m[1]:12.1f} {m[0] / m[1]:7.3f} {fl / m[0] / 1e6:9.1f} {fl / m[1] / 1e6:9.1f}", flush=True)
     print(f"{'SUM':24s} {tot[0]:12.1f} {tot[1]:12.1f} {tot[0] / tot[1]:7.3f}")
