@@ -13,6 +13,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_step -o r
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/prof_${TAG}_pmc_mfma -o run -- $B > $O/prof_${TAG}_pmc_mfma.log 2>&1 && echo mfma ok &&
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/prof_${TAG}_pmc_fetch -o run -- $B > $O/prof_${TAG}_pmc_fetch.log 2>&1 && echo fetch ok &&
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/prof_${TAG}_pmc_write -o run -- $B > $O/prof_${TAG}_pmc_write.log 2>&1 && echo write ok &&
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_parity -o run -- $B --precision parity > $O/prof_${TAG}_parity.log 2>&1 && echo parity ok &&
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/prof_${TAG}_pmc_mfma_parity -o run -- $B --precision parity > $O/prof_${TAG}_pmc_mfma_parity.log 2>&1 && echo mfma parity ok &&
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_train -o run -- python3 $R/tools/bench_train.py > $O/prof_${TAG}_train.log 2>&1 && echo train ok &&
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_svit -o run -- python3 $R/tools/bench_svit.py bf16 8 > $O/prof_${TAG}_svit.log 2>&1 && echo svit ok &&
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_swin -o run -- python3 $R/tools/bench_swin.py bf16 128 32 > $O/prof_${TAG}_swin.log 2>&1 && echo swin ok
