@@ -696,3 +696,60 @@ def test_two_rank_step_through_the_latent_diffusion_surface(dev):
     worst = max(float(np.abs(got[n] - ref[n]).max()) for n in ref)
     print(f"two-rank training_step_hip vs accumulation: max |dw| = {worst:.2e} (lr 1e-3)")
     assert worst < 2e-5
+
+
+@pytest.mark.parametrize("B,H,W,c1,c2,act,use_add,acc", [
+    (4, 8, 8, 1024, 0, 1, True, False), (3, 8, 8, 1024, 1024, 1, False, True), (2, 16, 16, 512, 0, 1, True, False),
+    (2, 16, 16, 1024, 512, 1, True, False), (2, 32, 32, 128, 0, 1, False, False), (2, 32, 32, 256, 128, 1, True, True),
+    (3, 10, 10, 64, 0, 0, True, False), (2, 16, 16, 512, 512, 0, False, False), (1, 64, 64, 128, 0, 1, True, False)])
+def test_group_norm_backward_kernels_vs_autograd(dev, B, H, W, c1, c2, act, use_add, acc):
+    """stedm_gn_bwd (one-pass LDS-resident form where a channel run of whole groups fits, the statistics / fold / apply chain otherwise:
+    1536 and 384 channels, 64 x 64 pixels) against torch autograd of act(GroupNorm32([x1|x2])): dx (+ add, + accumulate), the 16-bit
+    planes of dx, dgamma, dbeta. util.py:199-216."""
+    import torch.nn.functional as F
+    from stedm_amd import ops
+    C, G, HW = c1 + c2, 32, H * W
+    prec = ops.Precision.parse("parity")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = (torch.randn(B, C, H, W, generator=g, dtype=torch.float64) * 1.5 + 0.3).requires_grad_(True)
+    gamma = (1.0 + 0.3 * torch.randn(C, generator=g, dtype=torch.float64)).requires_grad_(True)
+    beta = (0.2 * torch.randn(C, generator=g, dtype=torch.float64)).requires_grad_(True)
+    dA = torch.randn(B, C, H, W, generator=g, dtype=torch.float64)
+    add = torch.randn(B, C, H, W, generator=g, dtype=torch.float64) if use_add else None
+    old = torch.randn(B, C, H, W, generator=g, dtype=torch.float64) if acc else None
+    y = F.group_norm(x, G, gamma, beta, eps=1e-5)
+    if act:
+        y = F.silu(y)
+    (y * dA).sum().backward()
+    want = x.grad + (add if use_add else 0) + (old if acc else 0)
+
+    def nhwc(t):
+        return t.permute(0, 2, 3, 1).contiguous().float().to(dev)
+    xf = nhwc(x.detach())
+    x1 = xf[..., :c1].contiguous()
+    x2 = xf[..., c1:].contiguous() if c2 else None
+    cs1 = torch.empty(B, ops.gn_chan_nslab(HW), c1, 2, device=dev); ops.gn_chan_stats(x1, cs1)
+    cs2 = None
+    if c2:
+        cs2 = torch.empty(B, ops.gn_chan_nslab(HW), c2, 2, device=dev); ops.gn_chan_stats(x2, cs2)
+    mr = torch.empty(B, G, 2, device=dev)
+    ops.gn_fold(cs1, cs2, G, HW, 1e-5, mr)
+    ws = torch.empty(ops.gn_bwd_ws_floats(B, HW, C, G), device=dev)
+    oldf = nhwc(old) if acc else None
+    dx1 = oldf[..., :c1].contiguous() if acc else torch.full((B, H, W, c1), float("nan"), device=dev)
+    dx2 = None
+    if c2:
+        dx2 = oldf[..., c1:].contiguous() if acc else torch.full((B, H, W, c2), float("nan"), device=dev)
+    hi = torch.empty(B, H, W, C, dtype=torch.int16, device=dev); lo = torch.empty_like(hi)
+    dgam = torch.full((C,), float("nan"), device=dev); dbet = torch.full((C,), float("nan"), device=dev)
+    ops.gn_bwd(x1, x2, mr, gamma.detach().float().to(dev), beta.detach().float().to(dev), G, act, nhwc(dA), nhwc(add) if use_add else None, ws,
+               dx1, acc, dx2, acc, (hi, lo) if not acc else None, prec, dgam, dbet, False)
+    torch.cuda.synchronize()
+    got = torch.cat([dx1] + ([dx2] if c2 else []), dim=-1).double().cpu().permute(0, 3, 1, 2)
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2e-5 * scale
+    assert float((dgam.double().cpu() - gamma.grad).abs().max()) <= 2e-5 * float(gamma.grad.abs().max()) + 1e-4
+    assert float((dbet.double().cpu() - beta.grad).abs().max()) <= 2e-5 * float(beta.grad.abs().max()) + 1e-4
+    if not acc:     # hi + lo planes (fp16 split) carry dx to ~2^-22
+        rec = (hi.view(torch.float16).double() + lo.view(torch.float16).double()).cpu().permute(0, 3, 1, 2)
+        assert float((rec - want).abs().max()) <= 1e-4 * scale
