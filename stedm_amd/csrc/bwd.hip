@@ -212,56 +212,68 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(GnBwdArgs a) {
   }
 }
 
-// One-pass form: a block owns (sample b, a run of `cb` channels made of whole groups) and keeps xhat and dy of its HW x cb slice in LDS, so x
-// and dA are read ONCE and the group means never leave the block: statistics, fold and apply in one launch (the three-kernel chain above
+// One-pass form: a block owns (sample b, a run of `cb` channels made of whole groups) and keeps xhat and dy of its HW x cb slice in REGISTERS
+// (512 threads = qb channel quads x 512 / qb pixel lanes, PPT pixels per thread), so x and dA are read ONCE, with every load of the slice
+// in flight at once, and the group means never leave the block: statistics, fold and apply in one launch (the three-kernel chain above
 // cost ~50 us of launches and tails per GroupNorm on tensors that stream in ~25 us). Writes bc[b][c][2] for gn_bwd_param_kernel.
-// 512 threads = qb channel quads x (512 / qb) pixel lanes; LDS: 2 x HW x cb floats + 8 KB of reduction scratch.
 struct GnBwdFusedArgs {
   GnBwdArgs g;
   float* bc;
   int cb;
 };
 
-template <typename T>
+template <typename T, int PPT>
 __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(GnBwdFusedArgs fa) {
   typedef T V4 __attribute__((ext_vector_type(4)));
-  extern __shared__ __attribute__((aligned(16))) float fsm[];
+  __shared__ float red[512 * 8 + 2 * 288 + 2 * 72];  // [npl][qb][8] lane partials | [cb][2] gamma-weighted sums | [groups of the block][2]
   const GnBwdArgs& a = fa.g;
   const int b = blockIdx.x, cb = fa.cb, c0 = blockIdx.y * cb;
   const int C = a.c1 + a.c2, cpg = C / a.groups, qb = cb >> 2, t = threadIdx.x;
   const int npl = 512 / qb, tq = t % qb, tp = t / qb;
   const bool on = tp < npl;
-  float* xs = fsm;                                   // [HW][cb] xhat
-  float* ds = xs + (long)a.HW * cb;                  // [HW][cb] dy
-  float* red = ds + (long)a.HW * cb;                 // [npl][qb][8] lane partials, then [cb][2] gamma-weighted sums and [groups of the block][2]
   const int c = c0 + tq * 4;
   const bool first = c0 < a.c1;                      // the host keeps a block on one side of the concat seam
   const float* px = first ? a.x1 + (long)b * a.HW * a.c1 + c : a.x2 + (long)b * a.HW * a.c2 + (c - a.c1);
   const int ldx = first ? a.c1 : a.c2;
   const float* pd = a.dA + (long)b * a.HW * C + c;
   float mean[4], rstd[4], ga[4], be[4];
+  float xh[PPT][4], dy[PPT][4];
+  float4 av[PPT];
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   if (on) {
+    float4 xv[PPT], dv[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const int pix = tp + k * npl;
+      xv[k] = dv[k] = av[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pix < a.HW) {
+        xv[k] = *reinterpret_cast<const float4*>(px + (long)pix * ldx);
+        dv[k] = *reinterpret_cast<const float4*>(pd + (long)pix * C);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int g = (c + j) / cpg;
       mean[j] = a.mr[((long)b * a.groups + g) * 2]; rstd[j] = a.mr[((long)b * a.groups + g) * 2 + 1];
       ga[j] = a.gamma[c + j]; be[j] = a.beta[c + j];
     }
-#pragma unroll 4
-    for (int pix = tp; pix < a.HW; pix += npl) {
-      const float4 xv = *reinterpret_cast<const float4*>(px + (long)pix * ldx);
-      const float4 dv = *reinterpret_cast<const float4*>(pd + (long)pix * C);
-      const float xi[4] = {xv.x, xv.y, xv.z, xv.w}, di[4] = {dv.x, dv.y, dv.z, dv.w};
-      float xh[4], dy[4];
+    if (a.add) {     // the residual branch's gradient is needed after the fold: in flight across it
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const int pix = tp + k * npl;
+        if (pix < a.HW) av[k] = *reinterpret_cast<const float4*>(a.add + ((long)b * a.HW + pix) * C + c);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const bool live = tp + k * npl < a.HW;
+      const float xi[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w}, di[4] = {dv[k].x, dv[k].y, dv[k].z, dv[k].w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        xh[j] = (xi[j] - mean[j]) * rstd[j];
-        dy[j] = a.act ? di[j] * silu_grad(xh[j] * ga[j] + be[j]) : di[j];
-        s1[j] += dy[j]; s2[j] += dy[j] * xh[j];
+        xh[k][j] = (xi[j] - mean[j]) * rstd[j];
+        dy[k][j] = a.act ? di[j] * silu_grad(xh[k][j] * ga[j] + be[j]) : di[j];
+        if (live) { s1[j] += dy[k][j]; s2[j] += dy[k][j] * xh[k][j]; }
       }
-      *reinterpret_cast<float4*>(xs + (long)pix * cb + tq * 4) = make_float4(xh[0], xh[1], xh[2], xh[3]);
-      *reinterpret_cast<float4*>(ds + (long)pix * cb + tq * 4) = make_float4(dy[0], dy[1], dy[2], dy[3]);
     }
     float* d = red + (tp * qb + tq) * 8;
 #pragma unroll
@@ -299,19 +311,15 @@ __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(GnBwdFusedArgs fa) {
   for (int j = 0; j < 4; ++j) { const int gl = (tq * 4 + j) / cpg; m1[j] = gmv[gl * 2]; m2[j] = gmv[gl * 2 + 1]; }
   float* pdx = first ? a.dx1 + (long)b * a.HW * a.c1 + c : a.dx2 + (long)b * a.HW * a.c2 + (c - a.c1);
   const bool acc = first ? a.acc1 : a.acc2;
-#pragma unroll 4
-  for (int pix = tp; pix < a.HW; pix += npl) {
-    const float4 xv = *reinterpret_cast<const float4*>(xs + (long)pix * cb + tq * 4);
-    const float4 dv = *reinterpret_cast<const float4*>(ds + (long)pix * cb + tq * 4);
-    const float xh[4] = {xv.x, xv.y, xv.z, xv.w}, dy[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int pix = tp + k * npl;
+    if (pix >= a.HW) break;
     float r[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = rstd[j] * (ga[j] * dy[j] - m1[j] - xh[j] * m2[j]);
+    for (int j = 0; j < 4; ++j) r[j] = rstd[j] * (ga[j] * dy[k][j] - m1[j] - xh[k][j] * m2[j]);
+    r[0] += av[k].x; r[1] += av[k].y; r[2] += av[k].z; r[3] += av[k].w;
     const long o = ((long)b * a.HW + pix) * C + c;
-    if (a.add) {
-      const float4 av = *reinterpret_cast<const float4*>(a.add + o);
-      r[0] += av.x; r[1] += av.y; r[2] += av.z; r[3] += av.w;
-    }
     float* dst = pdx + (long)pix * ldx;
     if (acc) {
       const float4 old = *reinterpret_cast<const float4*>(dst);
@@ -333,26 +341,32 @@ __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(GnBwdFusedArgs fa) {
   }
 }
 
+template <typename T>
+static void launch_gn_bwd_fused(const GnBwdFusedArgs& fa, int ppt, dim3 grid, hipStream_t st) {
+  if (ppt <= 2) gn_bwd_fused_kernel<T, 2><<<grid, 512, 0, st>>>(fa);
+  else if (ppt <= 4) gn_bwd_fused_kernel<T, 4><<<grid, 512, 0, st>>>(fa);
+  else gn_bwd_fused_kernel<T, 8><<<grid, 512, 0, st>>>(fa);
+}
+
 // channel run of the one-pass kernel for this shape (0: use the three-kernel chain): whole groups, one side of the concat seam, rows of
-// at least 64 B, slice within the LDS budget (72 KB -> two blocks per CU when the rows stay >= 128 B, else up to 144 KB)
-static int gn_bwd_fused_cb(int c1, int c2, int groups, int HW, size_t* lds_out) {
+// at least 64 B (128 B preferred), at most 8 pixels per thread; *ppt_out = pixels per thread
+static int gn_bwd_fused_cb(int c1, int c2, int groups, int HW, int* ppt_out) {
   static const bool off = getenv("STEDM_GN_BWD_CHAIN") != nullptr;
   if (off) return 0;
   const int C = c1 + c2, cpg = C / groups;
   int unit = cpg;
   while (unit % 4 != 0) unit *= 2;                   // whole groups and whole quads
-  auto fits = [&](int cb) { return cb <= 288 && c1 % cb == 0 && (c2 == 0 || c2 % cb == 0) && 512 / (cb / 4) >= 1; };
-  auto pick = [&](size_t budget, int min_cb) {
-    int best = 0;
-    for (int cb = unit; (size_t)2 * HW * cb * 4 <= budget && cb <= 288; cb += unit)
-      if (fits(cb) && cb >= min_cb) best = cb;
-    return best;
-  };
-  int cb = pick(72 * 1024 - 12 * 1024, 32);
-  if (cb == 0) cb = pick(160 * 1024 - 24 * 1024, 16);
-  if (cb == 0) return 0;
-  *lds_out = (size_t)2 * HW * cb * 4 + (512 * 8 + 2 * 288 + 2 * 72) * sizeof(float);
-  return cb;
+  auto ppt_of = [&](int cb) { const int npl = 512 / (cb / 4); return npl > 0 ? (HW + npl - 1) / npl : 1 << 20; };
+  // the widest run at <= 4 pixels per thread (88 registers: two blocks per CU) with rows of >= 128 B; else the widest at <= 8 (164 registers)
+  int best = 0;
+  for (int pass = 0; pass < 2 && best == 0; ++pass)
+    for (int cb = unit; cb <= 288; cb += unit) {
+      if (c1 % cb != 0 || (c2 != 0 && c2 % cb != 0) || cb < (pass == 0 ? 32 : 16) || ppt_of(cb) > (pass == 0 ? 4 : 8)) continue;
+      best = cb;
+    }
+  if (best == 0) return 0;
+  *ppt_out = ppt_of(best);
+  return best;
 }
 
 // ------------------------------------------------------------------------------------------------ transposed im2col (16-bit)
@@ -868,19 +882,12 @@ extern "C" int stedm_gn_bwd(const float* x1, int c1, const float* x2, int c2, co
   float* gm = bc + (long)B * C * 2;
   GnBwdArgs a{x1, x2, c1, c2, mean_rstd, gamma, beta, dA, groups, HW, act, part, gm, add, dx1, dx2, acc1, acc2, dx16_hi, dx16_lo};
   hipStream_t st = as_stream(stream);
-  size_t flds = 0;
-  const int cb = gn_bwd_fused_cb(c1, c2, groups, HW, &flds);
+  int ppt = 0;
+  const int cb = gn_bwd_fused_cb(c1, c2, groups, HW, &ppt);
   if (cb > 0) {     // one pass: x and dA read once, no slab partials
     GnBwdFusedArgs fa{a, bc, cb};
-    static size_t lds_set[2] = {0, 0};
-    const int ti = mm_dtype == STEDM_F16 ? 0 : 1;
-    const void* fn = ti == 0 ? (const void*)gn_bwd_fused_kernel<_Float16> : (const void*)gn_bwd_fused_kernel<__bf16>;
-    if (flds > lds_set[ti]) {
-      STEDM_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-      lds_set[ti] = flds;
-    }
-    if (ti == 0) gn_bwd_fused_kernel<_Float16><<<dim3(B, C / cb), 512, flds, st>>>(fa);
-    else gn_bwd_fused_kernel<__bf16><<<dim3(B, C / cb), 512, flds, st>>>(fa);
+    if (mm_dtype == STEDM_F16) launch_gn_bwd_fused<_Float16>(fa, ppt, dim3(B, C / cb), st);
+    else launch_gn_bwd_fused<__bf16>(fa, ppt, dim3(B, C / cb), st);
     gn_bwd_param_kernel<<<(C + 63) / 64, 256, 0, st>>>(bc, B, C, dgamma, dbeta, acc_param);
     STEDM_LAUNCH_CHECK();
     return 0;
