@@ -410,20 +410,23 @@ __global__ void __launch_bounds__(256) im2col_t16_kernel(const uint16_t* __restr
 }
 
 // dw [taps][cin_ld][cout_ld] fp32 (GEMM result) -> grad OIHW [cout][cin][taps] (+= when accumulate).
-// grid (ceil(cout/32), ceil(cin/16)): a [taps][16 ci][32 co] block goes through LDS: 128-B runs in, (16 ci x taps)-float runs out.
+// grid (ceil(cout/32), ceil(cin/CIT)): a [taps][CIT ci][32 co] block goes through LDS: 128-B runs in, (CIT ci x taps)-float runs out.
+// CIT = 16; 4 for small filters with many split-K partials (128 -> 128: a 4 x 8 grid of blocks walked 32 partials serially in 20 us).
+template <int CIT>
 __global__ void __launch_bounds__(256) wgrad_to_oihw_kernel(const float* __restrict__ dw, float* __restrict__ grad, int cout, int cin, int taps, int cin_ld,
                                                             int cout_ld, int accumulate, int nsplit) {
-  __shared__ float tile[9 * 16][33];
-  const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 16;
+  __shared__ float tile[9 * CIT][33];
+  constexpr int SH = CIT == 16 ? 4 : 2;
+  const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * CIT;
   if ((cout_ld & 3) == 0 && co0 + 32 <= cout && (reinterpret_cast<uintptr_t>(dw) & 15) == 0) {
     // 16-B loads along co (8 lanes cover a 128-B run): a quarter of the load instructions, four times the bytes in flight per lane
-    for (int e = threadIdx.x; e < taps * 16 * 8; e += 256) {
-      const int c4 = e & 7, r = e >> 3;               // r = tap * 16 + ci_local
-      const int tap = r >> 4, cil = r & 15;
+    for (int e = threadIdx.x; e < taps * CIT * 8; e += 256) {
+      const int c4 = e & 7, r = e >> 3;               // r = tap * CIT + ci_local
+      const int tap = r >> SH, cil = r & (CIT - 1);
       const int ci = ci0 + cil;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ci < cin)
-#pragma unroll 4
+#pragma unroll 8
         for (int z = 0; z < nsplit; ++z) {            // split-K partials, fixed order
           const float4 w = *reinterpret_cast<const float4*>(dw + (((long)z * taps + tap) * cin_ld + ci) * cout_ld + co0 + c4 * 4);
           v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
@@ -431,9 +434,9 @@ __global__ void __launch_bounds__(256) wgrad_to_oihw_kernel(const float* __restr
       tile[r][c4 * 4] = v.x; tile[r][c4 * 4 + 1] = v.y; tile[r][c4 * 4 + 2] = v.z; tile[r][c4 * 4 + 3] = v.w;
     }
   } else
-  for (int e = threadIdx.x; e < taps * 16 * 32; e += 256) {
-    const int col = e & 31, r = e >> 5;               // r = tap * 16 + ci_local
-    const int tap = r >> 4, cil = r & 15;
+  for (int e = threadIdx.x; e < taps * CIT * 32; e += 256) {
+    const int col = e & 31, r = e >> 5;               // r = tap * CIT + ci_local
+    const int tap = r >> SH, cil = r & (CIT - 1);
     const int co = co0 + col, ci = ci0 + cil;
     float v = 0.f;
     if (co < cout && ci < cin)
@@ -442,14 +445,14 @@ __global__ void __launch_bounds__(256) wgrad_to_oihw_kernel(const float* __restr
     tile[r][col] = v;
   }
   __syncthreads();
-  const int run = 16 * taps;                          // contiguous floats of one output row: [ci0 .. ci0+15][taps]
+  const int run = CIT * taps;                         // contiguous floats of one output row: [ci0 .. ci0+CIT-1][taps]
   for (int e = threadIdx.x; e < 32 * run; e += 256) {
     const int col = e / run, k = e - col * run;       // k = ci_local * taps + tap
     const int cil = k / taps, tap = k - cil * taps;
     const int co = co0 + col, ci = ci0 + cil;
     if (co < cout && ci < cin) {
       const long o = ((long)co * cin + ci) * taps + tap;
-      grad[o] = (accumulate ? grad[o] : 0.f) + tile[tap * 16 + cil][col];
+      grad[o] = (accumulate ? grad[o] : 0.f) + tile[tap * CIT + cil][col];
     }
   }
 }
@@ -921,7 +924,10 @@ extern "C" int stedm_wgrad_to_oihw(const float* dw, float* grad, int cout, int c
                                    void* stream) {
   STEDM_CHECK_ARG(dw && grad && cin_ld >= cin && cout_ld >= cout && nsplit >= 1, "wgrad_to_oihw: bad args");
   STEDM_CHECK_ARG(taps >= 1 && taps <= 9, "wgrad_to_oihw: taps must be 1..9");
-  wgrad_to_oihw_kernel<<<dim3((cout + 31) / 32, (cin + 15) / 16), 256, 0, as_stream(stream)>>>(dw, grad, cout, cin, taps, cin_ld, cout_ld, accumulate, nsplit);
+  if (((cout + 31) / 32) * ((cin + 15) / 16) < 128 && nsplit >= 4)     // few blocks, long serial walks: quarter tiles
+    wgrad_to_oihw_kernel<4><<<dim3((cout + 31) / 32, (cin + 3) / 4), 256, 0, as_stream(stream)>>>(dw, grad, cout, cin, taps, cin_ld, cout_ld, accumulate, nsplit);
+  else
+    wgrad_to_oihw_kernel<16><<<dim3((cout + 31) / 32, (cin + 15) / 16), 256, 0, as_stream(stream)>>>(dw, grad, cout, cin, taps, cin_ld, cout_ld, accumulate, nsplit);
   STEDM_LAUNCH_CHECK();
   return 0;
 }
