@@ -711,16 +711,17 @@ def test_group_norm_backward_kernels_vs_autograd(dev, B, H, W, c1, c2, act, use_
     C, G, HW = c1 + c2, 32, H * W
     prec = ops.Precision.parse("parity")
     g = torch.Generator(device="cpu").manual_seed(5)
-    x = (torch.randn(B, C, H, W, generator=g, dtype=torch.float64) * 1.5 + 0.3).requires_grad_(True)
-    gamma = (1.0 + 0.3 * torch.randn(C, generator=g, dtype=torch.float64)).requires_grad_(True)
-    beta = (0.2 * torch.randn(C, generator=g, dtype=torch.float64)).requires_grad_(True)
+    x = (torch.randn(B, C, H, W, generator=g, dtype=torch.float64) * 1.5 + 0.3).detach().requires_grad_(True)
+    gamma = (1.0 + 0.3 * torch.randn(C, generator=g, dtype=torch.float64)).detach().requires_grad_(True)
+    beta = (0.2 * torch.randn(C, generator=g, dtype=torch.float64)).detach().requires_grad_(True)
     dA = torch.randn(B, C, H, W, generator=g, dtype=torch.float64)
     add = torch.randn(B, C, H, W, generator=g, dtype=torch.float64) if use_add else None
     old = torch.randn(B, C, H, W, generator=g, dtype=torch.float64) if acc else None
-    y = F.group_norm(x, G, gamma, beta, eps=1e-5)
-    if act:
-        y = F.silu(y)
-    (y * dA).sum().backward()
+    with torch.enable_grad():      # (other tests of the session switch autograd off globally)
+        y = F.group_norm(x, G, gamma, beta, eps=1e-5)
+        if act:
+            y = F.silu(y)
+        (y * dA).sum().backward()
     want = x.grad + (add if use_add else 0) + (old if acc else 0)
 
     def nhwc(t):
