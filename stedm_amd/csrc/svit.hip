@@ -624,11 +624,11 @@ __global__ void __launch_bounds__(256, NBUF == 2 ? 4 : 3) lsa_flash_dma_kernel(F
   for (int d = 0; d < 2; ++d)
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  float l_run = 0.f;
   const int qidx = q0 + r;
   const int ntiles = (a.T + 63) / 64;
   // fragment byte offsets inside a tile buffer: row * 128 + ((piece ^ f(row)) << 4), f(row) = (row >> 1) & 7. The piece index of a fragment
-  // is (compile-time even part) ^ (lane's h or 0), so each offset is a per-lane base XOR a compile-time constant: 4 registers, not 16
+  // is (compile-time even part) ^ (lane's h or 0), so each offset is a per-lane base XOR a compile-time constant
   unsigned kb[2], vb[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -637,21 +637,40 @@ __global__ void __launch_bounds__(256, NBUF == 2 ? 4 : 3) lsa_flash_dma_kernel(F
     vb[i] = 8192 + row * 128 + (((row >> 1) & 7) << 4) + 8 * h;     // V^T: piece 4 sub + 2 s2 (+ 1) -> vb[d] ^ ((4 sub + 2 s2) << 4) (^ 16)
   }
 
+  // The softmax is the kernel's issue budget (per tile and wave 16 MFMAs = 512 pipe cycles against ~830 cycles of vector issue), so the loop
+  // removes vector instructions: (1) the logits come out of the MFMA already relative to a per-query reference m_ref - a fifth k-step whose
+  // K side is the constant 1 and whose Q side is -m_ref - so p = exp2(s') needs no subtraction; m_ref is the running maximum rounded to the
+  // operand type and only moves when a tile exceeds it by more than 2^kThr (then O and l are rescaled and this tile's p take the difference
+  // explicitly); (2) the ring walk is unrolled by NBUF, so the tile base is an immediate of the LDS reads and the fragment offsets are
+  // loop-invariant registers (the adds of the base were 40 of ~170 vector instructions per tile).
+  constexpr float kThr = 8.0f;
+  float m_ref = 0.f;                    // reference of the exponentials kept in O and l (0 until the first tile sets it)
+  V8 ka, qa;                            // fifth k-step: K side = 1 in k-slot 0, Q side = -m_ref in k-slot 0 (lanes of the k-group h = 0)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ka[j] = (T)0.f; qa[j] = (T)0.f; }
+  if (h == 0) ka[0] = (T)1.f;
   issue(0);
   if (NBUF == 3 && ntiles > 1) issue(1);
-  for (int kt = 0; kt < ntiles; ++kt) {
+  for (int kt0 = 0; kt0 < ntiles; kt0 += NBUF) {
+#pragma unroll
+  for (int u = 0; u < NBUF; ++u) {
+    const int kt = kt0 + u;
+    if (kt >= ntiles) break;
     // this wave's share of tile kt has landed (NBUF 3: its 4 newest DMAs belong to tile kt + 1, when there is one)
     if (NBUF == 3 && kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // tile kt is complete in LDS; every wave is done with tile kt - 1, whose buffer takes the next tile fetched
+    // raw barrier: __syncthreads() makes the compiler wait for vmcnt(0) first, i.e. for the DMA of tile kt + 1 issued one tile ago
+    // (found in the ISA: the ring never ran ahead). Every wave's LDS reads of tile kt - 1 fed MFMAs it has already issued.
+    __builtin_amdgcn_s_barrier();   // tile kt is complete in LDS; every wave is done with tile kt - 1, whose buffer takes the next tile fetched
     if (kt + NBUF - 1 < ntiles) issue(kt + NBUF - 1);
-    const unsigned char* tb = ring + (kt % NBUF) * TILE_B;
-    // ---- S^T tiles (2 x 32 keys) x 32 queries
+    const unsigned char* tb = ring + u * TILE_B;       // (kt % NBUF == u: kt0 is a multiple of NBUF)
+    // ---- S^T tiles (2 x 32 keys) x 32 queries, relative to m_ref
     f32x16 s[2];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[sub][e] = 0.f;
+      s[sub] = MM<T>::mfma(ka, qa, s[sub]);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const V8 kf = *reinterpret_cast<const V8*>(tb + (kb[sub] ^ (unsigned)(ks << 5)));
@@ -678,26 +697,35 @@ __global__ void __launch_bounds__(256, NBUF == 2 ? 4 : 3) lsa_flash_dma_kernel(F
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[sub][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    if (kt == 0 || __builtin_amdgcn_ballot_w64(mx > kThr)) {
+      // move the reference (rare after the first tiles): new m_ref = old + max(mx, 0) rounded to the operand type (exactly what the fifth
+      // k-step can carry); O and l go to the new reference, this tile's logits take the difference explicitly
+      const float up = kt == 0 ? fmaxf(mx, -30000.f) : fmaxf(mx, 0.f);     // (first tile: any sign; a fully masked row stays finite, fp16 included)
+      const float m_new = (float)(T)(m_ref + up);
+      const float delta = m_new - m_ref;
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      m_ref = m_new;
+      if (h == 0) qa[0] = (T)(-m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[sub][e] -= delta;
+    }
     float rs = 0.f;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float pv = __builtin_amdgcn_exp2f(s[sub][e] - m_new);
+        const float pv = __builtin_amdgcn_exp2f(s[sub][e]);
         s[sub][e] = pv;
         rs += pv;
       }
-    rs += __shfl_xor(rs, 32, 64);
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
-    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
-#pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
-    }
+    l_run += rs;           // (per lane half: the two halves of a query are added once, after the loop)
     // ---- O^T += V^T P^T
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
@@ -719,6 +747,8 @@ __global__ void __launch_bounds__(256, NBUF == 2 ? 4 : 3) lsa_flash_dma_kernel(F
         }
       }
   }
+  }
+  l_run += __shfl_xor(l_run, 32, 64);
   // ---- epilogue: O^T / l through LDS so that every token row is written contiguously (token-major [B][T][H*64])
   __syncthreads();   // all waves are done with the ring: it is reused for the transpose
   const float inv = 1.0f / l_run;
