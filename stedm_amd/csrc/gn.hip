@@ -486,24 +486,29 @@ __global__ void __launch_bounds__(256) gn_apply16c_kernel(GnApplyCArgs a, int sl
 // per lane (8-B stores run at 0.5-0.7 of the 16-B rate, MI355X_MICROARCH.md). The per-channel constants {mean, rstd * gamma, beta}
 // come from LDS tables built once per block (no per-element group arithmetic, no gamma / beta loads in the stream).
 // Needs C % 8 == 0, c1 % 8 == 0 and an even number of quads per block iteration (256 threads: always).
+// cb > 0: the block takes a CHANNEL run of cb channels (whole groups, a multiple of 8) of every pixel of its sample instead of a pixel run
+// of all channels: it folds the statistics and builds the table of its own groups only (the samples of the 8 x 8 level are 64 pixels of
+// 1024 - 2048 channels: six pixel-run blocks per sample each built the whole table for 11 pixels of streaming).
 template <typename T>
-__global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int slab) {
+__global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int slab, int cb) {
   typedef T V4 __attribute__((ext_vector_type(4)));
   __shared__ double dsu[256], dsq[256];
   __shared__ float lmean[64], lrstd[64];
   extern __shared__ __attribute__((aligned(16))) float tab[];   // [3][C]: mean, rstd * gamma, beta per channel
   const int b = blockIdx.x, sl = blockIdx.y;
-  const int C = a.c1 + a.c2, Q = C >> 2;
+  const int C = a.c1 + a.c2, Qall = C >> 2;
   const int cpg = C / a.groups;
   const int b2 = a.bmod > 0 ? b % a.bmod : b;
   const float* p1 = a.x1 + (long)b * a.HW * a.c1;
   const float* p2 = a.x2 ? a.x2 + (long)b2 * a.HW * a.c2 : nullptr;
-  const int px0 = sl * slab, px1 = min(a.HW, px0 + slab);
+  const int c_lo = cb > 0 ? sl * cb : 0, c_n = cb > 0 ? cb : C;       // this block's channels
+  const int Q = c_n >> 2, q_lo = c_lo >> 2;                           // quads per pixel of this block, first quad
+  const int px0 = cb > 0 ? 0 : sl * slab, px1 = cb > 0 ? a.HW : min(a.HW, px0 + slab);
   const int total = (px1 - px0) * Q;             // quads of this block; even (Q is even)
-  uint2* oh = reinterpret_cast<uint2*>(a.out_hi) + (long)b * a.HW * Q;      // 8-B units (one quad of 16-bit values)
-  uint2* ol = a.out_lo ? reinterpret_cast<uint2*>(a.out_lo) + (long)b * a.HW * Q : nullptr;
-  uint2* rh = a.raw_hi ? reinterpret_cast<uint2*>(a.raw_hi) + (long)b * a.HW * Q : nullptr;
-  uint2* rl = a.raw_lo ? reinterpret_cast<uint2*>(a.raw_lo) + (long)b * a.HW * Q : nullptr;
+  uint2* oh = reinterpret_cast<uint2*>(a.out_hi) + (long)b * a.HW * Qall;      // 8-B units (one quad of 16-bit values)
+  uint2* ol = a.out_lo ? reinterpret_cast<uint2*>(a.out_lo) + (long)b * a.HW * Qall : nullptr;
+  uint2* rh = a.raw_hi ? reinterpret_cast<uint2*>(a.raw_hi) + (long)b * a.HW * Qall : nullptr;
+  uint2* rl = a.raw_lo ? reinterpret_cast<uint2*>(a.raw_lo) + (long)b * a.HW * Qall : nullptr;
   constexpr int U = 2;
   int pixs[U], qs[U];
 #pragma unroll
@@ -514,7 +519,7 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
 #pragma unroll
     for (int k = 0; k < U; ++k) {
       if (i + k * 256 < total) {
-        const int c = qs[k] * 4;
+        const int c = (q_lo + qs[k]) * 4;
         v[k] = c < a.c1 ? *reinterpret_cast<const float4*>(p1 + (long)pixs[k] * a.c1 + c)
                         : *reinterpret_cast<const float4*>(p2 + (long)pixs[k] * a.c2 + (c - a.c1));
       }
@@ -522,10 +527,11 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
   };
   load_batch(threadIdx.x);
   {
-    const int L = 256 / a.groups;                 // lanes per group (groups <= 64)
-    const int g = threadIdx.x / L, l = threadIdx.x % L;
+    const int g_lo = c_lo / cpg, ng = c_n / cpg;  // this block's groups
+    const int L = 256 / ng;                       // lanes per group (groups <= 64)
+    const int gl = threadIdx.x / L, l = threadIdx.x % L, g = g_lo + gl;
     double su = 0.0, sq = 0.0;
-    if (g < a.groups) {
+    if (gl < ng) {
       const int nmax = a.nslab1 > a.nslab2 ? a.nslab1 : a.nslab2;
       const int n = cpg * nmax;
       for (int e = l; e < n; e += L) {            // entry = (slab k, channel cc of the group); tensors may be partitioned differently
@@ -539,7 +545,7 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
     }
     dsu[threadIdx.x] = su; dsq[threadIdx.x] = sq;
     __syncthreads();
-    if (g < a.groups && l == 0) {
+    if (gl < ng && l == 0) {
       double s = 0.0, q = 0.0;
       for (int i = 0; i < L; ++i) { s += dsu[threadIdx.x + i]; q += dsq[threadIdx.x + i]; }   // fixed order
       const double inv_n = 1.0 / ((double)cpg * a.HW);
@@ -550,7 +556,7 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
       lrstd[g] = (float)(1.0 / sqrt(var + (double)a.eps));
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = c_lo + threadIdx.x; c < c_lo + c_n; c += 256) {
       const int gc = c / cpg;
       tab[c] = lmean[gc];
       tab[C + c] = lrstd[gc] * a.gamma[c];
@@ -581,7 +587,7 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
     uint2 oq[U], rq[U], olq[U], rlq[U];
 #pragma unroll
     for (int k = 0; k < U; ++k) {
-      const int c = qs[k] * 4;
+      const int c = (q_lo + qs[k]) * 4;
       float4 w = v[k];
       const bool live = k == 0 ? live0 : live1;
       if (!live) { w = make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -592,7 +598,7 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
           rlq[k] = pack4(w.x - (float)hq[0], w.y - (float)hq[1], w.z - (float)hq[2], w.w - (float)hq[3]);
         }
       }
-      const int cc = live ? c : 0;
+      const int cc = live ? c : c_lo;
       const float4 mn = *reinterpret_cast<const float4*>(tab + cc);
       const float4 sc = *reinterpret_cast<const float4*>(tab + C + cc);
       const float4 bt = *reinterpret_cast<const float4*>(tab + 2 * C + cc);
@@ -607,7 +613,7 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
     // my cursor: 0 on even lanes, 1 on odd lanes; the 16-B destination starts at the EVEN lane's quad of that cursor
     const int mk = odd ? 1 : 0;
     const bool mlive = odd ? live1 : live0;
-    const long o = (long)pixs[mk] * Q + (qs[mk] & ~1);
+    const long o = (long)pixs[mk] * Qall + q_lo + (qs[mk] & ~1);
     const uint4 so = pair16(oq[0], oq[1]);
     if (mlive) *reinterpret_cast<uint4*>(oh + o) = so;
     if (ol) { const uint4 t4 = pair16(olq[0], olq[1]); if (mlive) *reinterpret_cast<uint4*>(ol + o) = t4; }
@@ -654,8 +660,23 @@ extern "C" int stedm_gn_apply16c(const float* x1, int c1, const float* cs1, int 
   static const bool v4only = getenv("STEDM_GN_V4") != nullptr;     // A/B switch: the 4-channel-per-thread form
   if (!v4only && C % 8 == 0 && c1 % 8 == 0 && (size_t)3 * C * sizeof(float) <= 48 * 1024) {
     const size_t lds = (size_t)3 * C * sizeof(float);
-    if (mm_dtype == STEDM_F16) gn_apply16c_v8_kernel<_Float16><<<grid, 256, lds, as_stream(stream)>>>(a, slab);
-    else gn_apply16c_v8_kernel<__bf16><<<grid, 256, lds, as_stream(stream)>>>(a, slab);
+    // Small samples cut by pixels would need several blocks per sample, each building the whole table: cut those by CHANNELS instead
+    // (runs of whole groups, >= 512 B per pixel, on one side of the concat seam), so a block builds the table of its own groups only.
+    static const int cmode = getenv("STEDM_GN_CSPLIT") ? atoi(getenv("STEDM_GN_CSPLIT")) : -1;      // A/B: 0 off, n > 0 forces runs of n channels
+    int cb = 0;
+    if (cmode != 0 && grid.y > 1 && HW <= 256) {
+      const int cpg = C / groups;
+      int unit = cpg;
+      while (unit % 8 != 0) unit *= 2;
+      if (cmode > 0) cb = cmode;
+      else
+        for (int t = unit; t <= C / 2; t += unit)          // the widest run that still gives the grid its 768 blocks
+          if (C % t == 0 && c1 % t == 0 && t >= 128 && (long)B * (C / t) >= 768) cb = t;
+      if (cb > 0 && (C % cb != 0 || c1 % cb != 0 || cb % unit != 0 || cb / cpg > 64)) cb = 0;
+    }
+    if (cb > 0) grid = dim3(B, C / cb);
+    if (mm_dtype == STEDM_F16) gn_apply16c_v8_kernel<_Float16><<<grid, 256, lds, as_stream(stream)>>>(a, slab, cb);
+    else gn_apply16c_v8_kernel<__bf16><<<grid, 256, lds, as_stream(stream)>>>(a, slab, cb);
     STEDM_LAUNCH_CHECK();
     return 0;
   }

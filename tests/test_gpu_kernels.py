@@ -332,10 +332,12 @@ def test_gn_stats_apply16(dev, B, H, W, c1, c2, bmod):
 
 @pytest.mark.parametrize("B,H,W,c1,c2,bmod", [(2, 8, 8, 64, 0, 0), (3, 16, 16, 128, 0, 0), (2, 8, 8, 1024, 512, 0), (4, 8, 8, 128, 128, 2),
                                               (2, 32, 32, 128, 0, 0), (2, 16, 16, 512, 128, 0), (2, 32, 32, 512, 128, 0), (4, 16, 16, 1024, 512, 2),
-                                              (3, 4, 4, 1280, 0, 0), (2, 20, 20, 96, 32, 0)])
+                                              (3, 4, 4, 1280, 0, 0), (2, 20, 20, 96, 32, 0),
+                                              (200, 8, 8, 256, 256, 0), (400, 8, 8, 256, 0, 0), (200, 8, 8, 256, 256, 100), (128, 4, 4, 1024, 1024, 0)])
 def test_gn_chan_stats_apply16c(dev, B, H, W, c1, c2, bmod):
     """GroupNorm from per-(sample, slab, channel) partials: group boundaries straddle the concat seam (e.g. 1024+512: cpg 48),
-    ragged last slab (20x20), x2 shared modulo bmod; dual output (normalised + plain conversion planes)."""
+    ragged last slab (20x20), x2 shared modulo bmod; dual output (normalised + plain conversion planes). The large-batch 8 x 8 / 4 x 4
+    cases take the channel-run form of the kernel (a block = a run of whole groups of every pixel of its sample)."""
     from stedm_amd import ops
     prec = ops.Precision.parse("parity")
     C = c1 + c2
