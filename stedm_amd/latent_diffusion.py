@@ -565,8 +565,8 @@ class LatentDiffusion(nn.Module):
 
     def decode_first_stage(self, z, **kw):
         if self.first_stage_model is None:
-            raise NotImplementedError("first stage (VQ-f4 decoder) is out of this round's scope (SURVEY.md §8f next-1); "
-                                      "pass a first_stage module to LatentDiffusion to use decode_first_stage")
+            raise NotImplementedError("decode_first_stage: this LatentDiffusion was built without a first stage; pass first_stage_config "
+                                      "(built as stedm_amd.vq.VQModelInterface) or a first_stage module")
         return self.first_stage_model.decode(z / self.scale_factor)
 
 

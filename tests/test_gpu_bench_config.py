@@ -188,3 +188,54 @@ def test_bench_gpus2_self_launch_on_one_device(dev):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["config"]["global_batch"] == 128 and line["value"] > 0
     assert abs(line["value"] - 2 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-2 * line["value"]
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from stedm_amd import parallel as par
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=dev)                      # bench.py's call, with the real backend (RCCL)
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+dist.barrier()
+t = torch.tensor([1.25], dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)                            # bench.py's max-over-ranks of the timed region
+assert float(t.item()) == 1.25
+lo, hi = par.shard_range(6, 0, 1)
+local = par.per_sample_normal(1, list(range(lo, hi)), (4, 32, 32)).to(dev)
+assert par.all_gather_samples(local, 6) is local                    # the helpers short-cut a one-rank group ...
+bufs = [torch.empty_like(local)]
+dist.all_gather(bufs, local)                                        # ... so issue THEIR collectives directly: the sample all-gather
+assert torch.equal(bufs[0], local)
+flat = torch.arange(3 * 1024 + 17, dtype=torch.float32, device=dev)
+ref = flat.clone()
+works = [dist.all_reduce(flat[o:o + 1024], op=dist.ReduceOp.SUM, async_op=True) for o in range(0, flat.numel(), 1024)]
+for w in works:                                                     # in-place bucketed all-reduce over views of the gradient arena
+    w.wait()
+torch.cuda.synchronize()
+assert len(works) == 4 and torch.equal(flat, ref)
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_ONE_RANK_OK")
+"""
+
+
+def test_rccl_backend_single_rank_collectives(dev):
+    """The collectives of the N > 1 path on the REAL backend (`nccl` = RCCL), as far as a one-GPU box allows: a one-rank process group
+    created exactly as bench.py creates it, the timing all-reduce, `all_gather_samples` and the bucketed gradient all-reduce on device
+    tensors. RCCL refuses two ranks on one device, so the two-rank rehearsals above run over gloo; this one proves the library loads,
+    initialises on this image (HSA_ENABLE_IPC_MODE_LEGACY=0) and that every call the path makes is one RCCL accepts. In a child
+    process: the process group must not leak into the test session."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_ONE_RANK_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
