@@ -34,6 +34,15 @@ for _ in range(a.steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
 print(f"train step B={B} latent {L}x{L} {a.precision}: {dt * 1e3:.2f} ms  ({1 / dt:.2f} steps/s, {B / dt:.0f} samples/s)  loss {float(loss):.4f}")
+# host side of the same step: time until train_step returns (launches issued, nothing awaited) and the GPU time between two events
+torch.cuda.synchronize()
+e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+h = []
+e0.record()
+for _ in range(a.steps):
+    t0 = time.perf_counter(); tr.train_step(x, cc, t, ctx, tgt); h.append(time.perf_counter() - t0)
+e1.record(); torch.cuda.synchronize()
+print(f"host issue time per step {1e3 * sum(h) / len(h):.2f} ms (min {1e3 * min(h):.2f}); stream time per step {e0.elapsed_time(e1) / a.steps:.2f} ms")
 if a.parts:
     def tm(f, n=3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
