@@ -112,6 +112,11 @@ int stedm_gn_nslab(int C, int HW);
 int stedm_gn_chan_nslab(int HW);
 /* nslab: slot count of chan_stats; 0 or stedm_gn_chan_nslab(HW): runs of 256 pixels, otherwise nslab runs of ceil(HW/nslab). */
 int stedm_gn_chan_stats(const float* x, int C, int B, int HW, int nslab, float* chan_stats, void* stream);
+/* The same pass with the plain 16-bit conversion of x on the way (out_hi, and out_lo = x - hi when != NULL; NHWC [B][HW][C]): a gradient
+ * tensor of the training backward needs both — the channel sums are the bias gradient (what autograd's sum over (N, H, W) of
+ * F.conv2d's grad_output gives the reference, openaimodel.py:288), the planes the operand of its dgrad / wgrad. */
+int stedm_gn_chan_stats16(const float* x, int C, int B, int HW, int nslab, float* chan_stats, void* out_hi, void* out_lo, int mm_dtype,
+                          void* stream);
 /* nslab1 / nslab2: slot counts of cs1 / cs2. ANY partition of a sample's pixels into slots serves (the consumer adds all slots):
  * 256-pixel runs (3x3 / 1x1 epilogues), (tile, output parity) pairs (sub-pixel upsample), row pairs (stedm_conv_in). */
 int stedm_gn_apply16c(const float* x1, int c1, const float* cs1, int nslab1, const float* x2, int c2, const float* cs2, int nslab2, int x2_bmod,

@@ -302,7 +302,12 @@ extern "C" int stedm_gn_apply16(const float* x1, int c1, const float* x2, int c2
 extern "C" int stedm_gn_chan_nslab(int HW) { return (HW + 255) / 256; }
 
 // grid (B, slabs of 256 pixels, blocks of 64 channel quads): 256 threads = QB quads x (256 / QB) pixel lanes
-__global__ void __launch_bounds__(256) gn_chan_stats_kernel(const float* __restrict__ x, int C, int HW, int slab_px, float* __restrict__ cs) {
+// CAST: the same read also leaves the plain 16-bit conversion of x (hi, and lo = x - hi when o_lo != NULL) — the training backward
+// needs both of a gradient tensor (channel sums = bias gradient, 16-bit planes = operand of its dgrad / wgrad)
+template <typename T, bool CAST>
+__global__ void __launch_bounds__(256) gn_chan_stats_kernel(const float* __restrict__ x, int C, int HW, int slab_px, float* __restrict__ cs,
+                                                            T* __restrict__ o_hi, T* __restrict__ o_lo) {
+  typedef T V4 __attribute__((ext_vector_type(4)));
   __shared__ float cpart[256 * 8];   // [npl][QB][8]
   const int b = blockIdx.x, slab = blockIdx.y, nslab = gridDim.y;
   const int Q = C >> 2, t = threadIdx.x;
@@ -315,6 +320,15 @@ __global__ void __launch_bounds__(256) gn_chan_stats_kernel(const float* __restr
 #pragma unroll 4
     for (int pix = px0 + tp; pix < px1; pix += npl) {
       const float4 v = *reinterpret_cast<const float4*>(px + (long)pix * C);
+      if constexpr (CAST) {
+        const long o = ((long)b * HW + pix) * C + (qb0 + tq) * 4;
+        V4 h4; h4[0] = (T)v.x; h4[1] = (T)v.y; h4[2] = (T)v.z; h4[3] = (T)v.w;
+        *reinterpret_cast<V4*>(o_hi + o) = h4;
+        if (o_lo) {
+          V4 l4; l4[0] = (T)(v.x - (float)h4[0]); l4[1] = (T)(v.y - (float)h4[1]); l4[2] = (T)(v.z - (float)h4[2]); l4[3] = (T)(v.w - (float)h4[3]);
+          *reinterpret_cast<V4*>(o_lo + o) = l4;
+        }
+      }
       s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
       q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
     }
@@ -342,7 +356,25 @@ extern "C" int stedm_gn_chan_stats(const float* x, int C, int B, int HW, int nsl
   if (nslab == 0) nslab = (HW + 255) / 256;
   const int slab_px = nslab == (HW + 255) / 256 ? 256 : (HW + nslab - 1) / nslab;   // the default partition is 256-pixel runs
   dim3 grid(B, nslab, (Q + 63) / 64);
-  gn_chan_stats_kernel<<<grid, 256, 0, as_stream(stream)>>>(x, C, HW, slab_px, chan_stats);
+  gn_chan_stats_kernel<__bf16, false><<<grid, 256, 0, as_stream(stream)>>>(x, C, HW, slab_px, chan_stats, nullptr, nullptr);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int stedm_gn_chan_stats16(const float* x, int C, int B, int HW, int nslab, float* chan_stats, void* out_hi, void* out_lo, int mm_dtype,
+                                     void* stream) {
+  STEDM_CHECK_ARG(x && chan_stats && out_hi && C > 0 && C % 4 == 0 && B > 0 && HW > 0 && nslab >= 0, "gn_chan_stats16: bad args (C %% 4)");
+  STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "gn_chan_stats16: bad mm_dtype");
+  const int Q = C / 4;
+  if (nslab == 0) nslab = (HW + 255) / 256;
+  const int slab_px = nslab == (HW + 255) / 256 ? 256 : (HW + nslab - 1) / nslab;
+  // every pixel must fall into a slot, or its 16-bit values would not be written
+  STEDM_CHECK_ARG((long)nslab * slab_px >= HW, "gn_chan_stats16: the slots do not cover the sample");
+  dim3 grid(B, nslab, (Q + 63) / 64);
+  if (mm_dtype == STEDM_F16)
+    gn_chan_stats_kernel<_Float16, true><<<grid, 256, 0, as_stream(stream)>>>(x, C, HW, slab_px, chan_stats, (_Float16*)out_hi, (_Float16*)out_lo);
+  else
+    gn_chan_stats_kernel<__bf16, true><<<grid, 256, 0, as_stream(stream)>>>(x, C, HW, slab_px, chan_stats, (__bf16*)out_hi, (__bf16*)out_lo);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

@@ -225,6 +225,17 @@ def gn_chan_stats(x: torch.Tensor, out: torch.Tensor) -> None:
     check(lib().stedm_gn_chan_stats(x.data_ptr(), C, B, HW, out.shape[1], out.data_ptr(), _stream()), "stedm_gn_chan_stats")
 
 
+def gn_chan_stats16(x: torch.Tensor, out: torch.Tensor, out_hi: torch.Tensor, out_lo: Optional[torch.Tensor], prec: Precision) -> None:
+    """gn_chan_stats + the plain 16-bit conversion of x (hi / lo planes of x's shape) from the same read."""
+    _chk(x, name="x")
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    assert out.dtype == torch.float32 and out.dim() == 4 and out.shape[0] == B and tuple(out.shape[2:]) == (C, 2)
+    assert out_hi.numel() == x.numel() and out_hi.element_size() == 2 and (out_lo is None or out_lo.numel() == x.numel())
+    check(lib().stedm_gn_chan_stats16(x.data_ptr(), C, B, HW, out.shape[1], out.data_ptr(), out_hi.data_ptr(), _ptr(out_lo), prec.mm_dtype,
+                                      _stream()), "stedm_gn_chan_stats16")
+
+
 def gn_apply16c(x1: torch.Tensor, cs1: torch.Tensor, x2: Optional[torch.Tensor], cs2: Optional[torch.Tensor], out_hi: torch.Tensor,
                 out_lo: Optional[torch.Tensor], prec: Precision, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
                 groups: int = 32, act: int = 0, x2_bmod: int = 0, raw: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None) -> None:

@@ -45,6 +45,7 @@ class UNetTrainer:
         # cond_stage_trainable, ldm_diffusion.py:224-234); their gradients are filled by the caller; no EMA (LitEma covers `model` only)
         self.extra_params = list(extra_params)
         self.direct_wgrad = os.environ.get("STEDM_WGRAD_GEMM") is None    # STEDM_WGRAD_GEMM=1: im2col + GEMM form everywhere (A/B switch)
+        self._split_cast = os.environ.get("STEDM_BWD_SPLIT_CAST") is not None   # A/B: separate conversion and statistics passes of a gradient
         self.accumulate_grad_batches = int(accumulate_grad_batches)      # Trainer(accumulate_grad_batches=...) of train_diff.py
         self._micro = 0
         self.lr, self.betas, self.eps, self.wd = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
@@ -272,12 +273,22 @@ class UNetTrainer:
             gemm(0, rows)
         ops.wgrad_to_oihw(dw, self._param_grad(wparam), Cs, co, accumulate)
 
-    def _bias_grad(self, dy: torch.Tensor, bias: Optional[nn.Parameter], per_sample: Optional[torch.Tensor] = None, ld: int = 0) -> None:
-        """bias.grad = sum over (batch, pixels) of dy [B,H,W,C]; per_sample[b*ld + c] = sum over pixels (optional)"""
+    def _bias_grad(self, dy: torch.Tensor, bias: Optional[nn.Parameter], per_sample: Optional[torch.Tensor] = None, ld: int = 0,
+                   cast: Optional[str] = None):
+        """bias.grad = sum over (batch, pixels) of dy [B,H,W,C]; per_sample[b*ld + c] = sum over pixels (optional). `cast`: the same read
+        of dy also writes its 16-bit operand planes (buffer family `cast`, as _cast16 would) and returns them."""
         B, Cc = dy.shape[0], dy.shape[-1]
         cs = self._buf(f"cs.{B}x{Cc}x{dy.numel() // (B * Cc)}", (B, ops.gn_chan_nslab(dy.numel() // (B * Cc)), Cc, 2))
-        ops.gn_chan_stats(dy, cs)
+        planes = None
+        if cast is not None and not self._split_cast:
+            planes = self._planes(cast, tuple(dy.shape))
+            ops.gn_chan_stats16(dy, cs, planes[0], planes[1], self.bprec)
+        else:
+            if cast is not None:
+                planes = self._cast16(dy, kind=cast)
+            ops.gn_chan_stats(dy, cs)
         ops.chan_sum_fold(cs, per_sample, ld, None if bias is None else self._param_grad(bias), False)
+        return planes
 
     def _gn_bwd(self, norm: nn.GroupNorm, act: int, x1, x2, dA, add, dx16=None):
         m = self.m
@@ -420,9 +431,8 @@ class UNetTrainer:
         conv1, conv2 = rb.in_layers[2], rb.out_layers[3]
         dout, have = self._grad_of(out)
         assert have, "no gradient reached this block's output"
-        dout16 = self._cast16(dout, kind="dy")
         has_skip = not isinstance(rb.skip_connection, nn.Identity)
-        self._bias_grad(dout, conv2.bias)
+        dout16 = self._bias_grad(dout, conv2.bias, cast="dy")
         if has_skip:
             sk = rb.skip_connection
             self._param_grad(sk.bias).copy_(conv2.bias.grad)             # same sums: both biases add onto `out`
@@ -460,16 +470,14 @@ class UNetTrainer:
         T = H * W
         dout, have = self._grad_of(out)
         assert have
-        dout16 = self._cast16(dout, kind="dy")
-        self._bias_grad(dout, ab.proj_out.bias)
+        dout16 = self._bias_grad(dout, ab.proj_out.bias, cast="dy")
         a16 = self._cast16(a, kind="x16")
         self._wgrad(a16, dout16, dout, ab.proj_out.weight, 1, 0)
         da = self._buf(f"attn.da.{B}x{T}x{Cc}", (B, H, W, Cc))
         self._dgrad(ab.proj_out, dout16, da)
         dqkv = self._buf(f"attn.dqkv.{B}x{T}x{Cc}", (B, H, W, 3 * Cc))
         ops.attn_legacy_bwd(qkv.view(B, T, 3 * Cc), da.view(B, T, Cc), dqkv.view(B, T, 3 * Cc), ab.num_heads)
-        dqkv16 = self._cast16(dqkv, kind="dy3")
-        self._bias_grad(dqkv, ab.qkv.bias)
+        dqkv16 = self._bias_grad(dqkv, ab.qkv.bias, cast="dy3")
         n16 = self._norm16(ab.norm, 0, x)
         self._wgrad(n16, dqkv16, dqkv, ab.qkv.weight, 1, 0)
         dn = self._buf(f"attn.dn.{B}x{T}x{Cc}", (B, H, W, Cc))
@@ -480,8 +488,7 @@ class UNetTrainer:
         B, H, W, Cc = hin.shape
         dout, have = self._grad_of(out)
         assert have
-        dout16 = self._cast16(dout, kind="dy")
-        self._bias_grad(dout, layer.conv.bias)
+        dout16 = self._bias_grad(dout, layer.conv.bias, cast="dy")
         src16 = self._cast16(hin, kind="x16")
         if self.direct_wgrad and self.bprec.npass == 1 and ops.wgrad3x3_plan(B, 2 * H, 2 * W, Cc, out.shape[-1]) > 0:
             # the direct kernel reads plain NHWC planes: materialise the nearest-2x plane once (16-bit copy, layout only)
@@ -500,8 +507,7 @@ class UNetTrainer:
         co = out.shape[-1]
         dout, have = self._grad_of(out)
         assert have
-        dout16 = self._cast16(dout, kind="dy")
-        self._bias_grad(dout, layer.op.bias)
+        dout16 = self._bias_grad(dout, layer.op.bias, cast="dy")
         src16 = self._cast16(hin, kind="x16")
         self._wgrad(src16, dout16, dout, layer.op.weight, 3, 2)
         z16 = self._planes("z16", (B, H, W, co))

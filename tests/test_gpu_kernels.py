@@ -373,6 +373,36 @@ def test_gn_chan_stats_apply16c(dev, B, H, W, c1, c2, bmod):
     assert torch.equal(hi, hi2) and torch.equal(lo, lo2)
 
 
+@pytest.mark.parametrize("precs", ["bf16", "f16", "bf16x3"])
+@pytest.mark.parametrize("B,H,W,C", [(3, 32, 32, 128), (2, 16, 16, 1536), (5, 8, 8, 1024), (2, 20, 20, 96), (1, 4, 4, 32), (2, 64, 64, 4)])
+def test_gn_chan_stats16_equals_stats_plus_cast(dev, precs, B, H, W, C):
+    """The statistics pass that also leaves the 16-bit planes (training backward: a gradient's bias sums and its dgrad / wgrad operand from
+    ONE read): the partial sums are those of gn_chan_stats (to rounding; bitwise run to run), the planes bitwise those of the plain conversion kernel, and the hi plane
+    is torch's round-to-nearest-even cast; ragged last slot (20 x 20), narrow (4) and wide (1536) channel counts."""
+    from stedm_amd import ops
+    from stedm_amd._lib import BF16, F16
+    prec = ops.Precision(F16 if precs == "f16" else BF16, 3 if precs.endswith("x3") else 1)
+    x = (prng.normal(17, "cs16.x", (B, H, W, C)) * 2.3e-3 + 1e-4).to(dev)          # gradient-sized values
+    ns = ops.gn_chan_nslab(H * W)
+    cs_a = torch.full((B, ns, C, 2), float("nan"), device=dev); cs_b = torch.full_like(cs_a, float("nan"))
+    hi = torch.full((B, H, W, C), -1, dtype=torch.int16, device=dev)
+    lo = torch.full_like(hi, -1) if prec.npass == 3 else None
+    ops.gn_chan_stats(x, cs_a)
+    ops.gn_chan_stats16(x, cs_b, hi, lo, prec)
+    # (the two instantiations contract a*a + q differently: equal to rounding, not bitwise; each is deterministic run to run)
+    assert torch.allclose(cs_a, cs_b, rtol=1e-5, atol=1e-8)
+    cs_c = torch.empty_like(cs_b); hi_c = torch.empty_like(hi)
+    ops.gn_chan_stats16(x, cs_c, hi_c, None if lo is None else torch.empty_like(lo), prec)
+    assert torch.equal(cs_b, cs_c) and torch.equal(hi, hi_c)
+    rhi = torch.empty_like(hi); rlo = torch.empty_like(hi) if lo is not None else None
+    ops.gn_apply16(x, None, rhi, rlo, prec)
+    assert torch.equal(hi, rhi) and (lo is None or torch.equal(lo, rlo))
+    tdt = torch.float16 if precs == "f16" else torch.bfloat16
+    assert torch.equal(hi.view(tdt), x.to(tdt))
+    if lo is not None:
+        assert torch.equal(lo.view(tdt), (x - hi.view(tdt).float()).to(tdt))
+
+
 @pytest.mark.parametrize("prec", ["f16", "bf16", "parity"])
 @pytest.mark.parametrize("B,H,W,cin,cout", [(64, 32, 32, 32, 128), (200, 16, 16, 64, 96), (801, 8, 8, 32, 160), (2, 8, 8, 64, 64), (3, 32, 32, 64, 64)])
 def test_conv_epilogue_chan_stats(dev, prec, B, H, W, cin, cout):

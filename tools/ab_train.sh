@@ -1,0 +1,10 @@
+#!/bin/bash
+# Same-box A/B of a training-step switch (run through gpurun from the repo root):  bash tools/ab_train.sh STEDM_BWD_SPLIT_CAST
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$PWD}
+V=${1:-STEDM_BWD_SPLIT_CAST}
+cd $R
+for rep in 1 2 3; do
+  echo "== default #$rep"; python3 tools/bench_train.py --steps 10 2>&1 | grep "train step"
+  echo "== $V=1 #$rep"; env $V=1 python3 tools/bench_train.py --steps 10 2>&1 | grep "train step"
+done
