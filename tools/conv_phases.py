@@ -18,6 +18,7 @@ def main():
         x = torch.randn(B, H, W, cin, device=dev)
         w = torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
         hi, lo = ops.pack_conv_weight(w, prec); wf = ops.pack_conv_weight_frag(w, prec)
+        wf16 = ops.pack_conv_weight_frag16(w, prec) if cin >= 256 and not os.environ.get("PHASES_NO_M16") else None   # the 16x16x32 kind (the default from 256 channels)
         h16 = torch.empty(B, H, W, cin, dtype=torch.int16, device=dev)
         ops.gn_apply16(x, None, h16, None, prec)
         if os.environ.get("PHASES_ZERO_A"): h16.zero_()        # data-dependence experiment: all-zero activations
@@ -26,7 +27,7 @@ def main():
         cs = torch.empty(B, (H * W + 255) // 256, cout, 2, device=dev)
         for _ in range(3):
             ops.conv_igemm(None, hi, lo, out, prec=prec, src16=(h16, None), bias=bias, w_frag=wf, res=(out if os.environ.get("PHASES_RES") else None),
-                           chan_stats=(cs if os.environ.get("PHASES_STATS") else None))
+                           chan_stats=(cs if os.environ.get("PHASES_STATS") else None), w_frag16=wf16)
         torch.cuda.synchronize()
         nb = min(2048, (B * H * W // 256) * ((cout + 127) // 128))
         buf = np.zeros((nb, 8), dtype=np.uint64)
