@@ -113,6 +113,30 @@ def test_bench_gpus_flag_launches_the_ranks_itself():
     assert sum(ln.startswith("{") for ln in r.stdout.splitlines()) == 1          # ONE line, from rank 0
 
 
+def test_bench_under_torch_distributed_run_as_the_driver_launches_it():
+    """The driver's N > 1 command line, verbatim: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W`. bench.py must take RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher
+    (not start ranks of its own), and rank 0 alone prints the line (rehearsed on CPU tensors over gloo)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["STEDM_BENCH_DRY"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "3"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                                        # ONE line, from rank 0
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["config"]["global_batch"] == 6 and line["steps"] == 2 and line["warmup"] == 1
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     r, line = _bench(["--gpus", "1"], {"STEDM_BENCH_DRY": "1", "WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and line is None and "WORLD_SIZE=2" in r.stderr
