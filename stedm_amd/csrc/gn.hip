@@ -301,17 +301,17 @@ extern "C" int stedm_gn_apply16(const float* x1, int c1, const float* x2, int c2
 // next block's GroupNorm, the decoder's concat GroupNorm and nothing has to re-read the fp32 tensor for statistics.
 extern "C" int stedm_gn_chan_nslab(int HW) { return (HW + 255) / 256; }
 
-// grid (B, slabs of 256 pixels, blocks of 64 channel quads): 256 threads = QB quads x (256 / QB) pixel lanes
+// grid (B, slots, blocks of qbs channel quads): 256 threads = QB quads x (256 / QB) pixel lanes
 // CAST: the same read also leaves the plain 16-bit conversion of x (hi, and lo = x - hi when o_lo != NULL) — the training backward
 // needs both of a gradient tensor (channel sums = bias gradient, 16-bit planes = operand of its dgrad / wgrad)
 template <typename T, bool CAST>
 __global__ void __launch_bounds__(256) gn_chan_stats_kernel(const float* __restrict__ x, int C, int HW, int slab_px, float* __restrict__ cs,
-                                                            T* __restrict__ o_hi, T* __restrict__ o_lo) {
+                                                            T* __restrict__ o_hi, T* __restrict__ o_lo, int qbs) {
   typedef T V4 __attribute__((ext_vector_type(4)));
   __shared__ float cpart[256 * 8];   // [npl][QB][8]
   const int b = blockIdx.x, slab = blockIdx.y, nslab = gridDim.y;
   const int Q = C >> 2, t = threadIdx.x;
-  const int qb0 = blockIdx.z * 64, QB = min(64, Q - qb0);
+  const int qb0 = blockIdx.z * qbs, QB = min(qbs, Q - qb0);   // qbs in {8, 16, 32, 64}: small tensors take narrow blocks, for a grid that fills the chip
   const int npl = 256 / QB, tq = t % QB, tp = t / QB;
   const float* px = x + (long)b * HW * C + (qb0 + tq) * 4;
   const int px0 = min(HW, slab * slab_px), px1 = min(HW, px0 + slab_px);   // trailing slots of an over-allocated partition stay 0
@@ -350,13 +350,24 @@ __global__ void __launch_bounds__(256) gn_chan_stats_kernel(const float* __restr
   }
 }
 
+// channel quads per block: 64 (1 KiB per pixel and block) unless the grid would leave most of the chip idle — a 16 x 16 x 512 tensor at
+// batch 64 is 128 blocks of 64 quads; narrower blocks (>= 128 B per pixel) bring it to ~1024. STEDM_GN_STATS_QB fixes it for A/B runs.
+static int chan_stats_qbs(int B, int nslab, int Q) {
+  static const int forced = getenv("STEDM_GN_STATS_QB") ? atoi(getenv("STEDM_GN_STATS_QB")) : 0;
+  if (forced == 8 || forced == 16 || forced == 32 || forced == 64) return forced;
+  int qbs = 64;
+  while (qbs > 8 && (long)B * nslab * ((Q + qbs - 1) / qbs) < 1024) qbs >>= 1;
+  return qbs;
+}
+
 extern "C" int stedm_gn_chan_stats(const float* x, int C, int B, int HW, int nslab, float* chan_stats, void* stream) {
   STEDM_CHECK_ARG(x && chan_stats && C > 0 && C % 4 == 0 && B > 0 && HW > 0 && nslab >= 0, "gn_chan_stats: bad args (C %% 4)");
   const int Q = C / 4;
   if (nslab == 0) nslab = (HW + 255) / 256;
   const int slab_px = nslab == (HW + 255) / 256 ? 256 : (HW + nslab - 1) / nslab;   // the default partition is 256-pixel runs
-  dim3 grid(B, nslab, (Q + 63) / 64);
-  gn_chan_stats_kernel<__bf16, false><<<grid, 256, 0, as_stream(stream)>>>(x, C, HW, slab_px, chan_stats, nullptr, nullptr);
+  const int qbs = chan_stats_qbs(B, nslab, Q);
+  dim3 grid(B, nslab, (Q + qbs - 1) / qbs);
+  gn_chan_stats_kernel<__bf16, false><<<grid, 256, 0, as_stream(stream)>>>(x, C, HW, slab_px, chan_stats, nullptr, nullptr, qbs);
   STEDM_LAUNCH_CHECK();
   return 0;
 }
@@ -370,11 +381,12 @@ extern "C" int stedm_gn_chan_stats16(const float* x, int C, int B, int HW, int n
   const int slab_px = nslab == (HW + 255) / 256 ? 256 : (HW + nslab - 1) / nslab;
   // every pixel must fall into a slot, or its 16-bit values would not be written
   STEDM_CHECK_ARG((long)nslab * slab_px >= HW, "gn_chan_stats16: the slots do not cover the sample");
-  dim3 grid(B, nslab, (Q + 63) / 64);
+  const int qbs = chan_stats_qbs(B, nslab, Q);
+  dim3 grid(B, nslab, (Q + qbs - 1) / qbs);
   if (mm_dtype == STEDM_F16)
-    gn_chan_stats_kernel<_Float16, true><<<grid, 256, 0, as_stream(stream)>>>(x, C, HW, slab_px, chan_stats, (_Float16*)out_hi, (_Float16*)out_lo);
+    gn_chan_stats_kernel<_Float16, true><<<grid, 256, 0, as_stream(stream)>>>(x, C, HW, slab_px, chan_stats, (_Float16*)out_hi, (_Float16*)out_lo, qbs);
   else
-    gn_chan_stats_kernel<__bf16, true><<<grid, 256, 0, as_stream(stream)>>>(x, C, HW, slab_px, chan_stats, (__bf16*)out_hi, (__bf16*)out_lo);
+    gn_chan_stats_kernel<__bf16, true><<<grid, 256, 0, as_stream(stream)>>>(x, C, HW, slab_px, chan_stats, (__bf16*)out_hi, (__bf16*)out_lo, qbs);
   STEDM_LAUNCH_CHECK();
   return 0;
 }
