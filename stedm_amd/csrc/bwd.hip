@@ -131,19 +131,32 @@ __global__ void __launch_bounds__(256) gn_bwd_fold_kernel(const float* __restric
   }
 }
 
-// dgamma[c] (+)= sum_b bc[b][c][1]; dbeta[c] (+)= sum_b bc[b][c][0]; grid ceil(C/64), 256 threads = 64 channels x 4 sample lanes
+// dgamma[c] (+)= sum_b bc[b][c][1]; dbeta[c] (+)= sum_b bc[b][c][0]; grid ceil(C/16), 256 threads = 16 channels x 16 sample lanes: the kernel
+// is pure load latency, so a lane walks few samples (4 at batch 64, their loads in flight together) and the grid is 4x the 64-channel form's
 __global__ void __launch_bounds__(256) gn_bwd_param_kernel(const float* __restrict__ bc, int B, int C, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            int accumulate) {
-  __shared__ float red[4][64][2];
-  const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  __shared__ float red[16][16][2];
+  const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
   float u = 0.f, w = 0.f;
-  if (c < C)
-    for (int b = bl; b < B; b += 4) { u += bc[((long)b * C + c) * 2]; w += bc[((long)b * C + c) * 2 + 1]; }
+  if (c < C) {
+    int b = bl;
+    for (; b + 48 < B; b += 64) {
+      float2 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float2*>(bc + ((long)(b + 16 * i) * C + c) * 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { u += v[i].x; w += v[i].y; }
+    }
+    for (; b < B; b += 16) { const float2 v = *reinterpret_cast<const float2*>(bc + ((long)b * C + c) * 2); u += v.x; w += v.y; }
+  }
   red[bl][cl][0] = u; red[bl][cl][1] = w;
   __syncthreads();
   if (bl == 0 && c < C) {
-    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + ((red[0][cl][0] + red[1][cl][0]) + (red[2][cl][0] + red[3][cl][0]));
-    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + ((red[0][cl][1] + red[1][cl][1]) + (red[2][cl][1] + red[3][cl][1]));
+    float su = 0.f, sw = 0.f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) { su += red[l][cl][0]; sw += red[l][cl][1]; }   // fixed order
+    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + su;
+    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + sw;
   }
 }
 
@@ -458,28 +471,28 @@ __global__ void __launch_bounds__(256) wgrad_to_oihw_kernel(const float* __restr
 }
 
 // cs [B][nslab][C][2] (sums in [..][0]) -> per_sample[b*ld + c] (optional) and total[c] (+= when accumulate; optional)
-// grid ceil(C/64); 256 threads = 64 channels x 4 sample lanes (fixed-order fold of the 4 lanes through LDS)
+// grid ceil(C/16); 256 threads = 16 channels x 16 sample lanes (pure load latency: few samples per lane, their loads in flight together;
+// fixed-order fold of the 16 lanes through LDS)
 __global__ void __launch_bounds__(256) chan_sum_fold_kernel(const float* __restrict__ cs, int B, int nslab, int C, float* __restrict__ per_sample, long ld,
                                                             float* __restrict__ total, int accumulate) {
-  __shared__ float red[4][64];
-  const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  __shared__ float red[16][16];
+  const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
   float tot = 0.f;
   if (c < C) {
-    // four samples per step: their loads are independent and in flight together (the kernel is pure load latency); same summation order
     int b = bl;
-    for (; b + 12 < B; b += 16) {
+    for (; b + 48 < B; b += 64) {
       float u[4] = {0.f, 0.f, 0.f, 0.f};
       for (int k = 0; k < nslab; ++k) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) u[i] += cs[(((long)(b + 4 * i) * nslab + k) * C + c) * 2];
+        for (int i = 0; i < 4; ++i) u[i] += cs[(((long)(b + 16 * i) * nslab + k) * C + c) * 2];
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if (per_sample) per_sample[(long)(b + 4 * i) * ld + c] = u[i];
+        if (per_sample) per_sample[(long)(b + 16 * i) * ld + c] = u[i];
         tot += u[i];
       }
     }
-    for (; b < B; b += 4) {
+    for (; b < B; b += 16) {
       float u = 0.f;
       for (int k = 0; k < nslab; ++k) u += cs[(((long)b * nslab + k) * C + c) * 2];
       if (per_sample) per_sample[(long)b * ld + c] = u;
@@ -488,7 +501,12 @@ __global__ void __launch_bounds__(256) chan_sum_fold_kernel(const float* __restr
   }
   red[bl][cl] = tot;
   __syncthreads();
-  if (bl == 0 && c < C && total) total[c] = (accumulate ? total[c] : 0.f) + ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
+  if (bl == 0 && c < C && total) {
+    float t = 0.f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) t += red[l][cl];   // fixed order
+    total[c] = (accumulate ? total[c] : 0.f) + t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ resampling
@@ -891,13 +909,13 @@ extern "C" int stedm_gn_bwd(const float* x1, int c1, const float* x2, int c2, co
     GnBwdFusedArgs fa{a, bc, cb};
     if (mm_dtype == STEDM_F16) launch_gn_bwd_fused<_Float16>(fa, ppt, dim3(B, C / cb), st);
     else launch_gn_bwd_fused<__bf16>(fa, ppt, dim3(B, C / cb), st);
-    gn_bwd_param_kernel<<<(C + 63) / 64, 256, 0, st>>>(bc, B, C, dgamma, dbeta, acc_param);
+    gn_bwd_param_kernel<<<(C + 15) / 16, 256, 0, st>>>(bc, B, C, dgamma, dbeta, acc_param);
     STEDM_LAUNCH_CHECK();
     return 0;
   }
   gn_bwd_stats_kernel<<<dim3(B, nslab, (Q + 63) / 64), 256, 0, st>>>(a);
   gn_bwd_fold_kernel<<<B, 256, (size_t)C * 8, st>>>(part, nslab, C, groups, HW, gamma, bc, gm);
-  gn_bwd_param_kernel<<<(C + 63) / 64, 256, 0, st>>>(bc, B, C, dgamma, dbeta, acc_param);
+  gn_bwd_param_kernel<<<(C + 15) / 16, 256, 0, st>>>(bc, B, C, dgamma, dbeta, acc_param);
   const dim3 grid(B, (unsigned)(((long)HW * Q + 1023) / 1024));
   if (mm_dtype == STEDM_F16) gn_bwd_apply_kernel<_Float16><<<grid, 256, 0, st>>>(a);
   else gn_bwd_apply_kernel<__bf16><<<grid, 256, 0, st>>>(a);
@@ -934,7 +952,7 @@ extern "C" int stedm_wgrad_to_oihw(const float* dw, float* grad, int cout, int c
 
 extern "C" int stedm_chan_sum_fold(const float* cs, int B, int nslab, int C, float* per_sample, long ld, float* total, int accumulate, void* stream) {
   STEDM_CHECK_ARG(cs && (per_sample || total), "chan_sum_fold: bad args");
-  chan_sum_fold_kernel<<<(C + 63) / 64, 256, 0, as_stream(stream)>>>(cs, B, nslab, C, per_sample, ld, total, accumulate);
+  chan_sum_fold_kernel<<<(C + 15) / 16, 256, 0, as_stream(stream)>>>(cs, B, nslab, C, per_sample, ld, total, accumulate);
   STEDM_LAUNCH_CHECK();
   return 0;
 }
