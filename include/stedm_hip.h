@@ -122,6 +122,11 @@ int stedm_gn_chan_stats16(const float* x, int C, int B, int HW, int nslab, float
 int stedm_gn_apply16c(const float* x1, int c1, const float* cs1, int nslab1, const float* x2, int c2, const float* cs2, int nslab2, int x2_bmod,
                       const float* gamma, const float* beta, float eps, int groups, int act, int B, int HW,
                       void* out_hi, void* out_lo, void* raw_hi, void* raw_lo, int mm_dtype, void* stream);
+/* The same pass, also leaving mean_rstd [B][groups][2] = {mean, rstd} of every (sample, group) when != NULL: the statistics the pass folds
+ * anyway, kept for the training backward (what autograd saves of F.group_norm, util.py:214-216) instead of a second fold (stedm_gn_fold). */
+int stedm_gn_apply16c_mr(const float* x1, int c1, const float* cs1, int nslab1, const float* x2, int c2, const float* cs2, int nslab2, int x2_bmod,
+                         const float* gamma, const float* beta, float eps, int groups, int act, int B, int HW,
+                         void* out_hi, void* out_lo, void* raw_hi, void* raw_lo, float* mean_rstd, int mm_dtype, void* stream);
 int stedm_gn_stats(const float* x1, int c1, const float* x2, int c2, int x2_bmod, int groups, int B, int HW,
                    double* stats, void* stream);
 int stedm_gn_apply16(const float* x1, int c1, const float* x2, int c2, int x2_bmod, const float* gamma,

@@ -404,6 +404,7 @@ struct GnApplyCArgs {
   void* out_lo;
   void* raw_hi;
   void* raw_lo;
+  float* mr;     // optional [B][groups][2]: the {mean, rstd} this pass folds anyway, kept for the training backward
 };
 
 // y = act(GroupNorm([x1|x2])) from channel partials -> 16-bit planes; optionally also the plain conversion of [x1|x2]
@@ -472,6 +473,7 @@ __global__ void __launch_bounds__(256) gn_apply16c_kernel(GnApplyCArgs a, int sl
       var = var > 0.0 ? var : 0.0;
       lmean[g] = (float)mean;
       lrstd[g] = (float)(1.0 / sqrt(var + (double)a.eps));
+      if (a.mr && sl == 0) { a.mr[((long)b * a.groups + g) * 2] = lmean[g]; a.mr[((long)b * a.groups + g) * 2 + 1] = lrstd[g]; }
     }
     __syncthreads();
   }
@@ -598,6 +600,8 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
       var = var > 0.0 ? var : 0.0;
       lmean[g] = (float)mean;
       lrstd[g] = (float)(1.0 / sqrt(var + (double)a.eps));
+      // (pixel-run blocks all fold every group of their sample: the first writes; channel-run blocks own their groups)
+      if (a.mr && (cb > 0 || sl == 0)) { a.mr[((long)b * a.groups + g) * 2] = lmean[g]; a.mr[((long)b * a.groups + g) * 2 + 1] = lrstd[g]; }
     }
     __syncthreads();
     for (int c = c_lo + threadIdx.x; c < c_lo + c_n; c += 256) {
@@ -671,9 +675,20 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
   }
 }
 
+extern "C" int stedm_gn_apply16c_mr(const float* x1, int c1, const float* cs1, int nslab1, const float* x2, int c2, const float* cs2, int nslab2, int x2_bmod,
+                                    const float* gamma, const float* beta, float eps, int groups, int act, int B, int HW,
+                                    void* out_hi, void* out_lo, void* raw_hi, void* raw_lo, float* mean_rstd, int mm_dtype, void* stream);
+
 extern "C" int stedm_gn_apply16c(const float* x1, int c1, const float* cs1, int nslab1, const float* x2, int c2, const float* cs2, int nslab2, int x2_bmod,
                                  const float* gamma, const float* beta, float eps, int groups, int act, int B, int HW,
                                  void* out_hi, void* out_lo, void* raw_hi, void* raw_lo, int mm_dtype, void* stream) {
+  return stedm_gn_apply16c_mr(x1, c1, cs1, nslab1, x2, c2, cs2, nslab2, x2_bmod, gamma, beta, eps, groups, act, B, HW, out_hi, out_lo, raw_hi, raw_lo,
+                              nullptr, mm_dtype, stream);
+}
+
+extern "C" int stedm_gn_apply16c_mr(const float* x1, int c1, const float* cs1, int nslab1, const float* x2, int c2, const float* cs2, int nslab2, int x2_bmod,
+                                    const float* gamma, const float* beta, float eps, int groups, int act, int B, int HW,
+                                    void* out_hi, void* out_lo, void* raw_hi, void* raw_lo, float* mean_rstd, int mm_dtype, void* stream) {
   STEDM_CHECK_ARG(x1 && cs1 && out_hi && gamma && beta, "gn_apply16c: null pointer");
   STEDM_CHECK_ARG((x2 != nullptr) == (c2 > 0) && (x2 == nullptr || cs2 != nullptr), "gn_apply16c: x2/c2/cs2 mismatch");
   const int C = c1 + c2;
@@ -682,7 +697,7 @@ extern "C" int stedm_gn_apply16c(const float* x1, int c1, const float* cs1, int 
   STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "gn_apply16c: bad mm_dtype");
   STEDM_CHECK_ARG(raw_hi || !raw_lo, "gn_apply16c: raw_lo without raw_hi");
   STEDM_CHECK_ARG(nslab1 > 0 && (x2 == nullptr || nslab2 > 0), "gn_apply16c: nslab1 / nslab2 must be the slot counts of cs1 / cs2");
-  GnApplyCArgs a{x1, x2, cs1, cs2, c1, c2, x2_bmod, groups, HW, act, nslab1, x2 ? nslab2 : 0, gamma, beta, eps, out_hi, out_lo, raw_hi, raw_lo};
+  GnApplyCArgs a{x1, x2, cs1, cs2, c1, c2, x2_bmod, groups, HW, act, nslab1, x2 ? nslab2 : 0, gamma, beta, eps, out_hi, out_lo, raw_hi, raw_lo, mean_rstd};
   // Pixels per block. Every block folds the group statistics and builds its per-channel table first, a cost that grows with C, so wide
   // tensors want long runs (128 KiB of fp32 input: 21 pixels of the 1536-channel decoder concat; at a fixed 32 KiB that shape ran at 4.3
   // TB/s, now 5.3) — as long as the grid keeps >= 768 blocks (3 per CU), which the 64-pixel samples of the 8x8 level need (12 pixels per

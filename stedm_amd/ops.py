@@ -238,17 +238,21 @@ def gn_chan_stats16(x: torch.Tensor, out: torch.Tensor, out_hi: torch.Tensor, ou
 
 def gn_apply16c(x1: torch.Tensor, cs1: torch.Tensor, x2: Optional[torch.Tensor], cs2: Optional[torch.Tensor], out_hi: torch.Tensor,
                 out_lo: Optional[torch.Tensor], prec: Precision, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
-                groups: int = 32, act: int = 0, x2_bmod: int = 0, raw: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None) -> None:
-    """act(GroupNorm([x1|x2])) from channel partials -> 16-bit planes (+ optional plain conversion planes `raw`)."""
+                groups: int = 32, act: int = 0, x2_bmod: int = 0, raw: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None,
+                mean_rstd: Optional[torch.Tensor] = None) -> None:
+    """act(GroupNorm([x1|x2])) from channel partials -> 16-bit planes (+ optional plain conversion planes `raw`; + optional
+    mean_rstd [B][groups][2] fp32, the group statistics the pass folds, kept for the training backward)."""
     _chk(x1, name="x1")
     B = x1.shape[0]
     HW = x1.numel() // (B * x1.shape[-1])
     c2 = 0 if x2 is None else x2.shape[-1]
-    check(lib().stedm_gn_apply16c(x1.data_ptr(), x1.shape[-1], cs1.data_ptr(), cs1.shape[1], _ptr(x2), c2, _ptr(cs2),
-                                  0 if cs2 is None else cs2.shape[1], x2_bmod, gamma.data_ptr(),
-                                  beta.data_ptr(), float(eps), groups, act, B, HW, out_hi.data_ptr(), _ptr(out_lo),
-                                  None if raw is None else raw[0].data_ptr(), None if raw is None else _ptr(raw[1]),
-                                  prec.mm_dtype, _stream()), "stedm_gn_apply16c")
+    if mean_rstd is not None:
+        assert mean_rstd.dtype == torch.float32 and mean_rstd.is_contiguous() and tuple(mean_rstd.shape) == (B, groups, 2)
+    check(lib().stedm_gn_apply16c_mr(x1.data_ptr(), x1.shape[-1], cs1.data_ptr(), cs1.shape[1], _ptr(x2), c2, _ptr(cs2),
+                                     0 if cs2 is None else cs2.shape[1], x2_bmod, gamma.data_ptr(),
+                                     beta.data_ptr(), float(eps), groups, act, B, HW, out_hi.data_ptr(), _ptr(out_lo),
+                                     None if raw is None else raw[0].data_ptr(), None if raw is None else _ptr(raw[1]),
+                                     _ptr(mean_rstd), prec.mm_dtype, _stream()), "stedm_gn_apply16c_mr")
 
 
 # ------------------------------------------------------------------------------------------- conv

@@ -45,6 +45,7 @@ class UNetTrainer:
         # cond_stage_trainable, ldm_diffusion.py:224-234); their gradients are filled by the caller; no EMA (LitEma covers `model` only)
         self.extra_params = list(extra_params)
         self.direct_wgrad = os.environ.get("STEDM_WGRAD_GEMM") is None    # STEDM_WGRAD_GEMM=1: im2col + GEMM form everywhere (A/B switch)
+        self._refold = os.environ.get("STEDM_BWD_REFOLD") is not None             # A/B: fold the group statistics again in the backward
         self._split_cast = os.environ.get("STEDM_BWD_SPLIT_CAST") is not None   # A/B: separate conversion and statistics passes of a gradient
         self.accumulate_grad_batches = int(accumulate_grad_batches)      # Trainer(accumulate_grad_batches=...) of train_diff.py
         self._micro = 0
@@ -296,8 +297,10 @@ class UNetTrainer:
         c2 = 0 if x2 is None else x2.shape[-1]
         HW = x1.numel() // (B * c1)
         G = norm.num_groups
-        mr = self._buf(f"mr.{B}x{G}", (B, G, 2))
-        ops.gn_fold(m._chan_stats(x1), None if x2 is None else m._chan_stats(x2), G, HW, norm.eps, mr)
+        mr = None if self._refold else getattr(m, "_saved_mr", {}).get((id(norm), x1.data_ptr()))   # left by the forward's normalisation pass
+        if mr is None:
+            mr = self._buf(f"mr.{B}x{G}", (B, G, 2))
+            ops.gn_fold(m._chan_stats(x1), None if x2 is None else m._chan_stats(x2), G, HW, norm.eps, mr)
         ws = self._buf("gnws", (ops.gn_bwd_ws_floats(B, HW, c1 + c2, G),))
         g1, a1 = self._grad_of(x1)
         g2, a2 = self._grad_of(x2) if x2 is not None else (None, False)

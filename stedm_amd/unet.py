@@ -231,6 +231,8 @@ class UNetModel(nn.Module):
         self._cs: Dict[int, torch.Tensor] = {}
         self._raw16: Dict[int, Tuple] = {}
         self._saved16: Dict = {}
+        self._saved_mr: Dict = {}
+        self._mr_ctr = 0
         self._plane_ctr = 0
         self._tape: Optional[list] = None     # training forward (stedm_amd/train.py): one record per layer for the backward pass
 
@@ -439,8 +441,13 @@ class UNetModel(nn.Module):
             self._saved16[("raw", x1.data_ptr())] = raw
         else:
             raw = self._planes(B, H, W, C, "raw16") if want_raw else None
+        mr = None
+        if self._tape is not None:       # training forward: keep the group statistics this pass folds (the backward needs them again)
+            self._mr_ctr += 1
+            mr = self._buf(f"keep{self._mr_ctr}.mr", (B, norm.num_groups, 2))
+            self._saved_mr[(id(norm), x1.data_ptr())] = mr
         ops.gn_apply16c(x1, self._chan_stats(x1), x2, None if x2 is None else self._chan_stats(x2), hi, lo, self.precision,
-                        norm.weight, norm.bias, norm.eps, norm.num_groups, act, x2_bmod, raw)
+                        norm.weight, norm.bias, norm.eps, norm.num_groups, act, x2_bmod, raw, mean_rstd=mr)
         return ((hi, lo), raw) if want_raw else (hi, lo)
 
     def _res(self, tag: str, rb: ResBlock, x1, x2, emb_all, emb_off, emb_bstride, x2_bmod=0, want16=False):
@@ -661,7 +668,9 @@ class UNetModel(nn.Module):
         self._cs = {}
         self._raw16 = {}
         self._saved16 = {}
+        self._saved_mr = {}
         self._plane_ctr = 0
+        self._mr_ctr = 0
         x = x.float().contiguous()
         B, c1, H, W = x.shape
         nrep = len(contexts)

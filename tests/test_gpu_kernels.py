@@ -367,10 +367,18 @@ def test_gn_chan_stats_apply16c(dev, B, H, W, c1, c2, bmod):
     ops.gn_apply16c(d1, cs1, d2, cs2, hi, lo, prec, g.to(dev), b.to(dev), 1e-5, 32, 1, bmod, raw=(rhi, rlo))
     assert rel_err(nchw(_as_float(hi, prec) + _as_float(lo, prec)), ref) < 2e-5
     assert rel_err(nchw(_as_float(rhi, prec) + _as_float(rlo, prec)), xin) < 1e-6
-    # bitwise reproducible
+    # bitwise reproducible; the {mean, rstd} side output (training: kept for the backward) equals the separate fold and F.group_norm's statistics
     hi2 = torch.empty_like(hi); lo2 = torch.empty_like(hi)
-    ops.gn_apply16c(d1, cs1, d2, cs2, hi2, lo2, prec, g.to(dev), b.to(dev), 1e-5, 32, 1, bmod)
+    mr = torch.full((B, 32, 2), float("nan"), device=dev)
+    ops.gn_apply16c(d1, cs1, d2, cs2, hi2, lo2, prec, g.to(dev), b.to(dev), 1e-5, 32, 1, bmod, mean_rstd=mr)
     assert torch.equal(hi, hi2) and torch.equal(lo, lo2)
+    if not bmod:
+        mr2 = torch.empty_like(mr)
+        ops.gn_fold(cs1, cs2, 32, H * W, 1e-5, mr2)
+        assert torch.allclose(mr, mr2, rtol=1e-6, atol=1e-7)
+    xg = xin.double().view(B, 32, -1)
+    assert torch.allclose(mr[..., 0].cpu().double(), xg.mean(-1), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(mr[..., 1].cpu().double(), 1.0 / torch.sqrt(xg.var(-1, unbiased=False) + 1e-5), rtol=1e-4)
 
 
 @pytest.mark.parametrize("precs", ["bf16", "f16", "bf16x3"])
