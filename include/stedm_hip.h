@@ -398,6 +398,10 @@ int stedm_wgrad1x1(const void* x16, const void* dy16, float* part, long P, int C
  * total[c] (bias gradients; the per-sample sums are the gradient of the emb_layers output, openaimodel.py:277-280). */
 int stedm_chan_sum_fold(const float* cs, int B, int nslab, int C, float* per_sample, long ld, float* total, int accumulate,
                         void* stream);
+/* ... with the total also written to total2 (NULL: skip): two parameters that receive the same gradient — conv1.bias and
+ * emb_layers[1].bias both add onto h (openaimodel.py:276-280), conv2.bias and skip_connection.bias onto the block output (:288). */
+int stedm_chan_sum_fold2(const float* cs, int B, int nslab, int C, float* per_sample, long ld, float* total, int accumulate, float* total2,
+                         void* stream);
 /* backward of F.interpolate(scale 2, nearest): out [B][H][W][C] (+)= 2x2 block sums of in [B][2H][2W][C]. */
 int stedm_sum2x2(const float* in, float* out, int B, int H, int W, int C, int accumulate, void* stream);
 /* in [B][Ho][Wo][C] fp32 -> 16-bit planes [B][2Ho][2Wo][C], value at even positions, zero elsewhere (stride-2 dgrad). */

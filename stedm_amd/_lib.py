@@ -108,6 +108,7 @@ SIGNATURES = {
     "stedm_wgrad1x1_plan": (_I, [C.c_long, _I, _I, C.POINTER(C.c_int)]),
     "stedm_wgrad1x1": (_I, [_P, _P, _P, C.c_long, _I, _I, _I, _P]),
     "stedm_chan_sum_fold": (_I, [_P, _I, _I, _I, _P, C.c_long, _P, _I, _P]),
+    "stedm_chan_sum_fold2": (_I, [_P, _I, _I, _I, _P, C.c_long, _P, _I, _P, _P]),
     "stedm_sum2x2": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "stedm_zero_insert16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "stedm_attn_legacy_bwd_ws_floats": (C.c_long, [_I, _I, _I]),

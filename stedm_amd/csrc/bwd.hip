@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(256) wgrad_to_oihw_kernel(const float* __restr
 // grid ceil(C/16); 256 threads = 16 channels x 16 sample lanes (pure load latency: few samples per lane, their loads in flight together;
 // fixed-order fold of the 16 lanes through LDS)
 __global__ void __launch_bounds__(256) chan_sum_fold_kernel(const float* __restrict__ cs, int B, int nslab, int C, float* __restrict__ per_sample, long ld,
-                                                            float* __restrict__ total, int accumulate) {
+                                                            float* __restrict__ total, int accumulate, float* __restrict__ total2) {
   __shared__ float red[16][16];
   const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
   float tot = 0.f;
@@ -505,7 +505,9 @@ __global__ void __launch_bounds__(256) chan_sum_fold_kernel(const float* __restr
     float t = 0.f;
 #pragma unroll
     for (int l = 0; l < 16; ++l) t += red[l][cl];   // fixed order
-    total[c] = (accumulate ? total[c] : 0.f) + t;
+    const float v = (accumulate ? total[c] : 0.f) + t;
+    total[c] = v;
+    if (total2) total2[c] = v;      // a second parameter with the same gradient (two biases added onto one tensor)
   }
 }
 
@@ -950,11 +952,16 @@ extern "C" int stedm_wgrad_to_oihw(const float* dw, float* grad, int cout, int c
   return 0;
 }
 
-extern "C" int stedm_chan_sum_fold(const float* cs, int B, int nslab, int C, float* per_sample, long ld, float* total, int accumulate, void* stream) {
-  STEDM_CHECK_ARG(cs && (per_sample || total), "chan_sum_fold: bad args");
-  chan_sum_fold_kernel<<<(C + 15) / 16, 256, 0, as_stream(stream)>>>(cs, B, nslab, C, per_sample, ld, total, accumulate);
+extern "C" int stedm_chan_sum_fold2(const float* cs, int B, int nslab, int C, float* per_sample, long ld, float* total, int accumulate, float* total2,
+                                    void* stream) {
+  STEDM_CHECK_ARG(cs && (per_sample || total) && (total || !total2), "chan_sum_fold: bad args");
+  chan_sum_fold_kernel<<<(C + 15) / 16, 256, 0, as_stream(stream)>>>(cs, B, nslab, C, per_sample, ld, total, accumulate, total2);
   STEDM_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int stedm_chan_sum_fold(const float* cs, int B, int nslab, int C, float* per_sample, long ld, float* total, int accumulate, void* stream) {
+  return stedm_chan_sum_fold2(cs, B, nslab, C, per_sample, ld, total, accumulate, nullptr, stream);
 }
 
 extern "C" int stedm_sum2x2(const float* in, float* out, int B, int H, int W, int C, int accumulate, void* stream) {

@@ -760,9 +760,12 @@ def wgrad1x1(x16: torch.Tensor, dy16: torch.Tensor, part: torch.Tensor, prec: Pr
     check(lib().stedm_wgrad1x1(x16.data_ptr(), dy16.data_ptr(), part.data_ptr(), P, cin, cout, prec.mm_dtype, _stream()), "stedm_wgrad1x1")
 
 
-def chan_sum_fold(cs: torch.Tensor, per_sample: Optional[torch.Tensor], ld: int, total: Optional[torch.Tensor], accumulate: bool) -> None:
+def chan_sum_fold(cs: torch.Tensor, per_sample: Optional[torch.Tensor], ld: int, total: Optional[torch.Tensor], accumulate: bool,
+                  total2: Optional[torch.Tensor] = None) -> None:
+    """channel partials -> per-sample sums and the batch total (total2: a second destination of the same total)"""
     B, nslab, Cc, _ = cs.shape
-    check(lib().stedm_chan_sum_fold(cs.data_ptr(), B, nslab, Cc, _ptr(per_sample), ld, _ptr(total), int(accumulate), _stream()), "stedm_chan_sum_fold")
+    check(lib().stedm_chan_sum_fold2(cs.data_ptr(), B, nslab, Cc, _ptr(per_sample), ld, _ptr(total), int(accumulate), _ptr(total2), _stream()),
+          "stedm_chan_sum_fold2")
 
 
 def sum2x2(x: torch.Tensor, out: torch.Tensor, accumulate: bool) -> None:

@@ -46,6 +46,7 @@ class UNetTrainer:
         self.extra_params = list(extra_params)
         self.direct_wgrad = os.environ.get("STEDM_WGRAD_GEMM") is None    # STEDM_WGRAD_GEMM=1: im2col + GEMM form everywhere (A/B switch)
         self._refold = os.environ.get("STEDM_BWD_REFOLD") is not None             # A/B: fold the group statistics again in the backward
+        self._copy_bias = os.environ.get("STEDM_BWD_COPY_BIAS") is not None       # A/B: the twin bias gradients by a device copy
         self._split_cast = os.environ.get("STEDM_BWD_SPLIT_CAST") is not None   # A/B: separate conversion and statistics passes of a gradient
         self.accumulate_grad_batches = int(accumulate_grad_batches)      # Trainer(accumulate_grad_batches=...) of train_diff.py
         self._micro = 0
@@ -275,7 +276,7 @@ class UNetTrainer:
         ops.wgrad_to_oihw(dw, self._param_grad(wparam), Cs, co, accumulate)
 
     def _bias_grad(self, dy: torch.Tensor, bias: Optional[nn.Parameter], per_sample: Optional[torch.Tensor] = None, ld: int = 0,
-                   cast: Optional[str] = None):
+                   cast: Optional[str] = None, also: Optional[nn.Parameter] = None):
         """bias.grad = sum over (batch, pixels) of dy [B,H,W,C]; per_sample[b*ld + c] = sum over pixels (optional). `cast`: the same read
         of dy also writes its 16-bit operand planes (buffer family `cast`, as _cast16 would) and returns them."""
         B, Cc = dy.shape[0], dy.shape[-1]
@@ -288,7 +289,13 @@ class UNetTrainer:
             if cast is not None:
                 planes = self._cast16(dy, kind=cast)
             ops.gn_chan_stats(dy, cs)
-        ops.chan_sum_fold(cs, per_sample, ld, None if bias is None else self._param_grad(bias), False)
+        # `also`: a second bias added onto the same tensor receives the same sums (written by the same launch, no copy)
+        if also is not None and self._copy_bias:
+            ops.chan_sum_fold(cs, per_sample, ld, self._param_grad(bias), False)
+            self._param_grad(also).copy_(bias.grad)
+        else:
+            ops.chan_sum_fold(cs, per_sample, ld, None if bias is None else self._param_grad(bias), False,
+                              None if also is None else self._param_grad(also))
         return planes
 
     def _gn_bwd(self, norm: nn.GroupNorm, act: int, x1, x2, dA, add, dx16=None):
@@ -435,10 +442,9 @@ class UNetTrainer:
         dout, have = self._grad_of(out)
         assert have, "no gradient reached this block's output"
         has_skip = not isinstance(rb.skip_connection, nn.Identity)
-        dout16 = self._bias_grad(dout, conv2.bias, cast="dy")
+        dout16 = self._bias_grad(dout, conv2.bias, cast="dy", also=rb.skip_connection.bias if has_skip else None)   # both biases add onto `out`
         if has_skip:
             sk = rb.skip_connection
-            self._param_grad(sk.bias).copy_(conv2.bias.grad)             # same sums: both biases add onto `out`
             x16 = self.m._saved16.get(("raw", x1.data_ptr())) or self._cast16(x1, x2, kind="x16")
             self._wgrad(x16, dout16, dout, sk.weight, 1, 0)
             add = self._buf(f"add.{B}x{H}x{W}x{cin}", (B, H, W, cin))
@@ -455,12 +461,12 @@ class UNetTrainer:
         dh = self.G[h.data_ptr()]
         # the embedding enters between conv1 and the second GroupNorm (openaimodel.py:276-287): its gradient is the per-sample
         # channel sum of dh, conv1's bias gradient the batch total
+        eb = rb.emb_layers[1].bias                                        # same sums: both biases add onto h
         if emb_off is None:
             self.dEs = self._buf("dEs", (B, co))
-            self._bias_grad(dh, conv1.bias, self.dEs, co)
+            self._bias_grad(dh, conv1.bias, self.dEs, co, also=eb)
         else:
-            self._bias_grad(dh, conv1.bias, self.dE[:, emb_off:], self.dE.shape[1])
-        self._param_grad(rb.emb_layers[1].bias).copy_(conv1.bias.grad)    # same sums: both biases add onto h
+            self._bias_grad(dh, conv1.bias, self.dE[:, emb_off:], self.dE.shape[1], also=eb)
         # conv1 and the first GroupNorm + SiLU over the (virtual concat) input
         a16 = self._norm16(rb.in_layers[0], 1, x1, x2)
         self._wgrad(a16, dh16, dh, conv1.weight, 3, 0)
