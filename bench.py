@@ -526,6 +526,22 @@ def main():
                                    "decode_seconds": round(t2 - t1, 4), "images_per_s": round(B / (t2 - t0), 1),
                                    "decode_what": "decode_first_stage (VQ-f4 architecture: quantise over 8192 codes, post_quant_conv, Decoder 32^2 -> 128^2, "
                                                   "55 M parameters) + uint8 / class-map epilogue: predict_step end to end, images/s over the whole step"}
+            # PCIe-inclusive figure: predict_step of the reference receives its batch from the DataLoader on the HOST (ldm_diffusion.py:76-79);
+            # the legs above start with the batch resident in HBM. Time the host -> device copy of the same batch from pinned memory
+            # (what DataLoader(pin_memory=True) hands over) and report the end-to-end rate with it, beside the resident one — never as `value`.
+            try:
+                hb = {k: v.cpu().pin_memory() for k, v in batch.items()}
+                nbytes = sum(v.numel() * v.element_size() for v in hb.values())
+                for _ in range(2):
+                    torch.cuda.synchronize(); th0 = time.perf_counter()
+                    db = {k: v.to(dev, non_blocking=True) for k, v in hb.items()}
+                    torch.cuda.synchronize(); th1 = time.perf_counter()
+                out["sampling_run"]["h2d"] = {"seconds": round(th1 - th0, 4), "mbytes": round(nbytes / 1e6, 1), "gb_per_s": round(nbytes / 1e9 / (th1 - th0), 1),
+                                              "images_per_s_incl_h2d": round(B / (t2 - t0 + th1 - th0), 1),
+                                              "what": "pinned host batch (image, segmentation, 4 style images of 512^2 per sample, fp32) -> HBM, not overlapped"}
+                del hb, db
+            except RuntimeError as e:            # no pinned memory on this box: say so instead of a number
+                out["sampling_run"]["h2d"] = {"error": str(e)[:120]}
             # the default aggregator of the reference's config (conf/config_diff.yaml:16 style_agg: linear): Swin-V2-T over the same B x 4 style
             # images + the Agg_Linear MLP (networks/agg_blocks.py:24-33) — the style encoding that replaces the sViT's in predict_step
             zs = S_ZSS_DM("swin_v2_t", SimpleNamespace(name="mp", num_patches=4), SimpleNamespace(name="linear"), {"data": {"patch_size": 512}}, unet,
