@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) conv_in_fast_kernel(const float* __restri
                                                            int c2, int bmod, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ out, int H, int W,
                                                            int cout, int rblocks, float* __restrict__ cs) {
-  extern __shared__ __attribute__((aligned(16))) float smi[];   // [CI_ROWS+2][W+2][8], then [256][2] statistics partials
+  extern __shared__ __attribute__((aligned(16))) float smi[];   // [CI_ROWS+2][W+2][8], then [256][2] statistics partials, then the filter [cout][9 cin | 1]
   const int cin = c1 + c2;
   const int PW = W + 2;
   const int b = blockIdx.x / rblocks, y0 = (blockIdx.x % rblocks) * CI_ROWS;
@@ -69,14 +69,20 @@ __global__ void __launch_bounds__(256) conv_in_fast_kernel(const float* __restri
       v = ci < c1 ? x1[(((long)b * c1 + ci) * H + sy) * W + sxx] : x2[(((long)b2 * c2 + (ci - c1)) * H + sy) * W + sxx];
     smi[i] = v;
   }
+  // the filter through LDS: one coalesced read of the OIHW array (a thread's own 9 * cin weights are cin * 9 * 4 B apart between lanes:
+  // read from global they cost 72 requests of 64 cache lines each per wave, more than the block's arithmetic); row stride 9 * cin is odd
+  // or padded to odd, so the per-thread gather below is bank-conflict-free
+  float* swt = smi + (CI_ROWS + 2) * PW * 8 + 512;
+  const int wrow = 9 * cin, wst = wrow | 1;
+  for (int i = threadIdx.x; i < cout * wrow; i += 256) { const int r = i / wrow; swt[r * wst + (i - r * wrow)] = w[i]; }
   const int co = threadIdx.x % cout, pl = threadIdx.x / cout, npl = 256 / cout;
+  const float bv = bias ? bias[co] : 0.f;
+  __syncthreads();
   float wr[9][8];
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-    for (int ci = 0; ci < 8; ++ci) wr[tap][ci] = ci < cin ? w[((long)co * cin + ci) * 9 + tap] : 0.f;
-  const float bv = bias ? bias[co] : 0.f;
-  __syncthreads();
+    for (int ci = 0; ci < 8; ++ci) wr[tap][ci] = ci < cin ? swt[co * wst + ci * 9 + tap] : 0.f;
   const int rows = min(CI_ROWS, H - y0);
   float ssum = 0.f, ssq = 0.f;
   for (int pix = pl; pix < rows * W; pix += npl) {
@@ -112,7 +118,7 @@ extern "C" int stedm_conv_in(const float* x1, int c1, const float* x2, int c2, i
   STEDM_CHECK_ARG((x2 != nullptr) == (c2 > 0), "conv_in: x2/c2 mismatch");
   const int cin = c1 + c2;
   if (cin <= 8 && cout <= 256 && 256 % cout == 0) {
-    const size_t ldsf = ((size_t)(CI_ROWS + 2) * (W + 2) * 8 + 512) * sizeof(float);
+    const size_t ldsf = ((size_t)(CI_ROWS + 2) * (W + 2) * 8 + 512 + (size_t)cout * ((9 * cin) | 1)) * sizeof(float);   // patch | statistics | filter
     if (ldsf <= 64 * 1024 && (!chan_stats || H % CI_ROWS == 0)) {
       const int rblocks = (H + CI_ROWS - 1) / CI_ROWS;
       conv_in_fast_kernel<<<B * rblocks, 256, ldsf, as_stream(stream)>>>(x1, c1, x2, c2, x2_bmod, w, bias, out, H, W, cout, rblocks, chan_stats);
