@@ -45,9 +45,6 @@ class UNetTrainer:
         # cond_stage_trainable, ldm_diffusion.py:224-234); their gradients are filled by the caller; no EMA (LitEma covers `model` only)
         self.extra_params = list(extra_params)
         self.direct_wgrad = os.environ.get("STEDM_WGRAD_GEMM") is None    # STEDM_WGRAD_GEMM=1: im2col + GEMM form everywhere (A/B switch)
-        self._refold = os.environ.get("STEDM_BWD_REFOLD") is not None             # A/B: fold the group statistics again in the backward
-        self._copy_bias = os.environ.get("STEDM_BWD_COPY_BIAS") is not None       # A/B: the twin bias gradients by a device copy
-        self._split_cast = os.environ.get("STEDM_BWD_SPLIT_CAST") is not None   # A/B: separate conversion and statistics passes of a gradient
         self.accumulate_grad_batches = int(accumulate_grad_batches)      # Trainer(accumulate_grad_batches=...) of train_diff.py
         self._micro = 0
         self.lr, self.betas, self.eps, self.wd = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
@@ -282,20 +279,14 @@ class UNetTrainer:
         B, Cc = dy.shape[0], dy.shape[-1]
         cs = self._buf(f"cs.{B}x{Cc}x{dy.numel() // (B * Cc)}", (B, ops.gn_chan_nslab(dy.numel() // (B * Cc)), Cc, 2))
         planes = None
-        if cast is not None and not self._split_cast:
+        if cast is not None:
             planes = self._planes(cast, tuple(dy.shape))
             ops.gn_chan_stats16(dy, cs, planes[0], planes[1], self.bprec)
         else:
-            if cast is not None:
-                planes = self._cast16(dy, kind=cast)
             ops.gn_chan_stats(dy, cs)
         # `also`: a second bias added onto the same tensor receives the same sums (written by the same launch, no copy)
-        if also is not None and self._copy_bias:
-            ops.chan_sum_fold(cs, per_sample, ld, self._param_grad(bias), False)
-            self._param_grad(also).copy_(bias.grad)
-        else:
-            ops.chan_sum_fold(cs, per_sample, ld, None if bias is None else self._param_grad(bias), False,
-                              None if also is None else self._param_grad(also))
+        ops.chan_sum_fold(cs, per_sample, ld, None if bias is None else self._param_grad(bias), False,
+                          None if also is None else self._param_grad(also))
         return planes
 
     def _gn_bwd(self, norm: nn.GroupNorm, act: int, x1, x2, dA, add, dx16=None):
@@ -304,7 +295,7 @@ class UNetTrainer:
         c2 = 0 if x2 is None else x2.shape[-1]
         HW = x1.numel() // (B * c1)
         G = norm.num_groups
-        mr = None if self._refold else getattr(m, "_saved_mr", {}).get((id(norm), x1.data_ptr()))   # left by the forward's normalisation pass
+        mr = getattr(m, "_saved_mr", {}).get((id(norm), x1.data_ptr()))   # left by the forward's normalisation pass
         if mr is None:
             mr = self._buf(f"mr.{B}x{G}", (B, G, 2))
             ops.gn_fold(m._chan_stats(x1), None if x2 is None else m._chan_stats(x2), G, HW, norm.eps, mr)
