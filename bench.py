@@ -266,13 +266,14 @@ def cpu_baseline_train():
 
 
 def csrc_fingerprint():
-    """sha1 over the convolution kernels' sources (conv*.hip / .inc / .hpp + common.hpp: what the roofline's kernel is compiled from): a
-    profile-derived figure (roofline.traffic) is only reported for the kernels it was taken on"""
+    """sha1 over the sources a stedm_conv_igemm launch is compiled from (conv_rs.inc, conv_igemm*.{hip,inc}, conv_dma_*.hip,
+    conv_common.hpp, common.hpp — not conv_io.hip, whose first/last-conv kernels are other entry points): a profile-derived figure
+    (roofline.traffic) is only reported for the kernels it was taken on"""
     import hashlib
     h = hashlib.sha1()
     d = os.path.join(ROOT, "stedm_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".inc", ".hpp")) and (f.startswith("conv") or f == "common.hpp"):
+        if f.endswith((".hip", ".inc", ".hpp")) and ((f.startswith("conv") and f != "conv_io.hip") or f == "common.hpp"):
             h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -612,6 +613,24 @@ def main():
             out["deviation_vs_cpu_oracle"] = dev_rep
             if dev_rep and out["dtype"] in dev_rep:
                 out["headline_rel_l2_vs_oracle"] = round(dev_rep[out["dtype"]]["rel_l2"], 6)
+            if dev_rep:
+                # the throughput of the fastest mode that meets north_star's 1e-3 (fp32-relative) on the measured deviation, first class:
+                # `value` stays the bf16 figure BASELINE's config names, with its own deviation beside it
+                rates = {out["dtype"]: out["value"]}
+                for leg in ("f16_mode", "parity_mode"):
+                    if leg in out:
+                        rates[out[leg]["dtype"]] = out[leg]["value"]
+
+                def fastest(key):
+                    ok = [(rates[m], m) for m in rates if m in dev_rep and dev_rep[m][key] <= 1e-3]
+                    if not ok:
+                        return None
+                    v, m = max(ok)
+                    return {"mode": m, "value": v, "unit": "steps/s", "rel_l2": round(dev_rep[m]["rel_l2"], 8),
+                            "max_over_std": round(dev_rep[m]["max_over_std"], 8)}
+                out["value_at_tolerance"] = {"tolerance": 1e-3, "on_rel_l2": fastest("rel_l2"), "on_max_over_std": fastest("max_over_std"),
+                                             "what": "fastest measured mode whose eps deviates from the fp32 CPU oracle by <= 1e-3 — as rel-L2, and under "
+                                                     "the stricter max|diff|/std reading; same workload, batch and graph as `value`"}
         elif world == 1:
             out["cpu_baseline"] = None
     if world > 1:

@@ -4,19 +4,20 @@
 # MI355X_MICROARCH.md). Outputs under gpurun_out/prof_<tag>_*; tools/pmc_report.py + the copy into profiles/ happen afterwards.
 #   gpurun --timeout 1100 -- 'bash tools/profile_round.sh r02'
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity-leg --no-train-leg --no-e2e-leg"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_step -o run -- $B > $O/prof_${TAG}_step.log 2>&1 && echo step ok &&
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/prof_${TAG}_pmc_mfma -o run -- $B > $O/prof_${TAG}_pmc_mfma.log 2>&1 && echo mfma ok &&
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/prof_${TAG}_pmc_fetch -o run -- $B > $O/prof_${TAG}_pmc_fetch.log 2>&1 && echo fetch ok &&
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/prof_${TAG}_pmc_write -o run -- $B > $O/prof_${TAG}_pmc_write.log 2>&1 && echo write ok &&
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_parity -o run -- $B --precision parity > $O/prof_${TAG}_parity.log 2>&1 && echo parity ok &&
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/prof_${TAG}_pmc_mfma_parity -o run -- $B --precision parity > $O/prof_${TAG}_pmc_mfma_parity.log 2>&1 && echo mfma parity ok &&
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_train -o run -- python3 $R/tools/bench_train.py > $O/prof_${TAG}_train.log 2>&1 && echo train ok &&
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_svit -o run -- python3 $R/tools/bench_svit.py bf16 8 > $O/prof_${TAG}_svit.log 2>&1 && echo svit ok &&
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_swin -o run -- python3 $R/tools/bench_swin.py bf16 128 32 > $O/prof_${TAG}_swin.log 2>&1 && echo swin ok
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_swin -o run -- python3 $R/tools/bench_swin.py bf16 128 32 > $O/prof_${TAG}_swin.log 2>&1 && echo swin ok &&
+# the three PMC passes of the headline binary run LAST: no kernel source changes after them (roofline.traffic is keyed to the conv sources)
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/prof_${TAG}_pmc_mfma -o run -- $B > $O/prof_${TAG}_pmc_mfma.log 2>&1 && echo mfma ok &&
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/prof_${TAG}_pmc_fetch -o run -- $B > $O/prof_${TAG}_pmc_fetch.log 2>&1 && echo fetch ok &&
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/prof_${TAG}_pmc_write -o run -- $B > $O/prof_${TAG}_pmc_write.log 2>&1 && echo write ok
 # the trace CSVs of the PMC passes are large: keep the counter files and the stats only
 find $O -name "*kernel_trace.csv" -size +8M -delete
