@@ -302,6 +302,25 @@ int stedm_qkv_pack_fp8(const float* qkv, float qscale, const float* amax, void* 
                        void* stream);
 int stedm_lsa_flash_fp8(const void* q8, const void* k8, const void* vt8, const float* amax, void* out16, int B, int T, int Tp, int heads,
                         int mm_dtype, void* stream);
+/* Train-mode dropout of the style ViT — the reference runs S_ZSS_DM.get_input, and with it the agg block, inside the training step with the
+ * LightningModule in train mode (networks/s_zss_dm.py:45-60), so nn.Dropout is live at networks/vit_set.py:187 (after pos_embedding,
+ * emb_dropout), :43/:62 (attention probabilities), :49 (after to_out's Linear) and :28-30 (after the FeedForward's GELU and after its second
+ * Linear); conf/style_agg/svit.yaml: 0.1 each. torch's generator stream cannot be reproduced, so the masks are counter-based and specified
+ * here (oracle/dropmask.py restates them): keep iff u16 >= thr16 = lrint(p * 65536), kept values scaled by 1 / (1 - p), p in [0, 1).
+ *   elementwise sites (stedm_dropout_rows): element e of the tensor's linear index takes the 16-bit field (e & 7) — half (j & 1) of output
+ *     word j >> 1 — of Philox4x32-10(counter = (lo32(e >> 3), hi32(e >> 3), site, 0), key = (lo32 seed, hi32 seed)).
+ *     out[e] = drop(src[e]) (+ res[e]); written as fp32 (out) and / or 16-bit operand planes (out_hi, out_lo; type mm_dtype).
+ *     out may alias src or res.
+ *   attention site (stedm_lsa_flash_drop = stedm_lsa_flash with dropout on the normalised probabilities): one xorshift128 stream (Marsaglia
+ *     2003: t = x ^ x << 11; x, y, z = y, z, w; w ^= w >> 19 ^ t ^ t >> 8) per (query q, sample-head bh, key half h), state (x, y, z, w) =
+ *     Philox4x32-10(counter = (q, bh, site, h), key = seed); for every 64-key tile kt = 0, 1, ... the stream yields 16 words, the first the
+ *     most significant bit-plane of 32 16-bit uniforms; uniform i = 16 sub + e belongs to key 64 kt + 32 sub + (e & 3) + 8 (e >> 2) + 4 h.
+ * `site` separates the sites of one forward (stedm_amd/style.py: 8 * layer + kind); `seed` is drawn per forward from torch's generator. */
+int stedm_dropout_rows(const float* src, const float* res, float* out, void* out_hi, void* out_lo, long n, float p,
+                       unsigned long long seed, unsigned site, int mm_dtype, void* stream);
+int stedm_lsa_flash_drop(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi,
+                         const void* vt_lo, void* out_hi, void* out_lo, int B, int T, int Tp, int heads, int npass,
+                         int mm_dtype, float p, unsigned long long seed, unsigned site, void* stream);
 /* pool (0 mean, 1 cls, 2 sum) over tokens (+ c_old) -> mlp_head LayerNorm + Linear, vit_set.py:191-206. wt [dim][ncls].
  * ws (optional, ws_floats >= B * 2 * dim): lets the token pooling run as slab partials over ~1024 blocks before the per-sample head
  * (a batch of 8 alone would read its 34 MB of tokens on 8 of the 256 CUs); fixed summation order either way. */
@@ -329,6 +348,12 @@ int stedm_swin_patch16(const float* img, long sn, long sc, long sh, long sw, int
  * dim..ld16-1 are not written: a caller that pads K to the GEMM kernel's 64-channel chunks zeroes them once). res may alias out. dim <= 768. */
 int stedm_swin_ln(const float* y, const float* gamma, const float* beta, float eps, const float* res, float* out, void* out_hi,
                   void* out_lo, long rows, int dim, int ld16, int mm_dtype, void* stream);
+/* stedm_swin_ln with train-mode stochastic depth (torchvision.ops.StochasticDepth(p, "row") on both residual branches of
+ * SwinTransformerBlockV2; swin_v2_t: p rises linearly to 0.2 over the 12 blocks): out = res + gate[row / rows_per_gate] * LayerNorm(y),
+ * gate [rows / rows_per_gate] = bernoulli(1 - p) / (1 - p) per image, drawn by the caller (stedm_amd/swin.py). The reference runs the
+ * embedder inside the training step in train mode (networks/s_zss_dm.py:45-60, networks/agg_blocks.py:28,49,70). */
+int stedm_swin_ln_gated(const float* y, const float* gamma, const float* beta, float eps, const float* res, float* out, void* out_hi,
+                        void* out_lo, long rows, int dim, int ld16, const float* gate, int rows_per_gate, int mm_dtype, void* stream);
 /* torchvision shifted_window_attention with ShiftedWindowAttentionV2's cosine logits, 8 x 8 windows, head dim 32, on MFMA (npass 1: single
  * product; 3: hi/lo split products, the parity mode): qkv [N*H*W][3C] fp32 in token order (bias included, k bias zeroed) ->
  * softmax(normalize(q) normalize(k)^T * scale[h] + rpb + mask) v as the 16-bit plane(s) [N*H*W][C] `proj` consumes. Cyclic shift, window

@@ -89,8 +89,18 @@ def spt(P: Params, cfg: SViTConfig, x_set: torch.Tensor) -> torch.Tensor:
     return F.linear(x, P[pre + "2.weight"], P[pre + "2.bias"])
 
 
-def lsa(P: Params, pre: str, x: torch.Tensor, heads: int) -> torch.Tensor:
-    """vit_set.py:52-67."""
+def _drop(x: torch.Tensor, p: float, seed: int, site: int) -> torch.Tensor:
+    """Train-mode nn.Dropout(p) with the build's mask stream (oracle/dropmask.py) over the tensor's linear element index."""
+    from . import dropmask
+    keep = torch.from_numpy(dropmask.keep_elementwise(x.numel(), p, seed, site)).reshape(x.shape)
+    return torch.where(keep, x / (1.0 - p), torch.zeros_like(x))
+
+
+SITE_EMB, SITE_ATTN, SITE_OUT, SITE_FF1, SITE_FF2 = 0x10000, 1, 2, 3, 4      # stedm_amd/style.py: site = 8 * layer + kind
+
+
+def lsa(P: Params, pre: str, x: torch.Tensor, heads: int, drop=None) -> torch.Tensor:
+    """vit_set.py:52-67. drop = (p, seed, layer): train mode, dropout on the attention probabilities (:62) and after to_out (:49)."""
     b, n, _ = x.shape
     qkv = F.linear(x, P[pre + "to_qkv.weight"])
     inner = qkv.shape[-1] // 3
@@ -100,28 +110,39 @@ def lsa(P: Params, pre: str, x: torch.Tensor, heads: int) -> torch.Tensor:
     eye = torch.eye(n, dtype=torch.bool)
     dots = dots.masked_fill(eye, -torch.finfo(dots.dtype).max)
     attn = dots.softmax(dim=-1)
+    if drop is not None:
+        from . import dropmask
+        p, seed, layer = drop
+        keep = torch.from_numpy(dropmask.keep_attention(b * heads, n, p, seed, 8 * layer + SITE_ATTN)).reshape(b, heads, n, n)
+        attn = torch.where(keep, attn / (1.0 - p), torch.zeros_like(attn))
     out = torch.matmul(attn, v).permute(0, 2, 1, 3).reshape(b, n, inner)
-    return F.linear(out, P[pre + "to_out.0.weight"], P[pre + "to_out.0.bias"])
+    out = F.linear(out, P[pre + "to_out.0.weight"], P[pre + "to_out.0.bias"])
+    return out if drop is None else _drop(out, drop[0], drop[1], 8 * drop[2] + SITE_OUT)
 
 
-def transformer(P: Params, cfg: SViTConfig, x: torch.Tensor) -> torch.Tensor:
-    """vit_set.py:78-82 (dropout inactive in eval)."""
+def transformer(P: Params, cfg: SViTConfig, x: torch.Tensor, drop=None) -> torch.Tensor:
+    """vit_set.py:78-82. drop = (p, seed): train mode (dropout at :62, :49, :28-30); None: eval."""
     for l in range(cfg.depth):
         a = f"transformer.layers.{l}.0."
         f = f"transformer.layers.{l}.1."
         h = F.layer_norm(x, (cfg.dim,), P[a + "norm.weight"], P[a + "norm.bias"])
-        x = lsa(P, a + "fn.", h, cfg.heads) + x
+        x = lsa(P, a + "fn.", h, cfg.heads, None if drop is None else (drop[0], drop[1], l)) + x
         h = F.layer_norm(x, (cfg.dim,), P[f + "norm.weight"], P[f + "norm.bias"])
         h = F.linear(h, P[f + "fn.net.0.weight"], P[f + "fn.net.0.bias"])
         h = F.gelu(h)
+        if drop is not None:
+            h = _drop(h, drop[0], drop[1], 8 * l + SITE_FF1)
         h = F.linear(h, P[f + "fn.net.3.weight"], P[f + "fn.net.3.bias"])
+        if drop is not None:
+            h = _drop(h, drop[0], drop[1], 8 * l + SITE_FF2)
         x = h + x
     return x
 
 
 @torch.no_grad()
-def svit_forward(P: Params, cfg: SViTConfig, img: torch.Tensor) -> torch.Tensor:
-    """vit_set.py:165-208 with t_emb=None, c_old=None, eval mode. img [B, ns, H, W, 3] (NHWC per image)."""
+def svit_forward(P: Params, cfg: SViTConfig, img: torch.Tensor, train_drop=None) -> torch.Tensor:
+    """vit_set.py:165-208 with t_emb=None, c_old=None. img [B, ns, H, W, 3] (NHWC per image). train_drop = (emb_dropout, dropout, seed):
+    train mode with the build's mask streams (oracle/dropmask.py); None: eval mode."""
     img = img.permute(0, 1, 4, 2, 3)
     patches = spt(P, cfg, img)
     b, n, dim = patches.shape
@@ -129,7 +150,9 @@ def svit_forward(P: Params, cfg: SViTConfig, img: torch.Tensor) -> torch.Tensor:
     t_tok = torch.zeros(b, 1, dim)
     x = torch.cat((cls, t_tok, patches), dim=1)
     x = x + P["pos_embedding"][:, : n + 2]
-    xs = transformer(P, cfg, x)
+    if train_drop is not None and train_drop[0] > 0:
+        x = _drop(x.contiguous(), train_drop[0], train_drop[2], SITE_EMB)
+    xs = transformer(P, cfg, x, None if train_drop is None or train_drop[1] <= 0 else (train_drop[1], train_drop[2]))
     if cfg.pool == "mean":
         x = xs.mean(dim=1)
     elif cfg.pool == "sum":

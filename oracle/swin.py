@@ -97,13 +97,16 @@ def window_attention(x: torch.Tensor, p: Params, pre: str, heads: int, shift: in
     return x[:, :H, :W, :].contiguous()
 
 
-def block(x: torch.Tensor, p: Params, pre: str, heads: int, shift: int) -> torch.Tensor:
-    """SwinTransformerBlockV2.forward (eval: stochastic depth and dropout are identities)."""
+def block(x: torch.Tensor, p: Params, pre: str, heads: int, shift: int, gates=None) -> torch.Tensor:
+    """SwinTransformerBlockV2.forward. gates [2, N] (train mode): torchvision.ops.StochasticDepth(p, "row") on both residual branches, i.e.
+    the branch of image n times gates[j, n] = bernoulli(1 - p) / (1 - p); None (eval): identity. Dropout is 0 in swin_v2_*."""
     C = x.shape[-1]
-    x = x + F.layer_norm(window_attention(x, p, pre + "attn.", heads, shift), (C,), p[pre + "norm1.weight"], p[pre + "norm1.bias"], 1e-5)
+    a = F.layer_norm(window_attention(x, p, pre + "attn.", heads, shift), (C,), p[pre + "norm1.weight"], p[pre + "norm1.bias"], 1e-5)
+    x = x + (a if gates is None else a * gates[0].view(-1, 1, 1, 1))
     h = F.gelu(F.linear(x, p[pre + "mlp.0.weight"], p[pre + "mlp.0.bias"]))
     h = F.linear(h, p[pre + "mlp.3.weight"], p[pre + "mlp.3.bias"])
-    return x + F.layer_norm(h, (C,), p[pre + "norm2.weight"], p[pre + "norm2.bias"], 1e-5)
+    m = F.layer_norm(h, (C,), p[pre + "norm2.weight"], p[pre + "norm2.bias"], 1e-5)
+    return x + (m if gates is None else m * gates[1].view(-1, 1, 1, 1))
 
 
 def patch_merging(x: torch.Tensor, p: Params, pre: str) -> torch.Tensor:
@@ -115,14 +118,15 @@ def patch_merging(x: torch.Tensor, p: Params, pre: str) -> torch.Tensor:
     return F.layer_norm(x, (x.shape[-1],), p[pre + "norm.weight"], p[pre + "norm.bias"], 1e-5)
 
 
-def swin_v2_forward(p: Params, x: torch.Tensor, depths: List[int] = (2, 2, 6, 2), num_heads: List[int] = (3, 6, 12, 24)) -> torch.Tensor:
-    """SwinTransformer.forward: x [N, 3, H, W] -> [N, classes]."""
+def swin_v2_forward(p: Params, x: torch.Tensor, depths: List[int] = (2, 2, 6, 2), num_heads: List[int] = (3, 6, 12, 24), sd_gates=None) -> torch.Tensor:
+    """SwinTransformer.forward: x [N, 3, H, W] -> [N, classes]. sd_gates [blocks, 2, N]: train-mode stochastic-depth gates (see block)."""
     x = F.conv2d(x, p["features.0.0.weight"], p["features.0.0.bias"], stride=4).permute(0, 2, 3, 1)
     x = F.layer_norm(x, (x.shape[-1],), p["features.0.2.weight"], p["features.0.2.bias"], 1e-5)
-    fi = 1
+    fi, bi = 1, 0
     for s, depth in enumerate(depths):
         for i in range(depth):
-            x = block(x, p, f"features.{fi}.{i}.", num_heads[s], 0 if i % 2 == 0 else WS // 2)
+            x = block(x, p, f"features.{fi}.{i}.", num_heads[s], 0 if i % 2 == 0 else WS // 2, None if sd_gates is None else sd_gates[bi])
+            bi += 1
         fi += 1
         if s < len(depths) - 1:
             x = patch_merging(x, p, f"features.{fi}.")

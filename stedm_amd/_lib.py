@@ -83,6 +83,8 @@ SIGNATURES = {
     "stedm_ln_apply16": (_I, [_P, _P, _P, _F, _P, _P, C.c_long, _I, _I, _P]),
     "stedm_qkv_pack": (_I, [_P, _I, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "stedm_lsa_flash": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "stedm_lsa_flash_drop": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, C.c_ulonglong, C.c_uint, _P]),
+    "stedm_dropout_rows": (_I, [_P, _P, _P, _P, _P, C.c_long, _F, C.c_ulonglong, C.c_uint, _I, _P]),
     "stedm_qkv_amax": (_I, [_P, _F, C.c_long, _I, _P, _P]),
     "stedm_qkv_pack_fp8": (_I, [_P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "stedm_lsa_flash_fp8": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -93,6 +95,7 @@ SIGNATURES = {
     "stedm_pack_frag_multi": (_I, [_P, _I, _I, _I, _P]),
     "stedm_swin_patch16": (_I, [_P, C.c_long, C.c_long, C.c_long, C.c_long, _I, _I, _I, _P, _P, _I, _P]),
     "stedm_swin_ln": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, C.c_long, _I, _I, _I, _P]),
+    "stedm_swin_ln_gated": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, C.c_long, _I, _I, _P, _I, _I, _P]),
     "stedm_swin_window_attn": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "stedm_swin_merge16": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P]),
     "stedm_swin_rpb": (_I, [_P, _P, _P, _I, _I, _P]),

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "conv_common.hpp"
+#include "dropmask.hpp"
 using namespace stedm;
 
 #define GLDS16(gptr, lptr)                                                                                  \
@@ -346,9 +347,13 @@ struct FlashArgs {
   const void *qh, *ql, *kh, *kl, *vh, *vl;
   void *oh, *ol;   // [B][T][H*64]
   int T, Tp, H;
+  // train-mode dropout of the attention probabilities (vit_set.py:43, 62; DROP kernels only): keep iff u16 >= thr16, kept scaled by inv_keep
+  unsigned thr16, site;
+  unsigned long long seed;
+  float inv_keep;
 };
 
-template <typename T, int NPASS>
+template <typename T, int NPASS, bool DROP = false>
 __global__ void __launch_bounds__(256, 2) lsa_flash_kernel(FlashArgs a) {
   using V8 = typename MM<T>::V8;
   typedef T V4t __attribute__((ext_vector_type(4)));
@@ -395,6 +400,8 @@ __global__ void __launch_bounds__(256, 2) lsa_flash_kernel(FlashArgs a) {
     for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
   const int qidx = q0 + r;
+  U4 dstate{};
+  if (DROP) dstate = attn_stream_init((unsigned)qidx, (unsigned)bh, a.site, (unsigned)h, a.seed);
 
   const int ntiles = (a.T + 63) / 64;
   // K / V^T tiles travel global -> registers -> LDS with the loads of tile kt + 1 issued BEFORE the MFMAs of tile kt (async-stage
@@ -497,6 +504,14 @@ __global__ void __launch_bounds__(256, 2) lsa_flash_kernel(FlashArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
     }
+    if (DROP) {   // dropout acts on the normalised probabilities (vit_set.py:61-62): l keeps every p, the PV product only the kept ones
+      const unsigned keep = attn_keep_bits(dstate, a.thr16);
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (!((keep >> (sub * 16 + e)) & 1u)) s[sub][e] = 0.f;
+    }
     // ---- O^T += V^T P^T
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
@@ -534,7 +549,7 @@ __global__ void __launch_bounds__(256, 2) lsa_flash_kernel(FlashArgs a) {
 #undef LSA_FETCH
   // ---- epilogue: O^T / l through LDS so that every token row is written contiguously (token-major [B][T][H*64])
   __syncthreads();   // all waves are done with the K / V^T tiles: the block is reused for the transpose
-  const float inv = 1.0f / l_run;
+  const float inv = (DROP ? a.inv_keep : 1.0f) / l_run;
 #pragma unroll
   for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -565,7 +580,7 @@ __global__ void __launch_bounds__(256, 2) lsa_flash_kernel(FlashArgs a) {
 // A DMA instruction writes its 64 x 16 B linearly, so rows are unpadded (128 B) and the 16-B pieces are XOR-swizzled through
 // the SOURCE address: physical piece p of row w holds logical piece p ^ ((w >> 1) & 7) — conflict-free ds_read_b128 K fragments, 2-way
 // on the 8-B V^T reads (as the padded layout had before its stride fix: measured 1 %).
-template <typename T, int NBUF>
+template <typename T, int NBUF, bool DROP = false>
 __global__ void __launch_bounds__(256, NBUF == 2 ? 4 : 3) lsa_flash_dma_kernel(FlashArgs a) {
   using V8 = typename MM<T>::V8;
   typedef T V4t __attribute__((ext_vector_type(4)));
@@ -627,6 +642,8 @@ __global__ void __launch_bounds__(256, NBUF == 2 ? 4 : 3) lsa_flash_dma_kernel(F
   float l_run = 0.f;
   const int qidx = q0 + r;
   const int ntiles = (a.T + 63) / 64;
+  U4 dstate{};
+  if (DROP) dstate = attn_stream_init((unsigned)qidx, (unsigned)bh, a.site, (unsigned)h, a.seed);
   // fragment byte offsets inside a tile buffer: row * 128 + ((piece ^ f(row)) << 4), f(row) = (row >> 1) & 7. The piece index of a fragment
   // is (compile-time even part) ^ (lane's h or 0), so each offset is a per-lane base XOR a compile-time constant
   unsigned kb[2], vb[2];
@@ -726,6 +743,14 @@ __global__ void __launch_bounds__(256, NBUF == 2 ? 4 : 3) lsa_flash_dma_kernel(F
         rs += pv;
       }
     l_run += rs;           // (per lane half: the two halves of a query are added once, after the loop)
+    if (DROP) {   // dropout acts on the normalised probabilities (vit_set.py:61-62): l keeps every p, the PV product only the kept ones
+      const unsigned keep = attn_keep_bits(dstate, a.thr16);
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (!((keep >> (sub * 16 + e)) & 1u)) s[sub][e] = 0.f;
+    }
     // ---- O^T += V^T P^T
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
@@ -751,7 +776,7 @@ __global__ void __launch_bounds__(256, NBUF == 2 ? 4 : 3) lsa_flash_dma_kernel(F
   l_run += __shfl_xor(l_run, 32, 64);
   // ---- epilogue: O^T / l through LDS so that every token row is written contiguously (token-major [B][T][H*64])
   __syncthreads();   // all waves are done with the ring: it is reused for the transpose
-  const float inv = 1.0f / l_run;
+  const float inv = (DROP ? a.inv_keep : 1.0f) / l_run;
 #pragma unroll
   for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -768,31 +793,110 @@ __global__ void __launch_bounds__(256, NBUF == 2 ? 4 : 3) lsa_flash_dma_kernel(F
   }
 }
 
+static int lsa_flash_launch(FlashArgs a, int B, int npass, int mm_dtype, bool drop, hipStream_t st) {
+  dim3 grid(B * a.H, a.Tp / 128);
+  static const bool dma_off = getenv("STEDM_LSA_NODMA") != nullptr;      // A/B: the register-staged form for the single-product modes too
+  if (npass == 1 && !dma_off) {
+    // (a two-tile ring at four waves per SIMD measured 1-5 % slower than three tiles at three waves)
+    const dim3 grid1(B * a.H * (a.Tp / 128));
+    if (mm_dtype == STEDM_F16) {
+      if (drop) lsa_flash_dma_kernel<_Float16, 3, true><<<grid1, 256, 0, st>>>(a);
+      else lsa_flash_dma_kernel<_Float16, 3><<<grid1, 256, 0, st>>>(a);
+    } else {
+      if (drop) lsa_flash_dma_kernel<__bf16, 3, true><<<grid1, 256, 0, st>>>(a);
+      else lsa_flash_dma_kernel<__bf16, 3><<<grid1, 256, 0, st>>>(a);
+    }
+    STEDM_LAUNCH_CHECK();
+    return 0;
+  }
+  if (mm_dtype == STEDM_F16) {
+    if (npass == 3) { if (drop) lsa_flash_kernel<_Float16, 3, true><<<grid, 256, 0, st>>>(a); else lsa_flash_kernel<_Float16, 3><<<grid, 256, 0, st>>>(a); }
+    else { if (drop) lsa_flash_kernel<_Float16, 1, true><<<grid, 256, 0, st>>>(a); else lsa_flash_kernel<_Float16, 1><<<grid, 256, 0, st>>>(a); }
+  } else {
+    if (npass == 3) { if (drop) lsa_flash_kernel<__bf16, 3, true><<<grid, 256, 0, st>>>(a); else lsa_flash_kernel<__bf16, 3><<<grid, 256, 0, st>>>(a); }
+    else { if (drop) lsa_flash_kernel<__bf16, 1, true><<<grid, 256, 0, st>>>(a); else lsa_flash_kernel<__bf16, 1><<<grid, 256, 0, st>>>(a); }
+  }
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int stedm_lsa_flash(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi,
                                const void* vt_lo, void* out_hi, void* out_lo, int B, int T, int Tp, int heads, int npass,
                                int mm_dtype, void* stream) {
   STEDM_CHECK_ARG(q_hi && k_hi && vt_hi && out_hi, "lsa_flash: null pointer");
   STEDM_CHECK_ARG(npass == 1 || (q_lo && k_lo && vt_lo && out_lo), "lsa_flash: npass=3 needs lo planes");
   STEDM_CHECK_ARG(Tp % 128 == 0 && Tp >= T && T > 1, "lsa_flash: need Tp %% 128 == 0, Tp >= T > 1");
-  FlashArgs a{q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out_hi, npass == 3 ? out_lo : nullptr, T, Tp, heads};
-  dim3 grid(B * heads, Tp / 128);
-  hipStream_t st = as_stream(stream);
-  static const bool dma_off = getenv("STEDM_LSA_NODMA") != nullptr;      // A/B: the register-staged form for the single-product modes too
-  if (npass == 1 && !dma_off) {
-    // (a two-tile ring at four waves per SIMD measured 1-5 % slower than three tiles at three waves)
-    const dim3 grid1(B * heads * (Tp / 128));
-    if (mm_dtype == STEDM_F16) lsa_flash_dma_kernel<_Float16, 3><<<grid1, 256, 0, st>>>(a);
-    else lsa_flash_dma_kernel<__bf16, 3><<<grid1, 256, 0, st>>>(a);
-    STEDM_LAUNCH_CHECK();
-    return 0;
+  FlashArgs a{q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out_hi, npass == 3 ? out_lo : nullptr, T, Tp, heads, 0u, 0u, 0ull, 1.0f};
+  return lsa_flash_launch(a, B, npass, mm_dtype, false, as_stream(stream));
+}
+
+extern "C" int stedm_lsa_flash_drop(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi,
+                                    const void* vt_lo, void* out_hi, void* out_lo, int B, int T, int Tp, int heads, int npass,
+                                    int mm_dtype, float p, unsigned long long seed, unsigned site, void* stream) {
+  STEDM_CHECK_ARG(q_hi && k_hi && vt_hi && out_hi, "lsa_flash_drop: null pointer");
+  STEDM_CHECK_ARG(npass == 1 || (q_lo && k_lo && vt_lo && out_lo), "lsa_flash_drop: npass=3 needs lo planes");
+  STEDM_CHECK_ARG(Tp % 128 == 0 && Tp >= T && T > 1, "lsa_flash_drop: need Tp %% 128 == 0, Tp >= T > 1");
+  STEDM_CHECK_ARG(p >= 0.f && p < 1.f, "lsa_flash_drop: p must be in [0, 1)");
+  const unsigned thr = (unsigned)lrint((double)p * 65536.0);
+  STEDM_CHECK_ARG(thr <= 65535u, "lsa_flash_drop: p too close to 1");
+  FlashArgs a{q_hi, q_lo, k_hi, k_lo, vt_hi, vt_lo, out_hi, npass == 3 ? out_lo : nullptr, T, Tp, heads, thr, site, seed, 1.0f / (1.0f - p)};
+  return lsa_flash_launch(a, B, npass, mm_dtype, true, as_stream(stream));
+}
+
+// ------------------------------------------------------------------------------------------------ train-mode dropout (elementwise sites)
+// out = drop(src) (+ res), as fp32 and / or as 16-bit operand planes: the sites after pos_embedding (vit_set.py:187), after to_out's
+// Linear (:49), after the FeedForward's GELU and its second Linear (:28-30). A thread owns 8 consecutive elements = one Philox call.
+template <typename T>
+__global__ void __launch_bounds__(256) dropout_rows_kernel(const float* src, const float* res, float* out,   // (out may alias src or res: in-place sites)
+                                                           T* __restrict__ hi, T* __restrict__ lo, long n, unsigned thr16, float inv_keep,
+                                                           unsigned long long seed, unsigned site) {
+  const long ngroups = (n + 7) >> 3;
+  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (long)gridDim.x * 256) {
+    const U4 r = drop_group((uint64_t)g, site, seed);
+    const long e0 = g << 3;
+    float v[8];
+    if (e0 + 8 <= n) {
+      const float4 a0 = reinterpret_cast<const float4*>(src + e0)[0], a1 = reinterpret_cast<const float4*>(src + e0)[1];
+      v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = e0 + j < n ? src[e0 + j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = drop_u16(r, j) >= thr16 ? __fmul_rn(v[j], inv_keep) : 0.f;   // (rounded product: no fma with the residual)
+    if (res) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (e0 + j < n) v[j] += res[e0 + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (e0 + j >= n) break;
+      if (out) out[e0 + j] = v[j];
+      if (hi) {
+        const T hv = (T)v[j];
+        hi[e0 + j] = hv;
+        if (lo) lo[e0 + j] = (T)(v[j] - (float)hv);
+      }
+    }
   }
-  if (mm_dtype == STEDM_F16) {
-    if (npass == 3) lsa_flash_kernel<_Float16, 3><<<grid, 256, 0, st>>>(a);
-    else lsa_flash_kernel<_Float16, 1><<<grid, 256, 0, st>>>(a);
-  } else {
-    if (npass == 3) lsa_flash_kernel<__bf16, 3><<<grid, 256, 0, st>>>(a);
-    else lsa_flash_kernel<__bf16, 1><<<grid, 256, 0, st>>>(a);
-  }
+}
+
+extern "C" int stedm_dropout_rows(const float* src, const float* res, float* out, void* out_hi, void* out_lo, long n, float p,
+                                  unsigned long long seed, unsigned site, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(src && (out || out_hi) && n > 0, "dropout_rows: bad args");
+  STEDM_CHECK_ARG(!out_lo || out_hi, "dropout_rows: a lo plane needs its hi plane");
+  STEDM_CHECK_ARG(p >= 0.f && p < 1.f, "dropout_rows: p must be in [0, 1)");
+  STEDM_CHECK_ARG(((uintptr_t)src & 15) == 0, "dropout_rows: src must be 16-byte aligned");
+  const unsigned thr = (unsigned)lrint((double)p * 65536.0);
+  STEDM_CHECK_ARG(thr <= 65535u, "dropout_rows: p too close to 1");
+  const long ngroups = (n + 7) >> 3;
+  const int grid = (int)((ngroups + 255) / 256 < 32768 ? (ngroups + 255) / 256 : 32768);
+  const float inv_keep = 1.0f / (1.0f - p);
+  if (mm_dtype == STEDM_F16)
+    dropout_rows_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(src, res, out, (_Float16*)out_hi, (_Float16*)out_lo, n, thr, inv_keep, seed, site);
+  else
+    dropout_rows_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(src, res, out, (__bf16*)out_hi, (__bf16*)out_lo, n, thr, inv_keep, seed, site);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

@@ -54,7 +54,7 @@ __device__ __forceinline__ float rounded(float v) {
 template <typename T, int LPR>
 __global__ void __launch_bounds__(256) swin_ln_kernel(const float* __restrict__ y, const float* __restrict__ g, const float* __restrict__ bt,
                                                       float eps, const float* __restrict__ res, float* __restrict__ out, T* __restrict__ hi,
-                                                      T* __restrict__ lo, long rows, int dim, int ld16) {
+                                                      T* __restrict__ lo, long rows, int dim, int ld16, const float* __restrict__ gate, int rows_per_gate) {
   constexpr int RPB = 256 / LPR, NVMAX = 12;
   const long row = (long)blockIdx.x * RPB + threadIdx.x / LPR;
   if (row >= rows) return;
@@ -80,11 +80,14 @@ __global__ void __launch_bounds__(256) swin_ln_kernel(const float* __restrict__ 
 #pragma unroll
   for (int o = LPR / 2; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
   const float rstd = 1.0f / sqrtf(s2 / dim + eps);
+  // train-mode stochastic depth (torchvision StochasticDepth, mode "row"): the residual branch of image row / rows_per_gate is scaled by its gate
+  const float gt = gate ? gate[row / rows_per_gate] : 1.0f;
 #pragma unroll
   for (int j = 0; j < NVMAX; ++j) {
     const int k = l + j * LPR;
     if (k < dim) {
       float w = (v[j] - mean) * rstd * g[k] + bt[k];
+      if (gate) w *= gt;
       if (res) w += res[row * dim + k];
       w = rounded(w);
       if (out) out[row * dim + k] = w;
@@ -400,8 +403,8 @@ extern "C" int stedm_swin_patch16(const float* img, long sn, long sc, long sh, l
   return 0;
 }
 
-extern "C" int stedm_swin_ln(const float* y, const float* gamma, const float* beta, float eps, const float* res, float* out, void* out_hi,
-                             void* out_lo, long rows, int dim, int ld16, int mm_dtype, void* stream) {
+static int swin_ln_launch(const float* y, const float* gamma, const float* beta, float eps, const float* res, float* out, void* out_hi,
+                          void* out_lo, long rows, int dim, int ld16, const float* gate, int rows_per_gate, int mm_dtype, void* stream) {
   STEDM_CHECK_ARG(y && gamma && beta && (out || out_hi) && rows > 0 && dim > 0, "swin_ln: bad args");
   STEDM_CHECK_ARG(!out_lo || out_hi, "swin_ln: out_lo without out_hi");
   STEDM_CHECK_ARG(dim <= 768, "swin_ln: rows of up to 768 channels (dim=%d)", dim);
@@ -409,13 +412,24 @@ extern "C" int stedm_swin_ln(const float* y, const float* gamma, const float* be
   hipStream_t st = as_stream(stream);
 #define LAUNCH_SWIN_LN(TT)                                                                                                                        \
   {                                                                                                                                               \
-    if (dim <= 192) swin_ln_kernel<TT, 32><<<(unsigned)((rows + 7) / 8), 256, 0, st>>>(y, gamma, beta, eps, res, out, (TT*)out_hi, (TT*)out_lo, rows, dim, ld16); \
-    else swin_ln_kernel<TT, 64><<<(unsigned)((rows + 3) / 4), 256, 0, st>>>(y, gamma, beta, eps, res, out, (TT*)out_hi, (TT*)out_lo, rows, dim, ld16);          \
+    if (dim <= 192) swin_ln_kernel<TT, 32><<<(unsigned)((rows + 7) / 8), 256, 0, st>>>(y, gamma, beta, eps, res, out, (TT*)out_hi, (TT*)out_lo, rows, dim, ld16, gate, rows_per_gate); \
+    else swin_ln_kernel<TT, 64><<<(unsigned)((rows + 3) / 4), 256, 0, st>>>(y, gamma, beta, eps, res, out, (TT*)out_hi, (TT*)out_lo, rows, dim, ld16, gate, rows_per_gate);          \
   }
   if (mm_dtype == STEDM_F16) LAUNCH_SWIN_LN(_Float16) else LAUNCH_SWIN_LN(__bf16)
 #undef LAUNCH_SWIN_LN
   STEDM_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int stedm_swin_ln(const float* y, const float* gamma, const float* beta, float eps, const float* res, float* out, void* out_hi,
+                             void* out_lo, long rows, int dim, int ld16, int mm_dtype, void* stream) {
+  return swin_ln_launch(y, gamma, beta, eps, res, out, out_hi, out_lo, rows, dim, ld16, nullptr, 1, mm_dtype, stream);
+}
+
+extern "C" int stedm_swin_ln_gated(const float* y, const float* gamma, const float* beta, float eps, const float* res, float* out, void* out_hi,
+                                   void* out_lo, long rows, int dim, int ld16, const float* gate, int rows_per_gate, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(gate && rows_per_gate > 0 && rows % rows_per_gate == 0, "swin_ln_gated: rows must be a multiple of rows_per_gate");
+  return swin_ln_launch(y, gamma, beta, eps, res, out, out_hi, out_lo, rows, dim, ld16, gate, rows_per_gate, mm_dtype, stream);
 }
 
 extern "C" int stedm_swin_window_attn(const float* qkv, const void* qkv16, const float* bias_kzero, const float* scale, const float* rpb, void* out_hi, void* out_lo,

@@ -70,7 +70,7 @@ class LDM_Diffusion(_Base):
         ldm_dict.pop("ckpt_path", None)
         self._model = S_ZSS_DM(encoder="swin_v2_t", sampling_cfg=cfg.style_sampling, agg_cfg=cfg.style_agg, cfg=cfg, **ldm_dict)
         self.register_module("model", self._model)          # state-dict aliasing of ldm_diffusion.py:38-41: `_model.*` and `model.*`
-        self._loss_sum, self._loss_n = 0.0, 0
+        self._loss_sum, self._loss_n = None, 0          # device-side accumulator (the reference's MeanMetric, ldm_diffusion.py:44)
         self.predict_dir: Optional[str] = None
 
     def forward(self, x, *args, **kwargs):
@@ -96,21 +96,28 @@ class LDM_Diffusion(_Base):
             self.configure_optimizers()
         x, c = m.get_input(ldm_batch, m.first_stage_key)[:2]
         loss = m.training_step_hip(x, c)
-        self._loss_sum += float(loss)                # MeanMetric of ldm_diffusion.py:44,71
+        # MeanMetric of ldm_diffusion.py:44,71: accumulated on the device — no host sync per micro-batch; train_loss() converts once
+        ld = loss.detach().float().reshape(())
+        self._loss_sum = ld.clone() if self._loss_sum is None else self._loss_sum + ld
         self._loss_n += 1
         return loss
 
     def on_train_batch_start(self, batch, batch_idx):
-        self._model.on_train_batch_start(self.prepare_batch(batch), batch_idx, -1)
+        """ldm_diffusion.py:110-112 -> ddpm.py:479-494, which returns at once unless scale_by_std is set and this is batch 0: the batch is
+        only prepared (a seg_merge kernel plus copies) when that rescale will actually run."""
+        m = self._model
+        if not (getattr(m, "scale_by_std", False) and batch_idx == 0):
+            return
+        m.on_train_batch_start(self.prepare_batch(batch), batch_idx, -1)
 
     def on_train_batch_end(self, *args, **kwargs):
         self._model.on_train_batch_end(*args, **kwargs)
 
     def train_loss(self, reset: bool = True) -> float:
         """what on_train_epoch_end logs as "Train Loss" (ldm_diffusion.py:118-120)"""
-        v = self._loss_sum / max(1, self._loss_n)
+        v = 0.0 if self._loss_sum is None else float(self._loss_sum) / max(1, self._loss_n)
         if reset:
-            self._loss_sum, self._loss_n = 0.0, 0
+            self._loss_sum, self._loss_n = None, 0
         return v
 
     # ------------------------------------------------------------------------------------------ prediction

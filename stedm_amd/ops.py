@@ -528,6 +528,21 @@ def lsa_flash(q, k, vt, out, B: int, T: int, Tp: int, heads: int, prec: Precisio
                                 out[0].data_ptr(), _ptr(out[1]), B, T, Tp, heads, prec.npass, prec.mm_dtype, _stream()), "stedm_lsa_flash")
 
 
+def lsa_flash_drop(q, k, vt, out, B: int, T: int, Tp: int, heads: int, prec: Precision, p: float, seed: int, site: int):
+    """lsa_flash with train-mode dropout on the attention probabilities (vit_set.py:43, 62); mask stream: include/stedm_hip.h."""
+    check(lib().stedm_lsa_flash_drop(q[0].data_ptr(), _ptr(q[1]), k[0].data_ptr(), _ptr(k[1]), vt[0].data_ptr(), _ptr(vt[1]),
+                                     out[0].data_ptr(), _ptr(out[1]), B, T, Tp, heads, prec.npass, prec.mm_dtype, float(p), int(seed), int(site),
+                                     _stream()), "stedm_lsa_flash_drop")
+
+
+def dropout_rows(src: torch.Tensor, p: float, seed: int, site: int, prec: Precision, res: Optional[torch.Tensor] = None,
+                 out: Optional[torch.Tensor] = None, hi: Optional[torch.Tensor] = None, lo: Optional[torch.Tensor] = None) -> None:
+    """out = dropout(src) (+ res) as fp32 and / or 16-bit operand planes (train-mode nn.Dropout of the elementwise sViT sites)."""
+    _chk(src, name="src")
+    check(lib().stedm_dropout_rows(src.data_ptr(), _ptr(res), _ptr(out), _ptr(hi), _ptr(lo), src.numel(), float(p), int(seed), int(site),
+                                   prec.mm_dtype, _stream()), "stedm_dropout_rows")
+
+
 def qkv_amax(qkv: torch.Tensor, qscale: float, heads: int, amax: torch.Tensor) -> torch.Tensor:
     """amax[3] = per-tensor maxima of |q * qscale|, |k|, |v| (device floats) for the fp8 attention."""
     _chk(qkv, name="qkv")
@@ -576,10 +591,18 @@ def swin_patch16(img: torch.Tensor, hi: torch.Tensor, lo: Optional[torch.Tensor]
 
 
 def swin_ln(y: torch.Tensor, gamma, beta, eps: float, res: Optional[torch.Tensor], out: Optional[torch.Tensor], hi: Optional[torch.Tensor],
-            lo: Optional[torch.Tensor], prec: Precision) -> None:
-    """out = res + LayerNorm(y) as fp32 rows and / or 16-bit operand planes (row stride hi.shape[-1] >= dim; pad columns are left alone)."""
+            lo: Optional[torch.Tensor], prec: Precision, gate: Optional[torch.Tensor] = None, rows_per_gate: int = 1) -> None:
+    """out = res + LayerNorm(y) as fp32 rows and / or 16-bit operand planes (row stride hi.shape[-1] >= dim; pad columns are left alone).
+    gate [rows / rows_per_gate] fp32: train-mode stochastic depth, out = res + gate[row // rows_per_gate] * LayerNorm(y)."""
     _chk(y, name="y")
     dim = y.shape[-1]
+    if gate is not None:
+        _chk(gate, name="gate")
+        assert gate.numel() * rows_per_gate == y.numel() // dim
+        check(lib().stedm_swin_ln_gated(y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), _ptr(res), _ptr(out), _ptr(hi), _ptr(lo),
+                                        y.numel() // dim, dim, dim if hi is None else hi.shape[-1], gate.data_ptr(), rows_per_gate, prec.mm_dtype,
+                                        _stream()), "stedm_swin_ln_gated")
+        return
     check(lib().stedm_swin_ln(y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), _ptr(res), _ptr(out), _ptr(hi), _ptr(lo),
                               y.numel() // dim, dim, dim if hi is None else hi.shape[-1], prec.mm_dtype, _stream()), "stedm_swin_ln")
 

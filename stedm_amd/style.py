@@ -101,6 +101,13 @@ class sViT(nn.Module):
         self._packed: Dict = {}
         self._pack_key = None
         self._bufs: Dict[Tuple, torch.Tensor] = {}
+        # train-mode dropout: a forward draws its seed from torch's generator (so torch.manual_seed governs it) unless `dropout_seed` is set;
+        # `last_dropout_seed` is what the last forward used (tests rebuild the masks from it)
+        self.dropout_seed: Optional[int] = None
+        self.last_dropout_seed = 0
+
+    # mask stream ids of the dropout sites (include/stedm_hip.h, "train-mode dropout"): site = 8 * layer + kind, the embedding site alone
+    SITE_EMB, SITE_ATTN, SITE_OUT, SITE_FF1, SITE_FF2 = 0x10000, 1, 2, 3, 4
 
     # ---------------------------------------------------------------------------------------------- engine
     def set_precision(self, precision):
@@ -157,8 +164,16 @@ class sViT(nn.Module):
         """vit_set.py:165-208. img [B, ns, H, W, 3] fp32 (NHWC per image, as LDM_Diffusion.prepare_batch emits it)."""
         if t_emb is not None:
             raise NotImplementedError("t_emb is always None in STEDM (networks/s_zss_dm.py:55)")
-        if self.training and (self.dropout.p > 0):
-            raise NotImplementedError("HIP sViT runs in eval mode (dropout is inactive at prediction time)")
+        # train mode (the reference runs the agg block inside the training step: networks/s_zss_dm.py:45-60): nn.Dropout is live after the
+        # pos_embedding (vit_set.py:187), on the attention probabilities (:62), after to_out (:49) and twice in the FeedForward (:28-30)
+        p_emb = float(self.dropout.p) if self.training else 0.0
+        p_drop = float(self.transformer.layers[0][0].fn.to_out[1].p) if self.training and self.depth else 0.0
+        seed = 0
+        if p_emb > 0 or p_drop > 0:
+            if self.precision.attn_fp8:
+                raise NotImplementedError("train-mode dropout is not built for the fp8 attention experiment (prediction-only mode)")
+            seed = self.dropout_seed if self.dropout_seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
+        self.last_dropout_seed = seed
         self._prepare()
         P, prec = self._packed, self.precision
         img = img.float().contiguous()
@@ -181,6 +196,8 @@ class sViT(nn.Module):
         tok = self._buf("pe.tok", (B * n, dim))
         self._gemm(pe16, P["pe"], B * n, dim, bias=tp[2].bias, out=tok)
         ops.svit_tok_place(tok, self.pos_embedding, self.cls_token, x)
+        if p_emb > 0:
+            ops.dropout_rows(x, p_emb, seed, self.SITE_EMB, prec, out=x)
         ln = (self._buf("ln.hi", (M, dim), i16), self._buf("ln.lo", (M, dim), i16) if lo_ok else None)
         # single-product modes without the fp8 attention: to_qkv writes its 16-bit output only (the attention's operands are 16-bit anyway)
         q16 = prec.npass == 1 and not prec.attn_fp8
@@ -201,12 +218,27 @@ class sViT(nn.Module):
                 ops.qkv_amax(qkv, P[f"tau{l}"], heads, amax)
                 ops.qkv_pack_fp8(qkv, P[f"tau{l}"], amax, q8, k8, v8, B, T, Tp, heads)
                 ops.lsa_flash_fp8(q8, k8, v8, amax, att[0], B, T, Tp, heads, prec)
+            elif p_drop > 0:
+                ops.qkv_pack(qkv, P[f"tau{l}"], q, k, vt, B, T, Tp, heads, prec)
+                ops.lsa_flash_drop(q, k, vt, att, B, T, Tp, heads, prec, p_drop, seed, 8 * l + self.SITE_ATTN)
             else:
                 ops.qkv_pack(qkv, P[f"tau{l}"], q, k, vt, B, T, Tp, heads, prec)
                 ops.lsa_flash(q, k, vt, att, B, T, Tp, heads, prec)
+            h16 = (self._buf("h.hi", (M, mlp), i16), self._buf("h.lo", (M, mlp), i16) if lo_ok else None)
+            if p_drop > 0:
+                # the Linear's output goes to a scratch tensor, the dropout kernel masks it and adds the residual / writes the operand planes
+                y = self._buf("drop.y", (M, max(dim, mlp)))
+                yd, ym = y.view(-1)[:M * dim].view(M, dim), y.view(-1)[:M * mlp].view(M, mlp)
+                self._gemm(att, P[f"out{l}"], M, dim, bias=attn.fn.to_out[0].bias, out=yd)
+                ops.dropout_rows(yd, p_drop, seed, 8 * l + self.SITE_OUT, prec, res=x, out=x)                  # x = drop(attn(x)) + x
+                ops.ln_apply16(x, ff.norm.weight, ff.norm.bias, ff.norm.eps, ln[0], ln[1], prec)
+                self._gemm(ln, P[f"ff1{l}"], M, mlp, bias=ff.fn.net[0].bias, act_out=2, out=ym)                # GELU(Linear)
+                ops.dropout_rows(ym, p_drop, seed, 8 * l + self.SITE_FF1, prec, hi=h16[0], lo=h16[1])
+                self._gemm(h16, P[f"ff2{l}"], M, dim, bias=ff.fn.net[3].bias, out=yd)
+                ops.dropout_rows(yd, p_drop, seed, 8 * l + self.SITE_FF2, prec, res=x, out=x)                  # x = drop(ff(x)) + x
+                continue
             self._gemm(att, P[f"out{l}"], M, dim, bias=attn.fn.to_out[0].bias, res=x, out=x)          # x = attn(x) + x
             ops.ln_apply16(x, ff.norm.weight, ff.norm.bias, ff.norm.eps, ln[0], ln[1], prec)
-            h16 = (self._buf("h.hi", (M, mlp), i16), self._buf("h.lo", (M, mlp), i16) if lo_ok else None)
             self._gemm(ln, P[f"ff1{l}"], M, mlp, bias=ff.fn.net[0].bias, act_out=2, out16=h16)       # GELU(Linear)
             self._gemm(h16, P[f"ff2{l}"], M, dim, bias=ff.fn.net[3].bias, res=x, out=x)              # x = ff(x) + x
         out = torch.empty((B, self.mlp_head[1].out_features), dtype=torch.float32, device=img.device)

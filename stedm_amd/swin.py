@@ -61,7 +61,8 @@ class ShiftedWindowAttentionV2(nn.Module):
 
 
 class SwinTransformerBlockV2(nn.Module):
-    """x = x + norm1(attn(x)); x = x + norm2(mlp(x)) (post-norm; stochastic depth is the identity in eval mode)."""
+    """x = x + sd(norm1(attn(x))); x = x + sd(norm2(mlp(x))) (post-norm; sd = stochastic depth: per-image gates in train mode — drawn by
+    SwinTransformerV2.forward — and the identity in eval mode)."""
 
     def __init__(self, dim: int, num_heads: int, window_size: List[int], shift_size: List[int], mlp_ratio: float = 4.0):
         super().__init__()
@@ -85,7 +86,8 @@ class SwinTransformerV2(nn.Module):
     """torchvision.models.swin_transformer.SwinTransformer with the V2 block / merging layers. forward(x [N, 3, H, W]) -> [N, classes]."""
 
     def __init__(self, embed_dim: int = 96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), window_size=(WINDOW, WINDOW),
-                 mlp_ratio: float = 4.0, num_classes: int = 1000, precision: str = "parity", chunk_images: int = 32):
+                 mlp_ratio: float = 4.0, num_classes: int = 1000, precision: str = "parity", chunk_images: int = 32,
+                 stochastic_depth_prob: float = 0.0):
         super().__init__()
         if tuple(window_size) != (WINDOW, WINDOW) or any(embed_dim * 2 ** i != HEAD_DIM * h for i, h in enumerate(num_heads)):
             raise NotImplementedError("HIP Swin-V2: 8 x 8 windows and head dim 32 (swin_v2_t / swin_v2_s / swin_v2_b)")
@@ -113,6 +115,12 @@ class SwinTransformerV2(nn.Module):
                     nn.init.zeros_(m.bias)
         self.precision = Precision.parse(precision) if isinstance(precision, str) else precision
         self.chunk_images = chunk_images
+        # train-mode stochastic depth (torchvision: StochasticDepth(p_i, "row") on both residual branches of block i, p_i rising linearly to
+        # stochastic_depth_prob over all blocks). `sd_gates` ([blocks, 2, N] fp32, = bernoulli(1 - p_i) / (1 - p_i)) overrides the draw (tests).
+        nb = sum(depths)
+        self.sd_probs = [stochastic_depth_prob * i / max(nb - 1.0, 1.0) for i in range(nb)]
+        self.sd_gates: Optional[torch.Tensor] = None
+        self._gates: Optional[torch.Tensor] = None
         self._packed: Dict = {}
         self._pack_key = None
         self._bufs: Dict[Tuple, torch.Tensor] = {}
@@ -211,8 +219,6 @@ class SwinTransformerV2(nn.Module):
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if self.training:
-            raise NotImplementedError("HIP Swin-V2 runs in eval mode (the reference does not train the embedder: modules/ldm_diffusion.py:224-234)")
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError(f"expected images [N, 3, H, W], got {tuple(x.shape)}")
         if x.dtype != torch.float32:
@@ -220,11 +226,22 @@ class SwinTransformerV2(nn.Module):
         self._prepare()
         N = x.shape[0]
         out = torch.empty((N, self.head.out_features), dtype=torch.float32, device=x.device)
+        # train mode (the reference runs the embedder inside the training step in train mode, never optimising it: networks/s_zss_dm.py:45-60,
+        # modules/ldm_diffusion.py:224-234): per-image gates of the residual branches; eval / p = 0: no gates, the eval arithmetic bit for bit
+        self._gates = None
+        if self.training and any(p > 0 for p in self.sd_probs):
+            if self.sd_gates is not None:
+                g = self.sd_gates.to(device=x.device, dtype=torch.float32)
+                assert tuple(g.shape) == (len(self.sd_probs), 2, N), f"sd_gates must be [blocks, 2, N] = {(len(self.sd_probs), 2, N)}"
+            else:
+                surv = 1.0 - torch.tensor(self.sd_probs, dtype=torch.float32, device=x.device).view(-1, 1, 1)
+                g = (torch.rand((len(self.sd_probs), 2, N), device=x.device) < surv).float() / surv
+            self._gates = g.contiguous()
         for n0 in range(0, N, self.chunk_images):
-            self._forward_chunk(x[n0:n0 + self.chunk_images], out[n0:n0 + self.chunk_images])
+            self._forward_chunk(x[n0:n0 + self.chunk_images], out[n0:n0 + self.chunk_images], n0)
         return out
 
-    def _forward_chunk(self, x: torch.Tensor, out: torch.Tensor) -> None:
+    def _forward_chunk(self, x: torch.Tensor, out: torch.Tensor, n0: int = 0) -> None:
         P, prec = self._packed, self.precision
         N, _, Himg, Wimg = x.shape
         H, W = Himg // 4, Wimg // 4
@@ -238,6 +255,7 @@ class SwinTransformerV2(nn.Module):
         xc = self._buf("x0", (M, dim))
         x16 = self._planes("x16.0", (M, dim))
         ops.swin_ln(y, ln0.weight, ln0.bias, ln0.eps, None, xc, x16[0], x16[1], prec)
+        bi = 0          # block index over all stages (stochastic-depth gate row)
         for s, (blocks, merge) in enumerate(self._stages()):
             heads = self.heads[s]
             # single-product modes: the attention's operands are rounded to 16 bits anyway, so the qkv GEMM writes its 16-bit output only
@@ -255,12 +273,16 @@ class SwinTransformerV2(nn.Module):
                     self._gemm(x16, P["qkv" + nm], M, bias=P["qkvb" + nm], out=qkv)
                 ops.swin_window_attn(qkv, P["qkvb" + nm], P["scale" + nm], P["rpb" + nm], att[0], att[1], N, H, W, heads, at.shift_size[0], prec)
                 self._gemm(att, P["proj" + nm], M, bias=at.proj.bias, out=y)
-                ops.swin_ln(y, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, xc, xc, x16[0], x16[1], prec)     # x = x + norm1(attn(x))
+                g1 = g2 = None
+                if self._gates is not None and self.sd_probs[bi] > 0:
+                    g1, g2 = (self._gates[bi, j, n0:n0 + N].contiguous() for j in (0, 1))
+                bi += 1
+                ops.swin_ln(y, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, xc, xc, x16[0], x16[1], prec, gate=g1, rows_per_gate=H * W)     # x = x + sd(norm1(attn(x)))
                 hid = blk.mlp[0].out_features
                 h16 = self._planes(f"h{s}", (M, hid))
                 self._gemm(x16, P["fc1" + nm], M, bias=blk.mlp[0].bias, act_out=2, out16=h16)                      # GELU(Linear)
                 self._gemm(h16, P["fc2" + nm], M, bias=blk.mlp[3].bias, out=y)
-                ops.swin_ln(y, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, xc, xc, x16[0], x16[1], prec)     # x = x + norm2(mlp(x))
+                ops.swin_ln(y, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, xc, xc, x16[0], x16[1], prec, gate=g2, rows_per_gate=H * W)     # x = x + sd(norm2(mlp(x)))
             if merge is not None:
                 Ho, Wo = (H + 1) // 2, (W + 1) // 2
                 Mo = N * Ho * Wo
@@ -280,9 +302,9 @@ class SwinTransformerV2(nn.Module):
 
 
 _CONFIGS = {
-    "swin_v2_t": dict(embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24)),
-    "swin_v2_s": dict(embed_dim=96, depths=(2, 2, 18, 2), num_heads=(3, 6, 12, 24)),
-    "swin_v2_b": dict(embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32)),
+    "swin_v2_t": dict(embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), stochastic_depth_prob=0.2),
+    "swin_v2_s": dict(embed_dim=96, depths=(2, 2, 18, 2), num_heads=(3, 6, 12, 24), stochastic_depth_prob=0.3),
+    "swin_v2_b": dict(embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32), stochastic_depth_prob=0.5),
 }
 
 

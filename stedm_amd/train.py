@@ -60,6 +60,7 @@ class UNetTrainer:
         self._touched: Optional[list] = None
         self.bucket_mb = 256            # gradient all-reduce bucket (xGMI rings are per-link bound: few, large collectives)
         self.overlap_all_reduce = os.environ.get("STEDM_NO_OVERLAP") is None
+        self.overlap_fires = 0           # all-reduces started from inside a backward so far
         self.direct_wgrad1 = os.environ.get("STEDM_WGRAD1X1_GEMM") is None      # A/B: the 1x1 convolutions' weight gradients in the GEMM form
         self.G: Dict[int, torch.Tensor] = {}
 
@@ -774,7 +775,9 @@ class UNetTrainer:
         last = self._micro + 1 >= k
         works = []
         on_bucket = None
-        if multi and last and self.overlap_all_reduce and getattr(self, "grad_arena", None) is not None:
+        if getattr(self, "grad_arena", None) is None:
+            self._alloc_grads()              # before deciding: the FIRST step overlaps its all-reduce like every later one
+        if multi and last and self.overlap_all_reduce:
             # the collective of a bucket starts the moment the backward has produced its last gradient (the all-reduce then runs beside
             # the remaining dgrad / wgrad kernels); with accumulation the bucket is first folded into the running mean
             def on_bucket(b):
@@ -786,7 +789,8 @@ class UNetTrainer:
                     ops.axpby(self.grad_arena[lo:hi], self._acc_arena[lo:hi], 1.0 / k, 1.0 if self._micro > 0 else 0.0)
                     src = self._acc_arena
                 works.append(dist.all_reduce(src[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True))
-        if k > 1 and getattr(self, "_acc_arena", None) is None and getattr(self, "grad_arena", None) is not None:
+                self.overlap_fires += 1          # collectives issued from inside the backward (tests assert the overlap path really ran)
+        if k > 1 and getattr(self, "_acc_arena", None) is None:
             self._acc_arena = torch.empty_like(self.grad_arena)
         loss, dx, dctx = self.loss_and_backward(x, c_concat, t, context, target, on_bucket=on_bucket)
         if after_backward is not None:

@@ -248,7 +248,13 @@ class VQModelInterface(nn.Module):
 
     def init_from_ckpt(self, path, ignore_keys=()):
         """autoencoder.py:78-90."""
-        sd = torch.load(path, map_location="cpu")["state_dict"]
+        # a third-party checkpoint (vq-f4.ckpt): tensors only, never a full unpickle — if the safe loader refuses the file, say so and stop
+        try:
+            ck = torch.load(path, map_location="cpu", weights_only=True)
+        except Exception as e:
+            raise RuntimeError(f"{path}: torch.load(weights_only=True) refused this checkpoint ({type(e).__name__}: {e}); it is not loaded "
+                               f"with a full unpickle — re-save its state_dict as plain tensors (e.g. safetensors)") from e
+        sd = ck["state_dict"] if isinstance(ck, dict) and "state_dict" in ck else ck
         for k in list(sd.keys()):
             if any(k.startswith(ik) for ik in ignore_keys):
                 del sd[k]

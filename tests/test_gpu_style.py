@@ -189,3 +189,136 @@ def test_svit_fp8_attention_mode_reported(dev, golden):
         assert bool(torch.isfinite(y).all())
     print(f"[sViT ns=8, 64^2] rel-L2 vs reference golden: bf16 {res['bf16']:.3e}, bf16 + fp8 attention {res['fp8']:.3e}")
     assert res["fp8"] < 0.2 and res["bf16"] < 0.05
+
+
+# ------------------------------------------------------------------------------------------------ train-mode dropout (vit_set.py:28-30, 43/62, 49, 187)
+def test_dropout_rows_matches_the_mask_stream(dev):
+    """Elementwise sites: the kernel's keep mask is the specified Philox stream bit for bit; kept values carry torch's 1 / (1 - p) scale; the
+    residual add and the 16-bit operand planes follow; a ragged tail (n % 8 != 0) is handled."""
+    from oracle import dropmask as dm
+    from stedm_amd import ops
+    prec = ops.Precision.parse("parity")
+    for n, p, seed, site in [(8 * 4099 + 5, 0.1, 0x1234567890ABCDEF, 19), (1 << 16, 0.25, 7, 0x10000), (24, 0.1, 3, 1)]:
+        src = prng.normal(61, f"drop.src.{n}", (n,))
+        res = prng.normal(61, f"drop.res.{n}", (n,))
+        keep = torch.from_numpy(dm.keep_elementwise(n, p, seed, site))
+        scale = torch.tensor(1.0) / torch.tensor(1.0 - np.float32(p))
+        want = torch.where(keep, src * scale, torch.zeros_like(src))
+        out = torch.empty(n, device=dev)
+        ops.dropout_rows(src.to(dev), p, seed, site, prec, out=out)
+        assert torch.equal(out.cpu(), want), "mask or scale differs from the stream's definition"
+        hi, lo = torch.empty(n, dtype=torch.int16, device=dev), torch.empty(n, dtype=torch.int16, device=dev)
+        x = res.to(dev).clone()
+        ops.dropout_rows(src.to(dev), p, seed, site, prec, res=x, out=x, hi=hi, lo=lo)          # in place on the residual stream
+        assert torch.equal(x.cpu(), want + res)
+        planes = hi.view(torch.float16).float() + lo.view(torch.float16).float()
+        assert float((planes.cpu() - (want + res)).abs().max()) < 1e-5
+    # keep-rate statistics of a large draw: thr16 = round(0.1 * 65536) = 6554
+    n = 1 << 22
+    out = torch.empty(n, device=dev)
+    ops.dropout_rows(torch.ones(n, device=dev), 0.1, 99, 5, prec, out=out)
+    rate = float((out != 0).float().mean())
+    assert abs(rate - (1 - 6554 / 65536)) < 4 * math.sqrt(0.09 / n), rate
+
+
+def _lsa_ref(qkv, tau, heads, keep=None, p=0.0):
+    B, T, _ = qkv.shape
+    q, k, v = (t.reshape(B, T, heads, 64).permute(0, 2, 1, 3) for t in qkv.chunk(3, dim=-1))
+    dots = torch.matmul(q, k.transpose(-1, -2)) * tau
+    dots = dots.masked_fill(torch.eye(T, dtype=torch.bool), -torch.finfo(dots.dtype).max)
+    attn = dots.softmax(dim=-1)
+    if keep is not None:
+        attn = torch.where(keep, attn / (1.0 - p), torch.zeros_like(attn))
+    return torch.matmul(attn, v).permute(0, 2, 1, 3).reshape(B, T, heads * 64)
+
+
+@pytest.mark.parametrize("precision,tol", [("parity", 2e-4), ("f16", 5e-3), ("bf16", 3e-2)])
+@pytest.mark.parametrize("B,T,heads", [(2, 66, 12), (1, 130, 2), (1, 300, 3)])
+def test_lsa_flash_drop_vs_oracle_with_the_same_mask(dev, B, T, heads, precision, tol):
+    """Attention-probability dropout (vit_set.py:61-62) inside the flash kernels (the register-staged split-product one and the DMA one): the
+    softmax normalises over ALL keys, the PV product sees only the kept probabilities, scaled by 1 / (1 - p). Mask = the specified per-lane
+    xorshift128 streams, rebuilt in numpy; a wrong mask would show as an O(0.3) error."""
+    from oracle import dropmask as dm
+    from stedm_amd import ops
+    prec = ops.Precision.parse(precision)
+    p, seed, site = 0.1, 0xC0FFEE1234, 8 * 3 + 1
+    qkv = prng.normal(40, "lsa.qkv", (B, T, 3 * heads * 64))
+    tau = math.exp(math.log(64 ** -0.5) + 0.1)
+    keep = torch.from_numpy(dm.keep_attention(B * heads, T, p, seed, site)).reshape(B, heads, T, T)
+    ref = _lsa_ref(qkv, tau, heads, keep, p)
+    Tp = ((T + 127) // 128) * 128
+    i16 = torch.int16
+    lo_ok = prec.npass == 3
+    mk = lambda shp: (torch.zeros(shp, dtype=i16, device=dev), torch.zeros(shp, dtype=i16, device=dev) if lo_ok else None)
+    qd, kd, vd = mk((B * heads, Tp, 64)), mk((B * heads, Tp, 64)), mk((B * heads, 64, Tp))
+    ops.qkv_pack(qkv.to(dev).contiguous(), tau * math.log2(math.e), qd, kd, vd, B, T, Tp, heads, prec)
+    od = mk((B, T, heads * 64))
+    ops.lsa_flash_drop(qd, kd, vd, od, B, T, Tp, heads, prec, p, seed, site)
+    dt = torch.float16 if precision != "bf16" else torch.bfloat16
+    got = od[0].view(dt).float() + (od[1].view(dt).float() if lo_ok else 0)
+    err = rel(got, ref)
+    print(f"[lsa_flash_drop {precision} B{B} T{T} h{heads}] max|diff|/std vs oracle with the same mask: {err:.3e} "
+          f"(no-dropout reference would differ by {rel(_lsa_ref(qkv, tau, heads), ref):.2f})")
+    assert err < tol
+    # p = 0: thr16 = 0 keeps everything and the scale is 1 -> the eval kernel's output bit for bit
+    o0, o1 = mk((B, T, heads * 64)), mk((B, T, heads * 64))
+    ops.lsa_flash(qd, kd, vd, o0, B, T, Tp, heads, prec)
+    ops.lsa_flash_drop(qd, kd, vd, o1, B, T, Tp, heads, prec, 0.0, seed, site)
+    assert torch.equal(o0[0], o1[0]) and (not lo_ok or torch.equal(o0[1], o1[1]))
+
+
+def make_svit_cfg(dev, img, ns, depth, heads, precision="parity"):
+    from stedm_amd.style import sViT
+    m = sViT(image_size=img, patch_size=8, num_classes=512, dim=256, depth=depth, heads=heads, mlp_dim=256, pool="mean", channels=3,
+             dropout=0.1, emb_dropout=0.1, ns=ns, t_dim=256, precision=precision)
+    prng.fill_module_(m, seed=7)
+    for l, (attn, _ff) in enumerate(m.transformer.layers):
+        attn.fn.temperature.fill_(float(np.log(64 ** -0.5)) + 0.05 * l)
+    return m.to(dev)
+
+
+@pytest.mark.parametrize("tag,img,ns,B,depth,heads", [("i64_ns4_d2", 64, 4, 2, 2, 12), ("i32_ns1_d3", 32, 1, 3, 3, 4)])
+def test_svit_train_mode_vs_reference_golden(dev, golden, tag, img, ns, B, depth, heads):
+    """sViT.train() with the shipped dropout values (conf/style_agg/svit.yaml: 0.1 / 0.1) against the REFERENCE's own module in train mode
+    with the same masks injected at its nn.Dropout calls (fixture F16, tests/golden/make_golden_train_drop.py)."""
+    fx = golden("f16_svit_train_drop")
+    m = make_svit_cfg(dev, img, ns, depth, heads).train()
+    m.dropout_seed = int(fx["seed"][0])
+    x = prng.uniform(7, f"svit.train.{tag}.img", (B, ns, img, img, 3)).to(dev)
+    y = m(x).clone()
+    err = rel(y, fx[tag])
+    print(f"[sViT train {tag}] parity-mode rel err vs the reference in train mode with the same masks: {err:.3e} "
+          f"(eval output differs by {rel(y, fx[tag + '.eval']):.2f})")
+    assert err < 1e-3
+    assert torch.equal(m(x), y), "same seed, same masks"
+    assert rel(m.eval()(x), fx[tag + ".eval"]) < 1e-3
+    # a forward without an explicit seed draws one from torch's generator: torch.manual_seed governs it, successive forwards differ
+    m.train()
+    m.dropout_seed = None
+    torch.manual_seed(5)
+    a = m(x).clone(); s1 = m.last_dropout_seed
+    b = m(x).clone(); s2 = m.last_dropout_seed
+    torch.manual_seed(5)
+    c = m(x).clone()
+    assert s1 != s2 and not torch.equal(a, b) and torch.equal(a, c)
+
+
+@pytest.mark.parametrize("precision,tol", [("f16", 1e-2), ("bf16", 8e-2)])
+def test_svit_train_mode_fast_modes_reported(dev, golden, precision, tol):
+    fx = golden("f16_svit_train_drop")
+    m = make_svit_cfg(dev, 64, 4, 2, 12, precision).train()
+    m.dropout_seed = int(fx["seed"][0])
+    x = prng.uniform(7, "svit.train.i64_ns4_d2.img", (2, 4, 64, 64, 3)).to(dev)
+    err = rel(m(x), fx["i64_ns4_d2"])
+    print(f"[sViT train i64_ns4_d2 {precision}] rel err vs the reference in train mode with the same masks: {err:.3e}")
+    assert err < tol
+
+
+def test_svit_train_mode_with_zero_dropout_is_eval_bitwise(dev):
+    from stedm_amd.style import sViT
+    m = sViT(image_size=64, patch_size=8, num_classes=512, dim=256, depth=2, heads=12, mlp_dim=256, pool="mean", ns=4, dropout=0.0,
+             emb_dropout=0.0)
+    prng.fill_module_(m, seed=7)
+    m = m.to(dev)
+    x = prng.uniform(7, "svit.train.p0.img", (2, 4, 64, 64, 3)).to(dev)
+    assert torch.equal(m.train()(x).clone(), m.eval()(x))

@@ -182,3 +182,47 @@ def test_agg_blocks_with_hip_embedder(dev):
     want = F.relu(F.linear(F.relu(F.linear(F.relu(f.reshape(2, -1)), lb[1].weight, lb[1].bias)), lb[3].weight, lb[3].bias))
     lin = lin.to(dev)
     assert rel(lin(imgs.to(dev)), want) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ train mode: stochastic depth
+def test_swin_train_mode_stochastic_depth_vs_oracle_with_the_same_gates(dev):
+    """torchvision's swin_v2_t in train mode (the reference runs the embedder inside the training step: s_zss_dm.py:45-60) applies
+    StochasticDepth(p_i, "row") to both residual branches of block i, p_i = 0.2 i / 11: per-image gates bernoulli(1 - p) / (1 - p). torch's
+    draw cannot be matched, so the gates are injected on both sides."""
+    from oracle import swin as osw
+    m, params = make_swin(dev)
+    assert len(m.sd_probs) == 12 and m.sd_probs[0] == 0.0 and abs(m.sd_probs[-1] - 0.2) < 1e-12 and abs(m.sd_probs[5] - 0.2 * 5 / 11) < 1e-12
+    N = 5
+    g = torch.Generator().manual_seed(3)
+    surv = 1.0 - torch.tensor(m.sd_probs).view(-1, 1, 1)
+    gates = (torch.rand(12, 2, N, generator=g) < 0.6).float() / surv        # (a high drop rate so that every block sees both outcomes)
+    gates[0] = 1.0                                                           # p_0 = 0: torchvision returns the input unchanged
+    x = prng.uniform(11, "swin.img.train", (N, 64, 96, 3))
+    want = osw.swin_v2_forward(params, x.permute(0, 3, 1, 2).contiguous(), sd_gates=gates)
+    m.train()
+    m.sd_gates = gates
+    m.chunk_images = 2                                                       # gates follow the images through the chunks
+    got = m(x.to(dev).permute(0, 3, 1, 2))
+    err = rel(got, want)
+    ev = osw.swin_v2_forward(params, x.permute(0, 3, 1, 2).contiguous())
+    print(f"[swin_v2_t train] parity-mode max|diff|/std vs CPU oracle with the same gates: {err:.3e} (eval differs by {rel(got, ev):.2f})")
+    assert err < 1e-3 and rel(got, ev) > 0.05
+    # gates of one = eval arithmetic bit for bit
+    m.sd_gates = torch.ones(12, 2, N)
+    a = m(x.to(dev).permute(0, 3, 1, 2)).clone()
+    assert torch.equal(a, m.eval()(x.to(dev).permute(0, 3, 1, 2)))
+
+
+def test_swin_train_mode_draws_its_gates(dev):
+    m, _ = make_swin(dev)
+    m.train()
+    x = prng.uniform(11, "swin.img.train2", (64, 3, 32, 32)).to(dev)
+    torch.manual_seed(0)
+    a = m(x).clone()
+    g = m._gates.cpu()
+    assert tuple(g.shape) == (12, 2, 64)
+    for i, p in enumerate(m.sd_probs):                                       # values 0 or 1 / (1 - p_i); about p_i of them dropped
+        vals = set(np.round(g[i].unique().numpy(), 5).tolist())
+        assert vals <= {0.0, round(1.0 / (1.0 - p), 5)}, (i, vals)
+    assert abs(float((g[6:] == 0).float().mean()) - float(np.mean(m.sd_probs[6:]))) < 0.06
+    assert bool(torch.isfinite(a).all()) and not torch.equal(a, m.eval()(x))

@@ -313,7 +313,7 @@ def test_unet_backward_odd_shapes_vs_oracle(dev, B, H, W):
             assert float((p.grad.cpu() - grads[n]).norm()) / gn < 1e-3, n
 
 
-def _ddp_worker(rank, world, port, q, overlap=True, bucket_mb=256):
+def _ddp_worker(rank, world, port, q, overlap=True, bucket_mb=256, steps=1, accumulate=1):
     import os
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -322,14 +322,19 @@ def _ddp_worker(rank, world, port, q, overlap=True, bucket_mb=256):
     from stedm_amd.train import UNetTrainer
     dev = torch.device("cuda:0")
     m = build(TINY, 6, dev)
-    tr = UNetTrainer(m, lr=1e-3, weight_decay=0.0)
+    tr = UNetTrainer(m, lr=1e-3, weight_decay=0.0, accumulate_grad_batches=accumulate)
     tr.overlap_all_reduce, tr.bucket_mb = overlap, bucket_mb
-    x, ctx, target = _inputs("tiny", TINY, 2, 16, 6, dev)
-    t = torch.tensor([951, 21], device=dev)
-    sl = slice(rank, rank + 1)                       # each rank trains on its own sample
-    tr.train_step(x[sl, :4].contiguous(), x[sl, 4:].contiguous(), t[sl], ctx[sl].contiguous(), target[sl].contiguous())
+    n = world * steps * accumulate
+    x, ctx, target = _inputs("tiny", TINY, n, 16, 6, dev)
+    t = torch.tensor(([951, 21, 500, 7] * n)[:n], device=dev)
+    for i in range(steps * accumulate):
+        sl = slice(i * world + rank, i * world + rank + 1)                       # each rank trains on its own sample of every micro-batch
+        tr.train_step(x[sl, :4].contiguous(), x[sl, 4:].contiguous(), t[sl], ctx[sl].contiguous(), target[sl].contiguous())
     if rank == 0:
-        q.put({n: p.detach().cpu().numpy() for n, p in m.named_parameters()})       # numpy: no shared-memory handles across the exit
+        out = {n: p.detach().cpu().numpy() for n, p in m.named_parameters()}       # numpy: no shared-memory handles across the exit
+        out["__overlap_fires__"] = np.array([tr.overlap_fires])
+        out["__steps__"] = np.array([tr.step_count])
+        q.put(out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -359,6 +364,7 @@ def test_two_rank_data_parallel_step_equals_gradient_accumulation(dev):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    assert int(got["__overlap_fires__"][0]) > 0, "the overlapped all-reduce (the default) did not run on the first step"
     worst = max(float(np.abs(got[n] - ref[n].numpy()).max()) for n in ref)
     print(f"two-rank data-parallel step vs gradient accumulation: max |dw| = {worst:.2e} (lr 1e-3)")
     assert worst < 2e-5
@@ -371,19 +377,26 @@ def test_overlapped_gradient_all_reduce_equals_the_plain_one_bitwise(dev):
     import os
     import torch.multiprocessing as mp
     ctxm = mp.get_context("spawn")
-    res = []
-    for overlap in (True, False):
-        q = ctxm.Queue()
-        port = 36500 + (os.getpid() % 2000) + (1 if overlap else 0)
-        procs = [ctxm.Process(target=_ddp_worker, args=(r, 2, port, q, overlap, 1)) for r in range(2)]
-        for p in procs:
-            p.start()
-        res.append(q.get(timeout=300))
-        for p in procs:
-            p.join(timeout=120)
-            assert p.exitcode == 0
-    for n in res[0]:
-        assert np.array_equal(res[0][n], res[1][n]), n
+    # (steps, accumulate): two optimizer steps (the second runs on stepped weights and re-packed operands); and accumulate_grad_batches = 2,
+    # where a bucket is first folded into the running mean and the collective runs on the accumulation arena
+    for ci, (steps, accumulate) in enumerate([(2, 1), (2, 2)]):
+        res = []
+        for overlap in (True, False):
+            q = ctxm.Queue()
+            port = 36500 + (os.getpid() % 2000) + 2 * ci + (1 if overlap else 0)
+            procs = [ctxm.Process(target=_ddp_worker, args=(r, 2, port, q, overlap, 1, steps, accumulate)) for r in range(2)]
+            for p in procs:
+                p.start()
+            res.append(q.get(timeout=300))
+            for p in procs:
+                p.join(timeout=120)
+                assert p.exitcode == 0
+        fires_on, fires_off = int(res[0].pop("__overlap_fires__")[0]), int(res[1].pop("__overlap_fires__")[0])
+        assert int(res[0].pop("__steps__")[0]) == int(res[1].pop("__steps__")[0]) == steps
+        # every optimizer step fired at least two buckets from inside its backward (the first step included); the plain path none
+        assert fires_on >= 2 * steps and fires_off == 0, (fires_on, fires_off)
+        for n in res[0]:
+            assert np.array_equal(res[0][n], res[1][n]), (steps, accumulate, n)
     from stedm_amd.train import UNetTrainer
     m = build(TINY, 6, dev)
     tr = UNetTrainer(m)
@@ -543,11 +556,14 @@ MODULE_UNET = dict(image_size=16, in_channels=7, model_channels=128, out_channel
                    channel_mult=[1, 2], num_heads=4)
 
 
-def _module_cfg():
+# conf/style_agg/svit.yaml as shipped (dropout 0.1 / emb_dropout 0.1 are LIVE in training_step: the reference runs the agg block in train mode)
+SVIT_YAML = dict(name="svit", patch_size=8, dim=256, depth=6, heads=12, mlp_dim=256, pool="mean", channels=3, dropout=0.1, emb_dropout=0.1, t_dim=256)
+
+
+def _module_cfg(style_agg=None):
     return {"lr": 1e-3, "cfg_scale": 1.5, "ddim_steps": 4, "eta": 0.0, "data": {"patch_size": 64},
             "style_sampling": {"name": "mp", "num_patches": 2},
-            "style_agg": dict(name="svit", patch_size=8, dim=64, depth=1, heads=2, mlp_dim=64, pool="mean", channels=3, dropout=0.0, emb_dropout=0.0,
-                              t_dim=64),
+            "style_agg": dict(SVIT_YAML) if style_agg is None else style_agg,
             "diffusion": dict(linear_start=0.0015, linear_end=0.0205, timesteps=1000, loss_type="l1", first_stage_key="image",
                               cond_stage_key="segmentation", image_size=16, channels=4, conditioning_key="hybrid", cond_stage_trainable=True,
                               unet_config={"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": dict(MODULE_UNET)},
@@ -566,13 +582,18 @@ def _module_batches(dev, n, B=2):
     return out
 
 
-def _build_module(dev):
+def _build_module(dev, style_agg=None):
     from stedm_amd.ldm_module import LDM_Diffusion
-    mod = LDM_Diffusion(_module_cfg(), accumulate_grad_batches=2)
+    mod = LDM_Diffusion(_module_cfg(style_agg), accumulate_grad_batches=2)
     mod._model.first_stage_model = _PoolStage()
     prng.fill_module_(mod._model.model.diffusion_model, seed=6)
     prng.fill_module_(mod._model.cond_stage_model, seed=9)
-    prng.fill_module_(mod._model.agg_block, seed=51)
+    if style_agg is None:
+        prng.fill_module_(mod._model.agg_block, seed=51)
+    else:       # Swin-V2-T keeps torchvision's initialisation (trunc-normal weights); the aggregation MLP takes the PRNG recipe
+        lb = getattr(mod._model.agg_block, "linear_block", None)
+        if lb is not None:
+            prng.fill_module_(lb, seed=51)
     return mod.to(dev)
 
 
@@ -645,6 +666,43 @@ def test_ldm_module_training_loop_as_the_reference_drives_it(dev):
     res._model.first_stage_model = None
     with pytest.raises(StedmHipError):
         res.training_step(batches[0], 0)
+
+
+@pytest.mark.parametrize("agg", ["linear", "mean", "max"])
+def test_ldm_module_trains_with_the_default_style_agg(dev, agg):
+    """conf/config_diff.yaml:16 `style_agg: linear` (and mean / max): S_ZSS_DM builds Agg_* over Swin-V2-T (s_zss_dm.py:19-27) and get_input
+    runs it inside training_step with the module in train mode — torchvision's stochastic depth is live there (gates drawn per forward), the
+    embedder itself is not optimised (ldm_diffusion.py:224-234). The loop of the reference (on_train_batch_start -> training_step ->
+    on_train_batch_end) must run, step the U-Net, and leave the agg block's weights untouched."""
+    batches = _module_batches(dev, 2)
+    mod = _build_module(dev, style_agg={"name": agg})
+    mod.train()
+    agg_before = {n: p.detach().clone() for n, p in mod._model.agg_block.named_parameters()}
+    w_before = mod._model.model.diffusion_model.out[2].weight.detach().clone()
+    torch.manual_seed(7)
+    for idx, b in enumerate(batches):
+        mod.on_train_batch_start(b, idx)
+        loss = mod.training_step(b, idx)
+        mod.on_train_batch_end()
+        assert bool(torch.isfinite(loss))
+    tr = mod._model._trainer
+    assert tr.step_count == 1 and tr.ema_updates == 2
+    assert not torch.equal(w_before, mod._model.model.diffusion_model.out[2].weight)
+    for n, p in mod._model.agg_block.named_parameters():
+        assert torch.equal(p, agg_before[n]), n
+    # the style vector of the training step is the train-mode one: stochastic depth drew gates (12 blocks x 2 branches x B * n images)
+    emb = mod._model.agg_block.embedder
+    assert emb.training and emb._gates is not None and tuple(emb._gates.shape) == (12, 2, 4)
+    lb = mod.prepare_batch(batches[0])
+    torch.manual_seed(3)
+    a = mod._model.get_input(lb, "image")[1]["c_crossattn"][0].clone()
+    b2 = mod._model.get_input(lb, "image")[1]["c_crossattn"][0].clone()
+    mod.eval()
+    e1 = mod._model.get_input(lb, "image")[1]["c_crossattn"][0].clone()
+    e2 = mod._model.get_input(lb, "image")[1]["c_crossattn"][0].clone()
+    assert torch.equal(e1, e2) and tuple(a.shape) == (2, 512)
+    assert not torch.equal(a, b2) or not torch.equal(a, e1)       # (a draw may keep every branch of these 4 images; two draws both doing so is ~1e-3)
+
 
 
 def _surface_worker(rank, world, port, q):

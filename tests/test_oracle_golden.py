@@ -144,6 +144,45 @@ def test_f7_svit(golden):
         close(ostyle.svit_forward(P, cfg, x), fx[tag], 5e-5)
 
 
+def test_philox_known_answers_and_mask_statistics():
+    """The mask streams of the train-mode dropout (oracle/dropmask.py): Philox4x32-10 against Random123's known-answer vectors, keep rates of
+    both stream kinds, and independence of sites / seeds."""
+    from oracle import dropmask as dm
+    for c, k, want in dm.KAT:
+        got = dm.philox4x32_10(*[np.uint32(v) for v in c], k[0], k[1])
+        assert tuple(int(v) for v in got) == want
+    n = 1 << 20
+    a = dm.keep_elementwise(n, 0.1, 1234, 3)
+    assert abs(a.mean() - (1 - 6554 / 65536)) < 4 * np.sqrt(0.09 / n)
+    assert dm.keep_elementwise(n, 0.0, 1234, 3).all()
+    b = dm.keep_elementwise(n, 0.1, 1234, 4)
+    c = dm.keep_elementwise(n, 0.1, 1235, 3)
+    for other in (b, c):                                   # different site / seed: independent masks (joint drop rate ~ p^2)
+        assert abs((~a & ~other).mean() - 0.01) < 2e-3
+    assert (dm.keep_elementwise(1003, 0.1, 1234, 3) == a[:1003]).all()          # a prefix property of the linear index
+    k = dm.keep_attention(4, 200, 0.1, 99, 1)
+    assert k.shape == (4, 200, 200)
+    assert abs(k.mean() - 0.9) < 4 * np.sqrt(0.09 / k.size)
+    assert abs(k.mean(axis=(0, 1)).std()) < 0.02 and abs(k.mean(axis=(0, 2)).std()) < 0.03       # no key / query column stands out
+    assert dm.keep_attention(4, 200, 0.0, 99, 1).all()
+    assert (dm.keep_attention(2, 130, 0.1, 99, 1) == k[:2, :130, :130]).all()   # a tile's masks do not depend on T or on later sample-heads
+
+
+def test_f16_svit_train_mode_dropout(golden):
+    """The reference's sViT in train mode with the build's masks injected at every nn.Dropout (tests/golden/make_golden_train_drop.py): the
+    oracle's train-mode path applies the same masks at the same sites with torch's arithmetic."""
+    fx = golden("f16_svit_train_drop")
+    seed = int(fx["seed"][0])
+    for tag, (img, ns_, B, depth, heads) in {"i64_ns4_d2": (64, 4, 2, 2, 12), "i32_ns1_d3": (32, 1, 3, 3, 4)}.items():
+        cfg = ostyle.SViTConfig(image_size=img, ns=ns_, depth=depth, heads=heads)
+        P = prng.fill_state_dict(ostyle.svit_shapes(cfg), 7)
+        for l in range(cfg.depth):
+            P[f"transformer.layers.{l}.0.fn.temperature"] = torch.tensor(float(np.log(64 ** -0.5)) + 0.05 * l)
+        x = prng.uniform(7, f"svit.train.{tag}.img", (B, ns_, img, img, 3))
+        close(ostyle.svit_forward(P, cfg, x, train_drop=(0.1, 0.1, seed)), fx[tag], 5e-5)
+        close(ostyle.svit_forward(P, cfg, x), fx[tag + ".eval"], 5e-5)
+
+
 def test_f8_agg(golden):
     fx = golden("f8_agg")
     sty = prng.uniform(8, "agg.style", (2, 4, 16, 16, 3))
