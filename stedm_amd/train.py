@@ -776,6 +776,7 @@ class UNetTrainer:
         works = []
         on_bucket = None
         if getattr(self, "grad_arena", None) is None:
+            self.m._prepare()                # (the arena's layout follows the packed embedding-Linear order; cached for the forward)
             self._alloc_grads()              # before deciding: the FIRST step overlaps its all-reduce like every later one
         if multi and last and self.overlap_all_reduce:
             # the collective of a bucket starts the moment the backward has produced its last gradient (the all-reduce then runs beside

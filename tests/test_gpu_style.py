@@ -232,7 +232,7 @@ def _lsa_ref(qkv, tau, heads, keep=None, p=0.0):
     return torch.matmul(attn, v).permute(0, 2, 1, 3).reshape(B, T, heads * 64)
 
 
-@pytest.mark.parametrize("precision,tol", [("parity", 2e-4), ("f16", 5e-3), ("bf16", 3e-2)])
+@pytest.mark.parametrize("precision,tol", [("parity", 2e-4), ("f16", 1e-2), ("bf16", 6e-2)])
 @pytest.mark.parametrize("B,T,heads", [(2, 66, 12), (1, 130, 2), (1, 300, 3)])
 def test_lsa_flash_drop_vs_oracle_with_the_same_mask(dev, B, T, heads, precision, tol):
     """Attention-probability dropout (vit_set.py:61-62) inside the flash kernels (the register-staged split-product one and the DMA one): the
