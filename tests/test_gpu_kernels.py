@@ -514,6 +514,55 @@ def test_conv_3x3_mfma16x16x32_kind(dev, prec, tol, B, H, W, cin, cout, emb, res
     _conv_dma_case(dev, prec, tol, B, H, W, cin, cout, "s1", 3, use_emb=emb, use_res=res, frag=True, ws=ws, m16=True)
 
 
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+@pytest.mark.parametrize("B,H,W,cin,cout,ws", [
+    (128, 32, 32, 256, 128, False),     # 512 tiles of rows inside one sample: two tile rounds per CU
+    (128, 16, 16, 256, 512, False),     # 512 tiles over 4 N-tiles: the XCD-aware order
+    (201, 8, 8, 256, 256, False),       # whole-sample tiles (4 samples each), ragged batch: masked rows, one slot per sample
+    (1601, 4, 4, 256, 128, False),      # 16 samples per tile, one row fragment each
+    (50, 32, 32, 256, 96, False),       # partial N tile: masked columns
+    (96, 32, 32, 288, 128, False),      # 384 tiles on 256 CUs; odd chunk count
+    (3, 128, 128, 256, 64, False),      # 128-pixel rows, two rows per tile
+    (4, 8, 8, 1024, 1024, True),        # small grid: K split into the workspace, statistics from the reduce pass
+    (64, 8, 8, 2048, 1024, True)])
+def test_conv_3x3_16x16x32_full_epilogue(dev, prec, B, H, W, cin, cout, ws):
+    """the 16x16x32 3x3 kind with everything its epilogue carries at once — bias, per-sample embedding row (offset + batch stride), residual
+    rows, per-channel statistics in 256-pixel slots — over the grid shapes of the bench (two tile rounds per CU, the XCD-aware order, whole-sample
+    tiles with a ragged batch, partial N tiles, 384 tiles on 256 CUs, split K): output against F.conv2d at the mode's tolerance, statistics
+    against sums of the stored output, and bitwise run to run."""
+    from stedm_amd import ops
+    pr = ops.Precision.parse(prec)
+    tol = dict(PRECS)[prec]
+    g = torch.Generator(device="cpu").manual_seed(B * 7 + cin)
+    a = F.silu(torch.randn(B, cin, H, W, generator=g) * 1.3 + 0.1)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    bias = torch.randn(cout, generator=g) * 0.05
+    emb = torch.randn(B, cout + 24, generator=g)
+    res = torch.randn(B, cout, H, W, generator=g)
+    ref = F.conv2d(a, w, bias, padding=1) + emb[:, 8:8 + cout, None, None] + res
+    hi16 = torch.empty((B, H, W, cin), dtype=torch.int16, device=dev)
+    ops.gn_apply16(nhwc(a).to(dev), None, hi16, None, pr)
+    whi, wlo = ops.pack_conv_weight(w.to(dev), pr)
+    ns = ops.gn_chan_nslab(H * W)
+    kw = dict(prec=pr, ks=3, src16=(hi16, None), bias=bias.to(dev), emb=emb.to(dev), emb_offset=8, emb_bstride=emb.shape[1], res=nhwc(res).to(dev),
+              w_frag=ops.pack_conv_weight_frag(w.to(dev), pr), w_frag16=ops.pack_conv_weight_frag16(w.to(dev), pr))
+    outs, css = [], []
+    for _ in range(2):
+        out = torch.full((B, H, W, cout), float("nan"), device=dev)
+        cs = torch.full((B, ns, cout, 2), float("nan"), device=dev)
+        ops.conv_igemm(None, whi, wlo, out, chan_stats=cs, ws=torch.empty(16 * out.numel(), device=dev) if ws else None, **kw)
+        outs.append(out); css.append(cs)
+    torch.cuda.synchronize()
+    err = rel_err(nchw(outs[0]), ref)
+    assert err < tol, f"{prec}: rel err {err:.3e} >= {tol}"
+    flat = outs[0].view(B, H * W, cout).double()
+    for k in range(ns):
+        sl = flat[:, k * 256:(k + 1) * 256]
+        assert torch.allclose(css[0][:, k, :, 0].double(), sl.sum(1), rtol=1e-4, atol=2e-3)
+        assert torch.allclose(css[0][:, k, :, 1].double(), (sl * sl).sum(1), rtol=1e-4, atol=2e-3)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(css[0], css[1])          # no atomics, fixed summation orders
+
+
 @pytest.mark.parametrize("B,H,W,cin,cout,emb,res,ws", [
     (50, 32, 32, 256, 96, True, True, False), (200, 16, 16, 288, 128, True, False, False), (801, 8, 8, 256, 32, False, True, False),
     (12, 64, 64, 128, 32, True, True, False), (64, 32, 32, 128, 160, True, True, False), (400, 8, 8, 320, 256, True, True, False),
