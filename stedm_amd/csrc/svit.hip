@@ -793,10 +793,291 @@ __global__ void __launch_bounds__(256, NBUF == 2 ? 4 : 3) lsa_flash_dma_kernel(F
   }
 }
 
+// 64 queries per wave (round 3). lsa_flash_dma_kernel gives a wave 32 queries, so every wave of the block reads the whole K and V^T tile
+// from LDS for 16 + 2 MFMAs: 16 KB of fragment reads per 576 MFMA cycles and wave, 12 waves per CU — the LDS pipe (128 B/clk per CU, the
+// 8-B V^T reads 2-way conflicted) is as loaded as the matrix pipe, and the softmax of a wave (32 v_exp + ~60 other vector instructions)
+// runs strictly between its QK^T and PV products: measured 1578 cycles per wave and tile against 576 of MFMA (0.78 PFLOP/s, B = 8).
+// Here a wave owns TWO 32-query blocks: a K / V^T fragment is read once into registers and feeds both blocks' MFMAs (half the LDS bytes per
+// MFMA), and the two blocks give the in-order wave something to overlap with itself — the exponentials of block 0 are issued in the gaps
+// of block 1's QK^T MFMAs, those of block 1 in the gaps of block 0's PV MFMAs (one MFMA, then a slice of 3 - 4 exponentials + their sums /
+// conversions, fenced by sched_barrier). Two waves per SIMD (≈230 registers), 48 KB ring, same DMA ring / swizzle / barrier protocol,
+// same swapped S^T = K Q^T layout, m_ref fifth k-step and rescale rule as lsa_flash_dma_kernel (per 32-query block).
+template <typename T, bool DROP = false>
+__global__ void __launch_bounds__(256, 2) lsa_flash64_kernel(FlashArgs a) {
+  using V8 = typename MM<T>::V8;
+  typedef T V4t __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr int NBUF = 3, TILE_B = 16384;          // K 8 KiB | V^T 8 KiB
+  constexpr int O_BYTES = 4 * 32 * 65 * (int)sizeof(float);
+  constexpr int LDS_B = NBUF * TILE_B > O_BYTES ? NBUF * TILE_B : O_BYTES;
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[LDS_B];
+  float (*sO)[32][65] = reinterpret_cast<float (*)[32][65]>(ring);
+  // block -> (sample-head, 256-query tile), all tiles of a sample-head on one XCD (see lsa_flash_dma_kernel)
+  int bh, qtile;
+  {
+    const int nq = (a.Tp + 255) / 256, nbh = gridDim.x / nq, L = blockIdx.x;
+    if ((nbh & 7) == 0) { const int x = L & 7, j = L >> 3; bh = x + 8 * (j / nq); qtile = j % nq; }
+    else { bh = L % nbh; qtile = L / nbh; }
+  }
+  const int b = bh / a.H, hd = bh % a.H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int qw = qtile * 256 + wave * 64;           // first query of this wave; block qb covers qw + 32 qb ..
+  const T* qg = reinterpret_cast<const T*>(a.qh);
+  const T* kg = reinterpret_cast<const T*>(a.kh);
+  const T* vg = reinterpret_cast<const T*>(a.vh);
+
+  V8 qf[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    int row = qw + qb * 32 + r;
+    row = row < a.Tp ? row : a.Tp - 1;              // (Tp % 256 == 128: the last block's upper waves hold no queries; never stored)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *reinterpret_cast<const V8*>(qg + ((long)bh * a.Tp + row) * 64 + ks * 16 + h * 8);
+  }
+  const T* const kbase = kg + (long)bh * a.Tp * 64;
+  const T* const vbase = vg + (long)bh * 64 * a.Tp;
+  unsigned koff[2], voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 8 * (2 * wave + i) + (lane >> 3);
+    const int q = (lane & 7) ^ ((row >> 1) & 7);
+    koff[i] = row * 64 + q * 8;
+    voff[i] = row * a.Tp + q * 8;
+  }
+  auto issue = [&](int kt) __attribute__((always_inline)) {
+    unsigned char* dst = ring + (kt % NBUF) * TILE_B + (2 * wave) * 1024;
+    const T* kt_k = kbase + (long)kt * 4096;
+    const T* kt_v = vbase + (long)kt * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      GLDS16(kt_k + koff[i], dst + i * 1024);
+      GLDS16(kt_v + voff[i], dst + 8192 + i * 1024);
+    }
+  };
+  f32x16 o[2][2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[qb][d][e] = 0.f;
+  float l_run[2] = {0.f, 0.f}, m_ref[2] = {0.f, 0.f};
+  const int ntiles = (a.T + 63) / 64;
+  U4 dstate[2] = {};
+  if (DROP) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) dstate[qb] = attn_stream_init((unsigned)(qw + qb * 32 + r), (unsigned)bh, a.site, (unsigned)h, a.seed);
+  }
+  unsigned kb[2], vb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = i * 32 + r;
+    kb[i] = row * 128 + ((h ^ ((row >> 1) & 7)) << 4);
+    vb[i] = 8192 + row * 128 + (((row >> 1) & 7) << 4) + 8 * h;
+  }
+  V8 ka, qa[2];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ka[j] = (T)0.f; qa[0][j] = (T)0.f; qa[1][j] = (T)0.f; }
+  if (h == 0) ka[0] = (T)1.f;
+
+  // masks of the rare tiles: the block's own keys (diagonal, vit_set.py:58-60) and the keys beyond T
+  auto masks = [&](f32x16 (&s)[2], const int qb, const int kt) __attribute__((always_inline)) {
+    const int q0 = qw + qb * 32, qidx = q0 + r;
+    if ((q0 >> 6) == kt) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (kt * 64 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h == qidx) s[sub][e] = -FLT_MAX;
+    }
+    if (kt * 64 + 64 > a.T) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (kt * 64 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= a.T) s[sub][e] = -INFINITY;
+    }
+  };
+  // move of the reference m_ref to (at least) the block's maximum in this tile: O and l go to the new reference, the logits take the
+  // difference explicitly (see lsa_flash_dma_kernel). Runs on the first tile and in the rare redo below — NOT per tile: the common tile has
+  // no row maximum at all (32 v_max3 + a cross-half shuffle + a ballot per block were a quarter of the softmax's vector instructions)
+  auto move_ref = [&](f32x16 (&s)[2], const int qb, const bool first) __attribute__((always_inline)) {
+    float mx = s[0][0];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[sub][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float up = first ? fmaxf(mx, -30000.f) : fmaxf(mx, 0.f);
+    const float m_new = (float)(T)(m_ref[qb] + up);
+    const float delta = m_new - m_ref[qb];
+    const float alpha = __builtin_amdgcn_exp2f(-delta);
+    m_ref[qb] = m_new;
+    if (h == 0) qa[qb][0] = (T)(-m_new);
+    l_run[qb] *= alpha;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[qb][d][e] *= alpha;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[sub][e] -= delta;
+  };
+  // elements [E0, E1) of a block's 32 logits: p = exp2(s'), row sum (two chains), and every completed octet packed to the operand type
+  // (dropout: kept probabilities only; l keeps every p — vit_set.py:61-62)
+#define SM_SLICE(S, QB, E0, E1, PH, RS2, KEEP)                                                              \
+  _Pragma("unroll") for (int e_ = (E0); e_ < (E1); ++e_) {                                                 \
+    const float pv_ = __builtin_amdgcn_exp2f(S[e_ >> 4][e_ & 15]);                                         \
+    S[e_ >> 4][e_ & 15] = pv_;                                                                             \
+    RS2[e_ & 1] += pv_;                                                                                    \
+    if ((e_ & 7) == 7) {                                                                                   \
+      _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                                   \
+        float v_ = S[e_ >> 4][(e_ & 15) - 7 + j_];                                                         \
+        if (DROP && !(((KEEP) >> (e_ - 7 + j_)) & 1u)) v_ = 0.f;                                           \
+        PH[e_ >> 3][j_] = (T)v_;                                                                           \
+      }                                                                                                    \
+    }                                                                                                      \
+  }
+  // Guard of the exponentials WITHOUT a row maximum: a tile's probabilities are bounded by their own row sum, which the loop has anyway.
+  // If some query's sum exceeds kLimit (what the operand type — and with it the fp32 sums — can still carry: 2^14 for fp16, 2^80 for bf16;
+  // an overflowed exponential makes the sum inf, a NaN fails the comparison too), the block's tile is redone from the K fragments in LDS
+  // with the reference moved first.
+  constexpr float kLimit = sizeof(typename MM<T>::V8) == 16 && __is_same(T, _Float16) ? 16384.f : 1.2089258e24f;
+  auto redo = [&](const int qb, const int kt, const unsigned char* tb, V8 (&ph)[4], float (&rs2)[2], const unsigned keep) __attribute__((always_inline)) {
+    f32x16 s[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[sub][e] = 0.f;
+      s[sub] = MM<T>::mfma(ka, qa[qb], s[sub]);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const V8 kfr = *reinterpret_cast<const V8*>(tb + (kb[sub] ^ (unsigned)(ks << 5)));
+        s[sub] = MM<T>::mfma(kfr, qf[qb][ks], s[sub]);
+      }
+    }
+    masks(s, qb, kt);
+    move_ref(s, qb, false);
+    rs2[0] = 0.f; rs2[1] = 0.f;
+    SM_SLICE(s, qb, 0, 32, ph, rs2, keep)
+  };
+
+  issue(0);
+  if (ntiles > 1) issue(1);
+  for (int kt0 = 0; kt0 < ntiles; kt0 += NBUF) {
+#pragma unroll
+  for (int u = 0; u < NBUF; ++u) {
+    const int kt = kt0 + u;
+    if (kt >= ntiles) break;
+    if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // tile kt is complete in LDS; every wave is done with tile kt - 1, whose buffer takes the next tile fetched
+    if (kt + NBUF - 1 < ntiles) issue(kt + NBUF - 1);
+    const unsigned char* tb = ring + u * TILE_B;
+    // ---- K fragments: read once, used by both query blocks
+    V8 kf[2][4];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kf[sub][ks] = *reinterpret_cast<const V8*>(tb + (kb[sub] ^ (unsigned)(ks << 5)));
+    // ---- S^T of block 0
+    f32x16 s0[2], s1[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s0[sub][e] = 0.f;
+      s0[sub] = MM<T>::mfma(ka, qa[0], s0[sub]);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s0[sub] = MM<T>::mfma(kf[sub][ks], qf[0][ks], s0[sub]);
+    }
+    masks(s0, 0, kt);
+    if (kt == 0) move_ref(s0, 0, true);
+    unsigned keep0 = ~0u, keep1 = ~0u;
+    if (DROP) keep0 = attn_keep_bits(dstate[0], a.thr16);
+    // ---- S^T of block 1 (10 MFMAs) with block 0's exponentials in the gaps
+    V8 p0[4], p1[4];
+    float rs0[2] = {0.f, 0.f}, rs1[2] = {0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 10; ++m) {
+      const int sub = m / 5, km = m % 5;
+      __builtin_amdgcn_sched_barrier(0);
+      if (km == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s1[sub][e] = 0.f;
+        s1[sub] = MM<T>::mfma(ka, qa[1], s1[sub]);
+      } else s1[sub] = MM<T>::mfma(kf[sub][km - 1], qf[1][km - 1], s1[sub]);
+      __builtin_amdgcn_sched_barrier(0);
+      SM_SLICE(s0, 0, (m * 32) / 10, ((m + 1) * 32) / 10, p0, rs0, keep0)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (__builtin_amdgcn_ballot_w64(!(rs0[0] + rs0[1] <= kLimit))) redo(0, kt, tb, p0, rs0, keep0);
+    l_run[0] += rs0[0] + rs0[1];
+    // ---- V^T fragments: read once, used by both query blocks (fragment f = 4 sub + 2 s2 + d)
+    V8 vf[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      const unsigned vo = vb[f & 1] ^ (unsigned)((f >> 1) << 5);      // (4 sub + 2 s2) << 4 = (f >> 1) << 5
+      const V4t v0 = *reinterpret_cast<const V4t*>(tb + vo);
+      const V4t v1 = *reinterpret_cast<const V4t*>(tb + (vo ^ 16u));
+      vf[f][0] = v0[0]; vf[f][1] = v0[1]; vf[f][2] = v0[2]; vf[f][3] = v0[3];
+      vf[f][4] = v1[0]; vf[f][5] = v1[1]; vf[f][6] = v1[2]; vf[f][7] = v1[3];
+    }
+    masks(s1, 1, kt);
+    if (kt == 0) move_ref(s1, 1, true);
+    if (DROP) keep1 = attn_keep_bits(dstate[1], a.thr16);
+    // ---- O^T of block 0 (8 MFMAs) with block 1's exponentials in the gaps
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      __builtin_amdgcn_sched_barrier(0);
+      o[0][f & 1] = MM<T>::mfma(vf[f], p0[f >> 1], o[0][f & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      SM_SLICE(s1, 1, f * 4, f * 4 + 4, p1, rs1, keep1)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (__builtin_amdgcn_ballot_w64(!(rs1[0] + rs1[1] <= kLimit))) redo(1, kt, tb, p1, rs1, keep1);
+    l_run[1] += rs1[0] + rs1[1];
+    // ---- O^T of block 1
+#pragma unroll
+    for (int f = 0; f < 8; ++f) o[1][f & 1] = MM<T>::mfma(vf[f], p1[f >> 1], o[1][f & 1]);
+  }
+  }
+#undef SM_SLICE
+  // ---- epilogue: O^T / l through LDS, one query block after the other, every token row written contiguously ([B][T][H*64])
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    float lr = l_run[qb];
+    lr += __shfl_xor(lr, 32, 64);
+    const float inv = (DROP ? a.inv_keep : 1.0f) / lr;
+    __syncthreads();   // all waves are done with the ring (qb = 1: with the previous block's rows)
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sO[wave][r][d * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] = o[qb][d][e] * inv;
+    __syncthreads();
+    const int row = lane >> 1, half = lane & 1;
+    const int t = qw + qb * 32 + row;
+    if (t < a.T) {
+      T* oh = reinterpret_cast<T*>(a.oh) + ((long)b * a.T + t) * (a.H * 64) + hd * 64 + half * 32;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) oh[j] = (T)sO[wave][row][half * 32 + j];
+    }
+  }
+}
+
 static int lsa_flash_launch(FlashArgs a, int B, int npass, int mm_dtype, bool drop, hipStream_t st) {
   dim3 grid(B * a.H, a.Tp / 128);
   static const bool dma_off = getenv("STEDM_LSA_NODMA") != nullptr;      // A/B: the register-staged form for the single-product modes too
   if (npass == 1 && !dma_off) {
+    static const bool q32 = getenv("STEDM_LSA_Q32") != nullptr;         // A/B: the 32-queries-per-wave DMA kernel (round 2)
+    if (!q32) {
+      const dim3 grid64(B * a.H * ((a.Tp + 255) / 256));
+      if (mm_dtype == STEDM_F16) { if (drop) lsa_flash64_kernel<_Float16, true><<<grid64, 256, 0, st>>>(a); else lsa_flash64_kernel<_Float16><<<grid64, 256, 0, st>>>(a); }
+      else { if (drop) lsa_flash64_kernel<__bf16, true><<<grid64, 256, 0, st>>>(a); else lsa_flash64_kernel<__bf16><<<grid64, 256, 0, st>>>(a); }
+      STEDM_LAUNCH_CHECK();
+      return 0;
+    }
     // (a two-tile ring at four waves per SIMD measured 1-5 % slower than three tiles at three waves)
     const dim3 grid1(B * a.H * (a.Tp / 128));
     if (mm_dtype == STEDM_F16) {

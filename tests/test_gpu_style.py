@@ -101,6 +101,52 @@ def test_lsa_flash_vs_oracle(dev, B, T, heads):
     assert rel(got, ref) < 2e-4
 
 
+@pytest.mark.parametrize("precision,tol", [("f16", 6e-3), ("bf16", 4e-2)])
+def test_lsa_flash_rising_logits_take_the_redo_path(dev, precision, tol):
+    """The 64-queries-per-wave kernel has no per-tile row maximum: it exponentiates relative to a reference fixed on the first tile and redoes
+    a block's tile (reference moved to the tile's maximum) when a row sum shows that the operand type cannot carry the probabilities — fp16:
+    sums above 2^14; bf16: 2^80. Keys whose logits GROW along the sequence (here by ~40 in log2 units from the first tile to the last,
+    past fp16's range, with a jump beyond 2^80 for bf16 at the end) must come out as with a running maximum."""
+    from stedm_amd import ops
+    prec = ops.Precision.parse(precision)
+    B, T, heads = 1, 600, 2
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(B, T, heads, 64, generator=g)
+    kk = torch.randn(B, T, heads, 64, generator=g)
+    v = torch.randn(B, T, heads, 64, generator=g)
+    # every key gets a component along the queries' mean direction that grows with its index: logits rise steadily along the sequence
+    qdir = torch.nn.functional.normalize(q.mean(1, keepdim=True), dim=-1)
+    q = q + 6.0 * qdir
+    ramp = torch.linspace(0.0, 5.0, T).view(1, T, 1, 1)
+    if precision == "bf16":
+        ramp = ramp + (torch.arange(T).view(1, T, 1, 1) >= 560).float() * 14.0        # a late jump past 2^80
+    kk = kk + ramp * qdir
+    qkv = torch.cat([q.reshape(B, T, -1), kk.reshape(B, T, -1), v.reshape(B, T, -1)], dim=-1).contiguous()
+    tau = 1.0
+    # reference on the ROUNDED operands (what qkv_pack hands the kernel: q * tau * log2(e), k, v in the operand type): logits this large
+    # magnify the operands' own rounding, which is not what is tested here
+    dt = torch.float16 if precision == "f16" else torch.bfloat16
+    rq = (q * (tau * math.log2(math.e))).to(dt).double().permute(0, 2, 1, 3)
+    rk, rv = kk.to(dt).double().permute(0, 2, 1, 3), v.to(dt).double().permute(0, 2, 1, 3)
+    dots = torch.matmul(rq, rk.transpose(-1, -2))
+    dots = dots.masked_fill(torch.eye(T, dtype=torch.bool), -1e300)
+    pr = torch.exp2(dots - dots.max(-1, keepdim=True)[0])
+    ref = (torch.matmul(pr, rv) / pr.sum(-1, keepdim=True)).permute(0, 2, 1, 3).reshape(B, T, heads * 64).float()
+    spread = float(dots[..., 500:].max() - dots[..., :64].max())
+    assert spread > (90 if precision == "bf16" else 25), spread                       # the case really leaves the first tile's range
+    Tp = ((T + 127) // 128) * 128
+    mk = lambda shp: (torch.zeros(shp, dtype=torch.int16, device=dev), None)
+    qd, kd, vd = mk((B * heads, Tp, 64)), mk((B * heads, Tp, 64)), mk((B * heads, 64, Tp))
+    ops.qkv_pack(qkv.to(dev), tau * math.log2(math.e), qd, kd, vd, B, T, Tp, heads, prec)
+    od = mk((B, T, heads * 64))
+    ops.lsa_flash(qd, kd, vd, od, B, T, Tp, heads, prec)
+    got = od[0].view(dt).float()
+    assert bool(torch.isfinite(got).all())
+    err = rel(got, ref)
+    print(f"[lsa_flash rising logits {precision}] spread {spread:.0f} (log2 units), max|diff|/std {err:.3e}")
+    assert err < tol
+
+
 def test_agg_blocks_vs_reference_golden(dev, golden):
     import types
     from stedm_amd import style as st

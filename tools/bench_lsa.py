@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""MFMA rate of the LSA flash attention kernel alone (vit_set.py:52-66; T = 4098 tokens = 4096 patches of a 512^2 style image + cls + time
+token, 12 heads of 64): 4 * T^2 * 64 FLOP per head. Random operands. `STEDM_LSA_Q32=1`: the round-2 kernel (32 queries per wave).
+
+    python tools/bench_lsa.py [bf16|f16|parity] [B] [p_drop]
+"""
+import math, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from stedm_amd import ops
+
+
+def main():
+    prec = ops.Precision.parse(sys.argv[1] if len(sys.argv) > 1 else "bf16")
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    p = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+    T, heads = 4098, 12
+    dev = torch.device("cuda:0")
+    torch.set_grad_enabled(False)
+    Tp = (T + 127) // 128 * 128
+    qkv = torch.randn(B, T, 3 * heads * 64, device=dev)
+    i16 = torch.int16
+    lo = prec.npass == 3
+    mk = lambda shp: (torch.zeros(shp, dtype=i16, device=dev), torch.zeros(shp, dtype=i16, device=dev) if lo else None)
+    q, k, v = mk((B * heads, Tp, 64)), mk((B * heads, Tp, 64)), mk((B * heads, 64, Tp))
+    ops.qkv_pack(qkv, 0.125 * math.log2(math.e), q, k, v, B, T, Tp, heads, prec)
+    out = mk((B, T, heads * 64))
+    run = (lambda: ops.lsa_flash_drop(q, k, v, out, B, T, Tp, heads, prec, p, 1234, 1)) if p > 0 else (lambda: ops.lsa_flash(q, k, v, out, B, T, Tp, heads, prec))
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    n = 10
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        run()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / n * 1e3
+    fl = 4.0 * T * T * 64 * heads * B
+    print(f"lsa_flash {prec.label} B={B} T={T} p={p}: {us:.1f} us per call, {fl / us / 1e6:.1f} TFLOP/s ({fl / us / 1e6 / 2500 * 100:.1f} % of the 2.5 PF dense peak)"
+          f"{' [32 queries per wave]' if os.environ.get('STEDM_LSA_Q32') else ''}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
