@@ -137,6 +137,7 @@ def run_steps(ld, xT, cond, unc, warmup, steps, world):
                 sg.reset(n - 1); left = n - 1
             sg.replay(); left -= 1
         torch.cuda.synchronize()
+        run_steps.own_seconds = time.perf_counter() - t0          # this rank's K steps alone (before the closing barrier)
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
@@ -200,6 +201,20 @@ def cpu_baseline(seconds_budget=15.0, gpu_eval=None):
     out = {"value": sample_steps_per_s / 64.0, "unit": "steps/s (bs=64 equivalent)", "cores": cores, "kind": "port",
            "sample": f"{n} CFG denoising steps at batch {Bc} (fp32 torch-CPU oracle, {cores} threads), "
                      f"{el:.1f} s; scaled by {Bc}/64", "sample_steps_per_s": sample_steps_per_s}
+    if cores != 8:
+        # the second run BASELINE.md §4 promises: the same sample on 8 threads, comparable with the 8-vCPU figures of BASELINE.md §2
+        torch.set_num_threads(8)
+        x8 = step(x)
+        n8, t0 = 0, time.perf_counter()
+        while True:
+            x8 = step(x8); n8 += 1
+            el8 = time.perf_counter() - t0
+            if el8 > 6.0 or n8 >= 200:
+                break
+        out["threads8"] = {"value": n8 * Bc / el8 / 64.0, "unit": "steps/s (bs=64 equivalent)", "cores": 8,
+                           "sample": f"{n8} CFG denoising steps at batch {Bc}, 8 threads, {el8:.1f} s; scaled by {Bc}/64",
+                           "sample_steps_per_s": n8 * Bc / el8}
+        torch.set_num_threads(cores)
     return out, deviation
 
 
@@ -263,6 +278,51 @@ def cpu_baseline_train():
     torch.set_grad_enabled(False)
     return {"value": Bc / el, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"1 forward + L1 + backward at batch {Bc} (fp32 torch-CPU oracle under autograd, {cores} threads), {el:.1f} s"}
+
+
+def train_leg_multi(ld, dev, args, xT, cond, rank, world, steps=4, warmup=2):
+    """One data-parallel training step per rank at batch `args.batch` (weak scaling): returns the rank-0 record (max-over-ranks time)."""
+    import torch.distributed as dist
+    from stedm_amd.train import UNetTrainer
+    B = args.batch
+    unet = ld.model.diffusion_model
+    unet.set_precision(args.precision)
+    tr = UNetTrainer(unet, lr=1e-6)
+    g = torch.Generator(device="cpu").manual_seed(5 + rank)                 # every rank its own micro-batch
+    tt = torch.randint(0, 1000, (B,), generator=g).to(dev)
+    tgt = torch.randn(B, 4, 32, 32, generator=g).to(dev)
+    xs, ccs, ctxs = xT, cond["c_concat"][0], cond["c_crossattn"][0]
+    for _ in range(warmup):
+        tr.train_step(xs, ccs, tt, ctxs, tgt)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.train_step(xs, ccs, tt, ctxs, tgt)
+    torch.cuda.synchronize()
+    own = (time.perf_counter() - t0) / steps                                 # this rank alone (its collectives wait for the slowest rank)
+    dist.barrier()
+    torch.cuda.synchronize()
+    dtt = (time.perf_counter() - t0) / steps
+    t = torch.tensor([dtt], dtype=torch.float64, device=dev)
+    every = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(every, torch.tensor([own], dtype=torch.float64, device=dev))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # all ranks hold the same weights after the averaged step (the invariant DDP maintains): compare a checksum
+    w = unet.out[2].weight.detach().float().sum().reshape(1).double()
+    ws = [torch.zeros_like(w) for _ in range(world)]
+    dist.all_gather(ws, w)
+    same = all(float(x.item()) == float(ws[0].item()) for x in ws)
+    dmax = float(t.item())
+    rec = {"ms": round(dmax * 1e3, 2), "steps_per_s": round(1 / dmax, 2), "samples_per_s": round(world * B / dmax, 1), "n_gpus": world,
+           "batch_per_gpu": B, "global_batch": B * world, "ms_by_rank": [round(1e3 * float(x.item()), 2) for x in every],
+           "overlapped_all_reduces": tr.overlap_fires, "buckets": len(tr._sched.bounds), "weights_equal_across_ranks": same,
+           "dtype": unet.precision.label + " forward, bf16 backward operands, fp32 master/optimizer",
+           "what": "forward + L1 + backward with bucketed gradient all-reduce (SUM, 1/N in the optimizer) started from inside the backward, fused "
+                   "AdamW + EMA; weak scaling: every rank its own batch", "loss_rank0": round(float(loss), 4)}
+    del tr
+    return rec
 
 
 def csrc_fingerprint():
@@ -385,7 +445,11 @@ def main():
     xT, cond, unc = synth_inputs(dev, B, rank, world)
     dt, final = run_steps(ld, xT, cond, unc, args.warmup, args.steps, world)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    rank_ms = [round(1e3 * run_steps.own_seconds / args.steps, 3)]
     if world > 1:
+        every = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(every, torch.tensor([run_steps.own_seconds], dtype=torch.float64, device=dev))   # each rank's own K steps (stragglers show here)
+        rank_ms = [round(1e3 * float(x.item()) / args.steps, 3) for x in every]
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         from stedm_amd import parallel as par
         gathered = par.all_gather_samples(final, B * world)                # prediction-side RCCL all-gather of the samples
@@ -444,6 +508,7 @@ def main():
                        "parallelism": f"dp{world} (independent latents, no in-loop collective)"},
             "sample_steps_per_s": round(steps_per_s * B, 1),
             "rccl_ranks": ranks_seen,
+            "ms_per_step_by_rank": rank_ms,
             "step_reference_equivalent_tflops": round(step_tflops, 1),
             "step_reference_equivalent_frac_of_mfma_peak": round(step_tflops / PEAK_MFMA_TFLOPS, 4),
             "step_executed_conv_tflops": round(exec_tflops, 1), "step_executed_frac_of_mfma_peak": round(exec_tflops / PEAK_MFMA_TFLOPS, 4),
@@ -633,6 +698,13 @@ def main():
                                                      "the stricter max|diff|/std reading; same workload, batch and graph as `value`"}
         elif world == 1:
             out["cpu_baseline"] = None
+    if world > 1 and not args.no_train_leg:
+        # the training half of north_star on N ranks (train_diff.py:75-76: DDP over the ranks, one process per GPU): BASELINE config 2's step
+        # at the per-GPU batch — forward + L1 + backward with the gradient buckets all-reduced over RCCL while the backward still runs, then
+        # fused AdamW + EMA on the rank-averaged gradients. Timed like the headline: barrier + synchronize on both sides, max over ranks.
+        tl = train_leg_multi(ld, dev, args, xT, cond, rank, world)
+        if rank == 0:
+            out["train_step"] = tl
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -172,7 +172,8 @@ def test_config2_batch64_bf16_train_step_vs_cpu_oracle(dev, oracle_ns32):
 
 def test_bench_gpus2_self_launch_on_one_device(dev):
     """`python bench.py --gpus 2` starts its two ranks itself (rehearsal: both on cuda:0, gloo in RCCL's place): real model, real
-    steps, max-over-ranks timing, all-gather of the samples, ONE line from rank 0 that says n_gpus 2 and counts both ranks' steps."""
+    steps, max-over-ranks timing, all-gather of the samples, ONE line from rank 0 that says n_gpus 2 and counts both ranks' steps — and the
+    data-parallel training step on the same ranks (overlapped bucketed gradient all-reduce, weights equal across ranks afterwards)."""
     import json
     import os
     import subprocess
@@ -181,13 +182,19 @@ def test_bench_gpus2_self_launch_on_one_device(dev):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env.update(STEDM_BENCH_ONE_DEVICE="1", STEDM_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-                        "--no-parity-leg", "--no-train-leg", "--no-e2e-leg"], env=env, capture_output=True, text=True, timeout=600)
+                        "--no-parity-leg", "--no-e2e-leg", "--batch", "16"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["config"]["global_batch"] == 128 and line["value"] > 0
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["config"]["global_batch"] == 32 and line["value"] > 0
     assert abs(line["value"] - 2 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-2 * line["value"]
+    assert len(line["ms_per_step_by_rank"]) == 2 and max(line["ms_per_step_by_rank"]) <= line["ms_per_step"] + 1e-3
+    # the training half on the same two ranks: per-rank batch, overlapped bucketed all-reduce, identical weights afterwards
+    tl = line["train_step"]
+    assert tl["n_gpus"] == 2 and tl["global_batch"] == 32 and len(tl["ms_by_rank"]) == 2 and tl["ms"] >= max(tl["ms_by_rank"]) - 1e-2
+    assert tl["overlapped_all_reduces"] >= tl["buckets"] and tl["weights_equal_across_ranks"] is True
+    assert abs(tl["samples_per_s"] - 32 / (tl["ms"] * 1e-3)) < 1e-2 * tl["samples_per_s"]
 
 
 _RCCL_ONE_RANK = r"""
