@@ -244,3 +244,24 @@ def test_prepare_batch_matches_the_reference_lines(dev):
     ref[:, :, :, 1] = torch.sum(ref[:, :, :, 1:], dim=-1)
     assert torch.equal(out["segmentation"].cpu(), ref[:, :, :, :2])
     assert torch.equal(out["image"].cpu(), img.permute(0, 2, 3, 1)) and torch.equal(out["style_imgs"].cpu(), sty.permute(0, 1, 3, 4, 2))
+
+
+def test_batch_prefetcher_overlaps_and_preserves_data(dev):
+    """the next predict batch crosses PCIe on a side stream while the compute stream works: same bytes arrive, the compute stream only waits
+    for the copy's event, and two submissions in flight do not alias."""
+    from stedm_amd.parallel import BatchPrefetcher
+    pf = BatchPrefetcher(dev)
+    g = torch.Generator().manual_seed(3)
+    hosts = [{"a": torch.randn(64, 1024, generator=g).pin_memory(), "b": torch.randn(7, 3, generator=g).pin_memory(), "tag": i} for i in range(3)]
+    h0 = pf.submit(hosts[0])
+    h1 = pf.submit(hosts[1])
+    busy = torch.randn(2048, 2048, device=dev)
+    for _ in range(10):
+        busy = busy @ busy * 1e-3           # work on the compute stream while the copies fly
+    d0, d1 = pf.get(h0), pf.get(h1)
+    h2 = pf.submit(hosts[2])
+    d2 = pf.get(h2)
+    torch.cuda.synchronize()
+    for d, hst in zip((d0, d1, d2), hosts):
+        assert d["tag"] == hst["tag"] and torch.equal(d["a"].cpu(), hst["a"]) and torch.equal(d["b"].cpu(), hst["b"])
+    assert d0["a"].data_ptr() != d1["a"].data_ptr()

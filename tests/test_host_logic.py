@@ -200,3 +200,13 @@ def test_oracle_swin_window_attention_matches_per_window_bruteforce():
                     if y < H and x_ < W:
                         got[y, x_, sl] = o[i]
     assert float((got - want[0]).abs().max()) < 1e-5
+
+
+def test_batch_prefetcher_interface_without_gpu():
+    """BatchPrefetcher is GPU plumbing (side stream + event): constructing it without a GPU fails loudly rather than copying on the host."""
+    import pytest
+    from stedm_amd.parallel import BatchPrefetcher
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_sampler.py::test_batch_prefetcher_overlaps_and_preserves_data")
+    with pytest.raises(Exception):
+        BatchPrefetcher("cuda:0")
