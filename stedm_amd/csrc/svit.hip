@@ -925,13 +925,14 @@ __global__ void __launch_bounds__(256, 2) lsa_flash64_kernel(FlashArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[sub][e] -= delta;
   };
-  // elements [E0, E1) of a block's 32 logits: p = exp2(s'), row sum (two chains), and every completed octet packed to the operand type
+  // elements [E0, E1) of a block's 32 logits: p = exp2(s'), row sum, and every completed octet packed to the operand type
   // (dropout: kept probabilities only; l keeps every p — vit_set.py:61-62)
 #define SM_SLICE(S, QB, E0, E1, PH, RS2, KEEP)                                                              \
   _Pragma("unroll") for (int e_ = (E0); e_ < (E1); ++e_) {                                                 \
     const float pv_ = __builtin_amdgcn_exp2f(S[e_ >> 4][e_ & 15]);                                         \
     S[e_ >> 4][e_ & 15] = pv_;                                                                             \
-    RS2[e_ & 1] += pv_;                                                                                    \
+    RS2[0] += pv_;   /* ONE chain: two chains are SLP-packed into v_pk_add_f32, which costs more beside MFMAs (and inline-asm adds   */ \
+                     /* reading a v_exp result miss the transcendental-use wait state: measured wrong sums)                          */ \
     if ((e_ & 7) == 7) {                                                                                   \
       _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                                   \
         float v_ = S[e_ >> 4][(e_ & 15) - 7 + j_];                                                         \
