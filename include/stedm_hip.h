@@ -291,17 +291,19 @@ int stedm_qkv_pack(const void* qkv, int qkv_is16, float qscale, void* q_hi, void
 int stedm_lsa_flash(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi,
                     const void* vt_lo, void* out_hi, void* out_lo, int B, int T, int Tp, int heads, int npass,
                     int mm_dtype, void* stream);
-/* fp8 (OCP e4m3) variant of the LSA attention (BASELINE config 5 "fp8 MFMA attention"; same algorithm as stedm_lsa_flash on
- * v_mfma_f32_32x32x16_fp8_fp8): stedm_qkv_amax finds the per-tensor maxima amax[3] = {max |q * qscale|, max |k|, max |v|} of qkv fp32
- * [M][3*heads*64] (device floats, zeroed inside); stedm_qkv_pack_fp8 writes q8 / k8 [B*heads][Tp][64] and vT8 [B*heads][64][Tp] e4m3
- * bytes scaled by 448 / amax; stedm_lsa_flash_fp8 runs the flash attention on them (P as e4m3 of 256 p; fp32 logits / softmax /
- * accumulation) and writes the 16-bit plane [B][T][heads*64] (type mm_dtype) that to_out consumes. A precision experiment: its
- * deviation from the reference is reported, not asserted at 1e-3. */
-int stedm_qkv_amax(const float* qkv, float qscale, long M, int heads, float* amax, void* stream);
-int stedm_qkv_pack_fp8(const float* qkv, float qscale, const float* amax, void* q8, void* k8, void* vt8, int B, int T, int Tp, int heads,
-                       void* stream);
-int stedm_lsa_flash_fp8(const void* q8, const void* k8, const void* vt8, const float* amax, void* out16, int B, int T, int Tp, int heads,
-                        int mm_dtype, void* stream);
+/* MX-fp8 variant of the LSA attention (BASELINE config 5 "fp8 MFMA attention"; same algorithm as stedm_lsa_flash) on the block-scaled matrix
+ * instruction v_mfma_scale_f32_32x32x64_f8f6f4: OCP e4m3 bytes with one E8M0 power-of-two scale (byte = exponent + 127) per 32 elements of
+ * the contraction. stedm_qkv_pack_mx8: qkv [M][3*heads*64] (fp32, or 16-bit values of type mm_dtype when qkv_is16 — the qkv GEMM's out16) ->
+ *   q8, k8 [B*heads][Tp][64] bytes (q times qscale; rows >= T zero), qs, ks [B*heads][Tp][2]: scale of (token, channel half);
+ *   vt8 [B*heads][64][Tp]: V^T with the keys of every 64-key tile permuted — position 32 s + 16 h + m holds key 32 s + 8 (m >> 2) + 4 h + (m & 3),
+ *   the contraction order of the kernel's P fragment — and vs [B*heads][Tp/32][64]: scale of (32-key sub-tile, channel).
+ * stedm_lsa_flash_mx8 runs the flash attention on them (P as e4m3 of 16 p with the scale 2^-4; fp32 logits / sums / accumulation) and
+ * writes the 16-bit plane [B][T][heads*64] (type mm_dtype) that to_out consumes. One pack pass, no tensor-wide amax. A precision experiment:
+ * its deviation from the reference is reported, not asserted at 1e-3. Tp % 128 == 0. */
+int stedm_qkv_pack_mx8(const void* qkv, int qkv_is16, float qscale, void* q8, void* qs, void* k8, void* ks, void* vt8, void* vs, int B, int T,
+                       int Tp, int heads, int mm_dtype, void* stream);
+int stedm_lsa_flash_mx8(const void* q8, const void* qs, const void* k8, const void* ks, const void* vt8, const void* vs, void* out16, int B,
+                        int T, int Tp, int heads, int mm_dtype, void* stream);
 /* Train-mode dropout of the style ViT — the reference runs S_ZSS_DM.get_input, and with it the agg block, inside the training step with the
  * LightningModule in train mode (networks/s_zss_dm.py:45-60), so nn.Dropout is live at networks/vit_set.py:187 (after pos_embedding,
  * emb_dropout), :43/:62 (attention probabilities), :49 (after to_out's Linear) and :28-30 (after the FeedForward's GELU and after its second

@@ -85,9 +85,8 @@ SIGNATURES = {
     "stedm_lsa_flash": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "stedm_lsa_flash_drop": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, C.c_ulonglong, C.c_uint, _P]),
     "stedm_dropout_rows": (_I, [_P, _P, _P, _P, _P, C.c_long, _F, C.c_ulonglong, C.c_uint, _I, _P]),
-    "stedm_qkv_amax": (_I, [_P, _F, C.c_long, _I, _P, _P]),
-    "stedm_qkv_pack_fp8": (_I, [_P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "stedm_lsa_flash_fp8": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "stedm_qkv_pack_mx8": (_I, [_P, _I, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "stedm_lsa_flash_mx8": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "stedm_svit_head": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _I, _P, C.c_long, _P]),
     "stedm_geglu16": (_I, [_P, _P, _P, C.c_long, _I, _I, _P]),
     "stedm_agg_reduce": (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -1,19 +1,32 @@
-// fp8 (OCP e4m3) variant of the style encoder's LSA flash attention (BASELINE config 5: "fp8 MFMA attention"; vit_set.py:52-67).
-// Same algorithm and tiling as lsa_flash_kernel (svit.hip): one block = 128 queries of one (sample, head), 4 waves x 32 queries,
-// keys / values in tiles of 64, S^T = K Q^T with the softmax in the accumulators, O^T += V^T P^T with P taken from the accumulators
-// as the next MFMA's operand — but every MFMA operand is e4m3 (v_mfma_f32_32x32x16_fp8_fp8, fp32 accumulate):
-//   q, k, v : per-TENSOR scales 448 / amax (amax over the whole [B][T][H*64] block of q / k / v, found by stedm_qkv_amax);
-//   P       : exp2(s - max) in [0, 1] times 256 (e4m3 holds up to 448);
-//   logits, running max / sum, the rescale and the normalisation are fp32, as in every other mode.
-// Half the operand bytes of the 16-bit kernel through HBM, LDS and the registers; the non-scaled fp8 MFMA runs at the bf16 rate
-// (MI355X_MICROARCH.md, Matrix cores), so this is a bandwidth / capacity mode, and a precision experiment: its deviation from the
-// reference is measured and reported (tests/test_gpu_style.py), never asserted at 1e-3.
+// MX-fp8 variant of the style encoder's LSA flash attention (BASELINE config 5: "fp8 MFMA attention"; vit_set.py:52-67) on the block-scaled
+// matrix instruction of gfx950, v_mfma_scale_f32_32x32x64_f8f6f4: OCP e4m3 operands, one E8M0 (power-of-two) scale per 32 elements along
+// the contraction, applied by the hardware — twice the bf16 MFMA rate, a quarter of the MFMA instructions (K = 64 per instruction).
+//   q (times exp(temperature) log2 e), k : scale per (token, half of the 64 head channels);
+//   v                                   : scale per (head channel, 32 keys of a 64-key tile: the 32 keys ONE lane half contracts, see below);
+//   P                                   : 16 p = exp2(s' + 4) in [0, 448], one scale 2^-4 for all (the + 4 rides in the accumulator's
+//                                         initial value together with the softmax reference, so it costs nothing);
+//   logits, row sums, the reference / redo rule and the normalisation are fp32, as in lsa_flash64_kernel (svit.hip), whose structure this
+//   kernel has: 64 queries per wave (two 32-query blocks), K / V^T fragments read once for both blocks, no per-tile row maximum.
+// No tensor-wide amax pass (round 2's per-tensor scales needed one over all of q, k, v before anything could be packed): the scales are local
+// to a 32-element block, so ONE pack pass from the qkv GEMM's 16-bit output writes bytes + scales.
+// Operand lane maps (measured with exact integer data and per-lane scales, tools/probe_mx_fp8*.hip): lane l = (r = l & 31, h = l >> 5) holds,
+// in byte t of its 8 VGPRs, A[row r][k = 32 (t >> 4) + 16 h + (t & 15)] (B alike: B[k][col r]) — the two 16-byte halves of a lane belong to
+// the two 32-wide scale blocks; the scale VGPR (byte 0) of lane (r, h) scales block h = k in [32 h, 32 h + 32) of row r, i.e. bytes
+// 16 h .. 16 h + 15 of BOTH lanes (r, 0) and (r, 1). E8M0 127 = 1.0; C/D as the 32x32 bf16 forms.
+// A precision experiment like every fp8 mode here: its deviation from the reference is measured and reported (tests/test_gpu_style.py),
+// never asserted at 1e-3.
 #include <float.h>
 
 #include "conv_common.hpp"
 using namespace stedm;
 
+#define GLDS16(gptr, lptr)                                                                                  \
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gptr),                   \
+                                   (void __attribute__((address_space(3)))*)(lptr), 16, 0, 0)
+
 namespace {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d) {
   int w = 0;
@@ -22,137 +35,172 @@ __device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d
   return (unsigned)w;
 }
 
-// amax[0..2] = max |q * qscale|, max |k|, max |v| over qkv fp32 [M][3*HD] (HD = heads * 64): float bits of non-negative values order
-// like unsigned integers, so the block maxima are combined with atomicMax on the bit pattern (the result does not depend on order)
-__global__ void __launch_bounds__(256) qkv_amax_kernel(const float* __restrict__ qkv, float qscale, long M, int HD, unsigned* __restrict__ amax) {
-  __shared__ float red[3][4];
-  float m[3] = {0.f, 0.f, 0.f};
-  const long total = M * 3 * HD;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int which = (int)((i % (3 * HD)) / HD);
-    const float v = fabsf(qkv[i]) * (which == 0 ? fabsf(qscale) : 1.0f);
-    m[0] = which == 0 ? fmaxf(m[0], v) : m[0];
-    m[1] = which == 1 ? fmaxf(m[1], v) : m[1];
-    m[2] = which == 2 ? fmaxf(m[2], v) : m[2];
-  }
-#pragma unroll
-  for (int w = 0; w < 3; ++w) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m[w] = fmaxf(m[w], __shfl_xor(m[w], o, 64));
-    if ((threadIdx.x & 63) == 0) red[w][threadIdx.x >> 6] = m[w];
-  }
-  __syncthreads();
-  if (threadIdx.x < 3) {
-    const float v = fmaxf(fmaxf(red[threadIdx.x][0], red[threadIdx.x][1]), fmaxf(red[threadIdx.x][2], red[threadIdx.x][3]));
-    atomicMax(amax + threadIdx.x, __float_as_uint(v));
-  }
+// E8M0 exponent e (byte e + 127) with amax / 2^e <= 448 (e4m3's largest finite value): frexp gives amax / 448 = m 2^ex, m in [0.5, 1)
+__device__ __forceinline__ int mx_exp(float amax) {
+  if (!(amax > 0.f)) return -127;
+  int ex;
+  (void)frexpf(amax * (1.0f / 448.0f), &ex);
+  return ex < -127 ? -127 : (ex > 127 ? 127 : ex);
 }
 
-// qkv fp32 [B][T][3*H*64] -> q8 / k8 [B*H][Tp][64] bytes (rows >= T zero), vT8 [B*H][64][Tp] (cols >= T zero), each scaled by 448 / amax
-__global__ void __launch_bounds__(256) qkv_pack_fp8_kernel(const float* __restrict__ qkv, float qscale, const float* __restrict__ amax,
-                                                           unsigned char* __restrict__ q8, unsigned char* __restrict__ k8, unsigned char* __restrict__ v8,
-                                                           int Tn, int Tp, int H) {
-  __shared__ float sv[64][65];
+// One block = 64 tokens of one (sample, head). q / k: one thread per (token, channel half, tensor); v: one thread per (channel, key half).
+// Position p = 32 s + 16 h + m of a 64-key tile of V^T holds key 32 s + 8 (m >> 2) + 4 h + (m & 3): contraction index p of the PV product is
+// byte t = 16 s + m of lane half h (operand map above), and that byte of the flash kernel's P fragment is accumulator element e = m of
+// sub-tile s, i.e. row (e & 3) + 8 (e >> 2) + 4 h of S^T. A scale block (32 positions) is then one 32-key sub-tile, permuted inside.
+template <typename TI>
+__global__ void __launch_bounds__(256) qkv_pack_mx8_kernel(const TI* __restrict__ qkv, float qscale, unsigned char* __restrict__ q8, unsigned char* __restrict__ qs,
+                                                           unsigned char* __restrict__ k8, unsigned char* __restrict__ ks, unsigned char* __restrict__ v8,
+                                                           unsigned char* __restrict__ vs, int Tn, int Tp, int H) {
+  __shared__ float sx[3][64][65];
   const int bh = blockIdx.x, b = bh / H, hd = bh % H;
-  const int t0 = blockIdx.y * 64;
+  const int kt = blockIdx.y, t0 = kt * 64;
   const int HD = H * 64;
-  const float sq = 448.0f / fmaxf(amax[0], 1e-20f) * qscale, sk = 448.0f / fmaxf(amax[1], 1e-20f), sv_ = 448.0f / fmaxf(amax[2], 1e-20f);
-  for (int i = threadIdx.x; i < 64 * 16; i += 256) {          // one thread = 4 consecutive channels of a token
-    const int tl = i >> 4, d = (i & 15) * 4;
+  for (int i = threadIdx.x; i < 64 * 3 * 16; i += 256) {          // one thread = 4 consecutive channels of (token, tensor)
+    const int c4 = i & 15, w = (i >> 4) % 3, tl = i / 48;
     const int t = t0 + tl;
-    float4 q = make_float4(0.f, 0.f, 0.f, 0.f), k = q, v = q;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (t < Tn) {
-      const float* p = qkv + ((long)b * Tn + t) * (3 * HD) + hd * 64 + d;
-      q = *reinterpret_cast<const float4*>(p); k = *reinterpret_cast<const float4*>(p + HD); v = *reinterpret_cast<const float4*>(p + 2 * HD);
+      const TI* p = qkv + ((long)b * Tn + t) * (3 * HD) + w * HD + hd * 64 + c4 * 4;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = (float)p[u];
     }
-    const long o = ((long)bh * Tp + t) * 64 + d;
-    *reinterpret_cast<unsigned*>(q8 + o) = pack4_fp8(q.x * sq, q.y * sq, q.z * sq, q.w * sq);
-    *reinterpret_cast<unsigned*>(k8 + o) = pack4_fp8(k.x * sk, k.y * sk, k.z * sk, k.w * sk);
-    sv[tl][d] = v.x * sv_; sv[tl][d + 1] = v.y * sv_; sv[tl][d + 2] = v.z * sv_; sv[tl][d + 3] = v.w * sv_;
+    const float m = w == 0 ? qscale : 1.0f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) sx[w][tl][c4 * 4 + u] = v[u] * m;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 64 * 16; i += 256) {          // one thread = 4 consecutive positions of a channel
-    const int d = i >> 4, tl = (i & 15) * 4;
-    // V^T keys permuted inside every group of 16 (order 0-3, 8-11, 4-7, 12-15: the k order of the accumulator-as-operand tile), so that a
-    // lane's 8 values are one contiguous 8-B read: the 4 positions of this thread hold 4 consecutive keys starting at kq
-    const int p16 = tl & 15, kq = (tl & ~15) | ((p16 & 3) | ((p16 & 4) << 1) | ((p16 & 8) >> 1));
-    const long o = ((long)bh * 64 + d) * Tp + t0 + tl;
-    *reinterpret_cast<unsigned*>(v8 + o) = pack4_fp8(sv[kq][d], sv[kq + 1][d], sv[kq + 2][d], sv[kq + 3][d]);
+  {   // q, k rows: (token tl, half hf, tensor w)
+    const int tl = threadIdx.x & 63, hf = (threadIdx.x >> 6) & 1, w = threadIdx.x >> 7;
+    const float* row = &sx[w][tl][hf * 32];
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) amax = fmaxf(amax, fabsf(row[j]));
+    const int e = mx_exp(amax);
+    const float inv = ldexpf(1.0f, -e);
+    uint4 o[2];
+    unsigned* ow = reinterpret_cast<unsigned*>(o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ow[j] = pack4_fp8(row[4 * j] * inv, row[4 * j + 1] * inv, row[4 * j + 2] * inv, row[4 * j + 3] * inv);
+    unsigned char* d8 = (w == 0 ? q8 : k8) + ((long)bh * Tp + t0 + tl) * 64 + hf * 32;
+    reinterpret_cast<uint4*>(d8)[0] = o[0];
+    reinterpret_cast<uint4*>(d8)[1] = o[1];
+    (w == 0 ? qs : ks)[((long)bh * Tp + t0 + tl) * 2 + hf] = (unsigned char)(e + 127);
+  }
+  if (threadIdx.x < 128) {   // v: (channel d, 32-key sub-tile h = scale block)
+    const int d = threadIdx.x & 63, h = threadIdx.x >> 6;
+    float x[32];
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int key = 32 * h + ((j & 15) >> 2) * 8 + 4 * (j >> 4) + (j & 3);        // position 32 h + j
+      x[j] = sx[2][key][d];
+      amax = fmaxf(amax, fabsf(x[j]));
+    }
+    const int e = mx_exp(amax);
+    const float inv = ldexpf(1.0f, -e);
+    uint4 o[2];
+    unsigned* ow = reinterpret_cast<unsigned*>(o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ow[j] = pack4_fp8(x[4 * j] * inv, x[4 * j + 1] * inv, x[4 * j + 2] * inv, x[4 * j + 3] * inv);
+    unsigned char* d8 = v8 + ((long)bh * 64 + d) * Tp + t0 + h * 32;
+    reinterpret_cast<uint4*>(d8)[0] = o[0];
+    reinterpret_cast<uint4*>(d8)[1] = o[1];
+    vs[((long)bh * (Tp / 32) + kt * 2 + h) * 64 + d] = (unsigned char)(e + 127);
   }
 }
 
-struct Flash8Args {
-  const unsigned char *q, *k, *v;
-  const float* amax;
-  void* out;     // [B][T][H*64] 16-bit plane
+struct Mx8Args {
+  const unsigned char *q8, *qs, *k8, *ks, *v8, *vs;
+  void* oh;   // [B][T][H*64], 16-bit
   int T, Tp, H;
 };
 
 template <typename T>
-__global__ void __launch_bounds__(256, 2) lsa_flash_fp8_kernel(Flash8Args a) {
-  constexpr int RS = 80;                           // LDS row stride in bytes (64 + 16 pad)
-  constexpr int TILE = 64 * RS;
+__global__ void __launch_bounds__(256, 2) lsa_flash64_mx8_kernel(Mx8Args a) {
+  constexpr int NBUF = 3, TILE_B = 9216;          // K8 4 KiB | V8^T 4 KiB | K scales 128 B | V scales 128 B | pad
+  constexpr int KS_OFF = 8192, VS_OFF = 8320;
   constexpr int O_BYTES = 4 * 32 * 65 * (int)sizeof(float);
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * TILE > O_BYTES ? 2 * TILE : O_BYTES];
-  unsigned char* sK = lds_raw;
-  unsigned char* sV = lds_raw + TILE;
-  float (*sO)[32][65] = reinterpret_cast<float (*)[32][65]>(lds_raw);
-  // XCD-aware block -> (sample-head, query tile): the blocks of one sample-head all run on one XCD (block id mod 8), so its K / V^T stay in
-  // that XCD's L2 (see lsa_flash_dma_kernel, svit.hip)
+  constexpr int LDS_B = NBUF * TILE_B > O_BYTES ? NBUF * TILE_B : O_BYTES;
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[LDS_B];
+  float (*sO)[32][65] = reinterpret_cast<float (*)[32][65]>(ring);
   int bh, qtile;
   {
-    const int nbh = gridDim.x, nq = gridDim.y, L = blockIdx.x + nbh * blockIdx.y;      // dispatch order of the 2-D grid
+    const int nq = (a.Tp + 255) / 256, nbh = gridDim.x / nq, L = blockIdx.x;
     if ((nbh & 7) == 0) { const int x = L & 7, j = L >> 3; bh = x + 8 * (j / nq); qtile = j % nq; }
-    else { bh = blockIdx.x; qtile = blockIdx.y; }
+    else { bh = L % nbh; qtile = L / nbh; }
   }
   const int b = bh / a.H, hd = bh % a.H;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int q0 = qtile * 128 + wave * 32;
-  const float s_logit = (fmaxf(a.amax[0], 1e-20f) / 448.0f) * (fmaxf(a.amax[1], 1e-20f) / 448.0f);   // fp8 q.k -> log2-domain logit
-  const float s_out = (fmaxf(a.amax[2], 1e-20f) / 448.0f) / 256.0f;                                   // (256 P) (448 / amax_v v) -> P v
+  const int qw = qtile * 256 + wave * 64;
 
-  long qf[4];     // the wave's 32 queries: lane (r, h) holds q[q0 + r][16 ks + 8 h .. + 7] for k-step ks
+  v8i qf[2];
+  int qsc[2];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const long*>(a.q + ((long)bh * a.Tp + q0 + r) * 64 + ks * 16 + h * 8);
-
-  f32x16 o[2];
-#pragma unroll
-  for (int d = 0; d < 2; ++d)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-  const int qidx = q0 + r;
-  const int ntiles = (a.T + 63) / 64;
-  // 64 x 64 B per tile and operand: 256 threads x 16 B; next tile prefetched through registers
-  const int frow = tid >> 2, fc = tid & 3;
-  uint4 kr, vr;
-#define FETCH8(KT)                                                                                             \
-  {                                                                                                            \
-    kr = *reinterpret_cast<const uint4*>(a.k + ((long)bh * a.Tp + (KT) * 64 + frow) * 64 + fc * 16);           \
-    vr = *reinterpret_cast<const uint4*>(a.v + ((long)bh * 64 + frow) * a.Tp + (KT) * 64 + fc * 16);           \
+  for (int qb = 0; qb < 2; ++qb) {
+    int row = qw + qb * 32 + r;
+    row = row < a.Tp ? row : a.Tp - 1;
+    const uint4* p = reinterpret_cast<const uint4*>(a.q8 + ((long)bh * a.Tp + row) * 64 + h * 16);      // pieces h and 2 + h
+    const uint4 x0 = p[0], x1 = p[2];
+    qf[qb] = v8i{(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+    qsc[qb] = a.qs[((long)bh * a.Tp + row) * 2 + h];
   }
-  FETCH8(0)
-  for (int kt = 0; kt < ntiles; ++kt) {
-    __syncthreads();
-    *reinterpret_cast<uint4*>(sK + frow * RS + fc * 16) = kr;
-    *reinterpret_cast<uint4*>(sV + frow * RS + fc * 16) = vr;
-    __syncthreads();
-    if (kt + 1 < ntiles) FETCH8(kt + 1)
-    f32x16 s[2];
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) s[sub][e] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const long kf = *reinterpret_cast<const long*>(sK + (sub * 32 + r) * RS + ks * 16 + h * 8);
-        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(kf, qf[ks], s[sub], 0, 0, 0);
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) s[sub][e] *= s_logit;
+  // DMA sources of this wave: chunk `wave` (16 rows) of the K8 tile and of the V8^T tile; lane l fills physical 16-B piece l & 3 of row
+  // 16 wave + (l >> 2) with logical piece (l & 3) ^ ((row >> 2) & 3): conflict-free ds_read_b128 fragments on 64-B rows
+  const unsigned char* const kbase = a.k8 + (long)bh * a.Tp * 64;
+  const unsigned char* const vbase = a.v8 + (long)bh * 64 * a.Tp;
+  const unsigned char* const ksbase = a.ks + (long)bh * a.Tp * 2;
+  const unsigned char* const vsbase = a.vs + (long)bh * (a.Tp / 32) * 64;
+  unsigned koff, voff;
+  {
+    const int row = 16 * wave + (lane >> 2);
+    const int lg = (lane & 3) ^ ((row >> 2) & 3);
+    koff = row * 64 + lg * 16;
+    voff = row * a.Tp + lg * 16;
+  }
+  auto issue = [&](int kt) __attribute__((always_inline)) {
+    unsigned char* dst = ring + (kt % NBUF) * TILE_B;
+    GLDS16(kbase + (long)kt * 4096 + koff, dst + wave * 1024);
+    GLDS16(vbase + (long)kt * 64 + voff, dst + 4096 + wave * 1024);
+    if (wave == 0 && lane < 16) {
+      // K scales [64 keys][2] = 128 B, then V scales [2 halves][64 channels] = 128 B: 16 lanes x 16 B, contiguous in the tile
+      const unsigned char* src = lane < 8 ? ksbase + (long)kt * 128 + lane * 16 : vsbase + (long)kt * 128 + (lane - 8) * 16;
+      GLDS16(src, dst + KS_OFF);
     }
-    if ((q0 >> 6) == kt) {      // the diagonal: a token never attends to itself (vit_set.py:58-60)
+  };
+  f32x16 o[2][2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[qb][d][e] = 0.f;
+  // accumulator start of S^T: 4 - m_ref (16 p is what the bytes carry; m_ref: the softmax reference of lsa_flash64_kernel)
+  constexpr float kPShift = 4.0f;
+  constexpr int kPScale = 127 - 4;
+  f32x16 cinit[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cinit[qb][e] = kPShift;
+  float l_run[2] = {0.f, 0.f}, m_ref[2] = {0.f, 0.f};
+  const int ntiles = (a.T + 63) / 64;
+  // fragment byte offsets in a tile: K row = 32 sub + r, V^T row = 32 dblk + r; logical 16-B pieces h and 2 + h (operand map above)
+  unsigned kb[2][2], vb[2][2], ksb[2], vsb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = i * 32 + r;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      kb[i][j] = row * 64 + (((h + 2 * j) ^ ((row >> 2) & 3)) << 4);
+      vb[i][j] = 4096 + row * 64 + (((h + 2 * j) ^ ((row >> 2) & 3)) << 4);
+    }
+    ksb[i] = KS_OFF + row * 2 + h;
+    vsb[i] = VS_OFF + h * 64 + row;
+  }
+  auto masks = [&](f32x16 (&s)[2], const int qb, const int kt) __attribute__((always_inline)) {
+    const int q0 = qw + qb * 32, qidx = q0 + r;
+    if ((q0 >> 6) == kt) {
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -166,61 +214,111 @@ __global__ void __launch_bounds__(256, 2) lsa_flash_fp8_kernel(Flash8Args a) {
         for (int e = 0; e < 16; ++e)
           if (kt * 64 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= a.T) s[sub][e] = -INFINITY;
     }
+  };
+  auto move_ref = [&](f32x16 (&s)[2], const int qb, const bool first) __attribute__((always_inline)) {
     float mx = s[0][0];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[sub][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    float rs = 0.f;
+    mx -= kPShift;                                 // (the logits arrive with the + 4 of the byte scale)
+    const float delta = first ? fmaxf(mx, -30000.f) : fmaxf(mx, 0.f);
+    const float alpha = __builtin_amdgcn_exp2f(-delta);
+    m_ref[qb] += delta;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cinit[qb][e] = kPShift - m_ref[qb];
+    l_run[qb] *= alpha;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[qb][d][e] *= alpha;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float pv = __builtin_amdgcn_exp2f(s[sub][e] - m_new);
-        s[sub][e] = pv;
-        rs += pv;
-      }
-    rs += __shfl_xor(rs, 32, 64);
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
-    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+      for (int e = 0; e < 16; ++e) s[sub][e] -= delta;
+  };
+  // p' = 16 p = exp2(s'), row sum, bytes: element t = 16 sub + e of a lane is key 32 sub + 8 (e >> 2) + 4 h + (e & 3) = position
+  // 32 sub + 16 h + e of the tile's V^T image = the contraction index of byte t of the lane's B fragment
+  auto softmax = [&](f32x16 (&s)[2], v8i& p8, float& rs) __attribute__((always_inline)) {
 #pragma unroll
-      for (int d = 0; d < 2; ++d)
+    for (int n = 0; n < 8; ++n) {
+      float pv[4];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+      for (int u = 0; u < 4; ++u) { pv[u] = __builtin_amdgcn_exp2f(s[n >> 2][(n & 3) * 4 + u]); rs += pv[u]; }
+      p8[n] = (int)pack4_fp8(pv[0], pv[1], pv[2], pv[3]);
     }
-    // ---- O^T += V^T P^T: P registers 8 s2 .. 8 s2 + 7 of a 32-key sub-tile are the 8 k-slots of k-step s2 (same k permutation as the
-    // 16-bit kernel: slot j of lane half h is key 16 s2 + 8 (j >> 2) + 4 h + (j & 3)), V^T is gathered in that order
+  };
+  // no per-tile row maximum: the row sum of 16 p bounds every byte (e4m3 carries 448); beyond kLimit the tile is redone with the reference moved
+  constexpr float kLimit = 448.0f;     // (a sum of 16 p that fits e4m3 bounds each of them; a false alarm redoes the tile unchanged)
+  v8i kf[2], vf[2];
+  int ksc[2], vsc[2];
+  auto qk = [&](f32x16 (&s)[2], const int qb) __attribute__((always_inline)) {
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
+      s[sub] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf[sub], qf[qb], cinit[qb], 0, 0, 0, ksc[sub], 0, qsc[qb]);
+  };
+  auto load8 = [&](const unsigned char* tb, const unsigned (&off)[2]) __attribute__((always_inline)) {
+    const uint4 x0 = *reinterpret_cast<const uint4*>(tb + off[0]);
+    const uint4 x1 = *reinterpret_cast<const uint4*>(tb + off[1]);
+    return v8i{(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+  };
+
+  issue(0);
+  if (ntiles > 1) issue(1);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    // this wave's share of tile kt has landed (its newest DMAs, 2 or — wave 0 — 3, belong to tile kt + 1 when there is one)
+    if (kt + 1 < ntiles) { if (wave == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // tile kt is complete in LDS; every wave is done with tile kt - 1, whose buffer takes the next tile fetched
+    if (kt + NBUF - 1 < ntiles) issue(kt + NBUF - 1);
+    const unsigned char* tb = ring + (kt % NBUF) * TILE_B;
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const unsigned plo = pack4_fp8(s[sub][8 * s2] * 256.f, s[sub][8 * s2 + 1] * 256.f, s[sub][8 * s2 + 2] * 256.f, s[sub][8 * s2 + 3] * 256.f);
-        const unsigned phi = pack4_fp8(s[sub][8 * s2 + 4] * 256.f, s[sub][8 * s2 + 5] * 256.f, s[sub][8 * s2 + 6] * 256.f, s[sub][8 * s2 + 7] * 256.f);
-        const long pf = (long)(((unsigned long)phi << 32) | plo);
+    for (int i = 0; i < 2; ++i) { kf[i] = load8(tb, kb[i]); ksc[i] = tb[ksb[i]]; }
+    f32x16 s0[2], s1[2];
+    qk(s0, 0);
+    qk(s1, 1);
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          const long vf = *reinterpret_cast<const long*>(sV + (d * 32 + r) * RS + sub * 32 + s2 * 16 + h * 8);
-          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vf, pf, o[d], 0, 0, 0);
-        }
-      }
+    for (int i = 0; i < 2; ++i) { vf[i] = load8(tb, vb[i]); vsc[i] = tb[vsb[i]]; }
+    v8i p0, p1;
+    float rs0 = 0.f, rs1 = 0.f;
+    // ---- block 0 (block 1's S^T MFMAs run beneath its exponentials)
+    masks(s0, 0, kt);
+    if (kt == 0) move_ref(s0, 0, true);
+    softmax(s0, p0, rs0);
+    if (__builtin_amdgcn_ballot_w64(!(rs0 <= kLimit))) {
+      qk(s0, 0); masks(s0, 0, kt); move_ref(s0, 0, false); rs0 = 0.f; softmax(s0, p0, rs0);
+    }
+    l_run[0] += rs0;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) o[0][d] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[d], p0, o[0][d], 0, 0, 0, vsc[d], 0, kPScale);
+    // ---- block 1 (block 0's O^T MFMAs run beneath its exponentials)
+    masks(s1, 1, kt);
+    if (kt == 0) move_ref(s1, 1, true);
+    softmax(s1, p1, rs1);
+    if (__builtin_amdgcn_ballot_w64(!(rs1 <= kLimit))) {
+      qk(s1, 1); masks(s1, 1, kt); move_ref(s1, 1, false); rs1 = 0.f; softmax(s1, p1, rs1);
+    }
+    l_run[1] += rs1;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) o[1][d] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[d], p1, o[1][d], 0, 0, 0, vsc[d], 0, kPScale);
   }
-#undef FETCH8
-  __syncthreads();
-  const float inv = s_out / l_run;
+  // ---- epilogue: O^T / l through LDS, one query block after the other ([B][T][H*64]); l counted 16 p, O the true p
 #pragma unroll
-  for (int d = 0; d < 2; ++d)
+  for (int qb = 0; qb < 2; ++qb) {
+    float lr = l_run[qb];
+    lr += __shfl_xor(lr, 32, 64);
+    const float inv = 16.0f / lr;
+    __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 16; ++e) sO[wave][r][d * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] = o[d][e] * inv;
-  __syncthreads();
-  {
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sO[wave][r][d * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] = o[qb][d][e] * inv;
+    __syncthreads();
     const int row = lane >> 1, half = lane & 1;
-    const int t = q0 + row;
+    const int t = qw + qb * 32 + row;
     if (t < a.T) {
-      T* oh = reinterpret_cast<T*>(a.out) + ((long)b * a.T + t) * (a.H * 64) + hd * 64 + half * 32;
+      T* oh = reinterpret_cast<T*>(a.oh) + ((long)b * a.T + t) * (a.H * 64) + hd * 64 + half * 32;
 #pragma unroll
       for (int j = 0; j < 32; ++j) oh[j] = (T)sO[wave][row][half * 32 + j];
     }
@@ -229,36 +327,32 @@ __global__ void __launch_bounds__(256, 2) lsa_flash_fp8_kernel(Flash8Args a) {
 
 }  // namespace
 
-extern "C" int stedm_qkv_amax(const float* qkv, float qscale, long M, int heads, float* amax, void* stream) {
-  STEDM_CHECK_ARG(qkv && amax && M > 0 && heads > 0, "qkv_amax: bad args");
-  hipStream_t st = as_stream(stream);
-  STEDM_HIP_TRY(hipMemsetAsync(amax, 0, 3 * sizeof(float), st));
-  const long total = M * 3 * heads * 64;
-  const int grid = (int)((total + 256 * 16 - 1) / (256 * 16) < 2048 ? (total + 256 * 16 - 1) / (256 * 16) : 2048);
-  qkv_amax_kernel<<<grid, 256, 0, st>>>(qkv, qscale, M, heads * 64, reinterpret_cast<unsigned*>(amax));
-  STEDM_LAUNCH_CHECK();
-  return 0;
-}
-
-extern "C" int stedm_qkv_pack_fp8(const float* qkv, float qscale, const float* amax, void* q8, void* k8, void* vt8, int B, int T, int Tp, int heads,
-                                  void* stream) {
-  STEDM_CHECK_ARG(qkv && amax && q8 && k8 && vt8, "qkv_pack_fp8: null pointer");
-  STEDM_CHECK_ARG(Tp % 128 == 0 && Tp >= T, "qkv_pack_fp8: Tp must be a multiple of 128 and >= T");
+extern "C" int stedm_qkv_pack_mx8(const void* qkv, int qkv_is16, float qscale, void* q8, void* qs, void* k8, void* ks, void* vt8, void* vs, int B, int T,
+                                  int Tp, int heads, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(qkv && q8 && qs && k8 && ks && vt8 && vs, "qkv_pack_mx8: null pointer");
+  STEDM_CHECK_ARG(B > 0 && heads > 0 && T > 1 && Tp >= T && Tp % 128 == 0, "qkv_pack_mx8: need Tp %% 128 == 0, Tp >= T > 1");
   dim3 grid(B * heads, Tp / 64);
-  qkv_pack_fp8_kernel<<<grid, 256, 0, as_stream(stream)>>>(qkv, qscale, amax, (unsigned char*)q8, (unsigned char*)k8, (unsigned char*)vt8, T, Tp, heads);
+  hipStream_t st = as_stream(stream);
+  auto* p8 = reinterpret_cast<unsigned char*>(q8);
+  auto *pqs = reinterpret_cast<unsigned char*>(qs), *pk8 = reinterpret_cast<unsigned char*>(k8), *pks = reinterpret_cast<unsigned char*>(ks);
+  auto *pv8 = reinterpret_cast<unsigned char*>(vt8), *pvs = reinterpret_cast<unsigned char*>(vs);
+  if (!qkv_is16) qkv_pack_mx8_kernel<float><<<grid, 256, 0, st>>>(reinterpret_cast<const float*>(qkv), qscale, p8, pqs, pk8, pks, pv8, pvs, T, Tp, heads);
+  else if (mm_dtype == STEDM_F16) qkv_pack_mx8_kernel<_Float16><<<grid, 256, 0, st>>>(reinterpret_cast<const _Float16*>(qkv), qscale, p8, pqs, pk8, pks, pv8, pvs, T, Tp, heads);
+  else qkv_pack_mx8_kernel<__bf16><<<grid, 256, 0, st>>>(reinterpret_cast<const __bf16*>(qkv), qscale, p8, pqs, pk8, pks, pv8, pvs, T, Tp, heads);
   STEDM_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int stedm_lsa_flash_fp8(const void* q8, const void* k8, const void* vt8, const float* amax, void* out16, int B, int T, int Tp, int heads,
-                                   int mm_dtype, void* stream) {
-  STEDM_CHECK_ARG(q8 && k8 && vt8 && amax && out16, "lsa_flash_fp8: null pointer");
-  STEDM_CHECK_ARG(Tp % 128 == 0 && Tp >= T && T > 1, "lsa_flash_fp8: need Tp %% 128 == 0, Tp >= T > 1");
-  STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "lsa_flash_fp8: bad mm_dtype %d (type of the output plane)", mm_dtype);
-  Flash8Args a{(const unsigned char*)q8, (const unsigned char*)k8, (const unsigned char*)vt8, amax, out16, T, Tp, heads};
-  dim3 grid(B * heads, Tp / 128);
-  if (mm_dtype == STEDM_F16) lsa_flash_fp8_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(a);
-  else lsa_flash_fp8_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(a);
+extern "C" int stedm_lsa_flash_mx8(const void* q8, const void* qs, const void* k8, const void* ks, const void* vt8, const void* vs, void* out16, int B,
+                                   int T, int Tp, int heads, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(q8 && qs && k8 && ks && vt8 && vs && out16, "lsa_flash_mx8: null pointer");
+  STEDM_CHECK_ARG(Tp % 128 == 0 && Tp >= T && T > 1, "lsa_flash_mx8: need Tp %% 128 == 0, Tp >= T > 1");
+  Mx8Args a{reinterpret_cast<const unsigned char*>(q8), reinterpret_cast<const unsigned char*>(qs), reinterpret_cast<const unsigned char*>(k8),
+            reinterpret_cast<const unsigned char*>(ks), reinterpret_cast<const unsigned char*>(vt8), reinterpret_cast<const unsigned char*>(vs),
+            out16, T, Tp, heads};
+  const dim3 grid(B * heads * ((Tp + 255) / 256));
+  if (mm_dtype == STEDM_F16) lsa_flash64_mx8_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(a);
+  else lsa_flash64_mx8_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(a);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

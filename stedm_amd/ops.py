@@ -543,21 +543,16 @@ def dropout_rows(src: torch.Tensor, p: float, seed: int, site: int, prec: Precis
                                    prec.mm_dtype, _stream()), "stedm_dropout_rows")
 
 
-def qkv_amax(qkv: torch.Tensor, qscale: float, heads: int, amax: torch.Tensor) -> torch.Tensor:
-    """amax[3] = per-tensor maxima of |q * qscale|, |k|, |v| (device floats) for the fp8 attention."""
-    _chk(qkv, name="qkv")
-    check(lib().stedm_qkv_amax(qkv.data_ptr(), float(qscale), qkv.numel() // qkv.shape[-1], heads, amax.data_ptr(), _stream()), "stedm_qkv_amax")
-    return amax
+def qkv_pack_mx8(qkv, qscale: float, q8, qs, k8, ks, vt8, vs, B: int, T: int, Tp: int, heads: int, prec: Precision):
+    """qkv (fp32 rows, or int16 rows holding the qkv GEMM's 16-bit output) -> MX-fp8 operands of lsa_flash_mx8: e4m3 bytes + one E8M0 scale per
+    32 elements (include/stedm_hip.h)."""
+    check(lib().stedm_qkv_pack_mx8(qkv.data_ptr(), int(qkv.dtype == torch.int16), float(qscale), q8.data_ptr(), qs.data_ptr(), k8.data_ptr(), ks.data_ptr(),
+                                   vt8.data_ptr(), vs.data_ptr(), B, T, Tp, heads, prec.mm_dtype, _stream()), "stedm_qkv_pack_mx8")
 
 
-def qkv_pack_fp8(qkv, qscale: float, amax, q8, k8, vt8, B: int, T: int, Tp: int, heads: int):
-    check(lib().stedm_qkv_pack_fp8(qkv.data_ptr(), float(qscale), amax.data_ptr(), q8.data_ptr(), k8.data_ptr(), vt8.data_ptr(), B, T, Tp, heads, _stream()),
-          "stedm_qkv_pack_fp8")
-
-
-def lsa_flash_fp8(q8, k8, vt8, amax, out16, B: int, T: int, Tp: int, heads: int, prec: Precision):
-    check(lib().stedm_lsa_flash_fp8(q8.data_ptr(), k8.data_ptr(), vt8.data_ptr(), amax.data_ptr(), out16.data_ptr(), B, T, Tp, heads, prec.mm_dtype,
-                                    _stream()), "stedm_lsa_flash_fp8")
+def lsa_flash_mx8(q8, qs, k8, ks, vt8, vs, out16, B: int, T: int, Tp: int, heads: int, prec: Precision):
+    check(lib().stedm_lsa_flash_mx8(q8.data_ptr(), qs.data_ptr(), k8.data_ptr(), ks.data_ptr(), vt8.data_ptr(), vs.data_ptr(), out16.data_ptr(), B, T, Tp,
+                                    heads, prec.mm_dtype, _stream()), "stedm_lsa_flash_mx8")
 
 
 def svit_head(x, pool: int, c_old, ln_w, ln_b, eps, wt, bias, out, ws: Optional[torch.Tensor] = None):

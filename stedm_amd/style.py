@@ -199,8 +199,8 @@ class sViT(nn.Module):
         if p_emb > 0:
             ops.dropout_rows(x, p_emb, seed, self.SITE_EMB, prec, out=x)
         ln = (self._buf("ln.hi", (M, dim), i16), self._buf("ln.lo", (M, dim), i16) if lo_ok else None)
-        # single-product modes without the fp8 attention: to_qkv writes its 16-bit output only (the attention's operands are 16-bit anyway)
-        q16 = prec.npass == 1 and not prec.attn_fp8
+        # single-product modes: to_qkv writes its 16-bit output only (the attention's operands are 16-bit — or MX-fp8 packed from them — anyway)
+        q16 = prec.npass == 1
         qkv = self._buf("qkv16", (M, 3 * heads * 64), i16) if q16 else self._buf("qkv", (M, 3 * heads * 64))
         mk = lambda nm, shp: (self._buf(nm + ".hi", shp, i16, zero=True), self._buf(nm + ".lo", shp, i16, zero=True) if lo_ok else None)
         q, k, vt = mk("q", (B * heads, Tp, 64)), mk("k", (B * heads, Tp, 64)), mk("vt", (B * heads, 64, Tp))
@@ -212,12 +212,12 @@ class sViT(nn.Module):
                 self._gemm(ln, P[f"qkv{l}"], M, 3 * heads * 64, out16=(qkv, None))
             else:
                 self._gemm(ln, P[f"qkv{l}"], M, 3 * heads * 64, out=qkv)
-            if prec.attn_fp8:     # e4m3 operands with per-tensor scales (BASELINE config 5)
-                amax = self._buf("amax", (4,))
-                q8, k8, v8 = (self._buf(nm, shp, torch.uint8) for nm, shp in (("q8", (B * heads, Tp, 64)), ("k8", (B * heads, Tp, 64)), ("vt8", (B * heads, 64, Tp))))
-                ops.qkv_amax(qkv, P[f"tau{l}"], heads, amax)
-                ops.qkv_pack_fp8(qkv, P[f"tau{l}"], amax, q8, k8, v8, B, T, Tp, heads)
-                ops.lsa_flash_fp8(q8, k8, v8, amax, att[0], B, T, Tp, heads, prec)
+            if prec.attn_fp8:     # MX-fp8 operands: e4m3 bytes + one E8M0 scale per 32 elements (BASELINE config 5)
+                u8 = torch.uint8
+                q8, k8, v8 = (self._buf(nm, shp, u8, zero=True) for nm, shp in (("q8", (B * heads, Tp, 64)), ("k8", (B * heads, Tp, 64)), ("vt8", (B * heads, 64, Tp))))
+                qs, ks, vs = (self._buf(nm, shp, u8, zero=True) for nm, shp in (("qs8", (B * heads, Tp, 2)), ("ks8", (B * heads, Tp, 2)), ("vs8", (B * heads, Tp // 32, 64))))
+                ops.qkv_pack_mx8(qkv, P[f"tau{l}"], q8, qs, k8, ks, v8, vs, B, T, Tp, heads, prec)
+                ops.lsa_flash_mx8(q8, qs, k8, ks, v8, vs, att[0], B, T, Tp, heads, prec)
             elif p_drop > 0:
                 ops.qkv_pack(qkv, P[f"tau{l}"], q, k, vt, B, T, Tp, heads, prec)
                 ops.lsa_flash_drop(q, k, vt, att, B, T, Tp, heads, prec, p_drop, seed, 8 * l + self.SITE_ATTN)
