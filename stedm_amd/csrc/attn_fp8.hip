@@ -51,27 +51,42 @@ template <typename TI>
 __global__ void __launch_bounds__(256) qkv_pack_mx8_kernel(const TI* __restrict__ qkv, float qscale, unsigned char* __restrict__ q8, unsigned char* __restrict__ qs,
                                                            unsigned char* __restrict__ k8, unsigned char* __restrict__ ks, unsigned char* __restrict__ v8,
                                                            unsigned char* __restrict__ vs, int Tn, int Tp, int H) {
-  __shared__ float sx[3][64][65];
+  __shared__ float sv[64][65];          // the tile's V rows (token-major) for the transposed gather; q / k never touch LDS
   const int bh = blockIdx.x, b = bh / H, hd = bh % H;
   const int kt = blockIdx.y, t0 = kt * 64;
   const int HD = H * 64;
-  for (int i = threadIdx.x; i < 64 * 3 * 16; i += 256) {          // one thread = 4 consecutive channels of (token, tensor)
-    const int c4 = i & 15, w = (i >> 4) % 3, tl = i / 48;
+  typedef TI VI8 __attribute__((ext_vector_type(8)));
+  {   // V tile -> LDS: one thread = 16 consecutive channels of a token (two 8-element loads)
+    const int tl = threadIdx.x >> 2, c16 = (threadIdx.x & 3) * 16;
     const int t = t0 + tl;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = 0.f;
     if (t < Tn) {
-      const TI* p = qkv + ((long)b * Tn + t) * (3 * HD) + w * HD + hd * 64 + c4 * 4;
+      const TI* p = qkv + ((long)b * Tn + t) * (3 * HD) + 2 * HD + hd * 64 + c16;
+      const VI8 x0 = *reinterpret_cast<const VI8*>(p), x1 = *reinterpret_cast<const VI8*>(p + 8);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = (float)p[u];
+      for (int u = 0; u < 8; ++u) { v[u] = (float)x0[u]; v[8 + u] = (float)x1[u]; }
     }
-    const float m = w == 0 ? qscale : 1.0f;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) sx[w][tl][c4 * 4 + u] = v[u] * m;
+    for (int u = 0; u < 16; ++u) sv[tl][c16 + u] = v[u];
   }
-  __syncthreads();
-  {   // q, k rows: (token tl, half hf, tensor w)
+  {   // q, k rows straight from global: (token tl, channel half hf, tensor w): 32 contiguous values
     const int tl = threadIdx.x & 63, hf = (threadIdx.x >> 6) & 1, w = threadIdx.x >> 7;
-    const float* row = &sx[w][tl][hf * 32];
+    const int t = t0 + tl;
+    float row[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) row[j] = 0.f;
+    if (t < Tn) {
+      const TI* p = qkv + ((long)b * Tn + t) * (3 * HD) + w * HD + hd * 64 + hf * 32;
+      const float m = w == 0 ? qscale : 1.0f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const VI8 x = *reinterpret_cast<const VI8*>(p + 8 * g);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) row[8 * g + u] = (float)x[u] * m;
+      }
+    }
     float amax = 0.f;
 #pragma unroll
     for (int j = 0; j < 32; ++j) amax = fmaxf(amax, fabsf(row[j]));
@@ -86,6 +101,7 @@ __global__ void __launch_bounds__(256) qkv_pack_mx8_kernel(const TI* __restrict_
     reinterpret_cast<uint4*>(d8)[1] = o[1];
     (w == 0 ? qs : ks)[((long)bh * Tp + t0 + tl) * 2 + hf] = (unsigned char)(e + 127);
   }
+  __syncthreads();
   if (threadIdx.x < 128) {   // v: (channel d, 32-key sub-tile h = scale block)
     const int d = threadIdx.x & 63, h = threadIdx.x >> 6;
     float x[32];
@@ -93,7 +109,7 @@ __global__ void __launch_bounds__(256) qkv_pack_mx8_kernel(const TI* __restrict_
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
       const int key = 32 * h + ((j & 15) >> 2) * 8 + 4 * (j >> 4) + (j & 3);        // position 32 h + j
-      x[j] = sx[2][key][d];
+      x[j] = sv[key][d];
       amax = fmaxf(amax, fabsf(x[j]));
     }
     const int e = mx_exp(amax);
