@@ -627,6 +627,23 @@ def main():
                 del hb
             except RuntimeError as e:            # no pinned memory on this box: say so instead of a number
                 out["sampling_run"]["h2d"] = {"error": str(e)[:120]}
+            # BASELINE config 5's numerics mode for the style encoder: MX-fp8 attention operands (v_mfma_scale_f32_32x32x64_f8f6f4) beside the
+            # bf16 attention, same sViT, same B x 4 x 512^2 style images; deviations of both modes: tests/test_gpu_style.py
+            try:
+                sty = batch["style_imgs"]
+                tms = {}
+                for mode in (args.precision, "fp8"):
+                    zm.agg_block.set_precision(mode)
+                    zm.agg_block(sty)
+                    torch.cuda.synchronize(); ts0 = time.perf_counter()
+                    zm.agg_block(sty)
+                    torch.cuda.synchronize(); tms[mode] = time.perf_counter() - ts0
+                zm.agg_block.set_precision(args.precision)
+                out["sampling_run"]["svit_style_seconds"] = {args.precision: round(tms[args.precision], 4), "mx_fp8_attention": round(tms["fp8"], 4),
+                                                             "what": f"sViT forward over {B} x 4 style images of 512^2 (4098 tokens, 6 layers x 12 heads): "
+                                                                     "bf16 attention vs MX-fp8 attention operands (everything else bf16)"}
+            except Exception as e:      # never lose the line over the side measurement
+                out["sampling_run"]["svit_style_seconds"] = {"error": str(e)[:160]}
             # the default aggregator of the reference's config (conf/config_diff.yaml:16 style_agg: linear): Swin-V2-T over the same B x 4 style
             # images + the Agg_Linear MLP (networks/agg_blocks.py:24-33) — the style encoding that replaces the sViT's in predict_step
             zs = S_ZSS_DM("swin_v2_t", SimpleNamespace(name="mp", num_patches=4), SimpleNamespace(name="linear"), {"data": {"patch_size": 512}}, unet,
