@@ -433,6 +433,15 @@ int stedm_chan_sum_fold2(const float* cs, int B, int nslab, int C, float* per_sa
 int stedm_sum2x2(const float* in, float* out, int B, int H, int W, int C, int accumulate, void* stream);
 /* in [B][Ho][Wo][C] fp32 -> 16-bit planes [B][2Ho][2Wo][C], value at even positions, zero elsewhere (stride-2 dgrad). */
 int stedm_zero_insert16(const float* in, void* hi, void* lo, int B, int Ho, int Wo, int C, int mm_dtype, void* stream);
+/* SpatialTransformer backward pieces (ldm/modules/attention.py:196-261; the Linears and the attention go through the convolution / attention
+ * backward entry points above). LayerNorm backward over rows of dim <= 2048 (BasicTransformerBlock.norm1/2/3): dx = add + rstd (dxh - mean(dxh)
+ * - xh mean(dxh xh)) with dxh = dy gamma (add may be NULL; dx may alias add), dgamma / dbeta = column sums of dy xh / dy (accumulate: added onto
+ * the tensors). ws: 2 * dim * stedm_ln_bwd_blocks(rows) floats. GEGLU backward (attention.py:37-44, exact erf GELU): g [M][2 I] (value | gate),
+ * dh [M][I] -> dg [M][2 I]. */
+int stedm_ln_bwd_blocks(long rows);
+int stedm_ln_bwd(const float* x, const float* dy, const float* gamma, float eps, const float* add, float* dx, float* dgamma, float* dbeta,
+                 float* ws, long rows, int dim, int accumulate, void* stream);
+int stedm_geglu_bwd(const float* g, const float* dh, float* dg, long M, int I, void* stream);
 /* backward of QKVAttentionLegacy (openaimodel.py:378-394): qkv, d_qkv [B][T][heads*3*ch]; d_out [B][T][heads*ch]. ws: workspace of
  * stedm_attn_legacy_bwd_ws_floats(B, T, heads) floats (0 = none: both T x T matrices stay in LDS, T <= 128). */
 long stedm_attn_legacy_bwd_ws_floats(int B, int T, int heads);

@@ -88,6 +88,9 @@ SIGNATURES = {
     "stedm_qkv_pack_mx8": (_I, [_P, _I, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "stedm_lsa_flash_mx8": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "stedm_svit_head": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _I, _P, C.c_long, _P]),
+    "stedm_ln_bwd_blocks": (_I, [C.c_long]),
+    "stedm_ln_bwd": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _P, C.c_long, _I, _I, _P]),
+    "stedm_geglu_bwd": (_I, [_P, _P, _P, C.c_long, _I, _P]),
     "stedm_geglu16": (_I, [_P, _P, _P, C.c_long, _I, _I, _P]),
     "stedm_agg_reduce": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "stedm_spatial_rescale": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -104,8 +104,11 @@ class SpatialTransformer(nn.Module):
         return P
 
     @torch.no_grad()
-    def run(self, x, P, prec, buf):
-        """x [B,H,W,C] NHWC fp32 -> same shape. `buf(name, shape, dtype)` is the owning model's buffer cache."""
+    def run(self, x, P, prec, buf, save=None):
+        """x [B,H,W,C] NHWC fp32 -> same shape. `buf(name, shape, dtype)` is the owning model's buffer cache.
+        save (a dict, training): every stage keeps its own tensors — the token stream y0 (after proj_in), y{i}a / y{i}b / y{i}c (after attn1,
+        attn2 and the feed-forward of block i), the qkv rows and attention outputs of both attentions, the GEGLU input g — and they are
+        recorded in it for UNetTrainer's backward; without it the residual GEMMs update one token stream in place."""
         B, H, W, C = x.shape
         T, inner = H * W, self.inner_dim
         M = B * T
@@ -113,6 +116,7 @@ class SpatialTransformer(nn.Module):
         lo_ok = prec.npass == 3
         planes = lambda nm, width: (buf(f"st.{nm}.hi.{M}x{width}", (M, width), i16), buf(f"st.{nm}.lo.{M}x{width}", (M, width), i16) if lo_ok else None)
         v4 = lambda t, width: None if t is None else t.view(1, 1, M, width)
+        tag = f"st{id(self)}." if save is not None else "st."
 
         def gemm(a16, w, N, bias=None, res=None, out=None):
             K = a16[0].shape[-1]
@@ -124,29 +128,42 @@ class SpatialTransformer(nn.Module):
         ops.gn_stats(x, None, stats, 32)
         ops.gn_apply16(x, None, g16[0].view(B, H, W, C), None if g16[1] is None else g16[1].view(B, H, W, C), prec, self.norm.weight,
                        self.norm.bias, self.norm.eps, 32, 0, stats)
-        y = buf(f"st.y.{M}x{inner}", (M, inner))
+        y = buf(f"{tag}y.{M}x{inner}", (M, inner))
         gemm(g16, P["proj_in"], inner, bias=self.proj_in.bias, out=y)
+        if save is not None:
+            save["y0"] = y
         ln = planes("ln", inner)
-        qkv = buf(f"st.qkv.{M}", (B, T, 3 * inner))
-        att = buf(f"st.att.{M}", (B, T, inner))
         a16 = planes("a", inner)
         for i, blk in enumerate(self.transformer_blocks):
             for nm, norm in (("attn1", blk.norm1), ("attn2", blk.norm2)):
                 at = getattr(blk, nm)
+                sfx = f"{i}.{nm}.{M}" if save is not None else f"{M}"
+                qkv = buf(f"{tag}qkv.{sfx}", (B, T, 3 * inner))
+                att = buf(f"{tag}att.{sfx}", (B, T, inner))
                 ops.ln_apply16(y, norm.weight, norm.bias, norm.eps, ln[0], ln[1], prec)
                 gemm(ln, P[f"{i}.{nm}.qkv"], 3 * inner, out=qkv)
                 ops.attn_legacy(qkv, att, self.n_heads)
                 ops.gn_apply16(att.view(1, 1, M, inner), None, a16[0].view(1, 1, M, inner), None if a16[1] is None else a16[1].view(1, 1, M, inner), prec)
-                gemm(a16, P[f"{i}.{nm}.out"], inner, bias=at.to_out[0].bias, res=y, out=y)
+                yn = buf(f"{tag}y.{i}.{nm}.{M}x{inner}", (M, inner)) if save is not None else y
+                gemm(a16, P[f"{i}.{nm}.out"], inner, bias=at.to_out[0].bias, res=y, out=yn)
+                if save is not None:
+                    save[f"{i}.{nm}"] = (y, qkv, att, yn)          # (input tokens, qkv rows, attention output, output tokens)
+                y = yn
             ops.ln_apply16(y, blk.norm3.weight, blk.norm3.bias, blk.norm3.eps, ln[0], ln[1], prec)
-            g = buf(f"st.ffg.{M}", (M, 8 * inner))
+            g = buf(f"{tag}ffg.{i}.{M}" if save is not None else f"st.ffg.{M}", (M, 8 * inner))
             gemm(ln, P[f"{i}.ff.proj"], 8 * inner, bias=blk.ff.net[0].proj.bias, out=g)
             h16 = planes("ffh", 4 * inner)
             ops.geglu16(g, h16[0], h16[1], prec)
-            gemm(h16, P[f"{i}.ff.out"], inner, bias=blk.ff.net[2].bias, res=y, out=y)
-        out = buf(f"st.out.{B}x{H}x{W}x{C}", (B, H, W, C))
+            yn = buf(f"{tag}y.{i}.ff.{M}x{inner}", (M, inner)) if save is not None else y
+            gemm(h16, P[f"{i}.ff.out"], inner, bias=blk.ff.net[2].bias, res=y, out=yn)
+            if save is not None:
+                save[f"{i}.ff"] = (y, g, yn)                       # (input tokens, GEGLU input, output tokens)
+            y = yn
+        out = buf(f"{tag}out.{B}x{H}x{W}x{C}", (B, H, W, C))
         ops.gn_apply16(y.view(1, 1, M, inner), None, a16[0].view(1, 1, M, inner), None if a16[1] is None else a16[1].view(1, 1, M, inner), prec)
         ops.conv_igemm(None, P["proj_out"][0], P["proj_out"][1], out.view(1, 1, M, C), prec=prec, ks=1,
                        src16=(a16[0].view(1, 1, M, inner), None if a16[1] is None else a16[1].view(1, 1, M, inner)),
                        bias=self.proj_out.bias, res=x.view(1, 1, M, C))
+        if save is not None:
+            save["yL"] = y
         return out

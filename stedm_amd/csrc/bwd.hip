@@ -1076,3 +1076,123 @@ extern "C" int stedm_ema_update(const void* table, const int* chunk_tensor, cons
   STEDM_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ SpatialTransformer backward pieces
+// LayerNorm backward over rows of `dim` (BasicTransformerBlock.norm1/2/3, attention.py:205-215): xh = (x - mean) rstd, dxh = dy gamma,
+//   dx = add + rstd (dxh - mean(dxh) - xh mean(dxh xh));   dgamma = sum_rows dy xh, dbeta = sum_rows dy.
+// One wave per row (a lane holds dim / 64 <= 32 elements); a block of 4 waves walks its rows and leaves ONE partial row of (dgamma | dbeta)
+// in part[block][2][dim]; ln_bwd_fold adds the blocks in a fixed order.
+namespace {
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma, float eps,
+                                                     const float* add, float* dx, float* __restrict__ part, long rows, int dim, int rows_per_block) {
+  constexpr int NV = 32;
+  __shared__ float sp[4][2][2048];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dg[NV], db[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) { dg[j] = 0.f; db[j] = 0.f; }
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  for (long row = r0 + wave; row < r1; row += 4) {
+    const float* px = x + row * dim;
+    const float* pd = dy + row * dim;
+    float xv[NV], dv[NV];
+    float s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int k = lane + 64 * j;
+      xv[j] = k < dim ? px[k] : 0.f;
+      dv[j] = k < dim ? pd[k] : 0.f;
+      s1 += xv[j];
+    }
+    const float mean = wave_sum(s1) / dim;
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { const float d = lane + 64 * j < dim ? xv[j] - mean : 0.f; s2 += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(s2) / dim + eps);
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int k = lane + 64 * j;
+      if (k < dim) {
+        const float xh = (xv[j] - mean) * rstd;
+        const float dxh = dv[j] * gamma[k];
+        a1 += dxh; a2 += dxh * xh;
+        dg[j] += dv[j] * xh; db[j] += dv[j];
+        xv[j] = xh; dv[j] = dxh;
+      }
+    }
+    const float m1 = wave_sum(a1) / dim, m2 = wave_sum(a2) / dim;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int k = lane + 64 * j;
+      if (k < dim) {
+        float v = rstd * (dv[j] - m1 - xv[j] * m2);
+        if (add) v += add[row * dim + k];
+        dx[row * dim + k] = v;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int k = lane + 64 * j;
+    if (k < dim) { sp[wave][0][k] = dg[j]; sp[wave][1][k] = db[j]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * dim; i += 256) {
+    const int w = i / dim, k = i - w * dim;
+    part[((long)blockIdx.x * 2 + w) * dim + k] = sp[0][w][k] + sp[1][w][k] + sp[2][w][k] + sp[3][w][k];     // fixed order
+  }
+}
+
+__global__ void __launch_bounds__(256) ln_bwd_fold_kernel(const float* __restrict__ part, int nblk, int dim, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * dim) return;
+  const int w = i / dim, k = i - w * dim;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += part[((long)b * 2 + w) * dim + k];     // fixed order
+  float* d = w == 0 ? dgamma : dbeta;
+  d[k] = accumulate ? d[k] + s : s;
+}
+
+// GEGLU backward (attention.py:37-44: out = value * gelu(gate), exact erf GELU): g [M][2 I] = (value | gate), dh [M][I] -> dg [M][2 I]
+__global__ void __launch_bounds__(256) geglu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ dh, float* __restrict__ dg, long M, int I) {
+  const long total = M * I;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long row = i / I;
+    const int c = (int)(i - row * I);
+    const float val = g[row * 2 * I + c], gate = g[row * 2 * I + I + c], d = dh[i];
+    const float cdf = 0.5f * (1.0f + erff(gate * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * gate * gate);
+    dg[row * 2 * I + c] = d * gate * cdf;
+    dg[row * 2 * I + I + c] = d * val * (cdf + gate * pdf);
+  }
+}
+}  // namespace
+
+extern "C" int stedm_ln_bwd_blocks(long rows) { return (int)((rows + 63) / 64 < 2048 ? (rows + 63) / 64 : 2048); }
+
+extern "C" int stedm_ln_bwd(const float* x, const float* dy, const float* gamma, float eps, const float* add, float* dx, float* dgamma, float* dbeta,
+                            float* ws, long rows, int dim, int accumulate, void* stream) {
+  STEDM_CHECK_ARG(x && dy && gamma && dx && dgamma && dbeta && ws && rows > 0, "ln_bwd: bad args");
+  STEDM_CHECK_ARG(dim > 0 && dim <= 2048, "ln_bwd: rows of up to 2048 channels (dim=%d)", dim);
+  const int nblk = stedm_ln_bwd_blocks(rows);
+  const int rpb = (int)((rows + nblk - 1) / nblk);
+  const int nb = (int)((rows + rpb - 1) / rpb);
+  ln_bwd_kernel<<<nb, 256, 0, as_stream(stream)>>>(x, dy, gamma, eps, add, dx, ws, rows, dim, rpb);
+  STEDM_LAUNCH_CHECK();
+  ln_bwd_fold_kernel<<<(2 * dim + 255) / 256, 256, 0, as_stream(stream)>>>(ws, nb, dim, dgamma, dbeta, accumulate);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int stedm_geglu_bwd(const float* g, const float* dh, float* dg, long M, int I, void* stream) {
+  STEDM_CHECK_ARG(g && dh && dg && M > 0 && I > 0, "geglu_bwd: bad args");
+  const long total = M * I;
+  const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  geglu_bwd_kernel<<<grid, 256, 0, as_stream(stream)>>>(g, dh, dg, M, I);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+

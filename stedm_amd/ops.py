@@ -569,6 +569,23 @@ def geglu16(g, hi, lo, prec: Precision):
     check(lib().stedm_geglu16(g.data_ptr(), hi.data_ptr(), _ptr(lo), M, g.shape[-1] // 2, prec.mm_dtype, _stream()), "stedm_geglu16")
 
 
+def ln_bwd(x, dy, gamma, eps: float, dx, dgamma, dbeta, add=None, accumulate: bool = False) -> None:
+    """LayerNorm backward over the rows of x / dy [rows, dim]: dx = add + d(LN)/dx . dy; dgamma, dbeta (+)= column sums."""
+    _chk(x, name="x"); _chk(dy, name="dy")
+    dim = x.shape[-1]
+    rows = x.numel() // dim
+    ws = torch.empty((2 * dim * lib().stedm_ln_bwd_blocks(rows),), dtype=torch.float32, device=x.device)
+    check(lib().stedm_ln_bwd(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), float(eps), _ptr(add), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                             ws.data_ptr(), rows, dim, int(accumulate), _stream()), "stedm_ln_bwd")
+
+
+def geglu_bwd(g, dh, dg) -> None:
+    """g [M, 2I] (value | gate), dh [M, I] -> dg [M, 2I] (GEGLU of attention.py:37-44, exact GELU)."""
+    _chk(g, name="g"); _chk(dh, name="dh")
+    M = g.numel() // g.shape[-1]
+    check(lib().stedm_geglu_bwd(g.data_ptr(), dh.data_ptr(), dg.data_ptr(), M, g.shape[-1] // 2, _stream()), "stedm_geglu_bwd")
+
+
 def agg_reduce(feats, out, n: int, mode: int):
     _chk(feats, name="features")
     Bn, Fd = feats.shape

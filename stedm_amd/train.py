@@ -22,6 +22,7 @@ import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
+from types import SimpleNamespace
 import torch.nn as nn
 
 from . import ops
@@ -146,6 +147,8 @@ class UNetTrainer:
 
     def _w4(self, conv) -> torch.Tensor:
         w = conv.weight.detach().float()
+        if w.dim() == 2:          # nn.Linear (SpatialTransformer): a 1x1 convolution over the token rows
+            return w[:, :, None, None]
         return w.unsqueeze(-1) if w.dim() == 3 else w
 
     def _dpack(self, conv, pad_cin: int = 0, pad_cout: int = 0):
@@ -208,9 +211,12 @@ class UNetTrainer:
                        ws=self._ws(out.numel()))
         return out
 
-    def _wgrad(self, src16, dy16, dy_f32: Optional[torch.Tensor], wparam: nn.Parameter, ks: int, mode: int) -> None:
-        """wparam.grad = sum_p src[p + tap] (x) dy[p] (see module docstring); src16 / dy16 are (hi, lo) NHWC planes"""
+    def _wgrad(self, src16, dy16, dy_f32: Optional[torch.Tensor], wparam: Optional[nn.Parameter], ks: int, mode: int,
+               grad: Optional[torch.Tensor] = None) -> None:
+        """wparam.grad = sum_p src[p + tap] (x) dy[p] (see module docstring); src16 / dy16 are (hi, lo) NHWC planes. grad: write there instead
+        (a filter that is not one parameter: the stacked q | k | v rows of the SpatialTransformer's attentions)"""
         bp = self.bprec
+        gdst = (lambda: grad) if grad is not None else (lambda: self._param_grad(wparam))
         B, Hs, Ws, Cs = src16[0].shape
         Bo, Ho, Wo, co = dy16[0].shape
         if ks == 3 and mode == 0 and bp.npass == 1 and self.m.conv_path == "dma" and self.direct_wgrad:
@@ -218,14 +224,14 @@ class UNetTrainer:
             if nsplit > 0:    # direct kernel: both operands straight from the NHWC planes, transposed in the LDS reads
                 part = self._buf("wg.part", (nsplit * 9 * Cs * co,))
                 ops.wgrad3x3(src16[0], dy16[0], part, bp)
-                ops.wgrad_to_oihw(part, self._param_grad(wparam), Cs, co, False, nsplit)
+                ops.wgrad_to_oihw(part, gdst(), Cs, co, False, nsplit)
                 return
         if ks == 1 and mode == 0 and bp.npass == 1 and self.m.conv_path == "dma" and self.direct_wgrad and self.direct_wgrad1 and src16[0].is_contiguous() and dy16[0].is_contiguous():
             nsplit = ops.wgrad1x1_plan(B * Hs * Ws, Cs, co)
             if nsplit > 0:    # direct kernel for the 1x1 convolutions: flat [P][C] planes, no transposes through HBM
                 part = self._buf("wg.part1", (nsplit * Cs * co,))
                 ops.wgrad1x1(src16[0], dy16[0], part, bp)
-                ops.wgrad_to_oihw(part, self._param_grad(wparam), Cs, co, False, nsplit)
+                ops.wgrad_to_oihw(part, gdst(), Cs, co, False, nsplit)
                 return
         # GEMM form. Its contraction length K = (samples) * Ho * Wo is bounded by the conv kernels' zero page (65 536): larger problems go in
         # batch chunks that accumulate into the gradient
@@ -233,9 +239,9 @@ class UNetTrainer:
         for b0 in range(0, Bo, Bc):
             b1 = min(Bo, b0 + Bc)
             self._wgrad_gemm(tuple(None if t is None else t[b0:b1] for t in src16), tuple(None if t is None else t[b0:b1] for t in dy16),
-                             None if dy_f32 is None else dy_f32[b0:b1], wparam, ks, mode, accumulate=b0 > 0)
+                             None if dy_f32 is None else dy_f32[b0:b1], wparam, ks, mode, accumulate=b0 > 0, grad=grad)
 
-    def _wgrad_gemm(self, src16, dy16, dy_f32, wparam, ks: int, mode: int, accumulate: bool) -> None:
+    def _wgrad_gemm(self, src16, dy16, dy_f32, wparam, ks: int, mode: int, accumulate: bool, grad: Optional[torch.Tensor] = None) -> None:
         bp = self.bprec
         B, Hs, Ws, Cs = src16[0].shape
         Bo, Ho, Wo, co = dy16[0].shape
@@ -271,7 +277,7 @@ class UNetTrainer:
             gemm(m_full * 256, rows)
         else:
             gemm(0, rows)
-        ops.wgrad_to_oihw(dw, self._param_grad(wparam), Cs, co, accumulate)
+        ops.wgrad_to_oihw(dw, grad if grad is not None else self._param_grad(wparam), Cs, co, accumulate)
 
     def _bias_grad(self, dy: torch.Tensor, bias: Optional[nn.Parameter], per_sample: Optional[torch.Tensor] = None, ld: int = 0,
                    cast: Optional[str] = None, also: Optional[nn.Parameter] = None):
@@ -333,6 +339,7 @@ class UNetTrainer:
         complete back to front and their all-reduce overlaps the rest of the backward."""
         m = self.m
         self.G = {}
+        self._st_holders = []
         # dgrad weight packs: the fragment-order ones recorded by the last backward run again as ONE launch when the parameters kept their
         # storage (ops.PackPlan); everything else is packed when first needed, as before
         dkey = (self.bprec, m.conv_path, m._m16, tuple(p.data_ptr() for p in m.parameters()))
@@ -371,6 +378,8 @@ class UNetTrainer:
                 self._res_bwd(*rec[1:])
             elif kind == "attn":
                 self._attn_bwd(*rec[1:])
+            elif kind == "st":
+                self._st_bwd(*rec[1:])
             elif kind == "up":
                 self._up_bwd(*rec[1:])
             elif kind == "down":
@@ -484,6 +493,84 @@ class UNetTrainer:
         dn = self._buf(f"attn.dn.{B}x{T}x{Cc}", (B, H, W, Cc))
         self._dgrad(ab.qkv, dqkv16, dn)
         self._gn_bwd(ab.norm, 0, x, None, dn, dout)
+
+    def _st_bwd(self, st, x, saved, out):
+        """SpatialTransformer (ldm/modules/attention.py:218-261, routed without context: both attentions are self-attentions) from the stage
+        tensors its training-mode forward kept (SpatialTransformer.run(save=...)). Every Linear is a 1x1 convolution over the token rows
+        (dgrad / wgrad kernels of the convolutions), the attentions run the QKVAttentionLegacy backward on the stacked [head][q | k | v] rows
+        (the forward's own form), LayerNorm and GEGLU have their backward kernels (stedm_ln_bwd, stedm_geglu_bwd)."""
+        B, H, W, C = x.shape
+        T, inner, heads = H * W, st.inner_dim, st.n_heads
+        M = B * T
+        d = inner // heads
+        bp = self.bprec
+        v = lambda t, n: t.view(B, H, W, n)             # token rows [M, n] as an NHWC tensor for the helpers
+        dout, have = self._grad_of(out)
+        assert have
+        # ---- proj_out: out = conv1x1(tokens) + bias + x
+        dout16 = self._bias_grad(dout, st.proj_out.bias, cast="dy")
+        self._wgrad(self._cast16(v(saved["yL"], inner), kind="x16"), dout16, dout, st.proj_out.weight, 1, 0)
+        dy = self._buf(f"st.dy0.{M}x{inner}", (B, H, W, inner))
+        dy2 = self._buf(f"st.dy1.{M}x{inner}", (B, H, W, inner))
+        self._dgrad(st.proj_out, dout16, dy)
+
+        def ln_planes(y_in, norm):
+            hi, lo = self._planes("st.ln16", (B, H, W, inner))
+            ops.ln_apply16(y_in, norm.weight, norm.bias, norm.eps, hi, lo, bp)
+            return hi, lo
+
+        for i in reversed(range(len(st.transformer_blocks))):
+            blk = st.transformer_blocks[i]
+            # ---- feed-forward: y_out = y_in + W_out GEGLU(W_proj LN3(y_in) + b_proj) + b_out
+            y_in, g, _ = saved[f"{i}.ff"]
+            lin_out, lin_proj = blk.ff.net[2], blk.ff.net[0].proj
+            dy16 = self._bias_grad(dy, lin_out.bias, cast="dy")
+            h16 = self._planes("st.h16", (B, H, W, 4 * inner))
+            ops.geglu16(g, h16[0], h16[1], bp)
+            self._wgrad(h16, dy16, dy, lin_out.weight, 1, 0)
+            dh = self._buf(f"st.dh.{M}", (B, H, W, 4 * inner))
+            self._dgrad(lin_out, dy16, dh)
+            dg = self._buf(f"st.dg.{M}", (B, H, W, 8 * inner))
+            ops.geglu_bwd(g, dh.view(M, 4 * inner), dg.view(M, 8 * inner))
+            dg16 = self._bias_grad(dg, lin_proj.bias, cast="dy8")
+            self._wgrad(ln_planes(y_in, blk.norm3), dg16, dg, lin_proj.weight, 1, 0)
+            dln = self._buf(f"st.dln.{M}", (B, H, W, inner))
+            self._dgrad(lin_proj, dg16, dln)
+            ops.ln_bwd(y_in, dln.view(M, inner), blk.norm3.weight, blk.norm3.eps, dy2.view(M, inner), self._param_grad(blk.norm3.weight),
+                       self._param_grad(blk.norm3.bias), add=dy.view(M, inner))
+            dy, dy2 = dy2, dy
+            # ---- the two self-attentions: y_out = y_in + W_out attention(W_qkv LN(y_in)) + b_out
+            for nm, norm in (("attn2", blk.norm2), ("attn1", blk.norm1)):
+                at = getattr(blk, nm)
+                y_in, qkv, att, _ = saved[f"{i}.{nm}"]
+                lin_o = at.to_out[0]
+                dy16 = self._bias_grad(dy, lin_o.bias, cast="dy")
+                self._wgrad(self._cast16(v(att, inner), kind="x16"), dy16, dy, lin_o.weight, 1, 0)
+                datt = self._buf(f"st.datt.{M}", (B, H, W, inner))
+                self._dgrad(lin_o, dy16, datt)
+                dqkv = self._buf(f"st.dqkv.{M}", (B, H, W, 3 * inner))
+                ops.attn_legacy_bwd(qkv.view(B, T, 3 * inner), datt.view(B, T, inner), dqkv.view(B, T, 3 * inner), heads)
+                dqkv16 = self._cast16(dqkv, kind="dy3")
+                # the stacked filter rows [head][q | k | v][d] (SpatialTransformer.pack): one weight gradient, scattered to the three Linears
+                gq = self._buf(f"st.gqkv.{inner}", (3 * inner, inner))
+                self._wgrad(ln_planes(y_in, norm), dqkv16, dqkv, None, 1, 0, grad=gq)
+                g4 = gq.view(heads, 3, d, inner)
+                for j, lin in enumerate((at.to_q, at.to_k, at.to_v)):
+                    self._param_grad(lin.weight).copy_(g4[:, j].reshape(inner, inner))
+                holder = SimpleNamespace(weight=torch.stack([at.to_q.weight.detach().float().reshape(heads, d, -1),
+                                                             at.to_k.weight.detach().float().reshape(heads, d, -1),
+                                                             at.to_v.weight.detach().float().reshape(heads, d, -1)], dim=1).reshape(3 * inner, -1))
+                self._st_holders.append(holder)           # (keeps id(holder) unique for the per-step dgrad pack cache)
+                self._dgrad(holder, dqkv16, dln)
+                ops.ln_bwd(y_in, dln.view(M, inner), norm.weight, norm.eps, dy2.view(M, inner), self._param_grad(norm.weight),
+                           self._param_grad(norm.bias), add=dy.view(M, inner))
+                dy, dy2 = dy2, dy
+        # ---- proj_in: tokens = conv1x1(GroupNorm(x)) + bias
+        dy16 = self._bias_grad(dy, st.proj_in.bias, cast="dy")
+        self._wgrad(self._norm16(st.norm, 0, x), dy16, dy, st.proj_in.weight, 1, 0)
+        dn = self._buf(f"st.dn.{M}", (B, H, W, C))
+        self._dgrad(st.proj_in, dy16, dn)
+        self._gn_bwd(st.norm, 0, x, None, dn, dout)
 
     def _up_bwd(self, layer: Upsample, hin, out):
         B, H, W, Cc = hin.shape

@@ -573,10 +573,14 @@ class UNetModel(nn.Module):
             elif isinstance(layer, AttentionBlock):
                 h = self._attn(ltag, layer, h)
             elif type(layer).__name__ == "SpatialTransformer":
-                if self._tape is not None:
-                    raise NotImplementedError("training backward of the SpatialTransformer is not built (the shipped configs do not use it)")
                 # routed without context, exactly like the reference (openaimodel.py:99-100)
-                h = layer.run(h, self._packed[id(layer)], self.precision, self._buf)
+                if self._tape is not None:
+                    saved = {}
+                    x_in = h
+                    h = layer.run(h, self._packed[id(layer)], self.precision, self._buf, save=saved)
+                    self._tape.append(("st", layer, x_in, saved, h))
+                else:
+                    h = layer.run(h, self._packed[id(layer)], self.precision, self._buf)
             elif isinstance(layer, Downsample):
                 pk = self._packed[id(layer.op)]
                 B, H, W, _ = h.shape

@@ -313,6 +313,54 @@ def test_unet_backward_odd_shapes_vs_oracle(dev, B, H, W):
             assert float((p.grad.cpu() - grads[n]).norm()) / gn < 1e-3, n
 
 
+@pytest.mark.parametrize("depth,B", [(1, 2), (2, 3)])
+def test_unet_backward_with_spatial_transformer_vs_oracle(dev, depth, B):
+    """`use_spatial_transformer=True` (north_star names the SpatialTransformer; attention.py:218-261, routed without context as the
+    reference's TimestepEmbedSequential does): training backward through GroupNorm -> proj_in -> [LN -> self-attn -> +x; LN -> self-attn
+    -> +x; LN -> GEGLU FF -> +x] x depth -> proj_out (+x) against autograd over the oracle — every parameter gradient of the U-Net
+    (the transformer's 20+ tensors included), dL/dx and dL/dcontext."""
+    from oracle import train as otrain
+    from oracle import unet as ounet
+    from stedm_amd.train import UNetTrainer
+    cfg = dict(image_size=16, in_channels=7, model_channels=32, out_channels=4, num_res_blocks=1, attention_resolutions=[32, 16, 8],
+               channel_mult=[1, 2, 4], num_heads=4, use_spatial_transformer=True, transformer_depth=depth, context_dim=128)
+    m = build(cfg, 41, dev)
+    ocfg = ounet.UNetConfig(image_size=16, in_channels=7, model_channels=32, out_channels=4, num_res_blocks=1, channel_mult=(1, 2, 4), num_heads=4,
+                            use_spatial_transformer=True, transformer_depth=depth, context_dim=128)
+    P = prng.fill_state_dict(ounet.build_plan(ocfg).shapes, 41)
+    assert set(P) == set(m.state_dict())
+    x = prng.normal(41, "st.x", (B, 7, 16, 16)); ctx = prng.normal(41, "st.ctx", (B, 128)); target = prng.normal(41, "st.t", (B, 4, 16, 16))
+    t = torch.tensor(([951, 21, 500] * B)[:B], dtype=torch.long)
+    loss_ref, grads, dx_ref, dctx_ref, _ = otrain.unet_loss_and_grads(P, ocfg, x, t, ctx, target)
+    tr = UNetTrainer(m)
+    loss, dx, dctx = tr.loss_and_backward(x[:, :4].contiguous().to(dev), x[:, 4:].contiguous().to(dev), t.to(dev), ctx.to(dev), target.to(dev))
+    assert abs(float(loss) - loss_ref) < 1e-4 * loss_ref
+    assert float((dx.cpu() - dx_ref).norm() / dx_ref.norm()) < 1e-3
+    assert float((dctx.cpu() - dctx_ref).norm() / dctx_ref.norm()) < 1e-3
+    gmax = max(float(g.norm()) for g in grads.values())
+    worst = (0.0, "")
+    n_st = 0
+    for n, p in m.named_parameters():
+        gn = float(grads[n].norm())
+        if "transformer_blocks" in n or ".proj_in." in n or ".proj_out." in n:
+            n_st += 1
+        if gn > 1e-6 * gmax:
+            e = float((p.grad.cpu() - grads[n]).norm()) / gn
+            worst = max(worst, (e, n))
+    print(f"[U-Net + SpatialTransformer depth {depth}] worst parameter-gradient rel err {worst[0]:.2e} ({worst[1]}); {n_st} transformer tensors")
+    assert worst[0] < 1e-3 and n_st >= 20
+    # the fast mode (bf16 operands in forward and backward) through the same path: finite, close in norm; and a whole optimizer step runs
+    mb = build(cfg, 41, dev, "bf16")
+    trb = UNetTrainer(mb, lr=1e-4)
+    lossb, _, _ = trb.loss_and_backward(x[:, :4].contiguous().to(dev), x[:, 4:].contiguous().to(dev), t.to(dev), ctx.to(dev), target.to(dev))
+    assert abs(float(lossb) - loss_ref) < 3e-2 * loss_ref
+    errs = [abs(float(p.grad.norm()) - float(grads[n].norm())) / float(grads[n].norm()) for n, p in mb.named_parameters() if float(grads[n].norm()) > 1e-3 * gmax]
+    assert all(bool(torch.isfinite(p.grad).all()) for p in mb.parameters()) and float(np.median(errs)) < 3e-2
+    w0 = mb.middle_block[2].transformer_blocks[0].attn1.to_q.weight.detach().clone()
+    trb.train_step(x[:, :4].contiguous().to(dev), x[:, 4:].contiguous().to(dev), t.to(dev), ctx.to(dev), target.to(dev))
+    assert trb.step_count == 1 and not torch.equal(w0, mb.middle_block[2].transformer_blocks[0].attn1.to_q.weight)
+
+
 def _ddp_worker(rank, world, port, q, overlap=True, bucket_mb=256, steps=1, accumulate=1):
     import os
     os.environ["MASTER_ADDR"] = "127.0.0.1"
