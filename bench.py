@@ -542,6 +542,32 @@ def main():
                                 "step_reference_equivalent_tflops": round(fl64 / (dt64 / 6), 1),
                                 "step_reference_equivalent_frac_of_mfma_peak": round(fl64 / (dt64 / 6) / PEAK_MFMA_TFLOPS, 4)}
             del x64, lay64
+            # BASELINE config 5's per-GPU slice of the style encoding: 8 style inputs per sample through the set encoder (patch features 192 * 8 wide)
+            # with MX-fp8 attention operands, beside the bf16 attention; the 64x64x4 denoising step above is the same slice's U-Net half
+            try:
+                from stedm_amd.style import sViT
+                from stedm_amd.utils import prng as _prng
+                Bs = min(B, 32)              # (the 8-image style stack of 64 samples is 6.4 GB of fp32 pixels: half a batch is timed)
+                sv = sViT(image_size=512, patch_size=8, num_classes=512, dim=256, depth=6, heads=12, mlp_dim=256, pool="mean", channels=3, dropout=0.1,
+                          emb_dropout=0.1, ns=8, t_dim=256, precision=args.precision).eval()
+                _prng.fill_module_(sv, seed=7)
+                sv = sv.to(dev)
+                sty8 = torch.rand(Bs, 8, 512, 512, 3, device=dev) * 2 - 1
+                t8 = {}
+                y8 = {}
+                for mode in (args.precision, "fp8"):
+                    sv.set_precision(mode)
+                    sv(sty8)
+                    torch.cuda.synchronize(); ts0 = time.perf_counter()
+                    y8[mode] = sv(sty8).float().clone()
+                    torch.cuda.synchronize(); t8[mode] = time.perf_counter() - ts0
+                out["config5_style_slice"] = {"batch": Bs, "style_images_per_sample": 8, "seconds": {args.precision: round(t8[args.precision], 4), "mx_fp8_attention": round(t8["fp8"], 4)},
+                                              "samples_per_s": {args.precision: round(Bs / t8[args.precision], 1), "mx_fp8_attention": round(Bs / t8["fp8"], 1)},
+                                              "fp8_vs_" + args.precision + "_rel_l2": round(float((y8["fp8"] - y8[args.precision]).norm() / y8[args.precision].norm()), 5),
+                                              "what": "sViT(ns=8) over 8 x 512^2 style images per sample (CATCH-style set aggregation), 4098 tokens, 6 layers x 12 heads"}
+                del sv, sty8, y8
+            except Exception as e:
+                out["config5_style_slice"] = {"error": str(e)[:160]}
             # BASELINE config 3 end to end up to the sampled latents: style encoder (sViT, 4 style images of 512^2 per sample) + layout
             # rescaler + DDIM-50 with CFG, the call sequence of LDM_Diffusion.predict_step
             from stedm_amd.latent_diffusion import S_ZSS_DM, predict_latents

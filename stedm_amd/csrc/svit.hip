@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(256, 2) lsa_flash_kernel(FlashArgs a) {
   T (*sK)[TILE] = reinterpret_cast<T (*)[TILE]>(lds_raw);
   T (*sV)[TILE] = reinterpret_cast<T (*)[TILE]>(lds_raw + NPL * TILE * sizeof(T));
   float (*sO)[32][65] = reinterpret_cast<float (*)[32][65]>(lds_raw);
-  // XCD-aware block -> (sample-head, query tile): see lsa_flash_dma_kernel
+  // XCD-aware block -> (sample-head, query tile): see lsa_flash64_kernel
   int bh, qtile;
   {
     const int nbh = gridDim.x, nq = gridDim.y, L = blockIdx.x + nbh * blockIdx.y;      // dispatch order of the 2-D grid
@@ -572,236 +572,25 @@ __global__ void __launch_bounds__(256, 2) lsa_flash_kernel(FlashArgs a) {
   }
 }
 
-// Single-product form whose K / V^T tiles travel global -> LDS by DMA (global_load_lds_dwordx4) into a ring of three tiles, two tiles ahead
-// of the MFMAs, with ONE barrier per tile. Compile-time timing ablations of the kernel above (B = 8, random operands) put its 737 us at
-// 417 us of MFMA + softmax work plus 320 us added by the tile staging (global -> registers -> ds_write, two barriers per tile), which the
-// three resident blocks did not hide. Here a tile costs each wave four DMA instructions (1 KiB each, no VGPRs, no ds_write) and one counted
-// vmcnt wait; measured +3 % on the sViT forward (the kernel is insensitive to its staging, occupancy and barrier count: DESIGN.md §6.2).
-// A DMA instruction writes its 64 x 16 B linearly, so rows are unpadded (128 B) and the 16-B pieces are XOR-swizzled through
-// the SOURCE address: physical piece p of row w holds logical piece p ^ ((w >> 1) & 7) — conflict-free ds_read_b128 K fragments, 2-way
-// on the 8-B V^T reads (as the padded layout had before its stride fix: measured 1 %).
-template <typename T, int NBUF, bool DROP = false>
-__global__ void __launch_bounds__(256, NBUF == 2 ? 4 : 3) lsa_flash_dma_kernel(FlashArgs a) {
-  using V8 = typename MM<T>::V8;
-  typedef T V4t __attribute__((ext_vector_type(4)));
-  constexpr int TILE_B = 16384;          // K 8 KiB | V^T 8 KiB
-  constexpr int O_BYTES = 4 * 32 * 65 * (int)sizeof(float);
-  constexpr int LDS_B = NBUF * TILE_B > O_BYTES ? NBUF * TILE_B : O_BYTES;       // the epilogue's transpose buffer overlays the ring
-  __shared__ __attribute__((aligned(1024))) unsigned char ring[LDS_B];
-  float (*sO)[32][65] = reinterpret_cast<float (*)[32][65]>(ring);
-  // Block -> (sample-head, 128-query tile), XCD-aware: workgroups go to the 8 XCDs round-robin (block id mod 8), and each XCD has its own 4 MB
-  // L2. With the sample-head on the fast grid axis every XCD streams the K / V^T of ALL heads (104 MB at B = 8: far beyond L2, so every tile
-  // came from the fabric: 3.4 GB per call); here the blocks of one sample-head all run on one XCD and the ~3 heads resident there fit its L2.
-  int bh, qtile;
-  {
-    const int nq = a.Tp / 128, nbh = gridDim.x / nq, L = blockIdx.x;
-    if ((nbh & 7) == 0) { const int x = L & 7, j = L >> 3; bh = x + 8 * (j / nq); qtile = j % nq; }
-    else { bh = L % nbh; qtile = L / nbh; }
-  }
-  const int b = bh / a.H, hd = bh % a.H;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5;
-  const int q0 = qtile * 128 + wave * 32;
-  const T* qg = reinterpret_cast<const T*>(a.qh);
-  const T* kg = reinterpret_cast<const T*>(a.kh);
-  const T* vg = reinterpret_cast<const T*>(a.vh);
-
-  V8 qf[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const V8*>(qg + ((long)bh * a.Tp + q0 + r) * 64 + ks * 16 + h * 8);
-
-  // DMA sources of this wave: chunks 2 wave, 2 wave + 1 of the K tile (rows 16 wave .. 16 wave + 15) and of the V^T tile; lane l of a chunk
-  // fills physical piece l & 7 of row 8 c + (l >> 3)
-  // (uniform 64-bit base + 32-bit lane offset: the compiler keeps the base in scalar registers)
-  const T* const kbase = kg + (long)bh * a.Tp * 64;
-  const T* const vbase = vg + (long)bh * 64 * a.Tp;
-  unsigned koff[2], voff[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = 8 * (2 * wave + i) + (lane >> 3);
-    const int q = (lane & 7) ^ ((row >> 1) & 7);
-    koff[i] = row * 64 + q * 8;                    // + kt * 64 * 64 per tile
-    voff[i] = row * a.Tp + q * 8;                  // + kt * 64 per tile
-  }
-  auto issue = [&](int kt) {
-    unsigned char* dst = ring + (kt % NBUF) * TILE_B + (2 * wave) * 1024;
-    const T* kt_k = kbase + (long)kt * 4096;
-    const T* kt_v = vbase + (long)kt * 64;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      GLDS16(kt_k + koff[i], dst + i * 1024);
-      GLDS16(kt_v + voff[i], dst + 8192 + i * 1024);
-    }
-  };
-
-  f32x16 o[2];
-#pragma unroll
-  for (int d = 0; d < 2; ++d)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
-  float l_run = 0.f;
-  const int qidx = q0 + r;
-  const int ntiles = (a.T + 63) / 64;
-  U4 dstate{};
-  if (DROP) dstate = attn_stream_init((unsigned)qidx, (unsigned)bh, a.site, (unsigned)h, a.seed);
-  // fragment byte offsets inside a tile buffer: row * 128 + ((piece ^ f(row)) << 4), f(row) = (row >> 1) & 7. The piece index of a fragment
-  // is (compile-time even part) ^ (lane's h or 0), so each offset is a per-lane base XOR a compile-time constant
-  unsigned kb[2], vb[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = i * 32 + r;
-    kb[i] = row * 128 + ((h ^ ((row >> 1) & 7)) << 4);              // K: piece 2 ks + h     -> kb[sub] ^ (ks << 5)
-    vb[i] = 8192 + row * 128 + (((row >> 1) & 7) << 4) + 8 * h;     // V^T: piece 4 sub + 2 s2 (+ 1) -> vb[d] ^ ((4 sub + 2 s2) << 4) (^ 16)
-  }
-
-  // The softmax is the kernel's issue budget (per tile and wave 16 MFMAs = 512 pipe cycles against ~830 cycles of vector issue), so the loop
-  // removes vector instructions: (1) the logits come out of the MFMA already relative to a per-query reference m_ref - a fifth k-step whose
-  // K side is the constant 1 and whose Q side is -m_ref - so p = exp2(s') needs no subtraction; m_ref is the running maximum rounded to the
-  // operand type and only moves when a tile exceeds it by more than 2^kThr (then O and l are rescaled and this tile's p take the difference
-  // explicitly); (2) the ring walk is unrolled by NBUF, so the tile base is an immediate of the LDS reads and the fragment offsets are
-  // loop-invariant registers (the adds of the base were 40 of ~170 vector instructions per tile).
-  constexpr float kThr = 8.0f;
-  float m_ref = 0.f;                    // reference of the exponentials kept in O and l (0 until the first tile sets it)
-  V8 ka, qa;                            // fifth k-step: K side = 1 in k-slot 0, Q side = -m_ref in k-slot 0 (lanes of the k-group h = 0)
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { ka[j] = (T)0.f; qa[j] = (T)0.f; }
-  if (h == 0) ka[0] = (T)1.f;
-  issue(0);
-  if (NBUF == 3 && ntiles > 1) issue(1);
-  for (int kt0 = 0; kt0 < ntiles; kt0 += NBUF) {
-#pragma unroll
-  for (int u = 0; u < NBUF; ++u) {
-    const int kt = kt0 + u;
-    if (kt >= ntiles) break;
-    // this wave's share of tile kt has landed (NBUF 3: its 4 newest DMAs belong to tile kt + 1, when there is one)
-    if (NBUF == 3 && kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // raw barrier: __syncthreads() makes the compiler wait for vmcnt(0) first, i.e. for the DMA of tile kt + 1 issued one tile ago
-    // (found in the ISA: the ring never ran ahead). Every wave's LDS reads of tile kt - 1 fed MFMAs it has already issued.
-    __builtin_amdgcn_s_barrier();   // tile kt is complete in LDS; every wave is done with tile kt - 1, whose buffer takes the next tile fetched
-    if (kt + NBUF - 1 < ntiles) issue(kt + NBUF - 1);
-    const unsigned char* tb = ring + u * TILE_B;       // (kt % NBUF == u: kt0 is a multiple of NBUF)
-    // ---- S^T tiles (2 x 32 keys) x 32 queries, relative to m_ref
-    f32x16 s[2];
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) s[sub][e] = 0.f;
-      s[sub] = MM<T>::mfma(ka, qa, s[sub]);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const V8 kf = *reinterpret_cast<const V8*>(tb + (kb[sub] ^ (unsigned)(ks << 5)));
-        s[sub] = MM<T>::mfma(kf, qf[ks], s[sub]);
-      }
-    }
-    if ((q0 >> 6) == kt) {
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          if (kt * 64 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h == qidx) s[sub][e] = -FLT_MAX;
-    }
-    if (kt * 64 + 64 > a.T) {
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          if (kt * 64 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= a.T) s[sub][e] = -INFINITY;
-    }
-    float mx = s[0][0];
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[sub][e]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    if (kt == 0 || __builtin_amdgcn_ballot_w64(mx > kThr)) {
-      // move the reference (rare after the first tiles): new m_ref = old + max(mx, 0) rounded to the operand type (exactly what the fifth
-      // k-step can carry); O and l go to the new reference, this tile's logits take the difference explicitly
-      const float up = kt == 0 ? fmaxf(mx, -30000.f) : fmaxf(mx, 0.f);     // (first tile: any sign; a fully masked row stays finite, fp16 included)
-      const float m_new = (float)(T)(m_ref + up);
-      const float delta = m_new - m_ref;
-      const float alpha = __builtin_amdgcn_exp2f(-delta);
-      m_ref = m_new;
-      if (h == 0) qa[0] = (T)(-m_new);
-      l_run *= alpha;
-#pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[sub][e] -= delta;
-    }
-    float rs = 0.f;
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float pv = __builtin_amdgcn_exp2f(s[sub][e]);
-        s[sub][e] = pv;
-        rs += pv;
-      }
-    l_run += rs;           // (per lane half: the two halves of a query are added once, after the loop)
-    if (DROP) {   // dropout acts on the normalised probabilities (vit_set.py:61-62): l keeps every p, the PV product only the kept ones
-      const unsigned keep = attn_keep_bits(dstate, a.thr16);
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          if (!((keep >> (sub * 16 + e)) & 1u)) s[sub][e] = 0.f;
-    }
-    // ---- O^T += V^T P^T
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        V8 ph;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ph[j] = (T)s[sub][8 * s2 + j];
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          // A fragment of V^T: row = d*32 + r, keys 32*sub + 16*s2 + {4h .. 4h+3} and {8 + 4h .. 8 + 4h + 3}
-          const unsigned vo = vb[d] ^ (unsigned)((4 * sub + 2 * s2) << 4);
-          const V4t v0 = *reinterpret_cast<const V4t*>(tb + vo);
-          const V4t v1 = *reinterpret_cast<const V4t*>(tb + (vo ^ 16u));
-          V8 vf;
-          vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
-          vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
-          o[d] = MM<T>::mfma(vf, ph, o[d]);
-        }
-      }
-  }
-  }
-  l_run += __shfl_xor(l_run, 32, 64);
-  // ---- epilogue: O^T / l through LDS so that every token row is written contiguously (token-major [B][T][H*64])
-  __syncthreads();   // all waves are done with the ring: it is reused for the transpose
-  const float inv = (DROP ? a.inv_keep : 1.0f) / l_run;
-#pragma unroll
-  for (int d = 0; d < 2; ++d)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) sO[wave][r][d * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] = o[d][e] * inv;
-  __syncthreads();
-  {
-    const int row = lane >> 1, half = lane & 1;
-    const int t = q0 + row;
-    if (t < a.T) {
-      T* oh = reinterpret_cast<T*>(a.oh) + ((long)b * a.T + t) * (a.H * 64) + hd * 64 + half * 32;
-#pragma unroll
-      for (int j = 0; j < 32; ++j) oh[j] = (T)sO[wave][row][half * 32 + j];
-    }
-  }
-}
-
-// 64 queries per wave (round 3). lsa_flash_dma_kernel gives a wave 32 queries, so every wave of the block reads the whole K and V^T tile
-// from LDS for 16 + 2 MFMAs: 16 KB of fragment reads per 576 MFMA cycles and wave, 12 waves per CU — the LDS pipe (128 B/clk per CU, the
-// 8-B V^T reads 2-way conflicted) is as loaded as the matrix pipe, and the softmax of a wave (32 v_exp + ~60 other vector instructions)
-// runs strictly between its QK^T and PV products: measured 1578 cycles per wave and tile against 576 of MFMA (0.78 PFLOP/s, B = 8).
+// Single-product form, 64 queries per wave (round 3; replaces round 2's lsa_flash_dma_kernel, 32 queries per wave).
+// K / V^T tiles travel global -> LDS by DMA (global_load_lds_dwordx4) into a ring of three tiles, two tiles ahead of the MFMAs, with ONE
+// raw s_barrier per tile behind a counted vmcnt (a __syncthreads() makes the compiler wait for vmcnt(0) first, i.e. for the DMA of the NEXT
+// tile: found in the ISA in round 2 — the ring had never run ahead). A DMA instruction writes its 64 x 16 B linearly, so rows are unpadded
+// (128 B) and the 16-B pieces are XOR-swizzled through the SOURCE address: physical piece p of row w holds logical piece p ^ ((w >> 1) & 7) —
+// conflict-free ds_read_b128 K fragments, 2-way on the 8-B V^T reads (measured 1 %).
+// Blocks go to the 8 XCDs round-robin (block id mod 8) and each XCD has its own 4 MB L2: the blocks of one sample-head all run on one XCD,
+// so the ~3 heads resident there fit its L2 (with the sample-head on the fast grid axis every XCD streamed the K / V^T of ALL heads: 3.4 GB
+// of fabric traffic per call at B = 8).
+// Softmax without a per-element subtraction: the logits leave the MFMA already relative to a per-query reference m_ref — a fifth k-step
+// whose K side is the constant 1 and whose Q side is -m_ref — so p = exp2(s').
+// Round 2's kernel gave a wave 32 queries, so every wave of the block read the whole K and V^T tile from LDS for 16 + 2 MFMAs: 16 KB of
+// fragment reads per 576 MFMA cycles and wave, 12 waves per CU — the LDS pipe (128 B/clk per CU) as loaded as the matrix pipe — and its
+// softmax (32 v_exp + ~60 other vector instructions) ran strictly between its QK^T and PV products: 1578 cycles per wave and tile against
+// 576 of MFMA (0.78 PFLOP/s at B = 8, 0.87 at B = 64).
 // Here a wave owns TWO 32-query blocks: a K / V^T fragment is read once into registers and feeds both blocks' MFMAs (half the LDS bytes per
 // MFMA), and the two blocks give the in-order wave something to overlap with itself — the exponentials of block 0 are issued in the gaps
 // of block 1's QK^T MFMAs, those of block 1 in the gaps of block 0's PV MFMAs (one MFMA, then a slice of 3 - 4 exponentials + their sums /
-// conversions, fenced by sched_barrier). Two waves per SIMD (≈230 registers), 48 KB ring, same DMA ring / swizzle / barrier protocol,
-// same swapped S^T = K Q^T layout, m_ref fifth k-step and rescale rule as lsa_flash_dma_kernel (per 32-query block).
+// conversions, fenced by sched_barrier). Two waves per SIMD (247 registers), 48 KB ring. 0.98 PFLOP/s at B = 64.
 template <typename T, bool DROP = false>
 __global__ void __launch_bounds__(256, 2) lsa_flash64_kernel(FlashArgs a) {
   using V8 = typename MM<T>::V8;
@@ -812,7 +601,7 @@ __global__ void __launch_bounds__(256, 2) lsa_flash64_kernel(FlashArgs a) {
   constexpr int LDS_B = NBUF * TILE_B > O_BYTES ? NBUF * TILE_B : O_BYTES;
   __shared__ __attribute__((aligned(1024))) unsigned char ring[LDS_B];
   float (*sO)[32][65] = reinterpret_cast<float (*)[32][65]>(ring);
-  // block -> (sample-head, 256-query tile), all tiles of a sample-head on one XCD (see lsa_flash_dma_kernel)
+  // block -> (sample-head, 256-query tile), all tiles of a sample-head on one XCD
   int bh, qtile;
   {
     const int nq = (a.Tp + 255) / 256, nbh = gridDim.x / nq, L = blockIdx.x;
@@ -900,7 +689,7 @@ __global__ void __launch_bounds__(256, 2) lsa_flash64_kernel(FlashArgs a) {
     }
   };
   // move of the reference m_ref to (at least) the block's maximum in this tile: O and l go to the new reference, the logits take the
-  // difference explicitly (see lsa_flash_dma_kernel). Runs on the first tile and in the rare redo below — NOT per tile: the common tile has
+  // difference explicitly. Runs on the first tile and in the rare redo below — NOT per tile: the common tile has
   // no row maximum at all (32 v_max3 + a cross-half shuffle + a ballot per block were a quarter of the softmax's vector instructions)
   auto move_ref = [&](f32x16 (&s)[2], const int qb, const bool first) __attribute__((always_inline)) {
     float mx = s[0][0];
@@ -1071,23 +860,9 @@ static int lsa_flash_launch(FlashArgs a, int B, int npass, int mm_dtype, bool dr
   dim3 grid(B * a.H, a.Tp / 128);
   static const bool dma_off = getenv("STEDM_LSA_NODMA") != nullptr;      // A/B: the register-staged form for the single-product modes too
   if (npass == 1 && !dma_off) {
-    static const bool q32 = getenv("STEDM_LSA_Q32") != nullptr;         // A/B: the 32-queries-per-wave DMA kernel (round 2)
-    if (!q32) {
-      const dim3 grid64(B * a.H * ((a.Tp + 255) / 256));
-      if (mm_dtype == STEDM_F16) { if (drop) lsa_flash64_kernel<_Float16, true><<<grid64, 256, 0, st>>>(a); else lsa_flash64_kernel<_Float16><<<grid64, 256, 0, st>>>(a); }
-      else { if (drop) lsa_flash64_kernel<__bf16, true><<<grid64, 256, 0, st>>>(a); else lsa_flash64_kernel<__bf16><<<grid64, 256, 0, st>>>(a); }
-      STEDM_LAUNCH_CHECK();
-      return 0;
-    }
-    // (a two-tile ring at four waves per SIMD measured 1-5 % slower than three tiles at three waves)
-    const dim3 grid1(B * a.H * (a.Tp / 128));
-    if (mm_dtype == STEDM_F16) {
-      if (drop) lsa_flash_dma_kernel<_Float16, 3, true><<<grid1, 256, 0, st>>>(a);
-      else lsa_flash_dma_kernel<_Float16, 3><<<grid1, 256, 0, st>>>(a);
-    } else {
-      if (drop) lsa_flash_dma_kernel<__bf16, 3, true><<<grid1, 256, 0, st>>>(a);
-      else lsa_flash_dma_kernel<__bf16, 3><<<grid1, 256, 0, st>>>(a);
-    }
+    const dim3 grid64(B * a.H * ((a.Tp + 255) / 256));
+    if (mm_dtype == STEDM_F16) { if (drop) lsa_flash64_kernel<_Float16, true><<<grid64, 256, 0, st>>>(a); else lsa_flash64_kernel<_Float16><<<grid64, 256, 0, st>>>(a); }
+    else { if (drop) lsa_flash64_kernel<__bf16, true><<<grid64, 256, 0, st>>>(a); else lsa_flash64_kernel<__bf16><<<grid64, 256, 0, st>>>(a); }
     STEDM_LAUNCH_CHECK();
     return 0;
   }

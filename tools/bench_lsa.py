@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """MFMA rate of the LSA flash attention kernel alone (vit_set.py:52-66; T = 4098 tokens = 4096 patches of a 512^2 style image + cls + time
-token, 12 heads of 64): 4 * T^2 * 64 FLOP per head. Random operands. `STEDM_LSA_Q32=1`: the round-2 kernel (32 queries per wave).
+token, 12 heads of 64): 4 * T^2 * 64 FLOP per head. Random operands.
 
     python tools/bench_lsa.py [bf16|f16|parity] [B] [p_drop]
 """
@@ -58,7 +58,7 @@ def main():
     us = e0.elapsed_time(e1) / n * 1e3
     fl = 4.0 * T * T * 64 * heads * B
     print(f"lsa_flash {prec.label} B={B} T={T} p={p}: {us:.1f} us per call, {fl / us / 1e6:.1f} TFLOP/s ({fl / us / 1e6 / 2500 * 100:.1f} % of the 2.5 PF dense peak)"
-          f"{' [32 queries per wave]' if os.environ.get('STEDM_LSA_Q32') else ''}", flush=True)
+          "", flush=True)
 
 
 if __name__ == "__main__":
