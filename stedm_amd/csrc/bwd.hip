@@ -617,6 +617,144 @@ __global__ void __launch_bounds__(256) attn_legacy_bwd_kernel(const float* __res
   }
 }
 
+// T = 64 tokens (the 8 x 8 level of the 32 x 32 latents): the same five contractions on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32: both
+// operands stay fp32, so every numerics mode shares it). One workgroup of 4 waves per (sample, head); q, k, v, dO are whole in LDS
+// ([64][ch + 4] floats: the 16-B fragment reads of 16 consecutive rows cover the 64 banks once), P takes V's place after the first
+// phase, dS its own [64][68] image.
+//   phase 1: wave (ti, tj) owns the 32 x 32 tile of S = q k^T and dP = dO v^T; a lane (row r, half h) reads channels c0 + 4h .. + 3 of its A
+//            and B rows as one float4 and feeds four MFMAs (MFMA n contracts channels c0 + n and c0 + 4 + n);
+//   phase 2: softmax / dS rows by four lanes per row (xor-shuffles);
+//   phase 3: dV = P^T dO, dQ = s2 dS K, dK = s2 dS^T Q: a wave takes (output, 32-channel tile) items, both 32-row tiles of an item share
+//            the B reads.
+typedef float att_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int A64_PP = 68;
+__global__ void __launch_bounds__(256) attn64_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, float* __restrict__ dqkv,
+                                                              int heads, int ch) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int PT = ch + 4;
+  const int vrows = PT > A64_PP ? PT : A64_PP;
+  float* sq = sm;
+  float* sk = sq + 64 * PT;
+  float* sg = sk + 64 * PT;
+  float* sv = sg + 64 * PT;          // [64][PT], later P [64][68]
+  float* sP = sv;
+  float* sD = sv + 64 * vrows;       // dP, then dS [64][68]
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r = l & 31, hh = l >> 5;
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+  const long ld = (long)heads * 3 * ch, ldo = (long)heads * ch;
+  const float* q = qkv + (long)b * 64 * ld + (long)h * 3 * ch;
+  const float* k = q + ch;
+  const float* v = q + 2 * ch;
+  const float* go = dO + (long)b * 64 * ldo + (long)h * ch;
+  float* dq = dqkv + (long)b * 64 * ld + (long)h * 3 * ch;
+  const float s2 = 1.0f / sqrtf((float)ch);
+  const int c4n = ch >> 2;
+#pragma unroll 2
+  for (int idx = tid; idx < 64 * c4n; idx += 256) {
+    const int row = idx / c4n, c = (idx - row * c4n) * 4;
+    const float4 a = *reinterpret_cast<const float4*>(q + row * ld + c);
+    const float4 bb = *reinterpret_cast<const float4*>(k + row * ld + c);
+    const float4 cc = *reinterpret_cast<const float4*>(v + row * ld + c);
+    const float4 dd = *reinterpret_cast<const float4*>(go + row * ldo + c);
+    *reinterpret_cast<float4*>(sq + row * PT + c) = a;
+    *reinterpret_cast<float4*>(sk + row * PT + c) = bb;
+    *reinterpret_cast<float4*>(sv + row * PT + c) = cc;
+    *reinterpret_cast<float4*>(sg + row * PT + c) = dd;
+  }
+  __syncthreads();
+  {
+    const int ti = w >> 1, tj = w & 1;
+    att_f32x16 S, D;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { S[e] = 0.f; D[e] = 0.f; }
+    const float* pa = sq + (32 * ti + r) * PT + 4 * hh;
+    const float* pb = sk + (32 * tj + r) * PT + 4 * hh;
+    const float* pc = sg + (32 * ti + r) * PT + 4 * hh;
+    const float* pd = sv + (32 * tj + r) * PT + 4 * hh;
+#pragma unroll 2
+    for (int c0 = 0; c0 < ch; c0 += 8) {
+      const float4 a = *reinterpret_cast<const float4*>(pa + c0), bb = *reinterpret_cast<const float4*>(pb + c0);
+      const float4 g = *reinterpret_cast<const float4*>(pc + c0), vv = *reinterpret_cast<const float4*>(pd + c0);
+      S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb.x, S, 0, 0, 0);
+      D = __builtin_amdgcn_mfma_f32_32x32x2f32(g.x, vv.x, D, 0, 0, 0);
+      S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bb.y, S, 0, 0, 0);
+      D = __builtin_amdgcn_mfma_f32_32x32x2f32(g.y, vv.y, D, 0, 0, 0);
+      S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bb.z, S, 0, 0, 0);
+      D = __builtin_amdgcn_mfma_f32_32x32x2f32(g.z, vv.z, D, 0, 0, 0);
+      S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bb.w, S, 0, 0, 0);
+      D = __builtin_amdgcn_mfma_f32_32x32x2f32(g.w, vv.w, D, 0, 0, 0);
+    }
+    __syncthreads();                 // every wave is done with V before P lands on it
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = 32 * ti + (e & 3) + 8 * (e >> 2) + 4 * hh;
+      sP[row * A64_PP + 32 * tj + r] = S[e] * s2;
+      sD[row * A64_PP + 32 * tj + r] = D[e];
+    }
+  }
+  __syncthreads();
+  {
+    const int i = tid >> 2, qd = tid & 3;
+    float* prow = sP + i * A64_PP + 16 * qd;
+    float* drow = sD + i * A64_PP + 16 * qd;
+    float x[16], dp[16];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const float4 t4 = *reinterpret_cast<const float4*>(prow + 4 * n), u4 = *reinterpret_cast<const float4*>(drow + 4 * n);
+      x[4 * n] = t4.x; x[4 * n + 1] = t4.y; x[4 * n + 2] = t4.z; x[4 * n + 3] = t4.w;
+      dp[4 * n] = u4.x; dp[4 * n + 1] = u4.y; dp[4 * n + 2] = u4.z; dp[4 * n + 3] = u4.w;
+    }
+    float m = x[0];
+#pragma unroll
+    for (int n = 1; n < 16; ++n) m = fmaxf(m, x[n]);
+    m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2));
+    float s = 0.f;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) { x[n] = __expf(x[n] - m); s += x[n]; }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+    const float inv = 1.0f / s;
+    float delta = 0.f;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) { x[n] *= inv; delta += x[n] * dp[n]; }
+    delta += __shfl_xor(delta, 1); delta += __shfl_xor(delta, 2);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      *reinterpret_cast<float4*>(prow + 4 * n) = make_float4(x[4 * n], x[4 * n + 1], x[4 * n + 2], x[4 * n + 3]);
+      *reinterpret_cast<float4*>(drow + 4 * n) = make_float4(x[4 * n] * (dp[4 * n] - delta), x[4 * n + 1] * (dp[4 * n + 1] - delta),
+                                                             x[4 * n + 2] * (dp[4 * n + 2] - delta), x[4 * n + 3] * (dp[4 * n + 3] - delta));
+    }
+  }
+  __syncthreads();
+  const int nct = ch >> 5;
+  for (int it = w; it < 3 * nct; it += 4) {
+    const int ct = it % nct, o = it / nct;           // o: 0 dV (column offset 2 ch), 1 dQ (0), 2 dK (ch)
+    // A element (m, kk): o = 0: P[kk][m]; 1: dS[m][kk]; 2: dS[kk][m]   ->   base[kk * ak + m * am]
+    const float* abase = o == 0 ? sP : sD;
+    const int ak = o == 1 ? 1 : A64_PP, am = o == 1 ? A64_PP : 1;
+    const float* bbase = (o == 0 ? sg : (o == 1 ? sk : sq)) + 32 * ct + r;
+    const float* a0 = abase + hh * ak + r * am;
+    const float* a1 = a0 + 32 * am;
+    const float* bp = bbase + hh * PT;
+    att_f32x16 acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+#pragma unroll 8
+    for (int k0 = 0; k0 < 64; k0 += 2) {
+      const float bv = bp[k0 * PT];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[k0 * ak], bv, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[k0 * ak], bv, acc1, 0, 0, 0);
+    }
+    const float sc = o == 0 ? 1.0f : s2;
+    float* dst = dq + (o == 0 ? 2 * ch : (o == 1 ? 0 : ch)) + 32 * ct + r;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = (e & 3) + 8 * (e >> 2) + 4 * hh;
+      dst[(long)row * ld] = acc0[e] * sc;
+      dst[(long)(row + 32) * ld] = acc1[e] * sc;
+    }
+  }
+}
+
 // General-T form (T too large for both T x T matrices in LDS): two kernels over a global scratch [B*heads][2][T][T] (P, then dS).
 // A: grid (B*heads, ceil(T/QT)) — the QT query rows of this block against all keys: S, dP in LDS, softmax, dS, dQ; P and dS rows go to
 //    the scratch. B: grid (B*heads, ceil(T/32)) — 32 key rows: dV = P^T dO, dK = s2 dS^T Q reading scratch columns.
@@ -996,7 +1134,16 @@ extern "C" int stedm_attn_legacy_bwd(const float* qkv, const float* d_out, float
     STEDM_HIP_TRY(hipFuncSetAttribute((const void*)attn_bwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     attr = true;
   }
-  if (lds <= 160 * 1024 - 1024) {
+  const size_t lds64 = ((size_t)3 * 64 * (ch + 4) + (size_t)64 * (ch + 4 > A64_PP ? ch + 4 : A64_PP) + (size_t)64 * A64_PP) * sizeof(float);
+  if (T == 64 && ch % 32 == 0 && lds64 <= 160 * 1024 - 1024 &&
+      ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0) {
+    static bool attr64 = false;
+    if (!attr64) {
+      STEDM_HIP_TRY(hipFuncSetAttribute((const void*)attn64_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+      attr64 = true;
+    }
+    attn64_bwd_mfma_kernel<<<B * heads, 256, lds64, as_stream(stream)>>>(qkv, d_out, d_qkv, heads, ch);
+  } else if (lds <= 160 * 1024 - 1024) {
     attn_legacy_bwd_kernel<<<B * heads, 256, lds, as_stream(stream)>>>(qkv, d_out, d_qkv, T, heads, ch);
   } else {
     STEDM_CHECK_ARG(ws, "attn_legacy_bwd: T = %d tokens need the workspace of stedm_attn_legacy_bwd_ws_floats", T);

@@ -457,9 +457,9 @@ def test_overlapped_gradient_all_reduce_equals_the_plain_one_bitwise(dev):
     assert fired.index(0) > fired.index(nb - 2)                                        # the embedding Linears at the arena's start complete late
 
 
-@pytest.mark.parametrize("B,T,heads,ch", [(2, 64, 4, 32), (2, 256, 4, 32), (1, 1024, 2, 64), (3, 100, 2, 16)])
+@pytest.mark.parametrize("B,T,heads,ch", [(2, 64, 4, 32), (2, 64, 8, 128), (3, 64, 2, 64), (2, 64, 2, 16), (2, 256, 4, 32), (1, 1024, 2, 64), (3, 100, 2, 16)])
 def test_attention_backward_vs_autograd(dev, B, T, heads, ch):
-    """QKVAttentionLegacy backward: the LDS-resident form (T <= 128) and the two-kernel general form (T = 256 of the 64x64 latents, T = 1024 of
+    """QKVAttentionLegacy backward: the fp32-MFMA form (T = 64, head channels a multiple of 32), the LDS-resident VALU form (other T <= 128) and the two-kernel general form (T = 256 of the 64x64 latents, T = 1024 of
     the reference-native 128x128 ones) against autograd over the oracle's restatement."""
     from oracle import unet as ounet
     from stedm_amd import ops
