@@ -940,6 +940,17 @@ __global__ void l1_final_kernel(const double* __restrict__ part, int nb, double 
 // AdamW (torch.optim.AdamW semantics) + LitEma (ema.py:25-44) over many tensors in one launch. table[t] = {p, g, m, v, ema, n};
 // chunk_tensor[blockIdx.x] / chunk_off[blockIdx.x] map a block to 4096 elements of one tensor.
 struct OptTensor { float* p; const float* g; float* m; float* v; float* ema; long n; };
+// one element of torch.optim.AdamW (decoupled weight decay first, bias corrections bc1 = 1 - beta1^t, bc2_sqrt = sqrt(1 - beta2^t))
+__device__ __forceinline__ void adamw_one(float& p, float g_raw, float& m, float& v, float lr, float beta1, float beta2, float eps, float wd, float bc1,
+                                          float bc2_sqrt, float grad_scale) {
+  const float g = g_raw * grad_scale;
+  float pn = p * (1.0f - lr * wd);
+  m = beta1 * m + (1.0f - beta1) * g;
+  v = beta2 * v + (1.0f - beta2) * g * g;
+  const float denom = sqrtf(v) / bc2_sqrt + eps;
+  pn -= (lr / bc1) * (m / denom);
+  p = pn;
+}
 __global__ void __launch_bounds__(256) adamw_ema_kernel(const OptTensor* __restrict__ table, const int* __restrict__ chunk_tensor,
                                                         const long* __restrict__ chunk_off, float lr, float beta1, float beta2, float eps, float wd, float bc1,
                                                         float bc2_sqrt, float ema_decay, float grad_scale) {
@@ -948,16 +959,105 @@ __global__ void __launch_bounds__(256) adamw_ema_kernel(const OptTensor* __restr
   for (int k = 0; k < 16; ++k) {
     const long i = o0 + k * 256 + threadIdx.x;
     if (i >= t.n) return;
-    const float g = t.g[i] * grad_scale;
-    float p = t.p[i] * (1.0f - lr * wd);
-    const float m = beta1 * t.m[i] + (1.0f - beta1) * g;
-    const float v = beta2 * t.v[i] + (1.0f - beta2) * g * g;
-    const float denom = sqrtf(v) / bc2_sqrt + eps;
-    p -= (lr / bc1) * (m / denom);
+    float p = t.p[i], m = t.m[i], v = t.v[i];
+    adamw_one(p, t.g[i], m, v, lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, grad_scale);
     t.p[i] = p; t.m[i] = m; t.v[i] = v;
     if (t.ema) { const float s = t.ema[i]; t.ema[i] = s - (1.0f - ema_decay) * (s - p); }
   }
 }
+
+// AdamW + EMA for convolution weights that ALSO writes the 16-bit fragment-order copies the next forward / backward read (the packs of
+// stedm_pack_frag_multi: forward order and the flipped / transposed dgrad order, 32x32x16 and 16x16x32 fragment forms), so the optimizer's own
+// pass over the weights replaces the re-pack launches and their extra read. A block owns a 32 (cout) x 32 (cin) x taps piece of an OIHW
+// filter: rows of 32 * taps contiguous floats in, the updated values kept in LDS, and every fragment vector (8 consecutive channels of one
+// row and tap) that lies inside the piece written from there — a piece holds whole fragments of all four forms.
+struct FusedPackOut { void* out; int transposed, flip, m16, f16; };
+struct FusedOptDesc {
+  float* p; const float* g; float* m; float* v; float* ema;
+  int cout, cin, taps, blk0, nout, pad_;
+  FusedPackOut o[4];
+};
+static_assert(sizeof(FusedPackOut) == 24 && sizeof(FusedOptDesc) == 160, "FusedOptDesc layout is part of the ABI (stedm_adamw_ema_pack)");
+
+__global__ void __launch_bounds__(256) adamw_ema_pack_kernel(const FusedOptDesc* __restrict__ descs, const int nd, float lr, float beta1, float beta2,
+                                                             float eps, float wd, float bc1, float bc2_sqrt, float ema_decay, float grad_scale) {
+  extern __shared__ float ftile[];        // [32][32 * taps + 1]
+  int lo = 0, hi = nd - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const FusedOptDesc& d = descs[lo];
+  const int bid = blockIdx.x - d.blk0;
+  const int taps = d.taps, cin = d.cin, cout = d.cout;
+  const int ncb = cin >> 5;
+  const int co0 = (bid / ncb) * 32, ci0 = (bid % ncb) * 32;
+  const int run = 32 * taps, pitch = run + 1, r4 = run >> 2;
+  float* const P = d.p; const float* const G = d.g; float* const M = d.m; float* const V = d.v; float* const E = d.ema;
+#pragma unroll 3
+  for (int idx = threadIdx.x; idx < 32 * r4; idx += 256) {
+    const int row = idx / r4, r0 = (idx - row * r4) * 4;
+    const long off = ((long)(co0 + row) * cin + ci0) * taps + r0;
+    const float4 p4 = *reinterpret_cast<const float4*>(P + off), g4 = *reinterpret_cast<const float4*>(G + off);
+    const float4 m4 = *reinterpret_cast<const float4*>(M + off), v4 = *reinterpret_cast<const float4*>(V + off);
+    float pv[4] = {p4.x, p4.y, p4.z, p4.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+    const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) adamw_one(pv[j], gv[j], mv[j], vv[j], lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, grad_scale);
+    *reinterpret_cast<float4*>(P + off) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+    *reinterpret_cast<float4*>(M + off) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+    *reinterpret_cast<float4*>(V + off) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    if (E) {
+      const float4 e4 = *reinterpret_cast<const float4*>(E + off);
+      float ev[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ev[j] = ev[j] - (1.0f - ema_decay) * (ev[j] - pv[j]);
+      *reinterpret_cast<float4*>(E + off) = make_float4(ev[0], ev[1], ev[2], ev[3]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ftile[row * pitch + r0 + j] = pv[j];
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int oi = 0; oi < d.nout; ++oi) {
+    const FusedPackOut po = d.o[oi];
+    const int fr = po.m16 ? 16 : 32, fc = po.m16 ? 32 : 16;                 // fragment rows x channels
+    const int Rn = 32, Rc = 32;                                              // the piece in the pack's (row n, channel c) coordinates
+    const int n_base = po.transposed ? ci0 : co0, c_base = po.transposed ? co0 : ci0;
+    const int nch = (po.transposed ? cout : cin) / fc;                       // channel chunks of the pack
+    const int nfn = Rn / fr, nfrag = nfn * (Rc / fc) * taps;
+    const int g = lane >> 4;
+    for (int f = wave; f < nfrag; f += 4) {
+      const int tap = f % taps, ff = f / taps, fn = ff % nfn, fcx = ff / nfn;
+      int nl, cl;
+      if (!po.m16) { nl = fn * 32 + (lane & 31); cl = fcx * 16 + (lane >> 5) * 8; }
+      else { nl = fn * 16 + (lane & 15); cl = fcx * 32 + 8 * (taps == 9 ? 2 * (g & 1) + (g >> 1) : g); }
+      const int ts = po.flip ? taps - 1 - tap : tap;        // source tap
+      const float* src = po.transposed ? ftile + cl * pitch + nl * taps + ts : ftile + nl * pitch + cl * taps + ts;
+      const int es = po.transposed ? pitch : taps;
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = src[e * es];
+      const int n = n_base + nl, c = c_base + cl;
+      const long at = po.m16 ? ((((long)(n >> 7) * nch + (c >> 5)) * taps + tap) * 8 + ((n >> 4) & 7)) * 512 + ((n & 15) + 16 * g) * 8
+                             : ((((long)(n >> 7) * nch + (c >> 4)) * taps + tap) * 4 + ((n >> 5) & 3)) * 512 + ((n & 31) + 32 * ((c >> 3) & 1)) * 8;
+      if (po.f16) {
+        typedef _Float16 H8 __attribute__((ext_vector_type(8)));
+        H8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)x[e];
+        *reinterpret_cast<H8*>(reinterpret_cast<_Float16*>(po.out) + at) = o;
+      } else {
+        typedef __bf16 B8 __attribute__((ext_vector_type(8)));
+        B8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)x[e];
+        *reinterpret_cast<B8*>(reinterpret_cast<__bf16*>(po.out) + at) = o;
+      }
+    }
+  }
+}
+
 
 // LitEma.forward alone (ema.py:25-44, called from on_train_batch_end, ddpm.py:369-371): shadow -= (1 - decay) * (shadow - p) over the
 // optimizer's pointer table; tensors without a shadow are skipped.
@@ -1213,6 +1313,23 @@ extern "C" int stedm_adamw_ema(const void* table, const int* chunk_tensor, const
   const float bc2 = (float)(1.0 - pow((double)beta2, (double)step));
   adamw_ema_kernel<<<nchunks, 256, 0, as_stream(stream)>>>((const OptTensor*)table, chunk_tensor, chunk_off, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2),
                                                           ema_decay, grad_scale);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int stedm_adamw_ema_pack(const void* descs, int ndesc, int total_blocks, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                    int step, float ema_decay, float grad_scale, void* stream) {
+  STEDM_CHECK_ARG(descs && ndesc > 0 && total_blocks > 0 && step >= 1, "adamw_ema_pack: bad args");
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+  const size_t lds = (size_t)32 * (32 * 9 + 1) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    STEDM_HIP_TRY(hipFuncSetAttribute((const void*)adamw_ema_pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  adamw_ema_pack_kernel<<<total_blocks, 256, lds, as_stream(stream)>>>((const FusedOptDesc*)descs, ndesc, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2),
+                                                                      ema_decay, grad_scale);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

@@ -283,6 +283,9 @@ class PackPlan:
         self.items = []          # (w tensor (kept alive), sn, sc, flip, cout, cin, taps, m16, out)
         self._table = None
         self._blocks = 0
+        self._fused = frozenset()      # indices of items the optimizer kernel refreshes itself (stedm_adamw_ema_pack)
+        self._rest = None              # (table, blocks, n) of the other items
+        self._fresh = None             # parameter versions at the moment the fused items were last refreshed
 
     def frag(self, w: torch.Tensor, sn: int, sc: int, flip: bool, cout: int, cin: int, ks: int, m16: bool) -> torch.Tensor:
         """Pack now (single-tensor launch) and remember the problem. w: fp32 tensor whose element (n, ci, tap) is flat[n*sn + ci*sc + tap']."""
@@ -300,6 +303,8 @@ class PackPlan:
                                                        _stream()), "stedm_pack_conv_weight_strided")
         self.items.append((w, sn, sc, int(flip), cout, cin, taps, int(m16), out))
         self._table = None
+        self._rest = None
+        self._fresh = None
         return out
 
     def frag_oihw(self, w4: torch.Tensor, m16: bool) -> torch.Tensor:
@@ -307,18 +312,41 @@ class PackPlan:
         cout, cin, ks, _ = w4.shape
         return self.frag(w4, cin * ks * ks, ks * ks, False, cout, cin, ks, m16)
 
-    def run(self) -> None:
-        """all recorded packs again, one launch"""
+    def _build_table(self, idxs):
+        import struct
+        rec, blk = [], 0
+        for i in idxs:
+            (w, sn, sc, flip, cout, cin, taps, m16, out) = self.items[i]
+            rec.append(struct.pack("<QQqqiiiiii", w.data_ptr(), out.data_ptr(), sn, sc, cout, cin, taps, flip, m16, blk))
+            blk += ((cout + 127) // 128) * ((cin // 32) * 4 if m16 else (cin // 16) * 2)
+        if not rec:
+            return None, 0, 0
+        return torch.frombuffer(bytearray(b"".join(rec)), dtype=torch.uint8).to(self.items[0][0].device), blk, len(rec)
+
+    def set_fused(self, idxs) -> None:
+        """items the optimizer kernel refreshes itself; run(versions) skips them while mark_fresh(versions) still holds"""
+        self._fused = frozenset(idxs)
+        self._rest = None
+        self._fresh = None
+
+    def mark_fresh(self, versions) -> None:
+        self._fresh = versions
+
+    def run(self, versions=None) -> None:
+        """all recorded packs again, one launch. versions: the parameters' `_version`s now — when they are the ones mark_fresh() saw, the
+        fused items already hold the current weights (written by the optimizer kernel) and only the others run"""
         if not self.items:
             return
+        fresh, self._fresh = self._fresh, None
+        if self._fused and versions is not None and fresh == versions:
+            if self._rest is None:
+                self._rest = self._build_table([i for i in range(len(self.items)) if i not in self._fused])
+            table, blocks, n = self._rest
+            if n:
+                check(lib().stedm_pack_frag_multi(table.data_ptr(), n, blocks, self.prec.mm_dtype, _stream()), "stedm_pack_frag_multi")
+            return
         if self._table is None:
-            import struct
-            rec, blk = [], 0
-            for (w, sn, sc, flip, cout, cin, taps, m16, out) in self.items:
-                rec.append(struct.pack("<QQqqiiiiii", w.data_ptr(), out.data_ptr(), sn, sc, cout, cin, taps, flip, m16, blk))
-                blk += ((cout + 127) // 128) * ((cin // 32) * 4 if m16 else (cin // 16) * 2)
-            self._table = torch.frombuffer(bytearray(b"".join(rec)), dtype=torch.uint8).to(self.items[0][0].device)
-            self._blocks = blk
+            self._table, self._blocks, _ = self._build_table(range(len(self.items)))
         check(lib().stedm_pack_frag_multi(self._table.data_ptr(), len(self.items), self._blocks, self.prec.mm_dtype, _stream()), "stedm_pack_frag_multi")
 
 
@@ -885,6 +913,13 @@ def adamw_ema(table: torch.Tensor, chunk_tensor: torch.Tensor, chunk_off: torch.
               weight_decay: float, step: int, ema_decay: float, grad_scale: float = 1.0) -> None:
     check(lib().stedm_adamw_ema(table.data_ptr(), chunk_tensor.data_ptr(), chunk_off.data_ptr(), chunk_tensor.numel(), float(lr), float(beta1),
                                 float(beta2), float(eps), float(weight_decay), int(step), float(ema_decay), float(grad_scale), _stream()), "stedm_adamw_ema")
+
+
+def adamw_ema_pack(descs: torch.Tensor, ndesc: int, total_blocks: int, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float,
+                   step: int, ema_decay: float, grad_scale: float = 1.0) -> None:
+    """AdamW + EMA over convolution weights, refreshing their fragment-order packs in the same pass (stedm_adamw_ema_pack)"""
+    check(lib().stedm_adamw_ema_pack(descs.data_ptr(), int(ndesc), int(total_blocks), float(lr), float(beta1), float(beta2), float(eps),
+                                     float(weight_decay), int(step), float(ema_decay), float(grad_scale), _stream()), "stedm_adamw_ema_pack")
 
 
 def ema_update(table: torch.Tensor, chunk_tensor: torch.Tensor, chunk_off: torch.Tensor, ema_decay: float) -> None:

@@ -26,7 +26,7 @@ from types import SimpleNamespace
 import torch.nn as nn
 
 from . import ops
-from ._lib import BF16
+from ._lib import BF16, F16
 from .ops import Precision
 from .unet import AttentionBlock, Downsample, ResBlock, UNetModel, Upsample
 
@@ -46,6 +46,7 @@ class UNetTrainer:
         # cond_stage_trainable, ldm_diffusion.py:224-234); their gradients are filled by the caller; no EMA (LitEma covers `model` only)
         self.extra_params = list(extra_params)
         self.direct_wgrad = os.environ.get("STEDM_WGRAD_GEMM") is None    # STEDM_WGRAD_GEMM=1: im2col + GEMM form everywhere (A/B switch)
+        self.fuse_packs = os.environ.get("STEDM_OPT_NOFUSE") is None      # STEDM_OPT_NOFUSE=1: AdamW and the weight re-packs as separate launches (A/B switch)
         self.accumulate_grad_batches = int(accumulate_grad_batches)      # Trainer(accumulate_grad_batches=...) of train_diff.py
         self._micro = 0
         self.lr, self.betas, self.eps, self.wd = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
@@ -345,7 +346,7 @@ class UNetTrainer:
         dkey = (self.bprec, m.conv_path, m._m16, tuple(p.data_ptr() for p in m.parameters()))
         self._dpacks_step = {}
         if getattr(self, "_dplan", None) is not None and self._dplan_key == dkey:
-            self._dplan.run()
+            self._dplan.run(versions=tuple(p._version for p in m.parameters()))
             for ent in self._dpacks.values():
                 if isinstance(ent[0], ops.LazyPlanes):
                     ent[0].reset()
@@ -701,6 +702,70 @@ class UNetTrainer:
         if getattr(self, "_opt_resume", None) is not None:
             self._apply_opt_resume()
 
+    def _fused_opt(self):
+        """Descriptor table of stedm_adamw_ema_pack: every arena parameter that is a convolution weight with fragment-order packs recorded
+        in the forward's plan (UNetModel._plan) and / or the backward's (self._dplan), plus the chunk lists of the remaining tensors for the
+        plain kernel. None while no plan exists (before the first forward + backward) or nothing qualifies. Rebuilt when a plan changes."""
+        import struct
+        m = self.m
+        plans = [pl for pl in (getattr(m, "_plan", None), getattr(self, "_dplan", None)) if pl is not None and pl.items]
+        if not plans or (len(plans) == 2 and plans[0] is plans[1]):
+            return None
+        key = tuple((id(pl), len(pl.items)) for pl in plans)
+        fu = getattr(self, "_fused", None)
+        if fu is not None and fu["key"] == key:
+            return fu if fu["n"] else None
+        st = self._opt
+        params = st["params"]
+        tab = st["table"].cpu().numpy()
+        by_ptr = {}
+        for pl in plans:
+            if pl.prec.npass != 1:
+                continue
+            for j, (w, sn, sc, flip, cout, cin, taps, m16, out) in enumerate(pl.items):
+                by_ptr.setdefault(w.data_ptr(), []).append((pl, j, sn, sc, flip, cout, cin, taps, m16, out))
+        rec, blk, fused_idx, used = [], 0, set(), {id(pl): [] for pl in plans}
+        for i, p in enumerate(params):
+            its = by_ptr.get(p.data_ptr())
+            if not its or p.dim() < 3 or not p.is_contiguous():
+                continue
+            co, ci = p.shape[0], p.shape[1]
+            taps = p.numel() // (co * ci)
+            if co % 32 or ci % 32 or taps not in (1, 9) or len(its) > 4:
+                continue
+            outs = []
+            for (pl, j, sn, sc, flip, pcout, pcin, ptaps, m16, out) in its:
+                straight = (sn, sc, pcout, pcin, flip) == (ci * taps, taps, co, ci, 0)
+                transposed = (sn, sc, pcout, pcin, flip) == (taps, ci * taps, ci, co, 1)
+                if ptaps != taps or not (straight or transposed):
+                    outs = None
+                    break
+                outs.append((pl, j, struct.pack("<Qiiii", out.data_ptr(), int(transposed), int(flip), int(m16), int(pl.prec.mm_dtype == F16))))
+            if not outs:
+                continue
+            body = b"".join(o[2] for o in outs) + b"\0" * (24 * (4 - len(outs)))
+            rec.append(struct.pack("<QQQQQiiiiii", int(tab[i, 0]), int(tab[i, 1]), int(tab[i, 2]), int(tab[i, 3]), int(tab[i, 4]), co, ci, taps, blk,
+                                   len(outs), 0) + body)
+            blk += (co // 32) * (ci // 32)
+            fused_idx.add(i)
+            for (pl, j, _) in outs:
+                used[id(pl)].append(j)
+        dev = params[0].device
+        fu = {"key": key, "n": len(rec), "blocks": blk, "plans": plans}
+        if rec:
+            fu["descs"] = torch.frombuffer(bytearray(b"".join(rec)), dtype=torch.uint8).to(dev)
+            rest = [(i, p) for i, p in enumerate(params) if i not in fused_idx]
+            ct, co_ = [], []
+            for i, p in rest:
+                for o in range(0, p.numel(), 4096):
+                    ct.append(i); co_.append(o)
+            fu["ct"] = torch.tensor(ct, dtype=torch.int32, device=dev)
+            fu["co"] = torch.tensor(co_, dtype=torch.int64, device=dev)
+            for pl in plans:
+                pl.set_fused(used[id(pl)])
+        self._fused = fu
+        return fu if fu["n"] else None
+
     @torch.no_grad()
     def all_reduce_grads(self, group=None, bucket_mb: int = 256) -> int:
         """Data-parallel training (train_diff.py runs Lightning DDP): sum the gradient arena over the ranks in a few large buckets
@@ -726,8 +791,19 @@ class UNetTrainer:
         st = self._opt
         self.step_count += 1
         decay = self._next_ema_decay() if self.ema_decay is not None else 0.0
-        ops.adamw_ema(st["table"], st["ct"], st["co"], self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, decay,
-                      grad_scale=getattr(self, "_grad_scale", 1.0))
+        gs = getattr(self, "_grad_scale", 1.0)
+        fu = self._fused_opt() if self.fuse_packs else None
+        if fu is None:
+            ops.adamw_ema(st["table"], st["ct"], st["co"], self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, decay, grad_scale=gs)
+        else:
+            # convolution weights with fragment-order packs: the optimizer pass writes the packs of the next forward / backward itself
+            ops.adamw_ema_pack(fu["descs"], fu["n"], fu["blocks"], self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, decay, gs)
+            if fu["ct"].numel():
+                ops.adamw_ema(st["table"], fu["ct"], fu["co"], self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, decay,
+                              grad_scale=gs)
+            versions = tuple(p._version for p in self.m.parameters())
+            for plan in fu["plans"]:
+                plan.mark_fresh(versions)
         self.m.invalidate()      # parameters changed through raw pointers: repack on the next forward
         self._grads_ready = False
 

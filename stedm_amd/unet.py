@@ -358,7 +358,7 @@ class UNetModel(nn.Module):
             elif type(m).__name__ == "SpatialTransformer":
                 self._packed[id(m)] = m.pack(prec)
         if replay:
-            plan.run()
+            plan.run(versions=key[2])
         c = self._consts
         half = self.model_channels // 2
         # host-built frequency table (util.py:162-164 builds it on the CPU in fp32)

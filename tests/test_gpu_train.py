@@ -148,6 +148,48 @@ def test_train_steps_reduce_the_loss(dev):
     assert losses[-1] < losses[0] - 0.01
 
 
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+def test_optimizer_writes_the_weight_packs_itself(dev, precision):
+    """stedm_adamw_ema_pack: AdamW + EMA over the convolution weights that also refreshes their fragment-order packs (forward order and the
+    flipped / transposed dgrad order, 32x32x16 and 16x16x32 forms). Against the separate launches (AdamW, then stedm_pack_frag_multi before the
+    next forward / backward) on the same model and batch: losses of four steps, parameters, EMA shadows and every pack bit for bit; an in-place
+    edit of a weight between two steps still re-packs it (the freshness mark follows the parameters' versions)."""
+    from stedm_amd.train import UNetTrainer
+    cfg = dict(image_size=16, in_channels=7, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=[32, 16, 8], channel_mult=[1, 4, 8],
+               num_heads=4)
+    runs = []
+    for fuse in (True, False):
+        m = build(cfg, 6, dev, precision)
+        tr = UNetTrainer(m, lr=2e-4, weight_decay=0.01)
+        tr.fuse_packs = fuse
+        x, ctx, target = _inputs("fuse", cfg, 2, 16, 6, dev)
+        t = torch.tensor([951, 21], device=dev)
+        losses = []
+        for step in range(4):
+            if step == 3:      # a version bump: the packs of this weight must come from the parameter again
+                m.input_blocks[1][0].in_layers[2].weight.data.mul_(0.5)
+            losses.append(float(tr.train_step(x[:, :4].contiguous(), x[:, 4:].contiguous(), t, ctx, target)))
+        fu = getattr(tr, "_fused", None)
+        if fuse:
+            assert fu is not None and fu["n"] >= 8, "no convolution weight took the fused path"
+            assert all(len(pl._fused) > 0 for pl in fu["plans"]) and len(fu["plans"]) == 2
+        else:
+            assert fu is None
+        m._prepare()           # the forward's packs of the final weights (fused run: only what the optimizer did not write itself)
+        if not fuse:
+            tr._dplan.run()    # ... and the backward's: the fused run holds them already
+        packs = [it[8].clone() for pl in (m._plan, tr._dplan) for it in pl.items]
+        runs.append((losses, [p.detach().clone() for p in m.parameters()], [e.clone() for e in tr.ema_parameters()], packs))
+    (la, pa, ea, ka), (lb, pb, eb, kb) = runs
+    print("losses", ["%.5f" % v for v in la])
+    assert la == lb, (la, lb)
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        assert torch.equal(a, b), f"parameter {i}"
+    for i, (a, b) in enumerate(zip(ea, eb)):
+        assert torch.equal(a, b), f"ema {i}"
+    assert len(ka) == len(kb) and all(torch.equal(a, b) for a, b in zip(ka, kb))
+
+
 def test_spatial_rescaler_weight_gradient_vs_oracle(dev):
     """cond_stage_trainable: channel_mapper.weight gradient from the c_concat slice of the U-Net's input gradient, against autograd
     over the oracle's restatement of SpatialRescaler.forward (encoders/modules.py:123-130)."""
