@@ -326,6 +326,9 @@ class UNetModel(nn.Module):
                     frag16 = plan.frag_oihw(w4, True) if in_place else ops.pack_conv_weight_frag16(w4, prec)
                 # the [cout][tap][cin] planes are read only by the LDS-operand kernels: packed on first need
                 hi = ops.LazyPlanes(lambda w=conv.weight: ops.pack_conv_weight(w.float(), prec))
+            elif self.conv_path == "dma" and prec.npass == 1 and conv.stride == (2, 2) and conv.in_channels % 8 == 0:
+                # Downsample.op: runs as the space-to-depth form below; the plain planes serve odd sizes only
+                hi = ops.LazyPlanes(lambda w=conv.weight: ops.pack_conv_weight(w.float(), prec))
             else:
                 hi, lo = ops.pack_conv_weight(conv.weight.float(), prec)
                 if self.conv_path == "dma" and prec.npass == 3 and k3 and self._m16 and conv.in_channels % 32 == 0 and conv.in_channels >= 128:
@@ -349,8 +352,11 @@ class UNetModel(nn.Module):
             elif isinstance(m, Upsample):
                 pack(m.conv)
                 if self.conv_path == "dma":   # sub-pixel form: 4 parity 2x2 convs with pre-summed taps
-                    hi, lo = ops.pack_conv_weight_up(m.conv.weight.float(), prec)
                     frag = ops.pack_conv_weight_up_frag(m.conv.weight.float(), prec) if prec.npass == 1 and m.conv.in_channels % 32 == 0 else None
+                    if frag is not None:     # the planes are read only when a problem falls to the LDS-operand kernel: packed on first need
+                        hi, lo = ops.LazyPlanes(lambda w=m.conv.weight: ops.pack_conv_weight_up(w.float(), prec)), None
+                    else:
+                        hi, lo = ops.pack_conv_weight_up(m.conv.weight.float(), prec)
                     self._packed[(id(m.conv), "up")] = _Packed(hi, lo, self._packed[id(m.conv)].bias, frag)
             elif isinstance(m, AttentionBlock):
                 pack(m.qkv)
