@@ -471,14 +471,15 @@ int stedm_axpby_f32(const float* x, float* y, long n, float alpha, float beta, v
  * block i updates elements [chunk_off[i], chunk_off[i] + 4096) of tensor chunk_tensor[i]. step counts from 1. */
 int stedm_adamw_ema(const void* table, const int* chunk_tensor, const long* chunk_off, int nchunks, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int step, float ema_decay, float grad_scale, void* stream);
-/* The same update for convolution weights (OIHW fp32, cout %% 32 == 0, cin %% 32 == 0, 1 or 9 taps) that also refreshes the 16-bit
+/* The same update for convolution weights (OIHW fp32, cout %% rows == 0, cin %% ciw == 0, 1 or 9 taps) that also refreshes the 16-bit
  * fragment-order copies of stedm_pack_frag_multi in the same pass (torch.optim.AdamW.step of modules/ldm_diffusion.py:224-234 followed by the
  * weight packs of the next forward / backward). descs [ndesc] of
  *   { float* p; const float* g; float* m; float* v; float* ema|NULL; int cout, cin, taps, blk0, nout, pad;
  *     { void* out; int transposed, flip, m16, f16; } o[4]; }                                   (160 bytes)
- * blk0 = first block of the tensor (ascending; a tensor takes (cout / 32) * (cin / 32) blocks), total_blocks their sum. Output k is the
+ * blk0 = first block of the tensor (ascending; a tensor takes (cout / rows) * (cin / ciw) blocks, stedm_adamw_ema_pack_piece), total_blocks their sum. Output k is the
  * pack of element (n, c, tap) = W[n][c][tap] (transposed = 0: stedm_pack_conv_weight_frag / _frag16 of the OIHW filter) or
  * W[c][n][taps-1-tap] (transposed = 1, flip = 1: the dgrad filter), m16: the 16x16x32 fragment order, f16: fp16 instead of bf16. */
+int stedm_adamw_ema_pack_piece(int* rows, int* ciw);   /* the piece a block owns: a tensor takes (cout / rows) * (cin / ciw) blocks */
 int stedm_adamw_ema_pack(const void* descs, int ndesc, int total_blocks, float lr, float beta1, float beta2, float eps,
                          float weight_decay, int step, float ema_decay, float grad_scale, void* stream);
 /* LitEma.forward alone (ldm/modules/ema.py:25-44; on_train_batch_end, ddpm.py:369-371, runs it once per micro-batch, also on the

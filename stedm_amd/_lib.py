@@ -126,6 +126,7 @@ SIGNATURES = {
     "stedm_axpby_f32": (_I, [_P, _P, C.c_long, _F, _F, _P]),
     "stedm_adamw_ema": (_I, [_P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _F, _F, _P]),
     "stedm_adamw_ema_pack": (_I, [_P, _I, _I, _F, _F, _F, _F, _F, _I, _F, _F, _P]),
+    "stedm_adamw_ema_pack_piece": (_I, [_P, _P]),
     "stedm_ema_update": (_I, [_P, _P, _P, _I, _F, _P]),
     "stedm_vq_nearest": (_I, [_P, _P, _I, _I, _I, C.c_long, _P, _P, _P]),
     "stedm_conv1x1_nchw": (_I, [_P, _P, _P, _P, _I, _I, _I, C.c_long, _P]),

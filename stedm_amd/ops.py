@@ -915,6 +915,13 @@ def adamw_ema(table: torch.Tensor, chunk_tensor: torch.Tensor, chunk_off: torch.
                                 float(beta2), float(eps), float(weight_decay), int(step), float(ema_decay), float(grad_scale), _stream()), "stedm_adamw_ema")
 
 
+def adamw_ema_pack_piece() -> Tuple[int, int]:
+    """(rows, ciw): a convolution weight takes (cout / rows) * (cin / ciw) blocks of stedm_adamw_ema_pack"""
+    r, c = C.c_int(0), C.c_int(0)
+    check(lib().stedm_adamw_ema_pack_piece(C.byref(r), C.byref(c)), "stedm_adamw_ema_pack_piece")
+    return r.value, c.value
+
+
 def adamw_ema_pack(descs: torch.Tensor, ndesc: int, total_blocks: int, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float,
                    step: int, ema_decay: float, grad_scale: float = 1.0) -> None:
     """AdamW + EMA over convolution weights, refreshing their fragment-order packs in the same pass (stedm_adamw_ema_pack)"""

@@ -725,13 +725,14 @@ class UNetTrainer:
             for j, (w, sn, sc, flip, cout, cin, taps, m16, out) in enumerate(pl.items):
                 by_ptr.setdefault(w.data_ptr(), []).append((pl, j, sn, sc, flip, cout, cin, taps, m16, out))
         rec, blk, fused_idx, used = [], 0, set(), {id(pl): [] for pl in plans}
+        prow, pciw = ops.adamw_ema_pack_piece()
         for i, p in enumerate(params):
             its = by_ptr.get(p.data_ptr())
             if not its or p.dim() < 3 or not p.is_contiguous():
                 continue
             co, ci = p.shape[0], p.shape[1]
             taps = p.numel() // (co * ci)
-            if co % 32 or ci % 32 or taps not in (1, 9) or len(its) > 4:
+            if co % prow or ci % pciw or taps not in (1, 9) or len(its) > 4:
                 continue
             outs = []
             for (pl, j, sn, sc, flip, pcout, pcin, ptaps, m16, out) in its:
@@ -746,7 +747,7 @@ class UNetTrainer:
             body = b"".join(o[2] for o in outs) + b"\0" * (24 * (4 - len(outs)))
             rec.append(struct.pack("<QQQQQiiiiii", int(tab[i, 0]), int(tab[i, 1]), int(tab[i, 2]), int(tab[i, 3]), int(tab[i, 4]), co, ci, taps, blk,
                                    len(outs), 0) + body)
-            blk += (co // 32) * (ci // 32)
+            blk += (co // prow) * (ci // pciw)
             fused_idx.add(i)
             for (pl, j, _) in outs:
                 used[id(pl)].append(j)
