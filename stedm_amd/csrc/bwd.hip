@@ -956,6 +956,33 @@ __global__ void __launch_bounds__(256) adamw_ema_kernel(const OptTensor* __restr
                                                         float bc2_sqrt, float ema_decay, float grad_scale) {
   const OptTensor t = table[chunk_tensor[blockIdx.x]];
   const long o0 = chunk_off[blockIdx.x];
+  const uintptr_t al = reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.g) | reinterpret_cast<uintptr_t>(t.m) |
+                       reinterpret_cast<uintptr_t>(t.v) | reinterpret_cast<uintptr_t>(t.ema);
+  if (o0 + 4096 <= t.n && (al & 15) == 0) {      // a whole chunk of 16-B aligned streams: 16 B per lane and access
+    const bool has_e = t.ema != nullptr;
+#pragma unroll 2
+    for (int k = 0; k < 4; ++k) {
+      const long i = o0 + (k * 256 + threadIdx.x) * 4;
+      const float4 p4 = *reinterpret_cast<const float4*>(t.p + i), g4 = *reinterpret_cast<const float4*>(t.g + i);
+      const float4 m4 = *reinterpret_cast<const float4*>(t.m + i), v4 = *reinterpret_cast<const float4*>(t.v + i);
+      float4 e4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (has_e) e4 = *reinterpret_cast<const float4*>(t.ema + i);
+      float pv[4] = {p4.x, p4.y, p4.z, p4.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+      const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) adamw_one(pv[j], gv[j], mv[j], vv[j], lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, grad_scale);
+      *reinterpret_cast<float4*>(t.p + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+      *reinterpret_cast<float4*>(t.m + i) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+      *reinterpret_cast<float4*>(t.v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      if (has_e) {
+        float ev[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ev[j] = ev[j] - (1.0f - ema_decay) * (ev[j] - pv[j]);
+        *reinterpret_cast<float4*>(t.ema + i) = make_float4(ev[0], ev[1], ev[2], ev[3]);
+      }
+    }
+    return;
+  }
   for (int k = 0; k < 16; ++k) {
     const long i = o0 + k * 256 + threadIdx.x;
     if (i >= t.n) return;
@@ -1321,8 +1348,8 @@ extern "C" int stedm_adamw_ema(const void* table, const int* chunk_tensor, const
 }
 
 // piece geometry of stedm_adamw_ema_pack: a tensor takes (cout / rows) * (cin / ciw) blocks. 32 x 32, 64 x 32, 32 x 64 and 64 x 64 measured the
-// same on the north-star U-Net (2.34 - 2.42 ms for the optimizer step with the remaining packs; 2.79 ms unfused): the pass is bound by its
-// 40 bytes per weight, not by the segment length
+// same on the north-star U-Net: the pass is bound by its 40 bytes per weight (234.6 M weights in 1.72 ms = 5.4 TB/s; the plain kernel moves
+// its 36 bytes per weight at 5.5 TB/s), not by the segment length (tools/bench_opt.py)
 constexpr int kOptRows = 32, kOptCiw = 32;
 extern "C" int stedm_adamw_ema_pack_piece(int* rows, int* ciw) {
   STEDM_CHECK_ARG(rows && ciw, "adamw_ema_pack_piece: null pointer");
