@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STEDM_ABI_VERSION 4
+#define STEDM_ABI_VERSION 5
 
 #define STEDM_F16 0
 #define STEDM_BF16 1

@@ -46,7 +46,7 @@ class UNetTrainer:
         # cond_stage_trainable, ldm_diffusion.py:224-234); their gradients are filled by the caller; no EMA (LitEma covers `model` only)
         self.extra_params = list(extra_params)
         self.direct_wgrad = os.environ.get("STEDM_WGRAD_GEMM") is None    # STEDM_WGRAD_GEMM=1: im2col + GEMM form everywhere (A/B switch)
-        self.fuse_packs = os.environ.get("STEDM_OPT_NOFUSE") is None      # STEDM_OPT_NOFUSE=1: AdamW and the weight re-packs as separate launches (A/B switch)
+        self.fuse_packs = True       # the optimizer pass writes the convolution weights' fragment-order packs itself; False: separate launches (tests)
         self.accumulate_grad_batches = int(accumulate_grad_batches)      # Trainer(accumulate_grad_batches=...) of train_diff.py
         self._micro = 0
         self.lr, self.betas, self.eps, self.wd = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
