@@ -87,8 +87,9 @@ class ConvTimer:
             M = out.numel() // out.shape[-1]
             if w_hi is None:   # space-to-depth Downsample: 9 taps x cin of the stride-2 conv (the 2x2 x 4cin form executes 16/9 of that)
                 flops = 2.0 * M * out.shape[-1] * 9 * kw["src16"][0].shape[-1] / 4
-            elif isinstance(w_hi, ops.LazyPlanes):   # fragment-order weights in use: K = taps x cin from the call
-                flops = 2.0 * M * out.shape[-1] * kw.get("ks", 3) ** 2 * kw["src16"][0].shape[-1]
+            elif isinstance(w_hi, ops.LazyPlanes):   # fragment-order weights in use: K = taps x cin from the call (sub-pixel upsample: 4 executed taps)
+                taps = 4 if kw.get("mode", 0) == ops.CONV_UP_SUBPIXEL else kw.get("ks", 3) ** 2
+                flops = 2.0 * M * out.shape[-1] * taps * kw["src16"][0].shape[-1]
             else:
                 flops = 2.0 * M * out.shape[-1] * w_hi.shape[1] * w_hi.shape[2]     # executed MACs (sub-pixel upsample: 4 taps, not 9)
             if kw.get("skip") is not None:                                       # fused 1x1 skip_connection phase
