@@ -12,9 +12,13 @@ SHAPES = [("L0 128->128 @32 B64", 64, 32, 32, 128, 128), ("L0 640->128 @32 B128"
           ("L1 512->512 @16 B128", 128, 16, 16, 512, 512), ("L1 1536->512 @16 B128", 128, 16, 16, 1536, 512),
           ("L2 2048->1024 @8 B128", 128, 8, 8, 2048, 1024)]
 
+SMALL = [("L2 1024->1024 @8 B2", 2, 8, 8, 1024, 1024), ("L1 512->512 @16 B2", 2, 16, 16, 512, 512), ("L0 128->128 @32 B2", 2, 32, 32, 128, 128),
+         ("L2 2048->1024 @8 B2", 2, 8, 8, 2048, 1024)]      # PHASES_SMALL=1: the split-K launches of the batch-1 CFG step
+
 def main():
     prec = ops.Precision.parse("bf16"); dev = torch.device("cuda:0")
-    for name, B, H, W, cin, cout in SHAPES:
+    small = bool(os.environ.get("PHASES_SMALL"))
+    for name, B, H, W, cin, cout in (SMALL if small else SHAPES):
         x = torch.randn(B, H, W, cin, device=dev)
         w = torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
         hi, lo = ops.pack_conv_weight(w, prec); wf = ops.pack_conv_weight_frag(w, prec)
@@ -27,9 +31,10 @@ def main():
         cs = torch.empty(B, (H * W + 255) // 256, cout, 2, device=dev)
         for _ in range(3):
             ops.conv_igemm(None, hi, lo, out, prec=prec, src16=(h16, None), bias=bias, w_frag=wf, res=(out if os.environ.get("PHASES_RES") else None),
-                           chan_stats=(cs if os.environ.get("PHASES_STATS") else None), w_frag16=wf16)
+                           chan_stats=(cs if os.environ.get("PHASES_STATS") else None), w_frag16=wf16,
+                           ws=(torch.empty(16 * out.numel(), device=dev) if small else None))
         torch.cuda.synchronize()
-        nb = min(2048, (B * H * W // 256) * ((cout + 127) // 128))
+        nb = min(2048, max(1, B * H * W // 256) * ((cout + 127) // 128) * (16 if small else 1))
         buf = np.zeros((nb, 8), dtype=np.uint64)
         check(lib().stedm_debug_conv_stamps(buf.ctypes.data_as(ctypes.c_void_p), nb), "stamps")
         t = buf[:, :5].astype(np.int64); t0 = t[:, 0].min()
