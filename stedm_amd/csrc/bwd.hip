@@ -364,8 +364,6 @@ static void launch_gn_bwd_fused(const GnBwdFusedArgs& fa, int ppt, dim3 grid, hi
 // channel run of the one-pass kernel for this shape (0: use the three-kernel chain): whole groups, one side of the concat seam, rows of
 // at least 64 B (128 B preferred), at most 8 pixels per thread; *ppt_out = pixels per thread
 static int gn_bwd_fused_cb(int c1, int c2, int groups, int HW, int* ppt_out) {
-  static const bool off = getenv("STEDM_GN_BWD_CHAIN") != nullptr;
-  if (off) return 0;
   const int C = c1 + c2, cpg = C / groups;
   int unit = cpg;
   while (unit % 4 != 0) unit *= 2;                   // whole groups and whole quads

@@ -700,11 +700,10 @@ extern "C" int stedm_gn_apply16c_mr(const float* x1, int c1, const float* cs1, i
   // Pixels per block. Every block folds the group statistics and builds its per-channel table first, a cost that grows with C, so wide
   // tensors want long runs (128 KiB of fp32 input: 21 pixels of the 1536-channel decoder concat; at a fixed 32 KiB that shape ran at 4.3
   // TB/s, now 5.3) — as long as the grid keeps >= 768 blocks (3 per CU), which the 64-pixel samples of the 8x8 level need (12 pixels per
-  // block there: 3.1 -> 3.9 TB/s); narrow tensors are indifferent (tools/bench_gn.py). STEDM_GN_SLAB_KB fixes the run length for A/B runs.
-  static const int slab_kb = getenv("STEDM_GN_SLAB_KB") ? atoi(getenv("STEDM_GN_SLAB_KB")) : 0;
+  // block there: 3.1 -> 3.9 TB/s); narrow tensors are indifferent (tools/bench_gn.py). Uniform run lengths of 96 / 160 / 256 KiB cost the
+  // denoising step 1.5 / 3 / 7 % (round 3)
   int slab;
-  if (slab_kb > 0) slab = (slab_kb * 256 + C - 1) / C;
-  else {
+  {
     const int want = (128 * 256 + C - 1) / C;                                   // 128 KiB of fp32 input
     int per_sample = (HW + want - 1) / want;                                    // blocks per sample at that run length
     const int need = (768 + B - 1) / B;                                         // ... and for 768 blocks in all
@@ -715,21 +714,17 @@ extern "C" int stedm_gn_apply16c_mr(const float* x1, int c1, const float* cs1, i
   if (slab < 1) slab = 1;
   if (slab > HW) slab = HW;
   dim3 grid(B, (HW + slab - 1) / slab);
-  static const bool v4only = getenv("STEDM_GN_V4") != nullptr;     // A/B switch: the 4-channel-per-thread form
-  if (!v4only && C % 8 == 0 && c1 % 8 == 0 && (size_t)3 * C * sizeof(float) <= 48 * 1024) {
+  if (C % 8 == 0 && c1 % 8 == 0 && (size_t)3 * C * sizeof(float) <= 48 * 1024) {
     const size_t lds = (size_t)3 * C * sizeof(float);
     // Small samples cut by pixels would need several blocks per sample, each building the whole table: cut those by CHANNELS instead
     // (runs of whole groups, >= 512 B per pixel, on one side of the concat seam), so a block builds the table of its own groups only.
-    static const int cmode = getenv("STEDM_GN_CSPLIT") ? atoi(getenv("STEDM_GN_CSPLIT")) : -1;      // A/B: 0 off, n > 0 forces runs of n channels
     int cb = 0;
-    if (cmode != 0 && grid.y > 1 && HW <= 256) {
+    if (grid.y > 1 && HW <= 256) {
       const int cpg = C / groups;
       int unit = cpg;
       while (unit % 8 != 0) unit *= 2;
-      if (cmode > 0) cb = cmode;
-      else
-        for (int t = unit; t <= C / 2; t += unit)          // the widest run that still gives the grid its 768 blocks
-          if (C % t == 0 && c1 % t == 0 && t >= 128 && (long)B * (C / t) >= 768) cb = t;
+      for (int t = unit; t <= C / 2; t += unit)          // the widest run that still gives the grid its 768 blocks
+        if (C % t == 0 && c1 % t == 0 && t >= 128 && (long)B * (C / t) >= 768) cb = t;
       if (cb > 0 && (C % cb != 0 || c1 % cb != 0 || cb % unit != 0 || cb / cpg > 64)) cb = 0;
     }
     if (cb > 0) grid = dim3(B, C / cb);

@@ -858,8 +858,7 @@ __global__ void __launch_bounds__(256, 2) lsa_flash64_kernel(FlashArgs a) {
 
 static int lsa_flash_launch(FlashArgs a, int B, int npass, int mm_dtype, bool drop, hipStream_t st) {
   dim3 grid(B * a.H, a.Tp / 128);
-  static const bool dma_off = getenv("STEDM_LSA_NODMA") != nullptr;      // A/B: the register-staged form for the single-product modes too
-  if (npass == 1 && !dma_off) {
+  if (npass == 1) {
     const dim3 grid64(B * a.H * ((a.Tp + 255) / 256));
     if (mm_dtype == STEDM_F16) { if (drop) lsa_flash64_kernel<_Float16, true><<<grid64, 256, 0, st>>>(a); else lsa_flash64_kernel<_Float16><<<grid64, 256, 0, st>>>(a); }
     else { if (drop) lsa_flash64_kernel<__bf16, true><<<grid64, 256, 0, st>>>(a); else lsa_flash64_kernel<__bf16><<<grid64, 256, 0, st>>>(a); }

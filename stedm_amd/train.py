@@ -45,7 +45,7 @@ class UNetTrainer:
         # parameters outside the U-Net that the same AdamW instance updates (the reference adds cond_stage_model's when
         # cond_stage_trainable, ldm_diffusion.py:224-234); their gradients are filled by the caller; no EMA (LitEma covers `model` only)
         self.extra_params = list(extra_params)
-        self.direct_wgrad = os.environ.get("STEDM_WGRAD_GEMM") is None    # STEDM_WGRAD_GEMM=1: im2col + GEMM form everywhere (A/B switch)
+        self.direct_wgrad = True     # False: im2col + GEMM weight gradients everywhere (tests / A/B runs set the attribute)
         self.fuse_packs = True       # the optimizer pass writes the convolution weights' fragment-order packs itself; False: separate launches (tests)
         self.accumulate_grad_batches = int(accumulate_grad_batches)      # Trainer(accumulate_grad_batches=...) of train_diff.py
         self._micro = 0
@@ -61,9 +61,9 @@ class UNetTrainer:
         self._ema = None
         self._touched: Optional[list] = None
         self.bucket_mb = 256            # gradient all-reduce bucket (xGMI rings are per-link bound: few, large collectives)
-        self.overlap_all_reduce = os.environ.get("STEDM_NO_OVERLAP") is None
+        self.overlap_all_reduce = True
         self.overlap_fires = 0           # all-reduces started from inside a backward so far
-        self.direct_wgrad1 = os.environ.get("STEDM_WGRAD1X1_GEMM") is None      # A/B: the 1x1 convolutions' weight gradients in the GEMM form
+        self.direct_wgrad1 = True    # False: the 1x1 convolutions' weight gradients in the GEMM form
         self.G: Dict[int, torch.Tensor] = {}
 
     # ------------------------------------------------------------------------------------------------ helpers
@@ -346,7 +346,7 @@ class UNetTrainer:
         dkey = (self.bprec, m.conv_path, m._m16, tuple(p.data_ptr() for p in m.parameters()))
         self._dpacks_step = {}
         if getattr(self, "_dplan", None) is not None and self._dplan_key == dkey:
-            self._dplan.run(versions=tuple(p._version for p in m.parameters()))
+            self._dplan.run(versions=(tuple(p._version for p in m.parameters()), getattr(m, "_values_gen", 0)))
             for ent in self._dpacks.values():
                 if isinstance(ent[0], ops.LazyPlanes):
                     ent[0].reset()
@@ -802,10 +802,13 @@ class UNetTrainer:
             if fu["ct"].numel():
                 ops.adamw_ema(st["table"], fu["ct"], fu["co"], self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, decay,
                               grad_scale=gs)
-            versions = tuple(p._version for p in self.m.parameters())
-            for plan in fu["plans"]:
-                plan.mark_fresh(versions)
         self.m.invalidate()      # parameters changed through raw pointers: repack on the next forward
+        if fu is not None:
+            # ... except what this pass wrote itself: valid while neither a parameter's version nor the model's value generation
+            # (UNetModel.invalidate(): EMA swap, checkpoint load, edits through .data / raw pointers) moves
+            token = (tuple(p._version for p in self.m.parameters()), self.m._values_gen)
+            for plan in fu["plans"]:
+                plan.mark_fresh(token)
         self._grads_ready = False
 
     @torch.no_grad()

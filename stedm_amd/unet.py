@@ -225,7 +225,7 @@ class UNetModel(nn.Module):
         #        LDS-DMA operands (default). "fused": GroupNorm applied inside the conv's patch loader (v1/v2 kernels).
         import os as _os
         self.conv_path = _os.environ.get("STEDM_CONV_PATH", "dma")
-        self._m16 = _os.environ.get("STEDM_CONV_M16", "1") != "0"     # 3x3 convs on v_mfma_f32_16x16x32 (conv_rs.inc RS_3X3M); 0: A/B runs
+        self._m16 = True             # 3x3 convs from 256 input channels on v_mfma_f32_16x16x32 (conv_rs.inc RS_3X3M)
         self._gn_slot = 0
         self._style_cache: Dict[Tuple, torch.Tensor] = {}
         self._cs: Dict[int, torch.Tensor] = {}
@@ -253,6 +253,7 @@ class UNetModel(nn.Module):
         self._style_cache.clear()
         self._consts.clear()
         self._pack_key = None
+        self._values_gen = getattr(self, "_values_gen", 0) + 1     # part of the freshness token of packs written by the optimizer kernel
 
     def _buf(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
         key = (name, tuple(shape), dtype)
@@ -364,7 +365,7 @@ class UNetModel(nn.Module):
             elif type(m).__name__ == "SpatialTransformer":
                 self._packed[id(m)] = m.pack(prec)
         if replay:
-            plan.run(versions=key[2])
+            plan.run(versions=(key[2], getattr(self, "_values_gen", 0)))
         c = self._consts
         half = self.model_channels // 2
         # host-built frequency table (util.py:162-164 builds it on the CPU in fp32)

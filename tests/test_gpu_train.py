@@ -152,8 +152,8 @@ def test_train_steps_reduce_the_loss(dev):
 def test_optimizer_writes_the_weight_packs_itself(dev, precision):
     """stedm_adamw_ema_pack: AdamW + EMA over the convolution weights that also refreshes their fragment-order packs (forward order and the
     flipped / transposed dgrad order, 32x32x16 and 16x16x32 forms). Against the separate launches (AdamW, then stedm_pack_frag_multi before the
-    next forward / backward) on the same model and batch: losses of four steps, parameters, EMA shadows and every pack bit for bit; an in-place
-    edit of a weight between two steps still re-packs it (the freshness mark follows the parameters' versions)."""
+    next forward / backward) on the same model and batch: losses of four steps, parameters, EMA shadows and every pack bit for bit; in-place
+    edits of a weight between two steps still re-pack it (the freshness mark follows the parameters' versions and UNetModel.invalidate())."""
     from stedm_amd.train import UNetTrainer
     cfg = dict(image_size=16, in_channels=7, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=[32, 16, 8], channel_mult=[1, 4, 8],
                num_heads=4)
@@ -166,8 +166,12 @@ def test_optimizer_writes_the_weight_packs_itself(dev, precision):
         t = torch.tensor([951, 21], device=dev)
         losses = []
         for step in range(4):
-            if step == 3:      # a version bump: the packs of this weight must come from the parameter again
-                m.input_blocks[1][0].in_layers[2].weight.data.mul_(0.5)
+            if step == 2:      # an in-place edit (version bump): the packs of this weight must come from the parameter again
+                with torch.no_grad():
+                    m.input_blocks[1][0].in_layers[2].weight.mul_(0.5)
+            if step == 3:      # an edit through .data moves no version: UNetModel.invalidate() is the contract for those
+                m.output_blocks[0][0].out_layers[3].weight.data.mul_(2.0)
+                m.invalidate()
             losses.append(float(tr.train_step(x[:, :4].contiguous(), x[:, 4:].contiguous(), t, ctx, target)))
         fu = getattr(tr, "_fused", None)
         if fuse:
