@@ -28,6 +28,7 @@ struct WgradArgs {
   int nunits;             // B * upi
   int ksplit, tiles_n;    // tiles_n = Cout / 64
   int NP, PW;             // patch positions (upr + 2) * (W + 2), patch width W + 2
+  int dbg;                // timing experiments (STEDM_WGRAD_DBG): 1 no global loads, 2 no MFMA phase, 4 no LDS stores
 };
 
 constexpr int WG_NPMAX = 198;                 // max over W of (64 / W + 2) * (W + 2): W = 64 -> 3 * 66
@@ -116,7 +117,7 @@ __global__ void __launch_bounds__(512) wgrad3x3_kernel(WgradArgs a) {
     const unsigned char* px = sX + buf * WG_XBUF;
     const unsigned char* py = sY + buf * WG_YBUF;
 #pragma unroll 1
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < ((a.dbg & 2) ? 0 : 4); ++s) {
       const int k_lo = 16 * s + 8 * h + q, k_hi = k_lo + 4;            // this lane's block rows (pixels of the unit)
       const bf16x8 bf = tr_pair(py, k_lo * WG_YS + colB, k_hi * WG_YS + colB);
       // patch row of tap (0, 0); tap (ky, kx) adds the compile-time constant (ky * PW + kx) rows
@@ -130,30 +131,31 @@ __global__ void __launch_bounds__(512) wgrad3x3_kernel(WgradArgs a) {
       }
     }
   };
+  const bool ld_on = !(a.dbg & 1), st_on = !(a.dbg & 4);
   if (u0 < u1) { load_unit(u0, rxA, ryA); store_unit(0, rxA, ryA); }
   if constexpr (DEEP) {
     // LDS holds unit u (computed) and u+1; registers hold u+1 / u+2 (sets A / B alternating)
-    if (u0 + 1 < u1) load_unit(u0 + 1, rxA, ryA);
-    if (u0 + 2 < u1) load_unit(u0 + 2, rxB, ryB);
+    if (u0 + 1 < u1 && ld_on) load_unit(u0 + 1, rxA, ryA);
+    if (u0 + 2 < u1 && ld_on) load_unit(u0 + 2, rxB, ryB);
     __syncthreads();
     for (int u = u0; u < u1; u += 2) {
       compute_unit(0);
-      if (u + 1 < u1) store_unit(1, rxA, ryA);
-      if (u + 3 < u1) load_unit(u + 3, rxA, ryA);
+      if (u + 1 < u1 && st_on) store_unit(1, rxA, ryA);
+      if (u + 3 < u1 && ld_on) load_unit(u + 3, rxA, ryA);
       __syncthreads();
       if (u + 1 >= u1) break;
       compute_unit(1);
-      if (u + 2 < u1) store_unit(0, rxB, ryB);
-      if (u + 4 < u1) load_unit(u + 4, rxB, ryB);
+      if (u + 2 < u1 && st_on) store_unit(0, rxB, ryB);
+      if (u + 4 < u1 && ld_on) load_unit(u + 4, rxB, ryB);
       __syncthreads();
     }
   } else {
     __syncthreads();
     for (int u = u0; u < u1; ++u) {
       const int buf = (u - u0) & 1;
-      if (u + 1 < u1) load_unit(u + 1, rxA, ryA);
+      if (u + 1 < u1 && ld_on) load_unit(u + 1, rxA, ryA);
       compute_unit(buf);
-      if (u + 1 < u1) store_unit(buf ^ 1, rxA, ryA);
+      if (u + 1 < u1 && st_on) store_unit(buf ^ 1, rxA, ryA);
       __syncthreads();
     }
   }
@@ -293,6 +295,8 @@ extern "C" int stedm_wgrad3x3(const void* x16, const void* dy16, float* part, in
   a.upr = 64 / W; a.upi = H / a.upr; a.nunits = B * a.upi;
   a.ksplit = ks; a.tiles_n = Cout / 64;
   a.PW = W + 2; a.NP = (a.upr + 2) * a.PW;
+  static const int dbg = getenv("STEDM_WGRAD_DBG") ? atoi(getenv("STEDM_WGRAD_DBG")) : 0;
+  a.dbg = dbg;
   const size_t lds = 2 * WG_XBUF + 2 * WG_YBUF;
   static bool attr = false;
   if (!attr) {
