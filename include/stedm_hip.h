@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STEDM_ABI_VERSION 5
+#define STEDM_ABI_VERSION 6
 
 #define STEDM_F16 0
 #define STEDM_BF16 1
@@ -192,6 +192,17 @@ typedef struct stedm_conv_args {
                        * right only — F.pad(x, (0,1,0,1)) + conv(stride 2, padding 0), the VQ encoder's Downsample (model.py:59-76):
                        * the 2x2 taps of the space-to-depth form then sit at offsets (0, +1); weights from
                        * stedm_pack_conv_weight_s2d_frag(..., pad_br = 1) */
+  /* Optional: the GroupNorm (+ SiLU) that consumes `out` — ResBlock.out_layers[0:2] after in_layers' convolution, openaimodel.py:236-241,
+   * 275-287. gn_out16 != NULL asks for gn_act(GroupNorm(out; gn_gamma, gn_beta, gn_eps, gn_groups)) as 16-bit planes [B][Hout][Wout][cout]
+   * (the operand planes of the next convolution, what stedm_gn_apply16c would write) besides `out`. Needs out, chan_stats, stride 1, a
+   * single-product mode. The split-K reduce pass writes them itself when one of its workgroups owns whole groups of a sample
+   * (Hout * Wout <= 256, 32 %% (cout / gn_groups) == 0); otherwise the call ends with the stedm_gn_apply16c pass. */
+  const float* gn_gamma;
+  const float* gn_beta;
+  float gn_eps;
+  int32_t gn_groups;
+  int32_t gn_act;    /* 0 none, 1 SiLU */
+  void* gn_out16;
 } stedm_conv_args;
 /* Replaces: GN->SiLU->conv3x3(+bias)(+emb)(+skip) of ResBlock._forward openaimodel.py:268-288,
  * Downsample/Upsample convs (:122-132,:156-173), 1x1 skip_connection (:254), and the 1x1

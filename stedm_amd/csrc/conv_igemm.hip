@@ -347,11 +347,24 @@ extern "C" int stedm_conv_igemm(const stedm_conv_args* args, void* stream) {
   p.a = *args;
   const stedm_conv_args& a = p.a;
   STEDM_CHECK_ARG(!a.chan_stats || a.out, "conv_igemm: chan_stats needs the fp32 output");
-  const int rc = conv_dispatch(p, stream);
-  if (rc != 0 || !a.chan_stats || p.stats_done) return rc;
-  // the kernel that ran has no statistics epilogue: one extra pass over the output
-  const int up = (a.mode == STEDM_CONV_UP || a.mode == STEDM_CONV_UP_SUBPIXEL) ? 4 : 1, down = a.mode == STEDM_CONV_DOWN ? 4 : 1;
-  return stedm_gn_chan_stats(a.out, a.cout, a.B, a.Hin * a.Win * up / down, a.chan_nslab, a.chan_stats, stream);
+  STEDM_CHECK_ARG(!a.gn_out16 || (a.out && a.chan_stats && a.gn_gamma && a.gn_beta && a.gn_groups > 0 && a.cout % a.gn_groups == 0 && a.npass == 1 &&
+                                  a.mode == STEDM_CONV_S1 && (a.gn_act == 0 || a.gn_act == 1)),
+                  "conv_igemm: gn_out16 needs out, chan_stats, gamma / beta, groups dividing cout, stride 1 and a single-product mode");
+  int rc = conv_dispatch(p, stream);
+  if (rc != 0) return rc;
+  if (a.chan_stats && !p.stats_done) {
+    // the kernel that ran has no statistics epilogue: one extra pass over the output
+    const int up = (a.mode == STEDM_CONV_UP || a.mode == STEDM_CONV_UP_SUBPIXEL) ? 4 : 1, down = a.mode == STEDM_CONV_DOWN ? 4 : 1;
+    rc = stedm_gn_chan_stats(a.out, a.cout, a.B, a.Hin * a.Win * up / down, a.chan_nslab, a.chan_stats, stream);
+    if (rc != 0) return rc;
+  }
+  if (a.gn_out16 && !p.gn_done) {
+    // no pass of this launch owned whole groups: the consumer's GroupNorm as its own pass, from the statistics just written
+    const int HW = a.Hin * a.Win;
+    rc = stedm_gn_apply16c(a.out, a.cout, a.chan_stats, a.chan_nslab > 0 ? a.chan_nslab : stedm_gn_chan_nslab(HW), nullptr, 0, nullptr, 0, 0, a.gn_gamma,
+                           a.gn_beta, a.gn_eps, a.gn_groups, a.gn_act, a.B, HW, a.gn_out16, nullptr, nullptr, nullptr, a.mm_dtype, stream);
+  }
+  return rc;
 }
 
 // validates the arguments and fills the derived sizes of `p`

@@ -359,13 +359,20 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
                out16: Optional[Tuple[torch.Tensor, Optional[torch.Tensor]]] = None, w_frag: Optional[torch.Tensor] = None,
                chan_stats: Optional[torch.Tensor] = None,
                skip: Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = None, query_fused: bool = False, query_rs: bool = False,
-               ws: Optional[torch.Tensor] = None, pad_br: bool = False, w_frag16: Optional[torch.Tensor] = None):
+               ws: Optional[torch.Tensor] = None, pad_br: bool = False, w_frag16: Optional[torch.Tensor] = None,
+               gn_next: Optional[tuple] = None):
     """src1 [B,Hin,Win,c1] NHWC fp32 (fused path) and/or src16 = (hi, lo) 16-bit NHWC planes [B,Hin,Win,Cin] from
     gn_apply16 (DMA path) -> out [B,Hout,Wout,cout] NHWC fp32 (see stedm_conv_igemm)."""
     if out is not None:
         _chk(out, name="out")
     a = ConvArgs()
     a.act_out = act_out
+    if gn_next is not None:
+        # (gamma, beta, eps, groups, act, out16): the GroupNorm (+ SiLU) reading `out`, written as 16-bit planes by the same call
+        g_w, g_b, g_eps, g_groups, g_act, g_out = gn_next
+        _chk(g_w, name="gn gamma"); _chk(g_b, name="gn beta")
+        assert g_out.dtype == torch.int16 and g_out.is_contiguous() and tuple(g_out.shape) == tuple(out.shape) and chan_stats is not None
+        a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_groups, a.gn_act, a.gn_out16 = g_w.data_ptr(), g_b.data_ptr(), float(g_eps), int(g_groups), int(g_act), g_out.data_ptr()
     a.pad_br = int(pad_br)
     a.w_frag16 = _ptr(w_frag16)      # npass 3: the hi + lo streams of pack_conv_weight_frag16 in that mode
     a.w_frag = _ptr(w_frag) if prec.npass == 1 else None

@@ -468,6 +468,7 @@ class UNetModel(nn.Module):
         h = self._buf(tag + ".h" if self._tape is not None else f"h.{B}x{H}x{W}x{co}", (B, H, W, co))
         self._last_h = h
         has_skip = not isinstance(rb.skip_connection, nn.Identity)
+        h16_next = gn_next = None
         if dma:
             if has_skip:
                 a16, x16 = self._norm16(rb.in_layers[0], 1, x1, x2, x2_bmod, want_raw=True)
@@ -476,8 +477,15 @@ class UNetModel(nn.Module):
             # split-K workspace (small grids only): room for up to 16 partial tiles when the tensor is small, 2 otherwise
             nel = B * H * W * co
             ws = self._buf("conv_ws", ((16 if nel <= (1 << 20) else (4 if nel <= (1 << 22) else 2)) * nel,)) if nel <= (1 << 23) else None
+            # out_layers' GroupNorm + SiLU of h rides on this call (inference, single product): where the convolution splits K, the reduce pass
+            # that sums the partial tiles owns whole groups of a sample and writes the normalised planes itself; otherwise the call ends with the
+            # same stedm_gn_apply16c pass as before
+            gn2 = rb.out_layers[0]
+            if self._tape is None and prec.npass == 1:
+                h16_next = self._planes(B, H, W, co)     # (the buffer _norm16 would use: often the planes this convolution has just read)
+                gn_next = (gn2.weight, gn2.bias, gn2.eps, gn2.num_groups, 1, h16_next[0])
             ops.conv_igemm(None, pk.hi, pk.lo, h, prec=prec, src16=a16, bias=pk.bias, emb=emb_all, emb_offset=emb_off,
-                           emb_bstride=emb_bstride, w_frag=pk.frag, chan_stats=self._cs_new(h), ws=ws, w_frag16=pk.frag16)
+                           emb_bstride=emb_bstride, w_frag=pk.frag, chan_stats=self._cs_new(h), ws=ws, w_frag16=pk.frag16, gn_next=gn_next)
         else:
             sc, sh = self._gn(tag + ".gn1", rb.in_layers[0], x1, x2, x2_bmod)
             ops.conv_igemm(x1, pk.hi, pk.lo, h, prec=prec, src2=x2, src2_bmod=x2_bmod, scale=sc, shift=sh, act=1, bias=pk.bias,
@@ -491,7 +499,7 @@ class UNetModel(nn.Module):
         if dma and has_skip:
             # conv2 + skip_connection(x) in one kernel when the register-streamed kernel covers the problem (asked once per shape)
             ps = self._packed[id(rb.skip_connection)]
-            h16 = self._norm16(rb.out_layers[0], 1, h)
+            h16 = h16_next if h16_next is not None else self._norm16(rb.out_layers[0], 1, h)
             fuse_key = ("fuse", id(rb), B, H, W)
             fused = self._consts.get(fuse_key)
             kw = dict(prec=prec, src16=h16, bias=pk2.bias, w_frag=pk2.frag, chan_stats=self._cs_new(out), ws=ws, out16=o16, w_frag16=pk2.frag16)
@@ -513,7 +521,7 @@ class UNetModel(nn.Module):
             ops.conv_igemm(x1, ps.hi, ps.lo, out, prec=prec, ks=1, src2=x2, src2_bmod=x2_bmod, bias=ps.bias)
             res = out
         if dma:
-            h16 = self._norm16(rb.out_layers[0], 1, h)
+            h16 = h16_next if h16_next is not None else self._norm16(rb.out_layers[0], 1, h)
             ops.conv_igemm(None, pk2.hi, pk2.lo, out, prec=prec, src16=h16, bias=pk2.bias, res=res, w_frag=pk2.frag,
                            chan_stats=self._cs_new(out), ws=ws, out16=o16, w_frag16=pk2.frag16)
         else:

@@ -696,6 +696,52 @@ def test_conv_dma_3x3_split_k(dev, prec, tol, B, H, W, cin, cout, emb, res):
     assert torch.allclose(outs[0][1][:, 0, :, 0].double(), outs[0][0].view(B, H * W, cout)[:, :256].double().sum(1), rtol=1e-4, atol=2e-3)
 
 
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+@pytest.mark.parametrize("B,H,W,cin,cout,groups,emb,res", [
+    (2, 8, 8, 1024, 1024, 32, True, False),      # batch-1 CFG step: split 16, one group per block of the reduce pass
+    (64, 8, 8, 512, 1024, 32, True, False),      # batch-64 encoder: split 2
+    (2, 16, 16, 512, 512, 32, True, True),       # 256 pixels per sample, two groups per block
+    (3, 16, 16, 256, 128, 32, False, False),     # 4 channels per group: eight groups per block
+    (2, 8, 8, 256, 96, 8, True, False),          # 12 channels per group: 32 % 12 != 0 -> the follow-up pass
+    (4, 32, 32, 128, 128, 32, True, False),      # 1024 pixels per sample -> the follow-up pass
+    (128, 16, 16, 512, 512, 32, True, False),    # full grid, no split -> the follow-up pass
+])
+def test_conv_with_the_consumers_groupnorm(dev, prec, B, H, W, cin, cout, groups, emb, res):
+    """stedm_conv_args.gn_*: the GroupNorm + SiLU that reads a convolution's output, written as 16-bit planes by the same call — inside the
+    split-K reduce pass where its workgroups own whole groups, by the stedm_gn_apply16c pass otherwise. Against the two calls made separately:
+    identical fp32 output, statistics equal up to rounding; the planes equal up to one unit of the 16-bit format on a few elements (the fused
+    pass adds the channel and group sums in another order), and within 1e-2 of the fp32 GroupNorm of the output everywhere."""
+    from stedm_amd import ops
+    pr = ops.Precision.parse(prec)
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + cout)
+    x = torch.randn(B, H, W, cin, generator=g).to(dev)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)).to(dev)
+    bias = torch.randn(cout, generator=g).to(dev)
+    embt = torch.randn(B, cout, generator=g).to(dev) if emb else None
+    rest = torch.randn(B, H, W, cout, generator=g).to(dev) if res else None
+    gamma = (1 + 0.2 * torch.randn(cout, generator=g)).to(dev); beta = (0.2 * torch.randn(cout, generator=g)).to(dev)
+    h16 = torch.empty((B, H, W, cin), dtype=torch.int16, device=dev)
+    ops.gn_apply16(x, None, h16, None, pr)
+    whi, wlo = ops.pack_conv_weight(w, pr); wf = ops.pack_conv_weight_frag(w, pr)
+    wf16 = ops.pack_conv_weight_frag16(w, pr) if cin >= 256 else None
+    kw = dict(prec=pr, src16=(h16, None), bias=bias, emb=embt, emb_bstride=cout if emb else 0, res=rest, w_frag=wf, w_frag16=wf16)
+    ns = ops.gn_chan_nslab(H * W)
+    out_a = torch.empty(B, H, W, cout, device=dev); cs_a = torch.empty(B, ns, cout, 2, device=dev)
+    ops.conv_igemm(None, whi, wlo, out_a, chan_stats=cs_a, ws=torch.empty(16 * out_a.numel(), device=dev), **kw)
+    pl_a = torch.zeros(B, H, W, cout, dtype=torch.int16, device=dev)
+    ops.gn_apply16c(out_a, cs_a, None, None, pl_a, None, pr, gamma, beta, 1e-5, groups, 1)
+    out_b = torch.empty_like(out_a); cs_b = torch.empty_like(cs_a); pl_b = torch.zeros_like(pl_a)
+    ops.conv_igemm(None, whi, wlo, out_b, chan_stats=cs_b, ws=torch.empty(16 * out_b.numel(), device=dev), gn_next=(gamma, beta, 1e-5, groups, 1, pl_b), **kw)
+    # (the channel sums are added in the order of the pass's own pixel-lane layout: equal up to fp32 rounding, not bit for bit)
+    assert torch.equal(out_a, out_b) and torch.allclose(cs_a, cs_b, rtol=2e-5, atol=1e-3)
+    fa, fb = _as_float(pl_a, pr), _as_float(pl_b, pr)
+    ulp = (2.0 ** -7 if prec == "bf16" else 2.0 ** -10)
+    diff = (fa - fb).abs()
+    assert float((diff > 0).float().mean()) < 1e-3 and bool((diff <= ulp * fa.abs().clamp_min(2.0 ** -14) * 1.01).all()), (float(diff.max()), float((diff > 0).float().mean()))
+    ref = torch.nn.functional.silu(torch.nn.functional.group_norm(out_a.permute(0, 3, 1, 2), groups, gamma, beta, 1e-5)).permute(0, 2, 3, 1)
+    assert float((fb - ref).abs().max()) < (2e-2 if prec == "bf16" else 4e-3) * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("prec,tol", PRECS[1:])
 @pytest.mark.parametrize("B,H,W,cin,cout,ws", [(64, 32, 32, 128, 128, True), (64, 16, 16, 512, 512, True), (3, 8, 8, 32, 32, False), (5, 16, 16, 64, 96, True),
                                                 (2, 64, 64, 32, 160, False), (9, 8, 8, 64, 64, True)])
