@@ -22,6 +22,7 @@ struct ConvParams {
   int ksplit;      // register-streamed 3x3 kernel: K split over 2..16 blocks per tile when the grid would not fill the chip (0/1: none)
   int stats_done;  // set by a launcher whose epilogue wrote a.chan_stats (otherwise the dispatcher runs gn_chan_stats)
   int gn_done;     // set by a launcher that wrote a.gn_out16 itself (otherwise the dispatcher runs gn_apply16c)
+  int gn_tile;     // register-streamed kernel: its tiles hold whole samples x whole groups -> the epilogue writes a.gn_out16 (conv_rs_try)
   int xcd_m;       // register-streamed kernel: XCD-aware block -> tile order: 0 plain, else gm in {8, 4, 2} = the M-tiles are dealt over gm XCD groups, the N-tiles over 8 / gm (conv_rs_kernel)
   int dbg;  // ablation bits (STEDM_CONV_DBG, timing experiments only): 1 no weight DMA, 2 no patch staging, 4 no MFMA, 8 no LDS frag reads
 };

@@ -704,11 +704,16 @@ def test_conv_dma_3x3_split_k(dev, prec, tol, B, H, W, cin, cout, emb, res):
     (3, 16, 16, 256, 128, 32, False, False),     # 4 channels per group: eight groups per block
     (2, 8, 8, 256, 96, 8, True, False),          # 12 channels per group: 32 % 12 != 0 -> the follow-up pass
     (4, 32, 32, 128, 128, 32, True, False),      # 1024 pixels per sample -> the follow-up pass
-    (128, 16, 16, 512, 512, 32, True, False),    # full grid, no split -> the follow-up pass
+    (128, 16, 16, 512, 512, 32, True, False),    # full grid, no split: one sample per tile, eight groups per 128 channels -> the conv epilogue
+    (128, 8, 8, 1024, 1024, 32, True, True),     # four samples per tile, four groups per 128 channels -> the conv epilogue
+    (126, 8, 8, 256, 128, 32, True, False),      # ... with a last tile of two samples and two masked ones
+    (64, 16, 16, 128, 512, 32, True, False),     # the 32x32x16 MFMA kind (128 input channels)
+    (96, 16, 16, 256, 320, 32, False, False),    # cout % 128 != 0 -> the follow-up pass
 ])
 def test_conv_with_the_consumers_groupnorm(dev, prec, B, H, W, cin, cout, groups, emb, res):
     """stedm_conv_args.gn_*: the GroupNorm + SiLU that reads a convolution's output, written as 16-bit planes by the same call — inside the
-    split-K reduce pass where its workgroups own whole groups, by the stedm_gn_apply16c pass otherwise. Against the two calls made separately:
+    split-K reduce pass or the convolution's own epilogue where a workgroup owns whole groups of whole samples, by the stedm_gn_apply16c pass
+    otherwise. Against the two calls made separately:
     identical fp32 output, statistics equal up to rounding; the planes equal up to one unit of the 16-bit format on a few elements (the fused
     pass adds the channel and group sums in another order), and within 1e-2 of the fp32 GroupNorm of the output everywhere."""
     from stedm_amd import ops
