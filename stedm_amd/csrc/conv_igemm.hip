@@ -361,8 +361,8 @@ extern "C" int stedm_conv_igemm(const stedm_conv_args* args, void* stream) {
   if (a.gn_out16 && !p.gn_done) {
     // no pass of this launch owned whole groups: the consumer's GroupNorm as its own pass, from the statistics just written
     const int HW = a.Hin * a.Win;
-    rc = stedm_gn_apply16c(a.out, a.cout, a.chan_stats, a.chan_nslab > 0 ? a.chan_nslab : stedm_gn_chan_nslab(HW), nullptr, 0, nullptr, 0, 0, a.gn_gamma,
-                           a.gn_beta, a.gn_eps, a.gn_groups, a.gn_act, a.B, HW, a.gn_out16, nullptr, nullptr, nullptr, a.mm_dtype, stream);
+    rc = stedm_gn_apply16c_mr(a.out, a.cout, a.chan_stats, a.chan_nslab > 0 ? a.chan_nslab : stedm_gn_chan_nslab(HW), nullptr, 0, nullptr, 0, 0, a.gn_gamma,
+                              a.gn_beta, a.gn_eps, a.gn_groups, a.gn_act, a.B, HW, a.gn_out16, nullptr, nullptr, nullptr, a.gn_mr, a.mm_dtype, stream);
   }
   return rc;
 }

@@ -369,7 +369,12 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
     a.act_out = act_out
     if gn_next is not None:
         # (gamma, beta, eps, groups, act, out16): the GroupNorm (+ SiLU) reading `out`, written as 16-bit planes by the same call
-        g_w, g_b, g_eps, g_groups, g_act, g_out = gn_next
+        g_w, g_b, g_eps, g_groups, g_act, g_out = gn_next[:6]
+        g_mr = gn_next[6] if len(gn_next) > 6 else None
+        if g_mr is not None:
+            _chk(g_mr, name="gn mean_rstd")
+            assert tuple(g_mr.shape) == (out.shape[0], int(g_groups), 2)
+            a.gn_mr = g_mr.data_ptr()
         _chk(g_w, name="gn gamma"); _chk(g_b, name="gn beta")
         assert g_out.dtype == torch.int16 and g_out.is_contiguous() and tuple(g_out.shape) == tuple(out.shape) and chan_stats is not None
         a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_groups, a.gn_act, a.gn_out16 = g_w.data_ptr(), g_b.data_ptr(), float(g_eps), int(g_groups), int(g_act), g_out.data_ptr()

@@ -481,9 +481,19 @@ class UNetModel(nn.Module):
             # that sums the partial tiles owns whole groups of a sample and writes the normalised planes itself; otherwise the call ends with the
             # same stedm_gn_apply16c pass as before
             gn2 = rb.out_layers[0]
-            if self._tape is None and prec.npass == 1:
-                h16_next = self._planes(B, H, W, co)     # (the buffer _norm16 would use: often the planes this convolution has just read)
-                gn_next = (gn2.weight, gn2.bias, gn2.eps, gn2.num_groups, 1, h16_next[0])
+            if prec.npass == 1 and (self._tape is None or prec.mm_dtype == BF16):
+                if self._tape is None:
+                    h16_next = self._planes(B, H, W, co)     # (the buffer _norm16 would use: often the planes this convolution has just read)
+                    mr2 = None
+                else:
+                    # training forward in the backward's operand format: the planes and the group statistics are kept, exactly as _norm16 keeps them
+                    self._plane_ctr += 1
+                    h16_next = self._planes(B, H, W, co, f"keep{self._plane_ctr}.a16")
+                    self._saved16[(id(gn2), h.data_ptr())] = h16_next
+                    self._mr_ctr += 1
+                    mr2 = self._buf(f"keep{self._mr_ctr}.mr", (B, gn2.num_groups, 2))
+                    self._saved_mr[(id(gn2), h.data_ptr())] = mr2
+                gn_next = (gn2.weight, gn2.bias, gn2.eps, gn2.num_groups, 1, h16_next[0], mr2)
             ops.conv_igemm(None, pk.hi, pk.lo, h, prec=prec, src16=a16, bias=pk.bias, emb=emb_all, emb_offset=emb_off,
                            emb_bstride=emb_bstride, w_frag=pk.frag, chan_stats=self._cs_new(h), ws=ws, w_frag16=pk.frag16, gn_next=gn_next)
         else:
