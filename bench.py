@@ -86,8 +86,9 @@ class ConvTimer:
             r = timer._orig(src1, w_hi, w_lo, out, **kw)
             e1.record()
             if gn_next is not None:
-                g_w, g_b, g_eps, g_groups, g_act, g_out = gn_next
-                ops.gn_apply16c(out, kw["chan_stats"], None, None, g_out, None, kw["prec"], g_w, g_b, g_eps, g_groups, g_act)
+                g_w, g_b, g_eps, g_groups, g_act, g_out = gn_next[:6]
+                ops.gn_apply16c(out, kw["chan_stats"], None, None, g_out, None, kw["prec"], g_w, g_b, g_eps, g_groups, g_act,
+                                mean_rstd=gn_next[6] if len(gn_next) > 6 else None)
             if out is None:    # 16-bit-plane output only (qkv of the attention block)
                 out = kw["out16"][0]
             M = out.numel() // out.shape[-1]

@@ -8,7 +8,13 @@ marks = [i for i, r in enumerate(rows) if "ddim_step_kernel" in r["Kernel_Name"]
 w = rows[marks[-2] + 1:marks[-1] + 1]
 sites = json.load(open(sys.argv[2]))
 gn = [r for r in w if "gn_apply16c" in r["Kernel_Name"]]
-assert len(gn) == len(sites), (len(gn), len(sites))
+if len(gn) != len(sites):
+    # (GroupNorm passes that ride on a convolution call — stedm_conv_args.gn_* — are launched by the library or fused away: no shapes for those)
+    print(f"{len(gn)} gn_apply16c launches in the trace, {len(sites)} recorded shapes: durations only")
+    for r in gn:
+        print(f"{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:6.1f} us  grid {int(r['Grid_Size_X']) // 256} x {r['Grid_Size_Y']}")
+    print(f"total {sum((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in gn):.1f} us")
+    sys.exit(0)
 tot = totb = 0.0
 for r, (B, HW, c1, c2) in zip(gn, sites):
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
