@@ -204,6 +204,9 @@ typedef struct stedm_conv_args {
   int32_t gn_act;    /* 0 none, 1 SiLU */
   void* gn_out16;
   float* gn_mr;      /* optional: [B][gn_groups][2] = {mean, rstd} of that GroupNorm (kept by a training forward for the backward) */
+  int32_t gn_only;   /* 1: nothing but that GroupNorm reads `out` (inference: h of ResBlock._forward) — a launch whose epilogue writes
+                      * gn_out16 itself may then leave `out` unwritten (4 of the 6 bytes per element of that store walk); `out` must
+                      * still be a valid buffer, the other forms fill it. chan_stats is always written. */
 } stedm_conv_args;
 /* Replaces: GN->SiLU->conv3x3(+bias)(+emb)(+skip) of ResBlock._forward openaimodel.py:268-288,
  * Downsample/Upsample convs (:122-132,:156-173), 1x1 skip_connection (:254), and the 1x1

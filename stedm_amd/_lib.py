@@ -37,7 +37,7 @@ class ConvArgs(C.Structure):
         ("w_frag", C.c_void_p), ("chan_stats", C.c_void_p),
         ("src16b_hi", C.c_void_p), ("w_frag_b", C.c_void_p), ("bias_b", C.c_void_p), ("cb", C.c_int32),
         ("ws", C.c_void_p), ("ws_floats", C.c_int64), ("chan_nslab", C.c_int32), ("w_frag16", C.c_void_p), ("w_frag_b16", C.c_void_p), ("pad_br", C.c_int32),
-        ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p), ("gn_eps", C.c_float), ("gn_groups", C.c_int32), ("gn_act", C.c_int32), ("gn_out16", C.c_void_p), ("gn_mr", C.c_void_p),
+        ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p), ("gn_eps", C.c_float), ("gn_groups", C.c_int32), ("gn_act", C.c_int32), ("gn_out16", C.c_void_p), ("gn_mr", C.c_void_p), ("gn_only", C.c_int32),
     ]
 
 

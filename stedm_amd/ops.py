@@ -371,6 +371,7 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
         # (gamma, beta, eps, groups, act, out16): the GroupNorm (+ SiLU) reading `out`, written as 16-bit planes by the same call
         g_w, g_b, g_eps, g_groups, g_act, g_out = gn_next[:6]
         g_mr = gn_next[6] if len(gn_next) > 6 else None
+        a.gn_only = int(bool(gn_next[7])) if len(gn_next) > 7 else 0
         if g_mr is not None:
             _chk(g_mr, name="gn mean_rstd")
             assert tuple(g_mr.shape) == (out.shape[0], int(g_groups), 2)

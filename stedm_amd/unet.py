@@ -493,7 +493,8 @@ class UNetModel(nn.Module):
                     self._mr_ctr += 1
                     mr2 = self._buf(f"keep{self._mr_ctr}.mr", (B, gn2.num_groups, 2))
                     self._saved_mr[(id(gn2), h.data_ptr())] = mr2
-                gn_next = (gn2.weight, gn2.bias, gn2.eps, gn2.num_groups, 1, h16_next[0], mr2)
+                # (inference: nothing but that GroupNorm reads h — an epilogue that writes the planes itself skips h's fp32 store)
+                gn_next = (gn2.weight, gn2.bias, gn2.eps, gn2.num_groups, 1, h16_next[0], mr2, self._tape is None)
             ops.conv_igemm(None, pk.hi, pk.lo, h, prec=prec, src16=a16, bias=pk.bias, emb=emb_all, emb_offset=emb_off,
                            emb_bstride=emb_bstride, w_frag=pk.frag, chan_stats=self._cs_new(h), ws=ws, w_frag16=pk.frag16, gn_next=gn_next)
         else:

@@ -745,6 +745,16 @@ def test_conv_with_the_consumers_groupnorm(dev, prec, B, H, W, cin, cout, groups
     assert float((diff > 0).float().mean()) < 1e-3 and bool((diff <= ulp * fa.abs().clamp_min(2.0 ** -14) * 1.01).all()), (float(diff.max()), float((diff > 0).float().mean()))
     ref = torch.nn.functional.silu(torch.nn.functional.group_norm(out_a.permute(0, 3, 1, 2), groups, gamma, beta, 1e-5)).permute(0, 2, 3, 1)
     assert float((fb - ref).abs().max()) < (2e-2 if prec == "bf16" else 4e-3) * max(1.0, float(ref.abs().max()))
+    # gn_only: the planes are the output's only consumer — a launch whose epilogue writes them itself leaves `out` alone (all of it), any
+    # other form still fills it; the planes are the same bits either way
+    out_c = torch.full_like(out_a, float("nan")); cs_c = torch.empty_like(cs_a); pl_c = torch.zeros_like(pl_a)
+    ops.conv_igemm(None, whi, wlo, out_c, chan_stats=cs_c, ws=torch.empty(16 * out_c.numel(), device=dev),
+                   gn_next=(gamma, beta, 1e-5, groups, 1, pl_c, None, True), **kw)
+    assert torch.equal(pl_c, pl_b) and torch.equal(cs_c, cs_b)
+    untouched = bool(torch.isnan(out_c).all())
+    assert untouched or torch.equal(out_c, out_a)
+    if (B, H, cout) in ((128, 16, 512), (128, 8, 1024)):
+        assert untouched, "the whole-sample tiles of this shape were expected to skip the fp32 store"
 
 
 @pytest.mark.parametrize("prec,tol", PRECS[1:])
