@@ -518,7 +518,12 @@ class UNetModel(nn.Module):
                 fused = bool((pk2.frag is not None or pk2.frag16 is not None) and ps.frag is not None and
                              ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias, ps.frag16), query_fused=True, **kw))
                 self._consts[fuse_key] = fused
-            if fused:
+            if fused and o16 is not None and self._tape is None and prec.npass == 1:
+                # inference: the Upsample that follows reads the 16-bit planes only — the fp32 tensor and its statistics are not written
+                # (`out` stays the handle the planes are filed under)
+                kw.update(chan_stats=None)
+                ops.conv_igemm(None, pk2.hi, pk2.lo, None, skip=(x16[0], ps.frag, ps.bias, ps.frag16), **kw)
+            elif fused:
                 ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias, ps.frag16), **kw)
             else:
                 ops.conv_igemm(None, ps.hi, ps.lo, out, prec=prec, ks=1, src16=x16, bias=ps.bias, w_frag=ps.frag, ws=ws)
