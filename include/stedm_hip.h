@@ -195,7 +195,7 @@ typedef struct stedm_conv_args {
   /* Optional: the GroupNorm (+ SiLU) that consumes `out` — ResBlock.out_layers[0:2] after in_layers' convolution, openaimodel.py:236-241,
    * 275-287. gn_out16 != NULL asks for gn_act(GroupNorm(out; gn_gamma, gn_beta, gn_eps, gn_groups)) as 16-bit planes [B][Hout][Wout][cout]
    * (the operand planes of the next convolution, what stedm_gn_apply16c would write) besides `out`. Needs out, chan_stats, stride 1, a
-   * single-product mode. The split-K reduce pass writes them itself when one of its workgroups owns whole groups of a sample
+   * single-product mode; gn_out16 must not be the planes the convolution reads (src16_*): a tile's epilogue may write it while others still load. The split-K reduce pass writes them itself when one of its workgroups owns whole groups of a sample
    * (Hout * Wout <= 256, 32 %% (cout / gn_groups) == 0); otherwise the call ends with the stedm_gn_apply16c pass. */
   const float* gn_gamma;
   const float* gn_beta;

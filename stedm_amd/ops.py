@@ -378,6 +378,8 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
             a.gn_mr = g_mr.data_ptr()
         _chk(g_w, name="gn gamma"); _chk(g_b, name="gn beta")
         assert g_out.dtype == torch.int16 and g_out.is_contiguous() and tuple(g_out.shape) == tuple(out.shape) and chan_stats is not None
+        # the convolution's own epilogue may write these planes while other tiles still gather their input: never the planes it reads
+        assert src16 is None or all(t is None or t.data_ptr() != g_out.data_ptr() for t in src16), "gn_next planes alias the convolution's input planes"
         a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_groups, a.gn_act, a.gn_out16 = g_w.data_ptr(), g_b.data_ptr(), float(g_eps), int(g_groups), int(g_act), g_out.data_ptr()
     a.pad_br = int(pad_br)
     a.w_frag16 = _ptr(w_frag16)      # npass 3: the hi + lo streams of pack_conv_weight_frag16 in that mode

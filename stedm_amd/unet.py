@@ -483,7 +483,9 @@ class UNetModel(nn.Module):
             gn2 = rb.out_layers[0]
             if prec.npass == 1 and (self._tape is None or prec.mm_dtype == BF16):
                 if self._tape is None:
-                    h16_next = self._planes(B, H, W, co)     # (the buffer _norm16 would use: often the planes this convolution has just read)
+                    # NOT the planes _norm16 would hand out: for cin == cout those are the planes this convolution is reading, and an epilogue
+                    # that writes the GroupNorm output would overwrite rows other tiles still gather
+                    h16_next = self._planes(B, H, W, co, "g16")
                     mr2 = None
                 else:
                     # training forward in the backward's operand format: the planes and the group statistics are kept, exactly as _norm16 keeps them
