@@ -524,6 +524,7 @@ class UNetModel(nn.Module):
                 # inference: the Upsample that follows reads the 16-bit planes only — the fp32 tensor and its statistics are not written
                 # (`out` stays the handle the planes are filed under)
                 kw.update(chan_stats=None)
+                self._cs.pop(out.data_ptr(), None)          # (no statistics are written for the handle: nothing may find a buffer for it)
                 ops.conv_igemm(None, pk2.hi, pk2.lo, None, skip=(x16[0], ps.frag, ps.bias, ps.frag16), **kw)
             elif fused:
                 ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias, ps.frag16), **kw)
