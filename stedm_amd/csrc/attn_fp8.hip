@@ -149,6 +149,7 @@ __global__ void __launch_bounds__(256, 2) lsa_flash64_mx8_kernel(Mx8Args a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int qw = qtile * 256 + wave * 64;
+  const bool live = qw < a.T;                       // wave-uniform
 
   v8i qf[2];
   int qsc[2];
@@ -288,6 +289,7 @@ __global__ void __launch_bounds__(256, 2) lsa_flash64_mx8_kernel(Mx8Args a) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // tile kt is complete in LDS; every wave is done with tile kt - 1, whose buffer takes the next tile fetched
     if (kt + NBUF - 1 < ntiles) issue(kt + NBUF - 1);
+    if (!live) continue;            // a wave without queries (tail of the last 256-query tile) only feeds the ring
     const unsigned char* tb = ring + (kt % NBUF) * TILE_B;
 #pragma unroll
     for (int i = 0; i < 2; ++i) { kf[i] = load8(tb, kb[i]); ksc[i] = tb[ksb[i]]; }
@@ -324,7 +326,7 @@ __global__ void __launch_bounds__(256, 2) lsa_flash64_mx8_kernel(Mx8Args a) {
   for (int qb = 0; qb < 2; ++qb) {
     float lr = l_run[qb];
     lr += __shfl_xor(lr, 32, 64);
-    const float inv = 16.0f / lr;
+    const float inv = live ? 16.0f / lr : 0.f;
     __syncthreads();
 #pragma unroll
     for (int d = 0; d < 2; ++d)

@@ -612,6 +612,7 @@ __global__ void __launch_bounds__(256, 2) lsa_flash64_kernel(FlashArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int qw = qtile * 256 + wave * 64;           // first query of this wave; block qb covers qw + 32 qb ..
+  const bool live = qw < a.T;                       // wave-uniform
   const T* qg = reinterpret_cast<const T*>(a.qh);
   const T* kg = reinterpret_cast<const T*>(a.kh);
   const T* vg = reinterpret_cast<const T*>(a.vh);
@@ -765,6 +766,8 @@ __global__ void __launch_bounds__(256, 2) lsa_flash64_kernel(FlashArgs a) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // tile kt is complete in LDS; every wave is done with tile kt - 1, whose buffer takes the next tile fetched
     if (kt + NBUF - 1 < ntiles) issue(kt + NBUF - 1);
+    if (!live) continue;            // a wave without queries (the tail of the last 256-query tile: T = 4097 leaves three of its four waves
+                                    // empty) only feeds the ring: no fragment reads, no MFMAs, no exponentials
     const unsigned char* tb = ring + u * TILE_B;
     // ---- K fragments: read once, used by both query blocks
     V8 kf[2][4];
@@ -839,7 +842,7 @@ __global__ void __launch_bounds__(256, 2) lsa_flash64_kernel(FlashArgs a) {
   for (int qb = 0; qb < 2; ++qb) {
     float lr = l_run[qb];
     lr += __shfl_xor(lr, 32, 64);
-    const float inv = (DROP ? a.inv_keep : 1.0f) / lr;
+    const float inv = live ? (DROP ? a.inv_keep : 1.0f) / lr : 0.f;
     __syncthreads();   // all waves are done with the ring (qb = 1: with the previous block's rows)
 #pragma unroll
     for (int d = 0; d < 2; ++d)
