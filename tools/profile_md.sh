@@ -12,3 +12,4 @@ python tools/stats_md.py gpurun_out/prof_${TAG}_svit ${TAG}_svit "$R, set-ViT st
 python tools/stats_md.py gpurun_out/prof_${TAG}_svit_fp8 ${TAG}_svit_fp8 "$R, set-ViT style encoder with MX-fp8 attention operands (B = 64)" "$S python3 tools/bench_svit.py fp8 64" | tail -1
 python tools/stats_md.py gpurun_out/prof_${TAG}_swin ${TAG}_swin "$R, Swin-V2-T embedder (128 images of 512^2, bf16)" "$S python3 tools/bench_swin.py bf16 128 32" | tail -1
 python tools/pmc_report.py gpurun_out/prof_${TAG}_pmc_mfma gpurun_out/prof_${TAG}_pmc_fetch gpurun_out/prof_${TAG}_pmc_write ${TAG} | tail -3
+python tools/pmc_attention.py gpurun_out/prof_${TAG}_pmc_lsa gpurun_out/prof_${TAG}_pmc_lsa_fp8 ${TAG} | tail -2
