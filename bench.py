@@ -5,7 +5,11 @@ One "step" = one iteration of the reference's DDIM loop (ddim.py:139-160) for a 
 classifier-free guidance: both U-Net evaluations (cond + uncond, ddim.py:177-178) + the fused CFG-rescale /
 DDIM update. Synthetic inputs resident in HBM, PRNG-recipe weights of the NS32 architecture.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision bf16|f16|parity] [--batch 64]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision f16|bf16|parity] [--batch 64]
+
+`value` / `dtype` are the fastest numerics mode that meets north_star's tolerance (1e-3 relative to the fp32 reference, as rel-L2) on the
+MEASURED deviation, single forward and over the whole DDIM-50 loop: fp16 single-product operands with fp32 accumulation (the reference is
+fp32, train_diff.py:48). The bf16 single-product figure (BASELINE config 2's dtype; 6e-3 off the oracle) is a side field (`bf16_mode`).
 
 N > 1: one rank per GPU; every rank denoises its own 64 latents (weak scaling, no collective inside the loop —
 samples are independent); the final latents are all-gathered over RCCL once after the timed region. Launched either by
@@ -68,8 +72,12 @@ class ConvTimer:
     """Brackets every stedm_conv_igemm launch with HIP events on the launch stream (torch's current stream is
     the stream ops.py launches on) and records its algorithmic FLOPs = 2*M*N*K."""
 
-    def __init__(self):
+    def __init__(self, split_gn: bool = False):
+        """split_gn False: every launch is timed as the product issues it (a consumer GroupNorm riding on the convolution's epilogue /
+        split-K reduce / trailing pass is inside the bracket: the shipped variant). True: that GroupNorm runs as its own launch after
+        the bracket (convolution work only; the non-fused form)."""
         self.rec = []
+        self.split_gn = split_gn
 
     def install(self):
         from stedm_amd import ops
@@ -79,9 +87,7 @@ class ConvTimer:
         def timed(src1, w_hi, w_lo, out, **kw):
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
-            # the consumer's GroupNorm that rides on the call (stedm_conv_args.gn_*) is not convolution work: in this timed pass it runs as
-            # its own launch after the bracket, so the roofline keeps dividing convolution FLOPs by convolution time
-            gn_next = kw.pop("gn_next", None)
+            gn_next = kw.pop("gn_next", None) if timer.split_gn else None
             e0.record()
             r = timer._orig(src1, w_hi, w_lo, out, **kw)
             e1.record()
@@ -116,6 +122,93 @@ class ConvTimer:
         fl = sum(f for _, _, f in self.rec)
         return {"launches": len(self.rec), "total_ms": ms, "avg_us": 1e3 * ms / max(1, len(self.rec)),
                 "flops_per_launch": fl / max(1, len(self.rec)), "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
+
+
+class AttnTimer:
+    """HIP-event bracket around every stedm_attn_legacy16 launch (the U-Net's MFMA attention): 4 * B * T^2 * C FLOP per call (QK^T and PV)."""
+
+    def __init__(self):
+        self.rec = []
+
+    def install(self):
+        from stedm_amd import ops
+        self._orig = ops.attn_legacy16
+        timer = self
+
+        def timed(qkv, out16, heads, prec):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = timer._orig(qkv, out16, heads, prec)
+            e1.record()
+            B, T, C3 = qkv.shape
+            timer.rec.append((e0, e1, 4.0 * B * T * T * (C3 // 3), T))
+            return r
+
+        ops.attn_legacy16 = timed
+
+    def remove(self):
+        from stedm_amd import ops
+        ops.attn_legacy16 = self._orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in self.rec)
+        fl = sum(f for _, _, f, _ in self.rec)
+        return {"launches": len(self.rec), "total_ms": ms, "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                "tokens": sorted({t for _, _, _, t in self.rec})}
+
+
+REF128 = dict(image_size=128, in_channels=6, model_channels=128, out_channels=3, num_res_blocks=2,
+              attention_resolutions=[32, 16, 8], channel_mult=[1, 4, 8], num_heads=8)
+GFLOP_PER_SAMPLE_FORWARD_REF128 = 872.37      # BASELINE.md §3 (hooks on the reference module, 128x128x3 latents)
+
+
+def ref128_leg(dev, precision, B, steps=6, warmup=2):
+    """The reference-native shape (conf/diffusion/unet_config/landscape.yaml:1-16, conf/diffusion/ldm_based.yaml:10-11: 128x128x3 latents,
+    Cin 6 / Cout 3; the only attention is the middle block's, T = 32 * 32 = 1024 tokens, openaimodel.py:644-649): the same DDIM-50 + CFG 1.5
+    denoising step, hipGraph replay, at batch B per GPU; convolution roofline and the attention kernel's MFMA fraction from HIP events."""
+    from stedm_amd.ddim import DDIMSampler, StepGraph
+    from stedm_amd.latent_diffusion import LatentDiffusion
+    from stedm_amd.unet import UNetModel
+    from stedm_amd.utils import prng
+    unet = UNetModel(precision=precision, **REF128).eval()
+    prng.fill_module_(unet, seed=0)
+    ld = LatentDiffusion(unet, linear_start=0.0015, linear_end=0.0205, image_size=128, channels=3, conditioning_key="hybrid", loss_type="l1",
+                         use_graph=True).to(dev)
+    g = torch.Generator(device="cpu").manual_seed(13)
+    xT = torch.randn(B, 3, 128, 128, generator=g).to(dev)
+    lay = (torch.randn(B, 3, 128, 128, generator=g) > 0).float().to(dev)
+    ctx, ctx_u = torch.randn(B, 512, generator=g).to(dev), torch.randn(1, 512, generator=g).repeat(B, 1).contiguous().to(dev)
+    cond, unc = {"c_concat": [lay], "c_crossattn": [ctx]}, {"c_concat": [lay], "c_crossattn": [ctx_u]}
+    dt, final = run_steps(ld, xT, cond, unc, warmup, steps, 1)
+    assert bool(torch.isfinite(final).all())
+    ms = 1e3 * dt / steps
+    smp = DDIMSampler(ld); smp.make_schedule(50, ddim_eta=0.0, verbose=False)
+    sg = StepGraph(smp, xT.clone(), cond, unc, 1.5)
+    sg.reset(49); sg.step_eager(); torch.cuda.synchronize()
+    ct, at = ConvTimer(), AttnTimer()
+    ct.install(); at.install()
+    for _ in range(2):
+        sg.step_eager()
+    cs, asum = ct.summary(), at.summary()
+    ct.remove(); at.remove()
+    fl = 2 * B * GFLOP_PER_SAMPLE_FORWARD_REF128 / 1e3
+    rec = {"value": round(steps / dt, 3), "unit": "steps/s", "ms_per_step": round(ms, 3), "latent": "128x128x3", "batch": B, "dtype": unet.precision.label,
+           "steps": steps, "warmup": warmup, "sample_steps_per_s": round(B * steps / dt, 1),
+           "step_reference_equivalent_tflops": round(fl / (ms * 1e-3), 1),
+           "step_reference_equivalent_frac_of_mfma_peak": round(fl / (ms * 1e-3) / PEAK_MFMA_TFLOPS, 4),
+           "roofline": {"bound": "mfma", "kernel": "all stedm_conv_igemm launches of a REF128 step (as issued)", "achieved": round(cs["tflops"], 2),
+                        "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(cs["tflops"] / PEAK_MFMA_TFLOPS, 4),
+                        "launches_per_step": cs["launches"] // 2, "conv_ms_per_step": round(cs["total_ms"] / 2, 3)},
+           "attention": {"kernel": "attn_mfma_tiles_kernel (middle block, one wave per 32 queries, 64-key tiles, online softmax)", "tokens": asum["tokens"],
+                         "launches_per_step": asum["launches"] // 2, "us_per_launch": round(1e3 * asum["total_ms"] / max(1, asum["launches"]), 1),
+                         "achieved": round(asum["tflops"], 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(asum["tflops"] / PEAK_MFMA_TFLOPS, 4)},
+           "what": "the reference-native U-Net (landscape.yaml: in 6 / out 3, 128^2 latents, 234.6 M parameters), one DDIM-50 + CFG 1.5 denoising step "
+                   "per batch, hipGraph replay; 872.37 GFLOP per sample-forward"}
+    del sg, smp, ld, unet
+    torch.cuda.empty_cache()
+    return rec
 
 
 def run_steps(ld, xT, cond, unc, warmup, steps, world):
@@ -154,11 +247,13 @@ def run_steps(ld, xT, cond, unc, warmup, steps, world):
     return dt, img
 
 
-def cpu_baseline(seconds_budget=15.0, gpu_eval=None):
-    """The CPU oracle (fixture-pinned restatement of the reference's PyTorch-CPU path) on this host's cores:
-    CFG denoising steps (2 sequential U-Net forwards + update, as the reference does) at a bounded batch.
+def cpu_baseline(gpu_eval=None, gpu_loop=None):
+    """The CPU oracle (fixture-pinned restatement of the reference's PyTorch-CPU path) on this host's cores: the WHOLE DDIM-50 + CFG 1.5 loop
+    of the headline workload (50 denoising steps = 100 sequential U-Net forwards, as the reference does) on a bounded batch of 4 samples.
     gpu_eval (optional): callable(x, c_concat, ctx, ctx_u, t) -> {mode: (e_c, e_u)} evaluating the SAME 4 samples inside a bench-sized
-    batch on the HIP path; the oracle's outputs of the first step then label every mode with its measured deviation (checker role)."""
+    batch on the HIP path; the oracle's outputs then label every mode with its measured single-forward deviation (checker role).
+    gpu_loop (optional): callable(x, c_concat, ctx, ctx_u) -> {mode: final latents of those 4 samples} after the same 50-step loop inside a
+    bench-sized batch on the HIP path (hipGraph replay): the deviation every mode ACCUMULATES over the loop."""
     from oracle import ddim as od
     from oracle import unet as ou
     from stedm_amd.utils import prng
@@ -176,54 +271,60 @@ def cpu_baseline(seconds_budget=15.0, gpu_eval=None):
     plan = ou.build_plan(cfg)
     P = prng.fill_state_dict(plan.shapes, 0)
     Bc = 4
-    x = prng.normal(1, "cpu.x", (Bc, 4, 32, 32)); cc = prng.normal(2, "cpu.cc", (Bc, 3, 32, 32))
+    x = prng.normal(1, "cpu.x", (Bc, 4, 32, 32)); cc = (prng.normal(2, "cpu.cc", (Bc, 3, 32, 32)) > 0).float()
     ctx = prng.normal(3, "cpu.ctx", (Bc, 512)); ctx_u = prng.normal(4, "cpu.ctxu", (Bc, 512))
     t = torch.full((Bc,), 951, dtype=torch.long)
-    ds = od.DDIMSchedule(od.Schedule(), 50, 0.0)
 
-    def evals(xx):
-        return (ou.unet_forward(P, cfg, torch.cat([xx, cc], 1), t, ctx, plan=plan),
-                ou.unet_forward(P, cfg, torch.cat([xx, cc], 1), t, ctx_u, plan=plan))
+    def apply_model(xx, tt, c):
+        return ou.unet_forward(P, cfg, torch.cat([xx, c["c_concat"][0]], 1), tt, c["c_crossattn"][0], plan=plan)
 
-    def step(xx):
-        e_c, e_u = evals(xx)
-        return od.ddim_update(xx, od.cfg_combine(e_c, e_u, 1.5), *ds.scalars(49))[0]
+    cond, unc = {"c_concat": [cc], "c_crossattn": [ctx]}, {"c_concat": [cc], "c_crossattn": [ctx_u]}
+
+    def stat(got, ref):
+        got, ref = got.double(), ref.double()
+        return {"rel_l2": float((got - ref).norm() / ref.norm()), "max_over_std": float((got - ref).abs().max() / ref.std())}
 
     deviation = None
     if gpu_eval is not None:
-        r_c, r_u = evals(x)
-        ref = torch.cat([r_c, r_u]).double()
+        ref = torch.cat([apply_model(x, t, cond), apply_model(x, t, unc)])      # (also the warm-up of the timed loop below)
         deviation = {"rows": Bc, "what": "eps of 4 samples inside the bench-sized CFG batch (cond + uncond) vs the fp32 CPU oracle on the same samples: "
                                          "rel-L2 and max|diff|/std; north_star tolerance 1e-3"}
         for mode, (g_c, g_u) in gpu_eval(x, cc, ctx, ctx_u, 951).items():
-            got = torch.cat([g_c, g_u]).double()
-            deviation[mode] = {"rel_l2": float((got - ref).norm() / ref.norm()), "max_over_std": float((got - ref).abs().max() / ref.std())}
-    x = step(x)  # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        x = step(x); n += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget or n >= 200:
-            break
-    sample_steps_per_s = n * Bc / el
+            deviation[mode] = stat(torch.cat([g_c, g_u]), ref)
+    else:
+        apply_model(x, t, cond)
+    S = int(os.environ.get("STEDM_CPU_LOOP_STEPS", "50"))
+    t0 = time.perf_counter()
+    final = od.ddim_sample(apply_model, od.Schedule(), x, cond, S, 0.0, uncond=unc, scale=1.5)
+    el = time.perf_counter() - t0
+    sample_steps_per_s = S * Bc / el
     out = {"value": sample_steps_per_s / 64.0, "unit": "steps/s (bs=64 equivalent)", "cores": cores, "kind": "port",
-           "sample": f"{n} CFG denoising steps at batch {Bc} (fp32 torch-CPU oracle, {cores} threads), "
-                     f"{el:.1f} s; scaled by {Bc}/64", "sample_steps_per_s": sample_steps_per_s}
+           "sample": f"the whole DDIM-{S} + CFG 1.5 loop ({S} denoising steps, {2 * S} U-Net forwards) at batch {Bc} (fp32 torch-CPU oracle, "
+                     f"{cores} threads), {el:.1f} s; scaled by {Bc}/64", "sample_steps_per_s": sample_steps_per_s}
+    loop_dev = None
+    if gpu_loop is not None:
+        loop_dev = {"rows": Bc, "steps": S,
+                    "what": f"final latents of 4 samples after the whole DDIM-{S} + CFG 1.5 loop inside the bench-sized batch (hipGraph replay) vs the "
+                            "fp32 CPU oracle's loop on the same samples: the deviation a mode accumulates over the loop; tolerance 1e-3 (rel-L2)"}
+        for mode, got in gpu_loop(x, cc, ctx, ctx_u, S).items():
+            loop_dev[mode] = stat(got, final)
     if cores != 8:
-        # the second run BASELINE.md §4 promises: the same sample on 8 threads, comparable with the 8-vCPU figures of BASELINE.md §2
+        # the second run BASELINE.md §4 promises: the same arithmetic on 8 threads, comparable with the 8-vCPU figures of BASELINE.md §2
         torch.set_num_threads(8)
-        x8 = step(x)
+        ds = od.DDIMSchedule(od.Schedule(), 50, 0.0)
+        x8 = x
         n8, t0 = 0, time.perf_counter()
         while True:
-            x8 = step(x8); n8 += 1
+            e8 = od.cfg_combine(apply_model(x8, t, cond), apply_model(x8, t, unc), 1.5)
+            x8 = od.ddim_update(x8, e8, *ds.scalars(49))[0]; n8 += 1
             el8 = time.perf_counter() - t0
-            if el8 > 6.0 or n8 >= 200:
+            if el8 > 4.0 or n8 >= 50:
                 break
         out["threads8"] = {"value": n8 * Bc / el8 / 64.0, "unit": "steps/s (bs=64 equivalent)", "cores": 8,
                            "sample": f"{n8} CFG denoising steps at batch {Bc}, 8 threads, {el8:.1f} s; scaled by {Bc}/64",
                            "sample_steps_per_s": n8 * Bc / el8}
         torch.set_num_threads(cores)
-    return out, deviation
+    return out, deviation, loop_dev
 
 
 def config1_leg(ld, dev, precision):
@@ -252,7 +353,7 @@ def config1_leg(ld, dev, precision):
     cond = {"c_concat": [cc.to(dev)], "c_crossattn": [ctx.to(dev)]}
     unc = {"c_concat": [cc.to(dev)], "c_crossattn": [ctx_u.to(dev)]}
     res = {}
-    for mode in dict.fromkeys([precision, "parity"]):
+    for mode in dict.fromkeys([precision, "f16", "bf16", "parity"]):
         unet.set_precision(mode)
         run = lambda: ld.sample_log(cond, 1, True, 20, eta=0.0, x_T=xT.to(dev), unconditional_conditioning=unc, unconditional_guidance_scale=1.5,
                                     log_every_t=1000)[0]
@@ -294,7 +395,7 @@ def train_leg_multi(ld, dev, args, xT, cond, rank, world, steps=4, warmup=2):
     from stedm_amd.train import UNetTrainer
     B = args.batch
     unet = ld.model.diffusion_model
-    unet.set_precision(args.precision)
+    unet.set_precision("bf16")               # BASELINE config 2's dtype
     tr = UNetTrainer(unet, lr=1e-6)
     g = torch.Generator(device="cpu").manual_seed(5 + rank)                 # every rank its own micro-batch
     tt = torch.randint(0, 1000, (B,), generator=g).to(dev)
@@ -415,7 +516,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--precision", default=os.environ.get("STEDM_BENCH_PRECISION", "bf16"))
+    ap.add_argument("--precision", default=os.environ.get("STEDM_BENCH_PRECISION", "f16"),
+                    help="numerics mode of the headline: f16 (default: the fastest mode inside north_star's 1e-3), bf16, parity")
+    ap.add_argument("--ref128-batch", type=int, default=16, help="batch of the reference-native 128x128x3 leg (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-leg", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true")
@@ -481,6 +584,10 @@ def main():
         for _ in range(2):
             sg.step_eager()
         cs = ct.summary(); ct.remove()
+        ct2 = ConvTimer(split_gn=True); ct2.install()        # the same launches with the riding GroupNorms split off (convolution work only)
+        for _ in range(2):
+            sg.step_eager()
+        cs2 = ct2.summary(); ct2.remove()
         # HBM-side bytes per launch from the PMC passes (tools/pmc_traffic.py); reported only when the profile was taken on THIS
         # binary (fingerprint of the kernel sources), null otherwise — never a stale constant
         traffic, traffic_note = None, "no PMC traffic profile for this build (tools/pmc_traffic.py)"
@@ -499,7 +606,13 @@ def main():
                     "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(cs["tflops"] / PEAK_MFMA_TFLOPS, 4),
                     "traffic": traffic, "traffic_source": traffic_note, "launches_per_step": cs["launches"] // 2, "avg_launch_us": round(cs["avg_us"], 2),
                     "algorithmic_gflop_per_launch": round(cs["flops_per_launch"] / 1e9, 3),
-                    "conv_ms_per_step": round(cs["total_ms"] / 2, 3)}
+                    "conv_ms_per_step": round(cs["total_ms"] / 2, 3), "mode": ld.model.diffusion_model.precision.label,
+                    "timed_variant": "the launches as the step issues them: a consumer GroupNorm + SiLU that rides on a convolution (epilogue form, "
+                                     "split-K reduce form, or the trailing stedm_gn_apply16c pass of the call) is INSIDE the bracket, its bytes are "
+                                     "not counted as work",
+                    "convolution_only": {"achieved": round(cs2["tflops"], 2), "frac": round(cs2["tflops"] / PEAK_MFMA_TFLOPS, 4),
+                                         "conv_ms_per_step": round(cs2["total_ms"] / 2, 3),
+                                         "what": "the same launches with every riding GroupNorm run as its own launch outside the bracket"}}
         # whole-step figures against the same peak: (a) reference-equivalent = the FLOPs of the reference's two full forwards per step
         # (what a user gets per second, in the reference's currency); (b) executed = the conv FLOPs the hardware really runs per step
         # (shared encoder evaluated once, sub-pixel upsample at 4/9 of the MACs): the honest MFMA utilisation of the whole step
@@ -524,18 +637,24 @@ def main():
         }
         if not args.no_parity_leg and world == 1:
             del sg, smp
-            if args.precision != "f16":
-                # fp16 single product: the same kernels and speed class as bf16 with 8x smaller operand rounding
-                ld.model.diffusion_model.set_precision("f16")
-                dtf, _ = run_steps(ld, xT, cond, unc, 2, max(4, args.steps // 2), 1)
-                out["f16_mode"] = {"dtype": "f16", "value": round(max(4, args.steps // 2) / dtf, 3), "unit": "steps/s",
-                                   "note": "fp16 single product; measured deviation from the CPU oracle: deviation_vs_cpu_oracle.f16"}
-            # fp32-parity mode (fp16 x3 split products) throughput next to the fast mode, same workload
-            ld.model.diffusion_model.set_precision("parity")
-            dtp, _ = run_steps(ld, xT, cond, unc, 2, max(4, args.steps // 2), 1)
-            out["parity_mode"] = {"dtype": "f16x3", "value": round(max(4, args.steps // 2) / dtp, 3), "unit": "steps/s",
-                                  "note": "split-precision mode that meets the 1e-3 fp32 parity tolerance (deviation_vs_cpu_oracle.f16x3; "
-                                          "tests/test_gpu_unet.py, tests/test_gpu_bench_config.py)"}
+            # the other numerics modes on the same workload, batch, graph, steps and warm-up as the headline
+            unet_ = ld.model.diffusion_model
+            for mode, leg, note in (("bf16", "bf16_mode", "bf16 single product (BASELINE config 2's dtype): outside the 1e-3 tolerance, see deviation_vs_cpu_oracle.bf16"),
+                                    ("f16", "f16_mode", "fp16 single product; measured deviation from the CPU oracle: deviation_vs_cpu_oracle.f16"),
+                                    ("parity", "parity_mode", "fp16 hi + lo split operands, 3 products: meets 1e-3 under the max-norm reading too "
+                                                              "(deviation_vs_cpu_oracle.f16x3; tests/test_gpu_unet.py, tests/test_gpu_bench_config.py)")):
+                if mode == args.precision:
+                    continue
+                unet_.set_precision(mode)
+                dtm, _ = run_steps(ld, xT, cond, unc, args.warmup, args.steps, 1)
+                out[leg] = {"dtype": unet_.precision.label, "value": round(args.steps / dtm, 3), "unit": "steps/s", "steps": args.steps,
+                            "warmup": args.warmup, "note": note}
+            unet_.set_precision(args.precision)
+            if args.ref128_batch > 0:
+                try:
+                    out["ref128_step"] = ref128_leg(dev, args.precision, args.ref128_batch)
+                except Exception as e:          # never lose the headline over a side leg
+                    out["ref128_step"] = {"error": str(e)[:200]}
         if not args.no_e2e_leg and world == 1:
             # BASELINE config 5's latent size (64x64x4, CATCH 512^2): the same denoising step on 4x the pixels, reported beside the headline
             ld.model.diffusion_model.set_precision(args.precision)
@@ -699,7 +818,7 @@ def main():
             # BASELINE config 2: one training step (forward + L1 + backward + AdamW/EMA) on the same U-Net and batch
             from stedm_amd.train import UNetTrainer
             unet = ld.model.diffusion_model
-            unet.set_precision(args.precision)
+            unet.set_precision("bf16")           # BASELINE config 2 names bf16: forward and backward operands bf16 (fp32 exponent range, no loss scaling)
             tr = UNetTrainer(unet, lr=1e-6)
             g = torch.Generator(device="cpu").manual_seed(5)
             tt = torch.randint(0, 1000, (B,), generator=g).to(dev)
@@ -720,6 +839,7 @@ def main():
                                          "gradients match the reference's autograd to 1e-5 in parity mode (tests/test_gpu_train.py)",
                                  "loss": round(float(loss), 4)}
             del tr
+            unet.set_precision(args.precision)
             if not args.no_cpu_baseline:
                 out["train_step"]["cpu_baseline"] = cpu_baseline_train()
         if not args.no_cpu_baseline and world == 1:
@@ -736,36 +856,63 @@ def main():
                 xb[:n4], ccb[:n4], cb[:n4], ub[:n4] = x4.to(dev), cc4.to(dev), ctx4.to(dev), ctxu4.to(dev)
                 tb = torch.full((B,), int(tval), dtype=torch.long, device=dev)
                 res = {}
-                for mode in dict.fromkeys([args.precision, "f16", "parity"]):
+                for mode in dict.fromkeys([args.precision, "f16", "bf16", "parity"]):
                     unet.set_precision(mode)
                     ec, eu = unet.forward_cfg(xb, ccb, tb, cb, ub, uniform_t=True)
                     res[unet.precision.label] = (ec[:n4].float().cpu(), eu[:n4].float().cpu())
                 unet.set_precision(args.precision)
                 return res
 
-            out["cpu_baseline"], dev_rep = cpu_baseline(gpu_eval=gpu_eval)
+            def gpu_loop(x4, cc4, ctx4, ctxu4, S):
+                # the same 4 samples through the WHOLE loop inside a bench-sized batch (hipGraph replay, as the headline runs it), every mode
+                n4 = x4.shape[0]
+                xb, ccb = xT.clone(), cond["c_concat"][0].clone()
+                cb, ub = cond["c_crossattn"][0].clone(), unc["c_crossattn"][0].clone()
+                xb[:n4], ccb[:n4], cb[:n4], ub[:n4] = x4.to(dev), cc4.to(dev), ctx4.to(dev), ctxu4.to(dev)
+                c_, u_ = {"c_concat": [ccb], "c_crossattn": [cb]}, {"c_concat": [ccb], "c_crossattn": [ub]}
+                res = {}
+                for mode in dict.fromkeys([args.precision, "f16", "bf16", "parity"]):
+                    unet.set_precision(mode)
+                    fin = ld.sample_log(c_, B, True, S, eta=0.0, x_T=xb, unconditional_conditioning=u_, unconditional_guidance_scale=1.5,
+                                        log_every_t=1000)[0]
+                    res[unet.precision.label] = fin[:n4].float().cpu()
+                unet.set_precision(args.precision)
+                return res
+
+            out["cpu_baseline"], dev_rep, loop_rep = cpu_baseline(gpu_eval=gpu_eval, gpu_loop=gpu_loop)
             out["config1_loop"] = config1_leg(ld, dev, args.precision)      # (after gpu_eval: it restores the PRNG weights the oracle holds)
             out["deviation_vs_cpu_oracle"] = dev_rep
+            out["loop_deviation_vs_cpu_oracle"] = loop_rep
             if dev_rep and out["dtype"] in dev_rep:
                 out["headline_rel_l2_vs_oracle"] = round(dev_rep[out["dtype"]]["rel_l2"], 6)
-            if dev_rep:
-                # the throughput of the fastest mode that meets north_star's 1e-3 (fp32-relative) on the measured deviation, first class:
-                # `value` stays the bf16 figure BASELINE's config names, with its own deviation beside it
+            if loop_rep and out["dtype"] in loop_rep:
+                out["headline_loop_rel_l2_vs_oracle"] = round(loop_rep[out["dtype"]]["rel_l2"], 6)
+            if dev_rep and loop_rep:
+                out["headline_meets_tolerance"] = bool(out.get("headline_rel_l2_vs_oracle", 1.0) <= 1e-3 and
+                                                       out.get("headline_loop_rel_l2_vs_oracle", 1.0) <= 1e-3)
+                for leg in ("bf16_mode", "f16_mode", "parity_mode"):
+                    if leg in out and out[leg]["dtype"] in dev_rep:
+                        out[leg]["rel_l2_vs_oracle"] = round(dev_rep[out[leg]["dtype"]]["rel_l2"], 6)
+                        out[leg]["loop_rel_l2_vs_oracle"] = round(loop_rep[out[leg]["dtype"]]["rel_l2"], 6)
+                # the throughput of the fastest mode that meets north_star's 1e-3 (fp32-relative) on the measured deviation — single forward
+                # AND accumulated over the DDIM-50 loop — first class; the headline is that mode unless --precision asked for another
                 rates = {out["dtype"]: out["value"]}
-                for leg in ("f16_mode", "parity_mode"):
+                for leg in ("bf16_mode", "f16_mode", "parity_mode"):
                     if leg in out:
                         rates[out[leg]["dtype"]] = out[leg]["value"]
 
                 def fastest(key):
-                    ok = [(rates[m], m) for m in rates if m in dev_rep and dev_rep[m][key] <= 1e-3]
+                    ok = [(rates[m], m) for m in rates if m in dev_rep and m in loop_rep and dev_rep[m][key] <= 1e-3 and loop_rep[m][key] <= 1e-3]
                     if not ok:
                         return None
                     v, m = max(ok)
                     return {"mode": m, "value": v, "unit": "steps/s", "rel_l2": round(dev_rep[m]["rel_l2"], 8),
-                            "max_over_std": round(dev_rep[m]["max_over_std"], 8)}
+                            "max_over_std": round(dev_rep[m]["max_over_std"], 8), "loop_rel_l2": round(loop_rep[m]["rel_l2"], 8),
+                            "loop_max_over_std": round(loop_rep[m]["max_over_std"], 8)}
                 out["value_at_tolerance"] = {"tolerance": 1e-3, "on_rel_l2": fastest("rel_l2"), "on_max_over_std": fastest("max_over_std"),
-                                             "what": "fastest measured mode whose eps deviates from the fp32 CPU oracle by <= 1e-3 — as rel-L2, and under "
-                                                     "the stricter max|diff|/std reading; same workload, batch and graph as `value`"}
+                                             "what": "fastest measured mode whose eps (one forward) AND final latents (whole DDIM-50 loop) deviate from "
+                                                     "the fp32 CPU oracle by <= 1e-3 — as rel-L2, and under the stricter max|diff|/std reading; same "
+                                                     "workload, batch, graph, steps and warm-up as `value`"}
         elif world == 1:
             out["cpu_baseline"] = None
     if world > 1 and not args.no_train_leg:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STEDM_ABI_VERSION 6
+#define STEDM_ABI_VERSION 7
 
 #define STEDM_F16 0
 #define STEDM_BF16 1
@@ -49,6 +49,22 @@ int stedm_abi_version(void);
 const char* stedm_last_error(void);
 /* number of CUs of the current device (host query; used for launch heuristics / tests) */
 int stedm_device_cus(void);
+
+/* ---- fp16 operand range guard ------------------------------------------------------------------
+ * The reference computes in fp32 (train_diff.py:48; convert_module_to_f16 is a no-op, openaimodel.py:25-29). In the `f16` and `parity`
+ * (fp16 hi + lo) modes the MFMA operand planes are fp16: a residual-stream value beyond 65 504 would become inf in the un-normalised planes
+ * (the operand of ResBlock.skip_connection openaimodel.py:247-254 / 288, of Upsample.conv :122-132 and of Downsample.op :156-173) and NaN one
+ * layer later. Every kernel that rounds such values to fp16 ORs a site bit into `flag_words[0]` (device memory, 4 x u32, owned by the caller,
+ * must outlive every launch and every captured graph) when a value it wrote has all exponent bits set (inf or NaN). bf16 planes are never
+ * flagged (fp32 exponent range). The host reads and clears the word at its own synchronisation points (end of a sampling loop, after a
+ * forward when asked) and raises. NULL switches the guard off. Set per device (the current one). */
+#define STEDM_F16G_RAW 1        /* un-normalised planes written by stedm_gn_apply16c (skip_connection operand)          */
+#define STEDM_F16G_NORM 2       /* normalised planes (GroupNorm output; bounded by sqrt(n) |gamma| + |beta|)             */
+#define STEDM_F16G_CONV_OUT16 4 /* 16-bit side output of a convolution epilogue (Upsample operand, qkv planes)           */
+#define STEDM_F16G_S2D 8        /* stedm_space_to_depth16 (Downsample operand)                                           */
+#define STEDM_F16G_CAST 16      /* stedm_gn_apply16 / stedm_gn_chan_stats16 plain conversions                            */
+#define STEDM_F16G_CONV_SRC 32  /* fp32-source convolution loader (hi/lo split in the kernel)                            */
+int stedm_f16_guard_set(void* flag_words);
 
 /* ---- weight packing (one-time, at load) -------------------------------------------------- */
 /* OIHW fp32 conv weight [cout][cin][ks][ks] -> MFMA operand planes [cout][ks*ks][cin] (16-bit).

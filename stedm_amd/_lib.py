@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STEDM_HIP_LIB") or os.path.join(_HERE, "libstedm_hip.so")     # STEDM_HIP_LIB: A/B timing of another build
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 F16, BF16 = 0, 1
 CONV_S1, CONV_DOWN, CONV_UP, CONV_UP_SUBPIXEL, CONV_S2D = 0, 1, 2, 3, 4
 
@@ -47,6 +47,7 @@ SIGNATURES = {
     "stedm_abi_version": (_I, []),
     "stedm_last_error": (C.c_char_p, []),
     "stedm_device_cus": (_I, []),
+    "stedm_f16_guard_set": (_I, [_P]),
     "stedm_pack_conv_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "stedm_pack_conv_weight_up": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "stedm_pack_conv_weight_frag": (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -33,6 +33,24 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 // after a kernel launch
 #define STEDM_LAUNCH_CHECK() STEDM_HIP_TRY(hipGetLastError())
 
+// fp16 operand range guard (stedm_f16_guard_set, include/stedm_hip.h): device address of the flag word of the current device, or nullptr.
+unsigned* f16_guard_flag();
+
+// nonzero iff one of the two / four 16-bit values packed in `w` / `q` is an fp16 inf or NaN (exponent 11111: adding one at the exponent's
+// lowest bit carries into the cleared sign position). For T = __bf16 the answer is a compile-time 0 and the callers' code folds away.
+template <typename T>
+__device__ __forceinline__ unsigned f16_over2(unsigned w) {
+  if constexpr (sizeof(T) == 2 && !__is_same(T, _Float16)) return 0u;
+  return ((w & 0x7c007c00u) + 0x04000400u) & 0x80008000u;
+}
+template <typename T>
+__device__ __forceinline__ unsigned f16_over4(uint2 q) { return f16_over2<T>(q.x) | f16_over2<T>(q.y); }
+template <typename T, typename V4>
+__device__ __forceinline__ unsigned f16_over_v4(V4 v) { return f16_over4<T>(__builtin_bit_cast(uint2, v)); }
+__device__ __forceinline__ void f16_guard_commit(unsigned* flag, unsigned bad, unsigned site) {
+  if (flag != nullptr && bad != 0u) atomicOr(flag, site);
+}
+
 __device__ __forceinline__ float silu_f(float v) {
   // x * sigmoid(x); exp/rcp are the hardware transcendental forms (<= 1 ulp-ish), far inside 1e-3.
   return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));

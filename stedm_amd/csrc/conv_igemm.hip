@@ -104,6 +104,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
 
   // ---- weight tile prefetch registers
   uint4 wreg[NPL][BPT];
+  unsigned bad_src = 0u;      // fp16 range guard: inf / NaN among the operands this kernel rounds from the fp32 source (common.hpp)
   auto load_w = [&](int step) {
     const int chunk = step / taps, tap = step - chunk * taps;
     const int c0 = chunk * BKC;
@@ -183,6 +184,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
       V4 hi;
       hi[0] = (T)v.x; hi[1] = (T)v.y; hi[2] = (T)v.z; hi[3] = (T)v.w;
       *reinterpret_cast<V4*>(sA + pos * AST + q * 8) = hi;
+      bad_src |= f16_over_v4<T>(hi);
       if (NPL == 2) {
         V4 lo;
         lo[0] = (T)(v.x - (float)hi[0]); lo[1] = (T)(v.y - (float)hi[1]);
@@ -262,6 +264,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
       }
     }
   }
+  f16_guard_commit(p.ovf, bad_src, STEDM_F16G_CONV_SRC);
 }
 
 template <int BKC, int NPASS, typename T>
@@ -414,6 +417,7 @@ static int conv_dispatch(ConvParams& p, void* stream) {
   hipStream_t st = as_stream(stream);
   static const int dbg0 = getenv("STEDM_CONV_DBG") ? atoi(getenv("STEDM_CONV_DBG")) : 0;
   p.dbg = dbg0;
+  p.ovf = a.mm_dtype == STEDM_F16 ? f16_guard_flag() : nullptr;
   if (a.src16_hi) {   // v3: both operands by LDS-DMA from pre-normalised 16-bit planes
     const int rc = conv_launch_dma(p, st);
     if (rc == 0 || !a.src1) return rc;

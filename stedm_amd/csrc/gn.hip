@@ -202,6 +202,7 @@ struct GnApplyArgs {
   void* out_hi;
   void* out_lo;
   long total_q;  // B*HW*C/4
+  unsigned* ovf; // fp16 range guard flag (common.hpp) or nullptr
 };
 
 template <typename T>
@@ -233,6 +234,7 @@ __global__ void __launch_bounds__(256) gn_apply16_kernel(GnApplyArgs a, int slab
   const int dpix = 256 / Q, dq = 256 % Q;
   V4* oh = reinterpret_cast<V4*>(a.out_hi) + (long)b * a.HW * Q;
   V4* ol = a.out_lo ? reinterpret_cast<V4*>(a.out_lo) + (long)b * a.HW * Q : nullptr;
+  unsigned bad = 0u;
   for (int i = threadIdx.x; i < total; i += 256) {
     const int c = q * 4;
     float4 v = c < a.c1 ? *reinterpret_cast<const float4*>(p1 + (long)pix * a.c1 + c)
@@ -256,6 +258,7 @@ __global__ void __launch_bounds__(256) gn_apply16_kernel(GnApplyArgs a, int slab
     hi[0] = (T)v.x; hi[1] = (T)v.y; hi[2] = (T)v.z; hi[3] = (T)v.w;
     const long o = (long)pix * Q + q;
     oh[o] = hi;
+    bad |= f16_over_v4<T>(hi);
     if (ol) {
       V4 lo;
       lo[0] = (T)(v.x - (float)hi[0]); lo[1] = (T)(v.y - (float)hi[1]);
@@ -265,6 +268,7 @@ __global__ void __launch_bounds__(256) gn_apply16_kernel(GnApplyArgs a, int slab
     pix += dpix; q += dq;
     if (q >= Q) { q -= Q; ++pix; }
   }
+  f16_guard_commit(a.ovf, bad, a.gamma ? STEDM_F16G_NORM : STEDM_F16G_CAST);
 }
 
 extern "C" int stedm_gn_apply16(const float* x1, int c1, const float* x2, int c2, int x2_bmod, const float* gamma,
@@ -278,7 +282,7 @@ extern "C" int stedm_gn_apply16(const float* x1, int c1, const float* x2, int c2
   STEDM_CHECK_ARG(!gamma || C % groups == 0, "gn_apply16: C %% groups != 0");
   STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "gn_apply16: bad mm_dtype");
   GnApplyArgs a{x1, x2, c1, c2, x2_bmod, groups > 0 ? groups : 1, HW, act, gamma, beta, eps, stats, out_hi, out_lo,
-                (long)B * HW * (C / 4)};
+                (long)B * HW * (C / 4), mm_dtype == STEDM_F16 ? f16_guard_flag() : nullptr};
   STEDM_CHECK_ARG(!gamma || groups <= 64, "gn_apply16: groups <= 64");
   const int slab = gn_slab_pixels(C, HW);
   const int nslab = (HW + slab - 1) / slab;
@@ -306,7 +310,7 @@ extern "C" int stedm_gn_chan_nslab(int HW) { return (HW + 255) / 256; }
 // needs both of a gradient tensor (channel sums = bias gradient, 16-bit planes = operand of its dgrad / wgrad)
 template <typename T, bool CAST>
 __global__ void __launch_bounds__(256) gn_chan_stats_kernel(const float* __restrict__ x, int C, int HW, int slab_px, float* __restrict__ cs,
-                                                            T* __restrict__ o_hi, T* __restrict__ o_lo, int qbs) {
+                                                            T* __restrict__ o_hi, T* __restrict__ o_lo, int qbs, unsigned* ovf = nullptr) {
   typedef T V4 __attribute__((ext_vector_type(4)));
   __shared__ float cpart[256 * 8];   // [npl][QB][8]
   const int b = blockIdx.x, slab = blockIdx.y, nslab = gridDim.y;
@@ -316,6 +320,7 @@ __global__ void __launch_bounds__(256) gn_chan_stats_kernel(const float* __restr
   const float* px = x + (long)b * HW * C + (qb0 + tq) * 4;
   const int px0 = min(HW, slab * slab_px), px1 = min(HW, px0 + slab_px);   // trailing slots of an over-allocated partition stay 0
   float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+  unsigned bad = 0u;
   if (tp < npl) {
 #pragma unroll 4
     for (int pix = px0 + tp; pix < px1; pix += npl) {
@@ -324,6 +329,7 @@ __global__ void __launch_bounds__(256) gn_chan_stats_kernel(const float* __restr
         const long o = ((long)b * HW + pix) * C + (qb0 + tq) * 4;
         V4 h4; h4[0] = (T)v.x; h4[1] = (T)v.y; h4[2] = (T)v.z; h4[3] = (T)v.w;
         *reinterpret_cast<V4*>(o_hi + o) = h4;
+        bad |= f16_over_v4<T>(h4);
         if (o_lo) {
           V4 l4; l4[0] = (T)(v.x - (float)h4[0]); l4[1] = (T)(v.y - (float)h4[1]); l4[2] = (T)(v.z - (float)h4[2]); l4[3] = (T)(v.w - (float)h4[3]);
           *reinterpret_cast<V4*>(o_lo + o) = l4;
@@ -336,6 +342,7 @@ __global__ void __launch_bounds__(256) gn_chan_stats_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < 4; ++j) { d[j] = s[j]; d[4 + j] = q[j]; }
   }
+  if constexpr (CAST) f16_guard_commit(ovf, bad, STEDM_F16G_CAST);
   __syncthreads();
   if (t < QB) {
     float su[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -383,7 +390,8 @@ extern "C" int stedm_gn_chan_stats16(const float* x, int C, int B, int HW, int n
   const int qbs = chan_stats_qbs(B, nslab, Q);
   dim3 grid(B, nslab, (Q + qbs - 1) / qbs);
   if (mm_dtype == STEDM_F16)
-    gn_chan_stats_kernel<_Float16, true><<<grid, 256, 0, as_stream(stream)>>>(x, C, HW, slab_px, chan_stats, (_Float16*)out_hi, (_Float16*)out_lo, qbs);
+    gn_chan_stats_kernel<_Float16, true><<<grid, 256, 0, as_stream(stream)>>>(x, C, HW, slab_px, chan_stats, (_Float16*)out_hi, (_Float16*)out_lo, qbs,
+                                                                                  f16_guard_flag());
   else
     gn_chan_stats_kernel<__bf16, true><<<grid, 256, 0, as_stream(stream)>>>(x, C, HW, slab_px, chan_stats, (__bf16*)out_hi, (__bf16*)out_lo, qbs);
   STEDM_LAUNCH_CHECK();
@@ -404,7 +412,12 @@ struct GnApplyCArgs {
   void* raw_hi;
   void* raw_lo;
   float* mr;     // optional [B][groups][2]: the {mean, rstd} this pass folds anyway, kept for the training backward
+  unsigned* ovf; // fp16 range guard flag (common.hpp) or nullptr
 };
+
+// A value beyond the fp16 range (65 504) in a run of pixels makes that run's sum of squares exceed 65 504^2 = 4.29e9: a block whose channel
+// partials all stay below the threshold cannot overflow and skips the per-element test of its stream (NaN / inf partials fail the `<` too).
+#define STEDM_F16_SQ_SAFE 4.0e9f
 
 // y = act(GroupNorm([x1|x2])) from channel partials -> 16-bit planes; optionally also the plain conversion of [x1|x2]
 // (raw planes: the operand of the ResBlock's 1x1 skip convolution) from the same read of the fp32 tensors.
@@ -445,24 +458,27 @@ __global__ void __launch_bounds__(256) gn_apply16c_kernel(GnApplyCArgs a, int sl
     }
   };
   load_batch(threadIdx.x);
+  bool maybe_over = false;       // block-uniform: some channel partial of this block's groups admits |x| > 65504 (fp16 guard)
+  unsigned bad_raw = 0u, bad_norm = 0u;
   {
     const int L = 256 / a.groups;                 // lanes per group (groups <= 64)
     const int g = threadIdx.x / L, l = threadIdx.x % L;
     double su = 0.0, sq = 0.0;
+    int big = 0;
     if (g < a.groups) {
       const int nmax = a.nslab1 > a.nslab2 ? a.nslab1 : a.nslab2;
       const int n = cpg * nmax;
       for (int e = l; e < n; e += L) {            // entry = (slab k, channel cc of the group); tensors may be partitioned differently
         const int k = e / cpg, c = g * cpg + (e - k * cpg);
         if (c < a.c1) {
-          if (k < a.nslab1) { const float* p = a.cs1 + (((long)b * a.nslab1 + k) * a.c1 + c) * 2; su += (double)p[0]; sq += (double)p[1]; }
+          if (k < a.nslab1) { const float* p = a.cs1 + (((long)b * a.nslab1 + k) * a.c1 + c) * 2; su += (double)p[0]; sq += (double)p[1]; big |= !(p[1] < STEDM_F16_SQ_SAFE); }
         } else if (k < a.nslab2) {
-          const float* p = a.cs2 + (((long)b2 * a.nslab2 + k) * a.c2 + (c - a.c1)) * 2; su += (double)p[0]; sq += (double)p[1];
+          const float* p = a.cs2 + (((long)b2 * a.nslab2 + k) * a.c2 + (c - a.c1)) * 2; su += (double)p[0]; sq += (double)p[1]; big |= !(p[1] < STEDM_F16_SQ_SAFE);
         }
       }
     }
     dsu[threadIdx.x] = su; dsq[threadIdx.x] = sq;
-    __syncthreads();
+    maybe_over = __syncthreads_or(big) != 0 && a.ovf != nullptr && __is_same(T, _Float16);
     if (g < a.groups && l == 0) {
       double s = 0.0, q = 0.0;
       for (int i = 0; i < L; ++i) { s += dsu[threadIdx.x + i]; q += dsq[threadIdx.x + i]; }   // fixed order
@@ -488,6 +504,7 @@ __global__ void __launch_bounds__(256) gn_apply16c_kernel(GnApplyCArgs a, int sl
           V4 hi;
           hi[0] = (T)w.x; hi[1] = (T)w.y; hi[2] = (T)w.z; hi[3] = (T)w.w;
           rh[o] = hi;
+          if (maybe_over) bad_raw |= f16_over_v4<T>(hi);
           if (rl) {
             V4 lo;
             lo[0] = (T)(w.x - (float)hi[0]); lo[1] = (T)(w.y - (float)hi[1]);
@@ -511,6 +528,7 @@ __global__ void __launch_bounds__(256) gn_apply16c_kernel(GnApplyCArgs a, int sl
         V4 hi;
         hi[0] = (T)w.x; hi[1] = (T)w.y; hi[2] = (T)w.z; hi[3] = (T)w.w;
         oh[o] = hi;
+        if (maybe_over) bad_norm |= f16_over_v4<T>(hi);
         if (ol) {
           V4 lo;
           lo[0] = (T)(w.x - (float)hi[0]); lo[1] = (T)(w.y - (float)hi[1]);
@@ -522,6 +540,7 @@ __global__ void __launch_bounds__(256) gn_apply16c_kernel(GnApplyCArgs a, int sl
       if (qs[k] >= Q) { qs[k] -= Q; ++pixs[k]; }
     }
   }
+  if (maybe_over) { f16_guard_commit(a.ovf, bad_raw, STEDM_F16G_RAW); f16_guard_commit(a.ovf, bad_norm, STEDM_F16G_NORM); }
 }
 
 
@@ -571,25 +590,28 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
     }
   };
   load_batch(threadIdx.x);
+  bool maybe_over = false;       // block-uniform: some channel partial of this block's groups admits |x| > 65504 (fp16 guard)
+  unsigned bad_raw = 0u, bad_norm = 0u;
   {
     const int g_lo = c_lo / cpg, ng = c_n / cpg;  // this block's groups
     const int L = 256 / ng;                       // lanes per group (groups <= 64)
     const int gl = threadIdx.x / L, l = threadIdx.x % L, g = g_lo + gl;
     double su = 0.0, sq = 0.0;
+    int big = 0;
     if (gl < ng) {
       const int nmax = a.nslab1 > a.nslab2 ? a.nslab1 : a.nslab2;
       const int n = cpg * nmax;
       for (int e = l; e < n; e += L) {            // entry = (slab k, channel cc of the group); tensors may be partitioned differently
         const int k = e / cpg, c = g * cpg + (e - k * cpg);
         if (c < a.c1) {
-          if (k < a.nslab1) { const float* p = a.cs1 + (((long)b * a.nslab1 + k) * a.c1 + c) * 2; su += (double)p[0]; sq += (double)p[1]; }
+          if (k < a.nslab1) { const float* p = a.cs1 + (((long)b * a.nslab1 + k) * a.c1 + c) * 2; su += (double)p[0]; sq += (double)p[1]; big |= !(p[1] < STEDM_F16_SQ_SAFE); }
         } else if (k < a.nslab2) {
-          const float* p = a.cs2 + (((long)b2 * a.nslab2 + k) * a.c2 + (c - a.c1)) * 2; su += (double)p[0]; sq += (double)p[1];
+          const float* p = a.cs2 + (((long)b2 * a.nslab2 + k) * a.c2 + (c - a.c1)) * 2; su += (double)p[0]; sq += (double)p[1]; big |= !(p[1] < STEDM_F16_SQ_SAFE);
         }
       }
     }
     dsu[threadIdx.x] = su; dsq[threadIdx.x] = sq;
-    __syncthreads();
+    maybe_over = __syncthreads_or(big) != 0 && a.ovf != nullptr && __is_same(T, _Float16);
     if (gl < ng && l == 0) {
       double s = 0.0, q = 0.0;
       for (int i = 0; i < L; ++i) { s += dsu[threadIdx.x + i]; q += dsq[threadIdx.x + i]; }   // fixed order
@@ -640,6 +662,7 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
       if (!live) { w = make_float4(0.f, 0.f, 0.f, 0.f); }
       if (rh) {
         rq[k] = pack4(w.x, w.y, w.z, w.w);
+        if (maybe_over) bad_raw |= f16_over4<T>(rq[k]);
         if (rl) {
           V4 hq = *reinterpret_cast<V4*>(&rq[k]);
           rlq[k] = pack4(w.x - (float)hq[0], w.y - (float)hq[1], w.z - (float)hq[2], w.w - (float)hq[3]);
@@ -652,6 +675,7 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
       w.x = (w.x - mn.x) * sc.x + bt.x; w.y = (w.y - mn.y) * sc.y + bt.y; w.z = (w.z - mn.z) * sc.z + bt.z; w.w = (w.w - mn.w) * sc.w + bt.w;
       if (a.act == 1) { w.x = silu_f(w.x); w.y = silu_f(w.y); w.z = silu_f(w.z); w.w = silu_f(w.w); }
       oq[k] = pack4(w.x, w.y, w.z, w.w);
+      if (maybe_over) bad_norm |= f16_over4<T>(oq[k]);
       if (ol) {
         V4 hq = *reinterpret_cast<V4*>(&oq[k]);
         olq[k] = pack4(w.x - (float)hq[0], w.y - (float)hq[1], w.z - (float)hq[2], w.w - (float)hq[3]);
@@ -672,6 +696,7 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
       if (qs[k] >= Q) { qs[k] -= Q; ++pixs[k]; }
     }
   }
+  if (maybe_over) { f16_guard_commit(a.ovf, bad_raw, STEDM_F16G_RAW); f16_guard_commit(a.ovf, bad_norm, STEDM_F16G_NORM); }
 }
 
 extern "C" int stedm_gn_apply16c_mr(const float* x1, int c1, const float* cs1, int nslab1, const float* x2, int c2, const float* cs2, int nslab2, int x2_bmod,
@@ -696,7 +721,8 @@ extern "C" int stedm_gn_apply16c_mr(const float* x1, int c1, const float* cs1, i
   STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "gn_apply16c: bad mm_dtype");
   STEDM_CHECK_ARG(raw_hi || !raw_lo, "gn_apply16c: raw_lo without raw_hi");
   STEDM_CHECK_ARG(nslab1 > 0 && (x2 == nullptr || nslab2 > 0), "gn_apply16c: nslab1 / nslab2 must be the slot counts of cs1 / cs2");
-  GnApplyCArgs a{x1, x2, cs1, cs2, c1, c2, x2_bmod, groups, HW, act, nslab1, x2 ? nslab2 : 0, gamma, beta, eps, out_hi, out_lo, raw_hi, raw_lo, mean_rstd};
+  GnApplyCArgs a{x1, x2, cs1, cs2, c1, c2, x2_bmod, groups, HW, act, nslab1, x2 ? nslab2 : 0, gamma, beta, eps, out_hi, out_lo, raw_hi, raw_lo, mean_rstd,
+                 mm_dtype == STEDM_F16 ? f16_guard_flag() : nullptr};
   // Pixels per block. Every block folds the group statistics and builds its per-channel table first, a cost that grows with C, so wide
   // tensors want long runs (128 KiB of fp32 input: 21 pixels of the 1536-channel decoder concat; at a fixed 32 KiB that shape ran at 4.3
   // TB/s, now 5.3) — as long as the grid keeps >= 768 blocks (3 per CU), which the 64-pixel samples of the 8x8 level need (12 pixels per

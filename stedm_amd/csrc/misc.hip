@@ -11,8 +11,23 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+static unsigned* g_f16_guard[64] = {nullptr};
+unsigned* f16_guard_flag() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  return g_f16_guard[dev];
+}
 }  // namespace stedm
 using namespace stedm;
+
+extern "C" int stedm_f16_guard_set(void* flag_words) {
+  int dev = 0;
+  STEDM_HIP_TRY(hipGetDevice(&dev));
+  STEDM_CHECK_ARG(dev >= 0 && dev < 64, "f16_guard_set: device index %d out of range", dev);
+  STEDM_CHECK_ARG(((uintptr_t)flag_words & 15) == 0, "f16_guard_set: the flag words must be 16-byte aligned");
+  stedm::g_f16_guard[dev] = reinterpret_cast<unsigned*>(flag_words);
+  return 0;
+}
 
 extern "C" int stedm_abi_version(void) { return STEDM_ABI_VERSION; }
 extern "C" const char* stedm_last_error(void) { return g_err; }
@@ -375,9 +390,10 @@ extern "C" int stedm_pack_conv_weight_s2d_frag(const float* w, void* out, int co
 // NHWC fp32 -> space-to-depth 16-bit planes [B][H/2][W/2][4C]; thread = one channel quad of one input pixel
 template <typename T>
 __global__ void __launch_bounds__(256) space_to_depth16_kernel(const float* __restrict__ x, T* __restrict__ hi, T* __restrict__ lo, int C, int H, int W,
-                                                               long total_q) {
+                                                               long total_q, unsigned* ovf) {
   typedef T V4 __attribute__((ext_vector_type(4)));
   const int Q = C >> 2;
+  unsigned bad = 0u;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total_q; i += (long)gridDim.x * blockDim.x) {
     const int q = (int)(i % Q);
     long pix = i / Q;
@@ -389,12 +405,14 @@ __global__ void __launch_bounds__(256) space_to_depth16_kernel(const float* __re
     V4 h4;
     h4[0] = (T)v.x; h4[1] = (T)v.y; h4[2] = (T)v.z; h4[3] = (T)v.w;
     reinterpret_cast<V4*>(hi)[o] = h4;
+    bad |= f16_over_v4<T>(h4);
     if (lo) {
       V4 l4;
       l4[0] = (T)(v.x - (float)h4[0]); l4[1] = (T)(v.y - (float)h4[1]); l4[2] = (T)(v.z - (float)h4[2]); l4[3] = (T)(v.w - (float)h4[3]);
       reinterpret_cast<V4*>(lo)[o] = l4;
     }
   }
+  f16_guard_commit(ovf, bad, STEDM_F16G_S2D);
 }
 
 extern "C" int stedm_space_to_depth16(const float* x, int C, int B, int H, int W, void* out_hi, void* out_lo, int mm_dtype, void* stream) {
@@ -402,8 +420,8 @@ extern "C" int stedm_space_to_depth16(const float* x, int C, int B, int H, int W
   STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "space_to_depth16: bad mm_dtype %d", mm_dtype);
   const long total_q = (long)B * H * W * (C / 4);
   const int grid = (int)((total_q + 255) / 256 < 16384 ? (total_q + 255) / 256 : 16384);
-  if (mm_dtype == STEDM_F16) space_to_depth16_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(x, (_Float16*)out_hi, (_Float16*)out_lo, C, H, W, total_q);
-  else space_to_depth16_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(x, (__bf16*)out_hi, (__bf16*)out_lo, C, H, W, total_q);
+  if (mm_dtype == STEDM_F16) space_to_depth16_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(x, (_Float16*)out_hi, (_Float16*)out_lo, C, H, W, total_q, f16_guard_flag());
+  else space_to_depth16_kernel<__bf16><<<grid, 256, 0, as_stream(stream)>>>(x, (__bf16*)out_hi, (__bf16*)out_lo, C, H, W, total_q, nullptr);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

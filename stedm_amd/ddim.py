@@ -87,8 +87,10 @@ class DDIMSampler(object):
 
         if self.use_graph and callback is None and img_callback is None and self._eta == 0.0 \
                 and hasattr(self.model, "apply_model_cfg"):
-            return self._sample_graph(img, cond, unconditional_conditioning, unconditional_guidance_scale, cfg,
-                                      total_steps, log_every_t, intermediates)
+            out = self._sample_graph(img, cond, unconditional_conditioning, unconditional_guidance_scale, cfg,
+                                     total_steps, log_every_t, intermediates)
+            ops.f16_guard_check("the DDIM sampling loop")       # fp16 modes: raise rather than return samples computed through an inf
+            return out
 
         pred_x0 = torch.empty_like(img)
         for i, step in enumerate(np.flip(timesteps)):
@@ -109,6 +111,7 @@ class DDIMSampler(object):
             if need_inter(index):
                 intermediates['x_inter'].append(img.clone())
                 intermediates['pred_x0'].append(pred_x0.clone())
+        ops.f16_guard_check("the DDIM sampling loop")
         return img, intermediates
 
     @torch.no_grad()

@@ -661,7 +661,7 @@ def prepare_batch(batch, device=None) -> dict:
 
 @torch.no_grad()
 def predict_latents(model: S_ZSS_DM, ldm_batch: dict, ddim_steps: int, eta: float = 0.0, cfg_scale: float = 1.0,
-                    style_sampling: str = "nearby", x_T: Optional[torch.Tensor] = None, dedup_uncond: bool = True):
+                    style_sampling: str = "nearby", x_T: Optional[torch.Tensor] = None, dedup_uncond: bool = True, noises=None):
     """Lightning-free restatement of LDM_Diffusion.predict_step (modules/ldm_diffusion.py:76-91) up to the sampled latents:
     conditional get_input, unconditional batch {image: 0, segmentation: same, style_imgs: -2}, DDIM + CFG.
 
@@ -671,6 +671,8 @@ def predict_latents(model: S_ZSS_DM, ldm_batch: dict, ddim_steps: int, eta: floa
     segmentation). False: the reference's literal second get_input."""
     z, c_0 = model.get_input(ldm_batch, "image", predict_only=True)
     kw = {} if x_T is None else {"x_T": x_T}
+    if noises is not None:          # one N(0,1) tensor per DDIM iteration in place of the global-RNG draw of ddim.py:206 (eta > 0)
+        kw["noises"] = noises
     if cfg_scale == 1 or style_sampling == "none":
         out, _ = model.sample_log(c_0, batch_size=len(z), ddim=True, ddim_steps=ddim_steps, eta=eta, log_every_t=1000, **kw)
     else:
@@ -686,6 +688,37 @@ def predict_latents(model: S_ZSS_DM, ldm_batch: dict, ddim_steps: int, eta: floa
         out, _ = model.sample_log(c_0, batch_size=len(z), ddim=True, ddim_steps=ddim_steps, eta=eta, log_every_t=1000,
                                   unconditional_conditioning=c_uncond, unconditional_guidance_scale=cfg_scale, **kw)
     return out
+
+
+@torch.no_grad()
+def predict_latents_sharded(model: S_ZSS_DM, shard_batch: dict, global_batch: int, ddim_steps: int, eta: float = 0.0, cfg_scale: float = 1.0,
+                            seed: int = 0, rank: Optional[int] = None, world: Optional[int] = None, group=None, gather: bool = True, **kw):
+    """predict_step on one rank of a data-parallel prediction run (predict_diff.py:86: Trainer.predict under DDP hands every rank its shard of
+    the dataset; modules/ldm_diffusion.py:76-107). `shard_batch` holds this rank's samples — the contiguous slice
+    parallel.shard_range(global_batch, rank, world) of the global batch. Latents are independent, so nothing is exchanged inside the loop;
+    the initial noise x_T (ddim.py:122) and, for eta > 0, every step's noise (ddim.py:206) come from per-SAMPLE streams keyed by the global
+    sample id (parallel.per_sample_normal), so sample i is the same for every world size, which the reference's batch-shaped global-RNG
+    draw cannot give. gather: all-gather the shards (RCCL over xGMI with backend "nccl") -> [global_batch, C, H, W] on every rank."""
+    import torch.distributed as dist
+    from . import parallel as par
+    if rank is None or world is None:
+        on = dist.is_available() and dist.is_initialized()
+        rank, world = (dist.get_rank(group), dist.get_world_size(group)) if on else (0, 1)
+    lo, hi = par.shard_range(int(global_batch), rank, world)
+    ids = list(range(lo, hi))
+    n = len(shard_batch["image"])
+    if n != hi - lo:
+        raise ValueError(f"rank {rank} of {world}: the shard holds {n} samples, shard_range({global_batch}) gives {hi - lo}")
+    shape = (model.channels, model.image_size, model.image_size)
+    dev = model.device
+    x_T = par.per_sample_normal(seed, ids, shape, stream=0).to(dev)
+    noises = None
+    if eta != 0.0:
+        noises = [par.per_sample_normal(seed, ids, shape, stream=1 + i).to(dev) for i in range(int(ddim_steps))]
+    lat = predict_latents(model, shard_batch, ddim_steps, eta=eta, cfg_scale=cfg_scale, x_T=x_T, noises=noises, **kw)
+    if gather and world > 1:
+        lat = par.all_gather_samples(lat, int(global_batch), group)
+    return lat
 
 
 @torch.no_grad()

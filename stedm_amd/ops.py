@@ -60,6 +60,43 @@ def device_cus() -> int:
     return lib().stedm_device_cus()
 
 
+# ------------------------------------------------------------------------------------------- fp16 operand range guard
+# The reference is fp32 (train_diff.py:48). The `f16` / `parity` modes round the residual stream to fp16 operand planes: a value beyond 65 504
+# becomes inf there. The kernels that do the rounding flag it (include/stedm_hip.h, stedm_f16_guard_set); the host checks at its own
+# synchronisation points and RAISES — a silently wrong sample is the one outcome this must exclude.
+_F16_GUARD: dict = {}          # device index -> the 4 flag words (kept for the life of the process: captured graphs hold the address)
+F16_GUARD_SITES = {1: "un-normalised operand planes of a 1x1 skip_connection (stedm_gn_apply16c)", 2: "GroupNorm output planes",
+                   4: "16-bit side output of a convolution (Upsample operand / qkv planes)", 8: "space-to-depth planes (Downsample operand)",
+                   16: "plain fp32 -> fp16 conversion (stedm_gn_apply16 / stedm_gn_chan_stats16)", 32: "fp32-source convolution loader"}
+
+
+def f16_guard_enable() -> torch.Tensor:
+    """Allocate (once per device) and register the guard's flag words for the current device. Not inside a graph capture."""
+    dev = torch.cuda.current_device()
+    w = _F16_GUARD.get(dev)
+    if w is None:
+        w = torch.zeros((4,), dtype=torch.int32, device=torch.device("cuda", dev))
+        check(lib().stedm_f16_guard_set(w.data_ptr()), "stedm_f16_guard_set")
+        _F16_GUARD[dev] = w
+    return w
+
+
+def f16_guard_check(where: str = "") -> None:
+    """Read (synchronising) and clear the flag of the current device; raise StedmHipError when an fp16 operand overflowed since the last
+    check. A no-op when no fp16-mode model ever enabled the guard on this device."""
+    w = _F16_GUARD.get(torch.cuda.current_device()) if torch.cuda.is_available() else None
+    if w is None:
+        return
+    bits = int(w[0].item())
+    if bits:
+        w.zero_()
+        sites = "; ".join(v for k, v in F16_GUARD_SITES.items() if bits & k)
+        raise _lib.StedmHipError(
+            f"fp16 operand overflow{' in ' + where if where else ''}: a value beyond the fp16 range (|x| > 65504) or a NaN was rounded into "
+            f"an MFMA operand plane [{sites}]. The reference computes in fp32; run this checkpoint with precision='bf16', or 'parity_bf16' for the 1e-3 tolerance (fp32 exponent "
+            f"range) — the 'f16' and 'parity' modes cannot represent its activations.")
+
+
 # ------------------------------------------------------------------------------------------- weights
 def pack_conv_weight(w: torch.Tensor, prec: Precision) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """OIHW (or [O][I][1] Conv1d) fp32 -> ([O][taps][I] 16-bit hi, lo or None)."""
@@ -612,12 +649,20 @@ def geglu16(g, hi, lo, prec: Precision):
     check(lib().stedm_geglu16(g.data_ptr(), hi.data_ptr(), _ptr(lo), M, g.shape[-1] // 2, prec.mm_dtype, _stream()), "stedm_geglu16")
 
 
-def ln_bwd(x, dy, gamma, eps: float, dx, dgamma, dbeta, add=None, accumulate: bool = False) -> None:
-    """LayerNorm backward over the rows of x / dy [rows, dim]: dx = add + d(LN)/dx . dy; dgamma, dbeta (+)= column sums."""
+def ln_bwd_ws_floats(rows: int, dim: int) -> int:
+    return 2 * dim * lib().stedm_ln_bwd_blocks(rows)
+
+
+def ln_bwd(x, dy, gamma, eps: float, dx, dgamma, dbeta, add=None, accumulate: bool = False, ws=None) -> None:
+    """LayerNorm backward over the rows of x / dy [rows, dim]: dx = add + d(LN)/dx . dy; dgamma, dbeta (+)= column sums.
+    ws: fp32 workspace of ln_bwd_ws_floats(rows, dim) elements (a caller's cached buffer; allocated here when absent)."""
     _chk(x, name="x"); _chk(dy, name="dy")
     dim = x.shape[-1]
     rows = x.numel() // dim
-    ws = torch.empty((2 * dim * lib().stedm_ln_bwd_blocks(rows),), dtype=torch.float32, device=x.device)
+    need = ln_bwd_ws_floats(rows, dim)
+    if ws is None:
+        ws = torch.empty((need,), dtype=torch.float32, device=x.device)
+    assert ws.dtype == torch.float32 and ws.numel() >= need and ws.is_contiguous()
     check(lib().stedm_ln_bwd(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), float(eps), _ptr(add), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                              ws.data_ptr(), rows, dim, int(accumulate), _stream()), "stedm_ln_bwd")
 
@@ -924,10 +969,25 @@ def axpby(x: torch.Tensor, y: torch.Tensor, alpha: float = 1.0, beta: float = 1.
     return y
 
 
+# Kernels that write PARAMETERS through raw pointers (no torch version bump) count here; the epoch is part of the freshness token of the
+# weight packs an optimizer pass wrote itself (UNetModel.freshness_token), so any later raw-pointer writer forces a full re-pack even if it
+# forgets UNetModel.invalidate().
+_RAW_WRITES = [0]
+
+
+def raw_write_epoch() -> int:
+    return _RAW_WRITES[0]
+
+
+def note_raw_write() -> None:
+    _RAW_WRITES[0] += 1
+
+
 def adamw_ema(table: torch.Tensor, chunk_tensor: torch.Tensor, chunk_off: torch.Tensor, lr: float, beta1: float, beta2: float, eps: float,
               weight_decay: float, step: int, ema_decay: float, grad_scale: float = 1.0) -> None:
     check(lib().stedm_adamw_ema(table.data_ptr(), chunk_tensor.data_ptr(), chunk_off.data_ptr(), chunk_tensor.numel(), float(lr), float(beta1),
                                 float(beta2), float(eps), float(weight_decay), int(step), float(ema_decay), float(grad_scale), _stream()), "stedm_adamw_ema")
+    note_raw_write()
 
 
 def adamw_ema_pack_piece() -> Tuple[int, int]:
@@ -942,6 +1002,7 @@ def adamw_ema_pack(descs: torch.Tensor, ndesc: int, total_blocks: int, lr: float
     """AdamW + EMA over convolution weights, refreshing their fragment-order packs in the same pass (stedm_adamw_ema_pack)"""
     check(lib().stedm_adamw_ema_pack(descs.data_ptr(), int(ndesc), int(total_blocks), float(lr), float(beta1), float(beta2), float(eps),
                                      float(weight_decay), int(step), float(ema_decay), float(grad_scale), _stream()), "stedm_adamw_ema_pack")
+    note_raw_write()
 
 
 def ema_update(table: torch.Tensor, chunk_tensor: torch.Tensor, chunk_off: torch.Tensor, ema_decay: float) -> None:

@@ -118,9 +118,8 @@ class UNetTrainer:
         self._n_unet_params = len(order) - len(self.extra_params)
         offs, off = [], 0
         for i, p in enumerate(order):
-            if i == self._n_unet_params:
-                off = (off + 3) // 4 * 4          # the cond stage's gradients form a bucket of their own: vector-aligned start
-            offs.append(off)
+            off = (off + 3) // 4 * 4              # every gradient starts 16-byte aligned: the optimizer kernels read float4 (the emb_layers
+            offs.append(off)                      # weights stay contiguous — their row blocks are multiples of 4 floats; gaps stay zero)
             off += p.numel()
         total = (off + 3) // 4 * 4
         self.grad_arena = torch.zeros((total,), dtype=torch.float32, device=order[0].device)
@@ -128,6 +127,7 @@ class UNetTrainer:
         for p, o in zip(order, offs):
             p.grad = self.grad_arena[o:o + p.numel()].view(p.shape)
         ted = m.model_channels * 4
+        assert not emb_w or offs[len(emb_w) - 1] + emb_w[-1].numel() == m._emb_ntot * ted, "emb_layers weight gradients are not one contiguous matrix"
         self._dWcat = self.grad_arena[:m._emb_ntot * ted].view(m._emb_ntot, ted)
         self._arena_params = order
         self._int_views = [p.grad for p in order]
@@ -162,7 +162,9 @@ class UNetTrainer:
             return hit
         bp = self.bprec
         w = self._w4(conv).contiguous()
-        in_place = w.data_ptr() == conv.weight.data_ptr()     # the plan re-reads the parameter's own storage on later steps
+        # the plan re-reads the parameter's own storage on later steps: only a module's parameter qualifies. A throw-away holder (the
+        # stacked q | k | v filter of _st_bwd) is its own storage too, but lives for one backward: it is packed for this step only
+        in_place = isinstance(conv, nn.Module) and w.data_ptr() == conv.weight.data_ptr()
         co_f, ci_f, ks = w.shape[0], w.shape[1], w.shape[-1]
         taps = ks * ks
         frag16 = None
@@ -346,7 +348,7 @@ class UNetTrainer:
         dkey = (self.bprec, m.conv_path, m._m16, tuple(p.data_ptr() for p in m.parameters()))
         self._dpacks_step = {}
         if getattr(self, "_dplan", None) is not None and self._dplan_key == dkey:
-            self._dplan.run(versions=(tuple(p._version for p in m.parameters()), getattr(m, "_values_gen", 0)))
+            self._dplan.run(versions=m.freshness_token())
             for ent in self._dpacks.values():
                 if isinstance(ent[0], ops.LazyPlanes):
                     ent[0].reset()
@@ -515,6 +517,8 @@ class UNetTrainer:
         dy2 = self._buf(f"st.dy1.{M}x{inner}", (B, H, W, inner))
         self._dgrad(st.proj_out, dout16, dy)
 
+        lnws = self._buf(f"st.lnws.{M}x{inner}", (ops.ln_bwd_ws_floats(M, inner),))
+
         def ln_planes(y_in, norm):
             hi, lo = self._planes("st.ln16", (B, H, W, inner))
             ops.ln_apply16(y_in, norm.weight, norm.bias, norm.eps, hi, lo, bp)
@@ -538,7 +542,7 @@ class UNetTrainer:
             dln = self._buf(f"st.dln.{M}", (B, H, W, inner))
             self._dgrad(lin_proj, dg16, dln)
             ops.ln_bwd(y_in, dln.view(M, inner), blk.norm3.weight, blk.norm3.eps, dy2.view(M, inner), self._param_grad(blk.norm3.weight),
-                       self._param_grad(blk.norm3.bias), add=dy.view(M, inner))
+                       self._param_grad(blk.norm3.bias), add=dy.view(M, inner), ws=lnws)
             dy, dy2 = dy2, dy
             # ---- the two self-attentions: y_out = y_in + W_out attention(W_qkv LN(y_in)) + b_out
             for nm, norm in (("attn2", blk.norm2), ("attn1", blk.norm1)):
@@ -564,7 +568,7 @@ class UNetTrainer:
                 self._st_holders.append(holder)           # (keeps id(holder) unique for the per-step dgrad pack cache)
                 self._dgrad(holder, dqkv16, dln)
                 ops.ln_bwd(y_in, dln.view(M, inner), norm.weight, norm.eps, dy2.view(M, inner), self._param_grad(norm.weight),
-                           self._param_grad(norm.bias), add=dy.view(M, inner))
+                           self._param_grad(norm.bias), add=dy.view(M, inner), ws=lnws)
                 dy, dy2 = dy2, dy
         # ---- proj_in: tokens = conv1x1(GroupNorm(x)) + bias
         dy16 = self._bias_grad(dy, st.proj_in.bias, cast="dy")
@@ -806,7 +810,7 @@ class UNetTrainer:
         if fu is not None:
             # ... except what this pass wrote itself: valid while neither a parameter's version nor the model's value generation
             # (UNetModel.invalidate(): EMA swap, checkpoint load, edits through .data / raw pointers) moves
-            token = (tuple(p._version for p in self.m.parameters()), self.m._values_gen)
+            token = self.m.freshness_token()
             for plan in fu["plans"]:
                 plan.mark_fresh(token)
         self._grads_ready = False

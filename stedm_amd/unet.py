@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._lib import BF16, CONV_S2D, CONV_DOWN, CONV_S1, CONV_UP, CONV_UP_SUBPIXEL, StedmHipError
+from ._lib import BF16, F16, CONV_S2D, CONV_DOWN, CONV_S1, CONV_UP, CONV_UP_SUBPIXEL, StedmHipError
 from .ops import Precision
 
 
@@ -135,9 +135,9 @@ class UNetModel(nn.Module):
                  context_dim=None, n_embed=None, legacy=True, style_imgs=1, precision: str = "parity"):
         super().__init__()
         if use_spatial_transformer:
-            assert context_dim is not None, 'Fool!! You forgot to include the dimension of your cross-attention conditioning...'
+            assert context_dim is not None, "use_spatial_transformer=True needs context_dim (width of the conditioning vector)"
         if context_dim is not None:
-            assert use_spatial_transformer, 'Fool!! You forgot to use the spatial transformer for your cross-attention conditioning...'
+            assert use_spatial_transformer, "context_dim is only meaningful with use_spatial_transformer=True"
             if not isinstance(context_dim, int):
                 context_dim = list(context_dim)
         if num_classes is not None or n_embed is not None or resblock_updown or not conv_resample or dims != 2 or dropout != 0:
@@ -255,6 +255,18 @@ class UNetModel(nn.Module):
         self._pack_key = None
         self._values_gen = getattr(self, "_values_gen", 0) + 1     # part of the freshness token of packs written by the optimizer kernel
 
+    def check_f16_range(self, where: str = "UNetModel.forward") -> None:
+        """Synchronise and raise StedmHipError if any fp16 operand plane written since the last check held an inf / NaN (ops.f16_guard_check).
+        The sampling loops call it once at their end; call it after an eager forward in the `f16` / `parity` modes when in doubt."""
+        ops.f16_guard_check(where)
+
+    def freshness_token(self, versions=None):
+        """What must be unchanged for weight packs written by the optimizer kernel to still be current: every parameter's torch version, this
+        model's value generation (invalidate()) and the process-wide count of raw-pointer parameter writes (ops.note_raw_write)."""
+        if versions is None:
+            versions = tuple(p._version for p in self.parameters())
+        return (versions, getattr(self, "_values_gen", 0), ops.raw_write_epoch())
+
     def _buf(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
         key = (name, tuple(shape), dtype)
         t = self._bufs.get(key)
@@ -284,6 +296,8 @@ class UNetModel(nn.Module):
         if key == self._pack_key:
             return
         prec = self.precision
+        if prec.mm_dtype == F16:
+            ops.f16_guard_enable()        # fp16 operand planes: the kernels flag an overflow, the sampling loops / check_f16_range() raise
         # Same storage, new values (an optimizer step): the fragment-order packs recorded last time run again as ONE launch into the same
         # tensors (ops.PackPlan); the few other packs below are redone as before. Anything else: pack from scratch and record.
         ptr_key = (prec, dev, ptrs, self.conv_path, self._m16)
@@ -365,7 +379,7 @@ class UNetModel(nn.Module):
             elif type(m).__name__ == "SpatialTransformer":
                 self._packed[id(m)] = m.pack(prec)
         if replay:
-            plan.run(versions=(key[2], getattr(self, "_values_gen", 0)))
+            plan.run(versions=self.freshness_token(key[2]))
         c = self._consts
         half = self.model_channels // 2
         # host-built frequency table (util.py:162-164 builds it on the CPU in fp32)

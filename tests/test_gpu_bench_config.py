@@ -72,6 +72,41 @@ def test_batch64_cfg_rows_vs_cpu_oracle(dev, oracle_ns32):
     assert out["bf16"][0] < 1.5e-2 and out["bf16"][1] < 8e-2
 
 
+def test_batch256_cfg_rows_vs_cpu_oracle(dev, oracle_ns32):
+    """The hazard that round 3's aliasing bug lived in: at B = 64 every NS32 launch has one tile round per CU (256 or 512 tiles on 256 CUs), so
+    a tile that overwrites rows another tile still gathers is never seen. B = 256 (512 decoder rows: 1024 - 2048 tiles, >= 4 rounds per
+    CU) drives the same kernels through several rounds: the epilogue-GroupNorm form (8^2 / 16^2 levels), the gn_only form (no fp32 store), the
+    16-bit-only output in front of the Upsample, the split-K reduce with GroupNorm — rows from the first, inner and last tiles against the CPU
+    oracle on those samples (openaimodel.py:247-254, 288; :122-132)."""
+    from oracle import unet as ou
+    cfg, plan, P = oracle_ns32
+    B = 256
+    x = prng.normal(8, "b256.x", (B, 4, 32, 32)); cc = prng.normal(8, "b256.cc", (B, 3, 32, 32))
+    ctx_c = prng.normal(8, "b256.ctx", (B, 512)); ctx_u = prng.normal(8, "b256.ctxu", (B, 512))
+    rows = [0, 101, 202, 255]
+    t4 = torch.full((4,), 951, dtype=torch.long)
+    xc4 = torch.cat([x[rows], cc[rows]], 1)
+    ref = torch.cat([ou.unet_forward(P, cfg, xc4, t4, ctx_c[rows], plan=plan), ou.unet_forward(P, cfg, xc4, t4, ctx_u[rows], plan=plan)])
+    m = build(dev, "parity")
+    t = torch.full((B,), 951, dtype=torch.long, device=dev)
+    out = {}
+    for precision in ("parity", "f16", "bf16"):
+        m.set_precision(precision)
+        ec, eu = m.forward_cfg(x.to(dev), cc.to(dev), t, ctx_c.to(dev), ctx_u.to(dev), uniform_t=True)
+        m.check_f16_range()
+        out[precision] = dev2(torch.cat([ec[rows], eu[rows]]), ref)
+        # every row of the big batch equals the same row evaluated inside a batch of 64 (other launch plan, other tile -> CU placement)
+        lo = 192
+        ec2, eu2 = m.forward_cfg(x[lo:].to(dev), cc[lo:].to(dev), t[:64], ctx_c[lo:].to(dev), ctx_u[lo:].to(dev), uniform_t=True)
+        d64 = dev2(torch.cat([ec[lo:], eu[lo:]]), torch.cat([ec2, eu2]))
+        print(f"[NS32 B=256 CFG, rows {rows}, {precision}] vs CPU oracle: rel-L2 {out[precision][0]:.3e}, max/std {out[precision][1]:.3e}; "
+              f"rows 192..255 vs the same samples at B=64: rel-L2 {d64[0]:.3e}, max/std {d64[1]:.3e}")
+        assert d64[0] < (1e-5 if precision == "parity" else 2e-3), (precision, d64)
+    assert out["parity"][0] < 1e-3 and out["parity"][1] < 1e-3
+    assert out["f16"][0] < 1e-3 and out["f16"][1] < 1e-2
+    assert out["bf16"][0] < 1.5e-2 and out["bf16"][1] < 8e-2
+
+
 def test_config5_latent64_batch64_cfg_rows_vs_cpu_oracle(dev, oracle_ns32):
     """BASELINE config 5's per-GPU share (CATCH 512^2 images: 64x64x4 latents, 512 / 8 = 64 per GPU; its ns = 8 fp8 style encoder is
     covered in tests/test_gpu_style.py): the same U-Net on 4x the pixels — 64-pixel rows, attention over 256 tokens, other tile

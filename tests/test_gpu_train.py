@@ -407,6 +407,48 @@ def test_unet_backward_with_spatial_transformer_vs_oracle(dev, depth, B):
     assert trb.step_count == 1 and not torch.equal(w0, mb.middle_block[2].transformer_blocks[0].attn1.to_q.weight)
 
 
+def test_spatial_transformer_backward_over_several_steps(dev):
+    """The stacked q | k | v filter of _st_bwd is a per-step tensor: its dgrad pack must never enter the persistent pack plan (a stale entry
+    under a recycled id() would feed LAST step's — or another attention's — weights to the dgrad through to_q / to_k / to_v from step 2 on).
+    bf16 (single-product backward operands), inner = 64 and 128 at the lower levels (3 * inner % 64 == 0: the fragment-order pack path). After
+    two optimizer steps with a large learning rate the third backward is compared (a) bit for bit with a FRESH trainer on a copy of the stepped
+    weights and (b) with autograd over the oracle on those weights; the plan's item count stays constant from the first backward on."""
+    from oracle import train as otrain
+    from oracle import unet as ounet
+    from stedm_amd.train import UNetTrainer
+    cfg = dict(image_size=16, in_channels=7, model_channels=32, out_channels=4, num_res_blocks=1, attention_resolutions=[32, 16, 8],
+               channel_mult=[1, 2, 4], num_heads=4, use_spatial_transformer=True, transformer_depth=1, context_dim=128)
+    ocfg = ounet.UNetConfig(image_size=16, in_channels=7, model_channels=32, out_channels=4, num_res_blocks=1, channel_mult=(1, 2, 4), num_heads=4,
+                            use_spatial_transformer=True, transformer_depth=1, context_dim=128)
+    B = 2
+    x = prng.normal(43, "st3.x", (B, 7, 16, 16)); ctx = prng.normal(43, "st3.ctx", (B, 128)); target = prng.normal(43, "st3.t", (B, 4, 16, 16))
+    t = torch.tensor([951, 21], dtype=torch.long)
+    args = (x[:, :4].contiguous().to(dev), x[:, 4:].contiguous().to(dev), t.to(dev), ctx.to(dev), target.to(dev))
+    m = build(cfg, 41, dev, "bf16")
+    tr = UNetTrainer(m, lr=2e-3, weight_decay=0.0)
+    n_items = []
+    for _ in range(2):
+        tr.train_step(*args)
+        n_items.append((len(tr._dplan.items), len(tr._dpacks)))
+    tr.loss_and_backward(*args)
+    n_items.append((len(tr._dplan.items), len(tr._dpacks)))
+    assert n_items[0] == n_items[1] == n_items[2], f"the persistent dgrad pack plan grows from step to step: {n_items}"
+    m2 = build(cfg, 41, dev, "bf16")
+    m2.load_state_dict(m.state_dict())
+    m2.invalidate()
+    tr2 = UNetTrainer(m2, lr=2e-3, weight_decay=0.0)
+    tr2.loss_and_backward(*args)
+    diff = [n for (n, p), q in zip(m.named_parameters(), m2.parameters()) if not torch.equal(p.grad, q.grad)]
+    assert not diff, f"step-3 gradients differ from a fresh trainer's on the same weights: {diff[:6]}"
+    P = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    _, grads, _, _, _ = otrain.unet_loss_and_grads(P, ocfg, x, t, ctx, target)
+    gmax = max(float(g.norm()) for g in grads.values())
+    errs = {n: float((p.grad.cpu() - grads[n]).norm()) / float(grads[n].norm()) for n, p in m.named_parameters() if float(grads[n].norm()) > 1e-3 * gmax}
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    print(f"[ST, step 3, bf16] median rel err {np.median(list(errs.values())):.2e}, worst {worst[1]:.2e} ({worst[0]})")
+    assert float(np.median(list(errs.values()))) < 3e-2 and worst[1] < 0.25
+
+
 def _ddp_worker(rank, world, port, q, overlap=True, bucket_mb=256, steps=1, accumulate=1):
     import os
     os.environ["MASTER_ADDR"] = "127.0.0.1"

@@ -241,3 +241,72 @@ def test_unet_64x64_latents_single_product_vs_parity(dev):
         l2 = float((got - ref).norm() / ref.norm())
         print(f"[ns32 widths @64x64 B={B} cfg {precision}] vs parity mode: rel-L2 {l2:.3e}")
         assert l2 < tol
+
+
+def _big_residual_model(dev, precision, scale):
+    """TINY U-Net whose first convolution is scaled so that the residual stream reaches `scale`-sized values: GroupNorm brings every
+    3x3's operand back to O(1), but the un-normalised stream feeds the 1x1 skip_connection (openaimodel.py:247-254, 288), Downsample.op
+    (:156-173) and Upsample.conv (:122-132) directly — the planes an fp16 mode cannot hold beyond 65 504."""
+    m = build(TINY, 6, dev, precision)
+    with torch.no_grad():
+        w = m.input_blocks[0][0].weight
+        w.mul_(scale / float(w.abs().max()) / 8.0)
+    m.invalidate()
+    return m
+
+
+@pytest.mark.parametrize("precision", ["f16", "parity"])
+def test_fp16_modes_raise_on_a_residual_beyond_the_fp16_range(dev, precision):
+    """a 1e5-magnitude residual in the fp16-operand modes must not turn into inf -> NaN silently. The kernels that
+    round the stream to fp16 flag it (stedm_f16_guard_set), check_f16_range() and the sampling loops raise; the flag clears with the raise;
+    the same weights run in bf16 (fp32 exponent range) and in the bf16 hi + lo 3-product mode, the latter inside 1e-3 of the fp32 oracle."""
+    from oracle import unet as ou
+    from stedm_amd._lib import StedmHipError
+    m = _big_residual_model(dev, precision, 4e5)
+    x = prng.normal(6, "guard.x", (2, 7, 16, 16)).to(dev)
+    ctx = prng.normal(6, "guard.ctx", (2, 128)).to(dev)
+    t = torch.tensor([501, 12], device=dev)
+    m.check_f16_range()                                   # clean start
+    h0 = torch.nn.functional.conv2d(x.cpu(), m.input_blocks[0][0].weight.cpu(), m.input_blocks[0][0].bias.cpu(), padding=1)
+    assert float(h0.abs().max()) > 1e5, "the test model does not reach the magnitude it is meant to"
+    m(x, t, context=ctx)
+    with pytest.raises(StedmHipError, match="fp16 operand overflow"):
+        m.check_f16_range()
+    m.check_f16_range()                                   # cleared by the raise
+    # the same weights below the range: no flag, finite output
+    m2 = _big_residual_model(dev, precision, 2e4)
+    y2 = m2(x, t, context=ctx)
+    m2.check_f16_range()
+    assert bool(torch.isfinite(y2).all())
+    # the fp32 oracle on the big-residual weights, and the two bf16-exponent modes against it
+    ocfg = ou.UNetConfig(image_size=16, in_channels=7, model_channels=32, out_channels=4, channel_mult=(1, 2, 4), num_heads=4)
+    P = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    ref = ou.unet_forward(P, ocfg, x.cpu(), t.cpu(), ctx.cpu(), plan=ou.build_plan(ocfg))
+    assert bool(torch.isfinite(ref).all())
+    errs = {}
+    for mode in ("bf16", "parity_bf16"):
+        m.set_precision(mode)
+        y = m(x, t, context=ctx)
+        m.check_f16_range()
+        assert bool(torch.isfinite(y).all()), mode
+        errs[mode] = float((y.cpu().double() - ref.double()).norm() / ref.double().norm())
+    print(f"[range guard, {precision}] residual max {float(h0.abs().max()):.3g}: raised; rel-L2 vs fp32 oracle bf16 {errs['bf16']:.2e}, bf16x3 {errs['parity_bf16']:.2e}")
+    assert errs["bf16"] < 5e-2 and errs["parity_bf16"] < 1e-3
+
+
+def test_sampling_loop_raises_on_fp16_overflow(dev):
+    """The DDIM loop (graph replay: no host check can sit inside it) reads the guard once at its end and raises instead of returning latents."""
+    from stedm_amd._lib import StedmHipError
+    from stedm_amd.latent_diffusion import LatentDiffusion
+    m = _big_residual_model(dev, "f16", 4e5)
+    ld = LatentDiffusion(m, linear_start=0.0015, linear_end=0.0205, image_size=16, channels=4, conditioning_key="hybrid", loss_type="l1",
+                         use_graph=True).to(dev)
+    cc = (prng.normal(2, "guard.layout", (2, 3, 16, 16)) > 0).float().to(dev)
+    cond = {"c_concat": [cc], "c_crossattn": [prng.normal(3, "guard.c", (2, 128)).to(dev)]}
+    unc = {"c_concat": [cc], "c_crossattn": [prng.normal(4, "guard.u", (2, 128)).to(dev)]}
+    xT = prng.normal(1, "guard.xT", (2, 4, 16, 16)).to(dev)
+    with pytest.raises(StedmHipError, match="fp16 operand overflow"):
+        ld.sample_log(cond, 2, True, 5, eta=0.0, x_T=xT, unconditional_conditioning=unc, unconditional_guidance_scale=1.5, log_every_t=1000)
+    m.set_precision("bf16")
+    s = ld.sample_log(cond, 2, True, 5, eta=0.0, x_T=xT, unconditional_conditioning=unc, unconditional_guidance_scale=1.5, log_every_t=1000)[0]
+    assert bool(torch.isfinite(s).all())

@@ -207,3 +207,12 @@ def test_two_rank_overlapped_buckets_equal_the_plain_bucketed_all_reduce():
         assert p.exitcode == 0
     assert nworks == nb and nb >= 3
     assert (plain == over).all()
+
+
+def test_sharded_noise_streams_do_not_depend_on_the_world_size():
+    """x_T / per-step noise of sample i under 1, 2 and 3 ranks (the host logic of latent_diffusion.predict_latents_sharded)"""
+    from stedm_amd import parallel as par
+    full = par.per_sample_normal(1234, list(range(GLOBAL_B)), (4, 32, 32), stream=3)
+    for world in (2, 3):
+        parts = [par.per_sample_normal(1234, list(range(*par.shard_range(GLOBAL_B, r, world))), (4, 32, 32), stream=3) for r in range(world)]
+        assert torch.equal(torch.cat(parts), full)
