@@ -714,7 +714,9 @@ def predict_latents_sharded(model: S_ZSS_DM, shard_batch: dict, global_batch: in
     x_T = par.per_sample_normal(seed, ids, shape, stream=0).to(dev)
     noises = None
     if eta != 0.0:
-        noises = [par.per_sample_normal(seed, ids, shape, stream=1 + i).to(dev) for i in range(int(ddim_steps))]
+        from .schedule import make_ddim_timesteps
+        n_iter = int(make_ddim_timesteps(int(ddim_steps), model.num_timesteps).shape[0])      # (S = 6 -> 7 iterations: ddim.py's uniform stride)
+        noises = [par.per_sample_normal(seed, ids, shape, stream=1 + i).to(dev) for i in range(n_iter)]
     lat = predict_latents(model, shard_batch, ddim_steps, eta=eta, cfg_scale=cfg_scale, x_T=x_T, noises=noises, **kw)
     if gather and world > 1:
         lat = par.all_gather_samples(lat, int(global_batch), group)

@@ -165,7 +165,8 @@ def test_config1_batch1_ddim20_cfg_loop_vs_cpu_oracle(dev, oracle_ns32):
               f"max/std {res[precision][1]:.3e}")
         assert bool(torch.isfinite(s).all())
     assert res["parity"][0] < 1e-3 and res["parity"][1] < 1e-3
-    assert res["f16"][0] < 1e-2 and res["bf16"][0] < 1e-1
+    # f16 (the bench headline's mode) stays inside the 1e-3 tolerance over the whole loop (measured 2.7e-4); bf16 does not (2.3e-3) and is bounded loosely
+    assert res["f16"][0] < 1e-3 and res["bf16"][0] < 1e-1
 
 
 def test_config2_batch64_bf16_train_step_vs_cpu_oracle(dev, oracle_ns32):
