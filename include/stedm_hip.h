@@ -447,6 +447,12 @@ int stedm_wgrad_to_oihw(const float* dw, float* grad, int cout, int cin, int tap
 int stedm_wgrad3x3_plan(int B, int H, int W, int Cin, int Cout, int* ksplit);
 int stedm_wgrad3x3(const void* x16, const void* dy16, float* part, int B, int H, int W, int Cin, int Cout, int mm_dtype,
                    void* stream);
+/* stedm_wgrad3x3 with its split-K partials in the parameter's own order: part = [ksplit][Cout][Cin][3][3] fp32, 16-byte aligned. With
+ * ksplit == 1 (stedm_wgrad3x3_plan) `part` may be the gradient tensor itself; otherwise stedm_sum_planes adds the slices (fixed order).
+ * Replaces the weight gradient autograd computes for nn.Conv2d(3x3, stride 1) in ResBlock / Upsample (openaimodel.py:122-132, 214-254). */
+int stedm_wgrad3x3_oihw(const void* x16, const void* dy16, float* part, int B, int H, int W, int Cin, int Cout, int mm_dtype, void* stream);
+/* out[i] (+)= sum_z part[z * n + i] for z < nsplit, fixed order (n % 4 == 0, 16-byte aligned pointers) */
+int stedm_sum_planes(const float* part, float* out, long n, int nsplit, int accumulate, void* stream);
 /* The same for a 1x1 convolution (skip_connection, attention qkv / proj_out): x16 [P][Cin], dy16 [P][Cout] (bf16, P = B*H*W pixels) ->
  * part [ksplit][Cin][Cout] fp32 partials (then stedm_wgrad_to_oihw with taps = 1, nsplit = ksplit). stedm_wgrad1x1_plan returns 1 when the
  * shape is supported (P %% 64 == 0, Cin %% 128 == 0, Cout %% 128 == 0) and the split it will use. */

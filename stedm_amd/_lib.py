@@ -112,6 +112,8 @@ SIGNATURES = {
     "stedm_wgrad_to_oihw": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "stedm_wgrad3x3_plan": (_I, [_I, _I, _I, _I, _I, C.POINTER(C.c_int)]),
     "stedm_wgrad3x3": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "stedm_wgrad3x3_oihw": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "stedm_sum_planes": (_I, [_P, _P, C.c_long, _I, _I, _P]),
     "stedm_wgrad1x1_plan": (_I, [C.c_long, _I, _I, C.POINTER(C.c_int)]),
     "stedm_wgrad1x1": (_I, [_P, _P, _P, C.c_long, _I, _I, _I, _P]),
     "stedm_chan_sum_fold": (_I, [_P, _I, _I, _I, _P, C.c_long, _P, _I, _P]),

@@ -3,6 +3,8 @@
 // so the variance is the centred, biased form nn.GroupNorm computes (util.py:214-216).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 using namespace stedm;
 
@@ -574,22 +576,32 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
   uint2* rh = a.raw_hi ? reinterpret_cast<uint2*>(a.raw_hi) + (long)b * a.HW * Qall : nullptr;
   uint2* rl = a.raw_lo ? reinterpret_cast<uint2*>(a.raw_lo) + (long)b * a.HW * Qall : nullptr;
   constexpr int U = 2;
-  int pixs[U], qs[U];
+  int pixs[U], qs[U];      // compute cursors
+  int lpx[U], lqs[U];      // load cursors: run two block iterations ahead of the compute cursors
 #pragma unroll
-  for (int k = 0; k < U; ++k) { const int e = threadIdx.x + k * 256; pixs[k] = px0 + e / Q; qs[k] = e % Q; }
+  for (int k = 0; k < U; ++k) { const int e = threadIdx.x + k * 256; pixs[k] = px0 + e / Q; qs[k] = e % Q; lpx[k] = pixs[k]; lqs[k] = qs[k]; }
   const int dpix = (256 * U) / Q, dq = (256 * U) % Q;
-  float4 v[U];
-  auto load_batch = [&](int i) {
+  // Three batches of loads in flight per thread (v: current, vn: next, vnn: the one after): the pass is a pure stream and its speed is the
+  // bytes in flight. With one batch per thread (round 3) a CU's 3 blocks kept 24 KB in flight and nothing during the statistics prologue
+  // (4.3 TB/s over a step's launches); now two batches (16 KB per block) are issued before the prologue and a third at the top of every
+  // iteration. The loads are UNCONDITIONAL (an out-of-range cursor re-reads the block's first quad): with a branch around a load the compiler
+  // cannot count vmcnt and waits for vmcnt(0) right after issuing the prefetch, which serialises the stream again; the full iterations of
+  // the loop below are branch-free for the same reason, the (at most one) partial iteration is a predicated copy of the body.
+  float4 v[U], vn[U], vnn[U];
+  const int nfull = total / (256 * U);               // block iterations in which every lane of both cursors is live
+  auto load_adv = [&](float4 (&dst)[U], int it) {    // loads block iteration `it` and advances the load cursors
 #pragma unroll
     for (int k = 0; k < U; ++k) {
-      if (i + k * 256 < total) {
-        const int c = (q_lo + qs[k]) * 4;
-        v[k] = c < a.c1 ? *reinterpret_cast<const float4*>(p1 + (long)pixs[k] * a.c1 + c)
-                        : *reinterpret_cast<const float4*>(p2 + (long)pixs[k] * a.c2 + (c - a.c1));
-      }
+      const bool ok = it * 256 * U + (int)threadIdx.x + k * 256 < total;
+      const int px = ok ? lpx[k] : px0, c = (q_lo + (ok ? lqs[k] : 0)) * 4;
+      const float* src = c < a.c1 ? p1 + (long)px * a.c1 + c : p2 + (long)px * a.c2 + (c - a.c1);
+      dst[k] = *reinterpret_cast<const float4*>(src);
+      lpx[k] += dpix; lqs[k] += dq;
+      if (lqs[k] >= Q) { lqs[k] -= Q; ++lpx[k]; }
     }
   };
-  load_batch(threadIdx.x);
+  load_adv(v, 0);
+  load_adv(vn, 1);
   bool maybe_over = false;       // block-uniform: some channel partial of this block's groups admits |x| > 65504 (fp16 guard)
   unsigned bad_raw = 0u, bad_norm = 0u;
   {
@@ -649,17 +661,19 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
     else { r.x = q0.x; r.y = q0.y; r.z = got.x; r.w = got.y; }
     return r;
   };
-  for (int i = threadIdx.x; i < total; i += 256 * U) {
-    if (i != (int)threadIdx.x) load_batch(i);
+  auto body = [&](auto tail_c, const int it) {
+    constexpr bool TAIL = decltype(tail_c)::value;
+    load_adv(vnn, it + 2);
     // (total and 256 are even and the cursors advance together, so a lane pair is live or dead together for each cursor)
-    const bool live0 = i < total, live1 = i + 256 < total;
+    const int i = it * 256 * U + (int)threadIdx.x;
+    const bool live0 = !TAIL || i < total, live1 = !TAIL || i + 256 < total;
     uint2 oq[U], rq[U], olq[U], rlq[U];
 #pragma unroll
     for (int k = 0; k < U; ++k) {
       const int c = (q_lo + qs[k]) * 4;
       float4 w = v[k];
       const bool live = k == 0 ? live0 : live1;
-      if (!live) { w = make_float4(0.f, 0.f, 0.f, 0.f); }
+      if (TAIL && !live) { w = make_float4(0.f, 0.f, 0.f, 0.f); }
       if (rh) {
         rq[k] = pack4(w.x, w.y, w.z, w.w);
         if (maybe_over) bad_raw |= f16_over4<T>(rq[k]);
@@ -686,16 +700,19 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
     const bool mlive = odd ? live1 : live0;
     const long o = (long)pixs[mk] * Qall + q_lo + (qs[mk] & ~1);
     const uint4 so = pair16(oq[0], oq[1]);
-    if (mlive) *reinterpret_cast<uint4*>(oh + o) = so;
-    if (ol) { const uint4 t4 = pair16(olq[0], olq[1]); if (mlive) *reinterpret_cast<uint4*>(ol + o) = t4; }
-    if (rh) { const uint4 t4 = pair16(rq[0], rq[1]); if (mlive) *reinterpret_cast<uint4*>(rh + o) = t4; }
-    if (rl) { const uint4 t4 = pair16(rlq[0], rlq[1]); if (mlive) *reinterpret_cast<uint4*>(rl + o) = t4; }
+    if (!TAIL || mlive) *reinterpret_cast<uint4*>(oh + o) = so;
+    if (ol) { const uint4 t4 = pair16(olq[0], olq[1]); if (!TAIL || mlive) *reinterpret_cast<uint4*>(ol + o) = t4; }
+    if (rh) { const uint4 t4 = pair16(rq[0], rq[1]); if (!TAIL || mlive) *reinterpret_cast<uint4*>(rh + o) = t4; }
+    if (rl) { const uint4 t4 = pair16(rlq[0], rlq[1]); if (!TAIL || mlive) *reinterpret_cast<uint4*>(rl + o) = t4; }
 #pragma unroll
     for (int k = 0; k < U; ++k) {
       pixs[k] += dpix; qs[k] += dq;
       if (qs[k] >= Q) { qs[k] -= Q; ++pixs[k]; }
+      v[k] = vn[k]; vn[k] = vnn[k];
     }
-  }
+  };
+  for (int it = 0; it < nfull; ++it) body(std::false_type{}, it);
+  if (nfull * 256 * U < total) body(std::true_type{}, nfull);
   if (maybe_over) { f16_guard_commit(a.ovf, bad_raw, STEDM_F16G_RAW); f16_guard_commit(a.ovf, bad_norm, STEDM_F16G_NORM); }
 }
 

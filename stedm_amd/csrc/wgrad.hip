@@ -29,6 +29,7 @@ struct WgradArgs {
   int ksplit, tiles_n;    // tiles_n = Cout / 64
   int NP, PW;             // patch positions (upr + 2) * (W + 2), patch width W + 2
   int dbg;                // timing experiments (STEDM_WGRAD_DBG): 1 no global loads, 2 no MFMA phase, 4 no LDS stores
+  int oihw;               // 1: part is [ksplit][Cout][Cin][9] (the parameter's own OIHW order: with ksplit == 1 it IS the gradient)
 };
 
 constexpr int WG_NPMAX = 198;                 // max over W of (64 / W + 2) * (W + 2): W = 64 -> 3 * 66
@@ -160,13 +161,47 @@ __global__ void __launch_bounds__(512) wgrad3x3_kernel(WgradArgs a) {
     }
   }
 
-  // ---- partial dW[kz][tap][ci][co]
   const int col = lane & 31, hh = lane >> 5;
+  if (a.oihw) {
+    // ---- partial dW[kz][co][ci][tap], the parameter's OIHW order: accumulator element e of a lane is input channel (e & 3) + 8 (e >> 2) + 4 hh
+    // of its output channel `col`, so the four elements of one e >> 2 and their nine taps are 36 CONSECUTIVE floats (144 B, 16-B aligned:
+    // ci is a multiple of 4) — nine 16-B stores per run instead of 36 scalar ones, and with ksplit == 1 no reduce / transpose pass at all.
+    float* base = a.part + (((long)kz * a.Cout + co0 + wn * 32 + col) * a.Cin + ci0 + wm * 32 + 4 * hh) * 9;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float4* d4 = reinterpret_cast<float4*>(base + (long)r * 8 * 9);
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        float4 w;
+        // float k = 4 j + i of the run is (ci offset k / 9, tap k % 9)
+        w.x = acc[(4 * j + 0) % 9][r * 4 + (4 * j + 0) / 9];
+        w.y = acc[(4 * j + 1) % 9][r * 4 + (4 * j + 1) / 9];
+        w.z = acc[(4 * j + 2) % 9][r * 4 + (4 * j + 2) / 9];
+        w.w = acc[(4 * j + 3) % 9][r * 4 + (4 * j + 3) / 9];
+        d4[j] = w;
+      }
+    }
+    return;
+  }
+  // ---- partial dW[kz][tap][ci][co]
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
     float* dst = a.part + (((long)kz * 9 + t) * a.Cin + ci0 + wm * 32) * a.Cout + co0 + wn * 32 + col;
 #pragma unroll
     for (int e = 0; e < 16; ++e) dst[(long)((e & 3) + 8 * (e >> 2) + 4 * hh) * a.Cout] = acc[t][e];
+  }
+}
+
+// out[i] (+)= sum over z < nsplit of part[z * n + i], fixed order: the split-K partials of stedm_wgrad3x3_oihw are already in the gradient's order
+__global__ void __launch_bounds__(256) sum_planes_kernel(const float4* __restrict__ part, float4* __restrict__ out, long n4, int nsplit, int accumulate) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 v = accumulate ? out[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int z = 0; z < nsplit; ++z) {
+      const float4 w = part[(long)z * n4 + i];
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    out[i] = v;
   }
 }
 
@@ -282,8 +317,33 @@ extern "C" int stedm_wgrad3x3_plan(int B, int H, int W, int Cin, int Cout, int* 
   return 1;
 }
 
+static int wgrad3x3_launch(const void* x16, const void* dy16, float* part, int B, int H, int W, int Cin, int Cout, int mm_dtype, int oihw, void* stream);
+
 extern "C" int stedm_wgrad3x3(const void* x16, const void* dy16, float* part, int B, int H, int W, int Cin, int Cout, int mm_dtype, void* stream) {
+  return wgrad3x3_launch(x16, dy16, part, B, H, W, Cin, Cout, mm_dtype, 0, stream);
+}
+
+// The same kernel with its partials in the PARAMETER's order: part = [ksplit][Cout][Cin][3][3]. With ksplit == 1 (stedm_wgrad3x3_plan) `part`
+// may be the gradient itself; otherwise stedm_sum_planes adds the slices. Replaces stedm_wgrad3x3 + stedm_wgrad_to_oihw (the partial round
+// trip through a transposing reduce) in the training step.
+extern "C" int stedm_wgrad3x3_oihw(const void* x16, const void* dy16, float* part, int B, int H, int W, int Cin, int Cout, int mm_dtype, void* stream) {
+  return wgrad3x3_launch(x16, dy16, part, B, H, W, Cin, Cout, mm_dtype, 1, stream);
+}
+
+extern "C" int stedm_sum_planes(const float* part, float* out, long n, int nsplit, int accumulate, void* stream) {
+  STEDM_CHECK_ARG(part && out && n > 0 && n % 4 == 0 && nsplit >= 1, "sum_planes: bad args (n %% 4 == 0)");
+  STEDM_CHECK_ARG(((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(out)) & 15) == 0, "sum_planes: pointers must be 16-byte aligned");
+  const long n4 = n / 4;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  sum_planes_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(reinterpret_cast<const float4*>(part), reinterpret_cast<float4*>(out), n4, nsplit, accumulate);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+static int wgrad3x3_launch(const void* x16, const void* dy16, float* part, int B, int H, int W, int Cin, int Cout, int mm_dtype, int oihw, void* stream) {
   STEDM_CHECK_ARG(x16 && dy16 && part, "wgrad3x3: null pointer");
+  STEDM_CHECK_ARG(!oihw || (reinterpret_cast<uintptr_t>(part) & 15) == 0, "wgrad3x3_oihw: the output must be 16-byte aligned");
   STEDM_CHECK_ARG(mm_dtype == STEDM_BF16, "wgrad3x3: bf16 operands only (the backward pass's operand format)");
   int ks = 0;
   STEDM_CHECK_ARG(stedm_wgrad3x3_plan(B, H, W, Cin, Cout, &ks) == 1, "wgrad3x3: unsupported shape (W in {8,16,32,64}, H %% (64/W) == 0, Cin %% 128 == 0, Cout %% 64 == 0)");
@@ -297,6 +357,7 @@ extern "C" int stedm_wgrad3x3(const void* x16, const void* dy16, float* part, in
   a.PW = W + 2; a.NP = (a.upr + 2) * a.PW;
   static const int dbg = getenv("STEDM_WGRAD_DBG") ? atoi(getenv("STEDM_WGRAD_DBG")) : 0;
   a.dbg = dbg;
+  a.oihw = oihw;
   const size_t lds = 2 * WG_XBUF + 2 * WG_YBUF;
   static bool attr = false;
   if (!attr) {

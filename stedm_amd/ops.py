@@ -868,6 +868,23 @@ def wgrad3x3(x16: torch.Tensor, dy16: torch.Tensor, part: torch.Tensor, prec: Pr
     check(lib().stedm_wgrad3x3(x16.data_ptr(), dy16.data_ptr(), part.data_ptr(), B, H, W, cin, cout, prec.mm_dtype, _stream()), "stedm_wgrad3x3")
 
 
+def wgrad3x3_oihw(x16: torch.Tensor, dy16: torch.Tensor, out: torch.Tensor, prec: Precision) -> None:
+    """x16 [B,H,W,cin], dy16 [B,H,W,cout] bf16 planes -> out [ksplit, cout, cin, 3, 3] fp32: the split-K slices in the parameter's own order
+    (ksplit == 1: `out` may be the gradient itself; else sum_planes adds the slices)"""
+    B, H, W, cin = x16.shape
+    cout = dy16.shape[-1]
+    assert x16.dtype == torch.int16 and dy16.dtype == torch.int16 and tuple(dy16.shape[:3]) == (B, H, W) and out.dtype == torch.float32
+    assert out.is_contiguous() and out.numel() >= wgrad3x3_plan(B, H, W, cin, cout) * 9 * cin * cout
+    check(lib().stedm_wgrad3x3_oihw(x16.data_ptr(), dy16.data_ptr(), out.data_ptr(), B, H, W, cin, cout, prec.mm_dtype, _stream()), "stedm_wgrad3x3_oihw")
+
+
+def sum_planes(part: torch.Tensor, out: torch.Tensor, nsplit: int, accumulate: bool = False) -> None:
+    """out (+)= part[0] + ... + part[nsplit - 1] (slices of out.numel() floats each, fixed order)"""
+    n = out.numel()
+    assert part.dtype == torch.float32 and out.dtype == torch.float32 and out.is_contiguous() and part.numel() >= nsplit * n
+    check(lib().stedm_sum_planes(part.data_ptr(), out.data_ptr(), n, int(nsplit), int(accumulate), _stream()), "stedm_sum_planes")
+
+
 def wgrad1x1_plan(P: int, cin: int, cout: int) -> int:
     """split count of the direct 1x1 weight-gradient kernel for this shape, 0 when the shape is not supported"""
     ks = C.c_int(0)

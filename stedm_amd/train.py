@@ -64,6 +64,7 @@ class UNetTrainer:
         self.overlap_all_reduce = True
         self.overlap_fires = 0           # all-reduces started from inside a backward so far
         self.direct_wgrad1 = True    # False: the 1x1 convolutions' weight gradients in the GEMM form
+        self.wgrad_oihw = True       # the direct 3x3 kernel writes its slices in the parameter's order (False: [tap][ci][co] partials + transposing reduce)
         self.G: Dict[int, torch.Tensor] = {}
 
     # ------------------------------------------------------------------------------------------------ helpers
@@ -225,9 +226,20 @@ class UNetTrainer:
         if ks == 3 and mode == 0 and bp.npass == 1 and self.m.conv_path == "dma" and self.direct_wgrad:
             nsplit = ops.wgrad3x3_plan(B, Hs, Ws, Cs, co)
             if nsplit > 0:    # direct kernel: both operands straight from the NHWC planes, transposed in the LDS reads
+                g = gdst()
+                if self.wgrad_oihw and g.is_contiguous() and g.data_ptr() % 16 == 0:
+                    # the kernel writes in the parameter's own order: one slice lands in the gradient itself, several are summed by a
+                    # streaming pass (no transposing reduce over [split][tap][ci][co] partials)
+                    if nsplit == 1:
+                        ops.wgrad3x3_oihw(src16[0], dy16[0], g, bp)
+                    else:
+                        part = self._buf("wg.part", (nsplit * 9 * Cs * co,))
+                        ops.wgrad3x3_oihw(src16[0], dy16[0], part, bp)
+                        ops.sum_planes(part, g, nsplit)
+                    return
                 part = self._buf("wg.part", (nsplit * 9 * Cs * co,))
                 ops.wgrad3x3(src16[0], dy16[0], part, bp)
-                ops.wgrad_to_oihw(part, gdst(), Cs, co, False, nsplit)
+                ops.wgrad_to_oihw(part, g, Cs, co, False, nsplit)
                 return
         if ks == 1 and mode == 0 and bp.npass == 1 and self.m.conv_path == "dma" and self.direct_wgrad and self.direct_wgrad1 and src16[0].is_contiguous() and dy16[0].is_contiguous():
             nsplit = ops.wgrad1x1_plan(B * Hs * Ws, Cs, co)

@@ -101,7 +101,10 @@ def test_batch256_cfg_rows_vs_cpu_oracle(dev, oracle_ns32):
         d64 = dev2(torch.cat([ec[lo:], eu[lo:]]), torch.cat([ec2, eu2]))
         print(f"[NS32 B=256 CFG, rows {rows}, {precision}] vs CPU oracle: rel-L2 {out[precision][0]:.3e}, max/std {out[precision][1]:.3e}; "
               f"rows 192..255 vs the same samples at B=64: rel-L2 {d64[0]:.3e}, max/std {d64[1]:.3e}")
-        assert d64[0] < (1e-5 if precision == "parity" else 2e-3), (precision, d64)
+        # parity: the two launch plans agree to fp32 rounding. Single-product modes: a different split-K order moves fp32 sums by ~1e-7, which
+        # flips operand roundings downstream — the two plans' rounding noise is only partly the same realisation (measured f16 5.8e-4,
+        # bf16 4.6e-3: of the size of the mode's own deviation from the oracle, as it must be), bounded by twice that deviation
+        assert d64[0] < {"parity": 1e-5, "f16": 2e-3, "bf16": 1.5e-2}[precision], (precision, d64)
     assert out["parity"][0] < 1e-3 and out["parity"][1] < 1e-3
     assert out["f16"][0] < 1e-3 and out["f16"][1] < 1e-2
     assert out["bf16"][0] < 1.5e-2 and out["bf16"][1] < 8e-2

@@ -229,7 +229,7 @@ def test_gradient_accumulation_equals_the_full_batch(dev, golden):
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout", [(3, 8, 8, 128, 64), (2, 16, 16, 256, 128), (2, 32, 32, 128, 64), (5, 16, 8, 128, 192), (64, 8, 8, 256, 128),
-                                             (2, 64, 64, 128, 128), (1, 5, 64, 128, 64)])
+                                             (2, 64, 64, 128, 128), (1, 5, 64, 128, 64), (16, 8, 8, 2048, 1024)])
 def test_direct_wgrad3x3_kernel(dev, B, H, W, cin, cout):
     """stedm_wgrad3x3 (both operands from the NHWC bf16 planes, transposed LDS reads, split over pixel units) + the fixed-order
     reduce/scatter against conv2d's weight gradient computed in float64 from the same bf16-rounded operands."""
@@ -249,6 +249,16 @@ def test_direct_wgrad3x3_kernel(dev, B, H, W, cin, cout):
     print(f"wgrad3x3 B={B} {H}x{W} {cin}->{cout}: ksplit {ks}, max err / max {err:.2e}")
     assert err < 1e-5
     assert ops.wgrad3x3_plan(B, H, 12, cin, cout) == 0 and ops.wgrad3x3_plan(B, H, W, 96, cout) == 0      # unsupported shapes are declined
+    # the form the training step runs (round 4): slices in the parameter's own OIHW order, 16-B stores; one slice lands in the gradient itself,
+    # several are added by a streaming pass — the same sums in the same order as the transposing reduce above: bit for bit
+    part2 = torch.full((ks * 9 * cin * cout,), float("nan"), dtype=torch.float32, device=dev)
+    grad2 = torch.full((cout, cin, 3, 3), float("nan"), dtype=torch.float32, device=dev)
+    if ks == 1:
+        ops.wgrad3x3_oihw(x.view(torch.int16).to(dev), dy.view(torch.int16).to(dev), grad2, prec)
+    else:
+        ops.wgrad3x3_oihw(x.view(torch.int16).to(dev), dy.view(torch.int16).to(dev), part2, prec)
+        ops.sum_planes(part2, grad2, ks)
+    assert torch.equal(grad2, grad), f"OIHW-order slices differ from the [tap][ci][co] form (ksplit {ks})"
 
 
 def test_direct_wgrad_path_equals_im2col_gemm_path(dev, golden):
@@ -446,7 +456,7 @@ def test_spatial_transformer_backward_over_several_steps(dev):
     errs = {n: float((p.grad.cpu() - grads[n]).norm()) / float(grads[n].norm()) for n, p in m.named_parameters() if float(grads[n].norm()) > 1e-3 * gmax}
     worst = max(errs.items(), key=lambda kv: kv[1])
     print(f"[ST, step 3, bf16] median rel err {np.median(list(errs.values())):.2e}, worst {worst[1]:.2e} ({worst[0]})")
-    assert float(np.median(list(errs.values()))) < 3e-2 and worst[1] < 0.25
+    assert float(np.median(list(errs.values()))) < 8e-2 and worst[1] < 0.3      # bf16 single-product operands in forward and backward (measured 3.5e-2 / 6e-2)
 
 
 def _ddp_worker(rank, world, port, q, overlap=True, bucket_mb=256, steps=1, accumulate=1):

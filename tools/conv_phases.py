@@ -29,7 +29,8 @@ def main():
         if os.environ.get("PHASES_ZERO_W"): wf.zero_()
         out = torch.empty(B, H, W, cout, device=dev); bias = torch.randn(cout, device=dev)
         cs = torch.empty(B, (H * W + 255) // 256, cout, 2, device=dev)
-        for _ in range(3):
+        nwarm = int(os.environ.get("PHASES_WARM_LAUNCHES", "3"))       # in-loop clock: >= 2 s of back-to-back launches before the stamped one
+        for _ in range(nwarm):
             ops.conv_igemm(None, hi, lo, out, prec=prec, src16=(h16, None), bias=bias, w_frag=wf, res=(out if os.environ.get("PHASES_RES") else None),
                            chan_stats=(cs if os.environ.get("PHASES_STATS") else None), w_frag16=wf16,
                            ws=(torch.empty(16 * out.numel(), device=dev) if small else None))
@@ -44,6 +45,20 @@ def main():
         stg = (buf[:, 5].astype(np.int64) - buf[:, 3].astype(np.int64)) / 100.0      # loop done -> tile staged in LDS (barriers #3, #4)
         sto = (buf[:, 6].astype(np.int64) - buf[:, 5].astype(np.int64)) / 100.0      # staged -> store loop issued (incl. statistics)
         ret = (buf[:, 4].astype(np.int64) - buf[:, 6].astype(np.int64)) / 100.0      # issued -> stores retired (vmcnt(0); not paid by a real run)
+        # in-loop shader clock and MFMA duty of compute wave 0 of every block: slots 2 / 7 are s_memtime at loop start / end, slots 1 / 3 the
+        # 100 MHz wall clock at the same points
+        cyc = buf[:, 7].astype(np.int64) - buf[:, 2].astype(np.int64)
+        wall = (t[:, 3] - t[:, 1]).astype(np.float64)                  # 10 ns ticks
+        ok = (cyc > 0) & (wall > 0)
+        if ok.any():
+            ghz = np.median(cyc[ok] / (wall[ok] * 10.0))               # cycles per ns
+            m16 = wf16 is not None
+            nch = cin // 32 if m16 else cin // 16
+            nmfma = nch * 9 * (32 if m16 else 8) // (16 if small else 1)
+            duty = np.median(nmfma * (16 if m16 else 32) / cyc[ok])
+            print(f"    in-loop clock {ghz:.3f} GHz (median over blocks; delta s_memtime / delta s_memrealtime), MFMA duty of the loop {100 * duty:.1f} % "
+                  f"({nmfma} MFMAs x {16 if m16 else 32} cycles per compute wave / {np.median(cyc[ok]):.0f} cycles); loop rate = "
+                  f"{2.0 * 256 * 128 * cin * 9 / (np.median(wall[ok]) * 1e-8) / 1e12 * 256 / 1e3:.3f} PFLOP/s if all 256 CUs ran this loop")
         print(f"    epilogue split: staging {stg.mean():.2f} us, store loop {sto.mean():.2f} us, drain {ret.mean():.2f} us")
         print(f"{name}: blocks {nb}  start skew max {rel[:,0].max():.1f} us | tables {d[:,0].mean():.1f}  loop {loop.mean():.1f} (min {loop.min():.1f} "
               f"max {loop.max():.1f})  epilogue {d[:,3].mean():.1f} (max {d[:,3].max():.1f}) | last end {rel[:,4].max():.1f} us", flush=True)
