@@ -49,7 +49,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* base, int off_lo,
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int W>
+template <int W, bool OIHW = false>
 __global__ void __launch_bounds__(512) wgrad3x3_kernel(WgradArgs a) {
   constexpr int PW = W + 2, WSH = W == 8 ? 3 : (W == 16 ? 4 : (W == 32 ? 5 : 6)), NP = (64 / W + 2) * PW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -162,27 +162,36 @@ __global__ void __launch_bounds__(512) wgrad3x3_kernel(WgradArgs a) {
   }
 
   const int col = lane & 31, hh = lane >> 5;
-  if (a.oihw) {
-    // ---- partial dW[kz][co][ci][tap], the parameter's OIHW order: accumulator element e of a lane is input channel (e & 3) + 8 (e >> 2) + 4 hh
-    // of its output channel `col`, so the four elements of one e >> 2 and their nine taps are 36 CONSECUTIVE floats (144 B, 16-B aligned:
-    // ci is a multiple of 4) — nine 16-B stores per run instead of 36 scalar ones, and with ksplit == 1 no reduce / transpose pass at all.
-    float* base = a.part + (((long)kz * a.Cout + co0 + wn * 32 + col) * a.Cin + ci0 + wm * 32 + 4 * hh) * 9;
+  if constexpr (OIHW) {
+    // ---- partial dW[kz][co][ci][tap], the parameter's own OIHW order: with ksplit == 1 no reduce / transpose pass exists at all, otherwise the
+    // reduce is a plain streaming sum. An accumulator's lanes run along co, so direct stores would put every lane on another 4.6-KB row (first
+    // version: +14 us per launch). The block goes through LDS instead (the unit buffers are dead): rows [32 co][128 ci x 9 taps] of 4608 contiguous
+    // bytes each, two passes (the waves of one co half write, all 512 threads stream the rows out as 16-B stores, fully coalesced). Row pitch
+    // 1156 floats: 16-B aligned rows, and the 32 lanes of a write instruction (one row each) fall 2-way on the banks, which costs a
+    // ds_write_b32 nothing (MI355X_MICROARCH.md, LDS).
+    constexpr int PITCH = 1156;
+    static_assert(32 * PITCH * 4 <= 2 * WG_XBUF + 2 * WG_YBUF, "staging rows must fit the unit buffers");
+    float* stg = reinterpret_cast<float*>(smem);
+    __syncthreads();              // every wave is done with the last unit's images
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      if (wn == pass) {
+        float* row = stg + col * PITCH + (wm * 32 + 4 * hh) * 9;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float4* d4 = reinterpret_cast<float4*>(base + (long)r * 8 * 9);
+        for (int t = 0; t < 9; ++t)
 #pragma unroll
-      for (int j = 0; j < 9; ++j) {
-        float4 w;
-        // float k = 4 j + i of the run is (ci offset k / 9, tap k % 9)
-        w.x = acc[(4 * j + 0) % 9][r * 4 + (4 * j + 0) / 9];
-        w.y = acc[(4 * j + 1) % 9][r * 4 + (4 * j + 1) / 9];
-        w.z = acc[(4 * j + 2) % 9][r * 4 + (4 * j + 2) / 9];
-        w.w = acc[(4 * j + 3) % 9][r * 4 + (4 * j + 3) / 9];
-        d4[j] = w;
+          for (int e = 0; e < 16; ++e) row[((e & 3) + 8 * (e >> 2)) * 9 + t] = acc[t][e];
       }
+      __syncthreads();
+      float* dst = a.part + (((long)kz * a.Cout + co0 + pass * 32) * a.Cin + ci0) * 9;
+      for (int idx = tid; idx < 32 * 288; idx += 512) {
+        const int r = idx / 288, c4 = idx - r * 288;
+        const float4 v = *reinterpret_cast<const float4*>(stg + r * PITCH + c4 * 4);
+        *reinterpret_cast<float4*>(dst + (long)r * a.Cin * 9 + c4 * 4) = v;
+      }
+      __syncthreads();
     }
-    return;
-  }
+  } else
   // ---- partial dW[kz][tap][ci][co]
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
@@ -365,11 +374,20 @@ static int wgrad3x3_launch(const void* x16, const void* dy16, float* part, int B
     STEDM_HIP_TRY(hipFuncSetAttribute((const void*)wgrad3x3_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     STEDM_HIP_TRY(hipFuncSetAttribute((const void*)wgrad3x3_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     STEDM_HIP_TRY(hipFuncSetAttribute((const void*)wgrad3x3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    STEDM_HIP_TRY(hipFuncSetAttribute((const void*)wgrad3x3_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    STEDM_HIP_TRY(hipFuncSetAttribute((const void*)wgrad3x3_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    STEDM_HIP_TRY(hipFuncSetAttribute((const void*)wgrad3x3_kernel<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    STEDM_HIP_TRY(hipFuncSetAttribute((const void*)wgrad3x3_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
   const int grid = (Cin / 128) * a.tiles_n * ks;
   hipStream_t st = as_stream(stream);
-  if (W == 8) wgrad3x3_kernel<8><<<grid, 512, lds, st>>>(a);
+  if (oihw) {
+    if (W == 8) wgrad3x3_kernel<8, true><<<grid, 512, lds, st>>>(a);
+    else if (W == 16) wgrad3x3_kernel<16, true><<<grid, 512, lds, st>>>(a);
+    else if (W == 32) wgrad3x3_kernel<32, true><<<grid, 512, lds, st>>>(a);
+    else wgrad3x3_kernel<64, true><<<grid, 512, lds, st>>>(a);
+  } else if (W == 8) wgrad3x3_kernel<8><<<grid, 512, lds, st>>>(a);
   else if (W == 16) wgrad3x3_kernel<16><<<grid, 512, lds, st>>>(a);
   else if (W == 32) wgrad3x3_kernel<32><<<grid, 512, lds, st>>>(a);
   else wgrad3x3_kernel<64><<<grid, 512, lds, st>>>(a);
