@@ -14,6 +14,7 @@ never materialised (the conv reads two sources).
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
