@@ -812,7 +812,8 @@ def main():
             assert tuple(sv.shape) == (B, 512) and bool(torch.isfinite(sv).all())
             out["sampling_run"]["swin_linear_style_seconds"] = round(t4 - t3, 4)
             out["sampling_run"]["swin_linear_what"] = (f"Agg_Linear over swin_v2_t (stedm_amd/swin.py, trunc-normal weights) on {B} x 4 style images of 512^2: "
-                                                       f"{4 * B / (t4 - t3):.0f} images/s, 47.4 GFLOP per image")
+                                                       f"{4 * B / (t4 - t3):.0f} images/s, 47.4 GFLOP per image; parity of the Swin restatement is UNPINNED "
+                                                       f"(torchvision absent, the reference holds no fixture)")
             del zm, zs, batch
         if not args.no_train_leg and world == 1:
             # BASELINE config 2: one training step (forward + L1 + backward + AdamW/EMA) on the same U-Net and batch

@@ -83,8 +83,8 @@ def main():
                    "counters include Infinity-Cache hits: an upper bound on HBM bytes"}
     json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
     with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_report.md"), "w") as fh:
-        fh.write(f"# {tag}: per-kernel PMC figures of the denoising bench (bf16, B=64 CFG step; kernel sources {out['csrc_fingerprint']})\n\n")
-        fh.write("| kernel | launches | avg us | share of GPU time | MFMA busy | eff. clock (GHz) | fetch x2 (MB/launch) | write (MB/launch) |\n|---|---|---|---|---|---|---|---|\n")
+        fh.write(f"# {tag}: per-kernel PMC figures of the denoising bench (the bench's default headline mode, B=64 CFG step; kernel sources {out['csrc_fingerprint']})\n\n")
+        fh.write("| kernel | launches | avg us | share of GPU time | MFMA busy | GRBM_GUI_ACTIVE / 8 / time (GHz; NOT the clock: reads high on dispatches under 0.3 ms - the in-loop clock is in the conv_loop_attribution profile) | fetch x2 (MB/launch) | write (MB/launch) |\n|---|---|---|---|---|---|---|---|\n")
         for r in rows:
             fmt = lambda v, p=1: "-" if v is None else f"{v:.{p}f}"
             fh.write(f"| {r['kernel']} | {r['launches']} | {r['avg_us']:.1f} | {r['share_pct']:.1f} % | {r['mfma_busy_pct']:.1f} % | {r['eff_clock_ghz']:.2f} | "

@@ -2,7 +2,7 @@
 # End-of-round refresh on the final binary (run through gpurun from the repo root): kernel-trace summaries of the denoising step and the
 # training step, then the full default bench line. Outputs under gpurun_out/; tools/stats_md.py turns the summaries into profiles/.
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
 mkdir -p $O

@@ -4,7 +4,7 @@
 # MI355X_MICROARCH.md). Outputs under gpurun_out/prof_<tag>_*; tools/pmc_report.py + the copy into profiles/ happen afterwards.
 #   gpurun --timeout 1100 -- 'bash tools/profile_round.sh r03'
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
