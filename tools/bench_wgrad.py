@@ -11,9 +11,9 @@ for B, H, W, ci, co in shapes:
     dy = torch.randn(B, H, W, co, device=dev).bfloat16().view(torch.int16)
     ks = ops.wgrad3x3_plan(B, H, W, ci, co)
     part = torch.empty((ks * 9 * ci * co,), dtype=torch.float32, device=dev)
-    for _ in range(3): ops.wgrad3x3(x, dy, part, prec)
+    for _ in range(3): ops.wgrad3x3_oihw(x, dy, part, prec)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(20): ops.wgrad3x3(x, dy, part, prec)
+    for _ in range(20): ops.wgrad3x3_oihw(x, dy, part, prec)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
     fl = 2.0 * B * H * W * 9 * ci * co
     print(f"B={B} {H}x{W} {ci}->{co} ksplit {ks}: {dt * 1e6:7.1f} us  {fl / dt / 1e12:7.1f} TFLOP/s")
