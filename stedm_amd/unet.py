@@ -775,7 +775,7 @@ class UNetModel(nn.Module):
         if nrep > 1:
             h2 = self._buf("mid.rep", (Bd,) + tuple(h.shape[1:]))
             cs1 = self._cs.get(h.data_ptr())
-            cs2 = self._cs_new(h2) if cs1 is not None else None
+            cs2 = self._cs_new(h2, nslab=cs1.shape[1]) if cs1 is not None else None
             for r in range(nrep):
                 h2[r * B:(r + 1) * B].copy_(h)
                 if cs2 is not None:      # the replicas share the statistics of the shared-encoder tensor
