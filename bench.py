@@ -93,7 +93,10 @@ class ConvTimer:
             e1.record()
             if gn_next is not None:
                 g_w, g_b, g_eps, g_groups, g_act, g_out = gn_next[:6]
-                ops.gn_apply16c(out, kw["chan_stats"], None, None, g_out, None, kw["prec"], g_w, g_b, g_eps, g_groups, g_act,
+                g_lo = None
+                if isinstance(g_out, (tuple, list)):          # 3-product modes: (hi, lo) planes
+                    g_out, g_lo = g_out
+                ops.gn_apply16c(out, kw["chan_stats"], None, None, g_out, g_lo, kw["prec"], g_w, g_b, g_eps, g_groups, g_act,
                                 mean_rstd=gn_next[6] if len(gn_next) > 6 else None)
             if out is None:    # 16-bit-plane output only (qkv of the attention block)
                 out = kw["out16"][0]

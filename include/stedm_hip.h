@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STEDM_ABI_VERSION 7
+#define STEDM_ABI_VERSION 8
 
 #define STEDM_F16 0
 #define STEDM_BF16 1
@@ -210,8 +210,8 @@ typedef struct stedm_conv_args {
                        * stedm_pack_conv_weight_s2d_frag(..., pad_br = 1) */
   /* Optional: the GroupNorm (+ SiLU) that consumes `out` — ResBlock.out_layers[0:2] after in_layers' convolution, openaimodel.py:236-241,
    * 275-287. gn_out16 != NULL asks for gn_act(GroupNorm(out; gn_gamma, gn_beta, gn_eps, gn_groups)) as 16-bit planes [B][Hout][Wout][cout]
-   * (the operand planes of the next convolution, what stedm_gn_apply16c would write) besides `out`. Needs out, chan_stats, stride 1, a
-   * single-product mode; gn_out16 must not be the planes the convolution reads (src16_*): a tile's epilogue may write it while others still load. The split-K reduce pass writes them itself when one of its workgroups owns whole groups of a sample
+   * (the operand planes of the next convolution, what stedm_gn_apply16c would write) besides `out`. Needs out, chan_stats, stride 1, and
+   * either a single-product mode or gn_out16_lo; gn_out16 must not be the planes the convolution reads (src16_*): a tile's epilogue may write it while others still load. The split-K reduce pass writes them itself when one of its workgroups owns whole groups of a sample
    * (Hout * Wout <= 256, 32 %% (cout / gn_groups) == 0); otherwise the call ends with the stedm_gn_apply16c pass. */
   const float* gn_gamma;
   const float* gn_beta;
@@ -223,6 +223,8 @@ typedef struct stedm_conv_args {
   int32_t gn_only;   /* 1: nothing but that GroupNorm reads `out` (inference: h of ResBlock._forward) — a launch whose epilogue writes
                       * gn_out16 itself may then leave `out` unwritten (4 of the 6 bytes per element of that store walk); `out` must
                       * still be a valid buffer, the other forms fill it. chan_stats is always written. */
+  void* gn_out16_lo; /* npass == 3 (round 4): the lo planes of that GroupNorm output (value - hi, rounded): with it the 3-product modes get the
+                      * same epilogue / reduce-pass GroupNorm as the single-product ones. NULL otherwise. */
 } stedm_conv_args;
 /* Replaces: GN->SiLU->conv3x3(+bias)(+emb)(+skip) of ResBlock._forward openaimodel.py:268-288,
  * Downsample/Upsample convs (:122-132,:156-173), 1x1 skip_connection (:254), and the 1x1

@@ -350,9 +350,10 @@ extern "C" int stedm_conv_igemm(const stedm_conv_args* args, void* stream) {
   p.a = *args;
   const stedm_conv_args& a = p.a;
   STEDM_CHECK_ARG(!a.chan_stats || a.out, "conv_igemm: chan_stats needs the fp32 output");
-  STEDM_CHECK_ARG(!a.gn_out16 || (a.out && a.chan_stats && a.gn_gamma && a.gn_beta && a.gn_groups > 0 && a.cout % a.gn_groups == 0 && a.npass == 1 &&
-                                  a.mode == STEDM_CONV_S1 && (a.gn_act == 0 || a.gn_act == 1)),
-                  "conv_igemm: gn_out16 needs out, chan_stats, gamma / beta, groups dividing cout, stride 1 and a single-product mode");
+  STEDM_CHECK_ARG(!a.gn_out16 || (a.out && a.chan_stats && a.gn_gamma && a.gn_beta && a.gn_groups > 0 && a.cout % a.gn_groups == 0 &&
+                                  (a.npass == 1 || a.gn_out16_lo) && a.mode == STEDM_CONV_S1 && (a.gn_act == 0 || a.gn_act == 1)),
+                  "conv_igemm: gn_out16 needs out, chan_stats, gamma / beta, groups dividing cout, stride 1 and a single-product mode (or gn_out16_lo)");
+  STEDM_CHECK_ARG(!a.gn_out16_lo || a.gn_out16, "conv_igemm: gn_out16_lo without gn_out16");
   int rc = conv_dispatch(p, stream);
   if (rc != 0) return rc;
   if (a.chan_stats && !p.stats_done) {
@@ -365,7 +366,7 @@ extern "C" int stedm_conv_igemm(const stedm_conv_args* args, void* stream) {
     // no pass of this launch owned whole groups: the consumer's GroupNorm as its own pass, from the statistics just written
     const int HW = a.Hin * a.Win;
     rc = stedm_gn_apply16c_mr(a.out, a.cout, a.chan_stats, a.chan_nslab > 0 ? a.chan_nslab : stedm_gn_chan_nslab(HW), nullptr, 0, nullptr, 0, 0, a.gn_gamma,
-                              a.gn_beta, a.gn_eps, a.gn_groups, a.gn_act, a.B, HW, a.gn_out16, nullptr, nullptr, nullptr, a.gn_mr, a.mm_dtype, stream);
+                              a.gn_beta, a.gn_eps, a.gn_groups, a.gn_act, a.B, HW, a.gn_out16, a.gn_out16_lo, nullptr, nullptr, a.gn_mr, a.mm_dtype, stream);
   }
   return rc;
 }

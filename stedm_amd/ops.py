@@ -407,6 +407,9 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
     if gn_next is not None:
         # (gamma, beta, eps, groups, act, out16): the GroupNorm (+ SiLU) reading `out`, written as 16-bit planes by the same call
         g_w, g_b, g_eps, g_groups, g_act, g_out = gn_next[:6]
+        g_lo = None
+        if isinstance(g_out, (tuple, list)):      # (hi, lo): the 3-product modes' planes
+            g_out, g_lo = g_out[0], g_out[1]
         g_mr = gn_next[6] if len(gn_next) > 6 else None
         a.gn_only = int(bool(gn_next[7])) if len(gn_next) > 7 else 0
         if g_mr is not None:
@@ -418,6 +421,11 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
         # the convolution's own epilogue may write these planes while other tiles still gather their input: never the planes it reads
         assert src16 is None or all(t is None or t.data_ptr() != g_out.data_ptr() for t in src16), "gn_next planes alias the convolution's input planes"
         a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_groups, a.gn_act, a.gn_out16 = g_w.data_ptr(), g_b.data_ptr(), float(g_eps), int(g_groups), int(g_act), g_out.data_ptr()
+        if g_lo is not None:
+            assert g_lo.dtype == torch.int16 and g_lo.is_contiguous() and tuple(g_lo.shape) == tuple(out.shape)
+            assert src16 is None or all(t is None or t.data_ptr() != g_lo.data_ptr() for t in src16), "gn_next lo planes alias the convolution's input planes"
+            a.gn_out16_lo = g_lo.data_ptr()
+        assert prec.npass == 1 or g_lo is not None, "gn_next in a 3-product mode needs the (hi, lo) planes"
     a.pad_br = int(pad_br)
     a.w_frag16 = _ptr(w_frag16)      # npass 3: the hi + lo streams of pack_conv_weight_frag16 in that mode
     a.w_frag = _ptr(w_frag) if prec.npass == 1 else None

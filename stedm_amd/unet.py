@@ -496,7 +496,7 @@ class UNetModel(nn.Module):
             # that sums the partial tiles owns whole groups of a sample and writes the normalised planes itself; otherwise the call ends with the
             # same stedm_gn_apply16c pass as before
             gn2 = rb.out_layers[0]
-            if prec.npass == 1 and (self._tape is None or prec.mm_dtype == BF16):
+            if (prec.npass == 1 and (self._tape is None or prec.mm_dtype == BF16)) or (prec.npass == 3 and self._tape is None):
                 if self._tape is None:
                     # NOT the planes _norm16 would hand out: for cin == cout those are the planes this convolution is reading, and an epilogue
                     # that writes the GroupNorm output would overwrite rows other tiles still gather
@@ -511,7 +511,8 @@ class UNetModel(nn.Module):
                     mr2 = self._buf(f"keep{self._mr_ctr}.mr", (B, gn2.num_groups, 2))
                     self._saved_mr[(id(gn2), h.data_ptr())] = mr2
                 # (inference: nothing but that GroupNorm reads h — an epilogue that writes the planes itself skips h's fp32 store)
-                gn_next = (gn2.weight, gn2.bias, gn2.eps, gn2.num_groups, 1, h16_next[0], mr2, self._tape is None)
+                # (3-product modes, round 4: the (hi, lo) pair; single-product: the hi plane)
+                gn_next = (gn2.weight, gn2.bias, gn2.eps, gn2.num_groups, 1, h16_next if prec.npass == 3 else h16_next[0], mr2, self._tape is None)
             ops.conv_igemm(None, pk.hi, pk.lo, h, prec=prec, src16=a16, bias=pk.bias, emb=emb_all, emb_offset=emb_off,
                            emb_bstride=emb_bstride, w_frag=pk.frag, chan_stats=self._cs_new(h), ws=ws, w_frag16=pk.frag16, gn_next=gn_next)
         else:
