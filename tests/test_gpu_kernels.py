@@ -696,6 +696,32 @@ def test_conv_dma_3x3_split_k(dev, prec, tol, B, H, W, cin, cout, emb, res):
     assert torch.allclose(outs[0][1][:, 0, :, 0].double(), outs[0][0].view(B, H * W, cout)[:, :256].double().sum(1), rtol=1e-4, atol=2e-3)
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout,run", [(2, 8, 8, 1024, 1024, 8), (2, 16, 16, 512, 512, 32), (1, 32, 32, 256, 128, 64), (4, 16, 16, 512, 256, 128)])
+def test_conv_split_k_caller_chosen_statistics_partition(dev, B, H, W, cin, cout, run):
+    """A split-K convolution fills the statistics partition the caller laid out (equal runs of 8..256 pixels per slot, so that the
+    reduce pass of a small batch has blocks for the whole chip): every slot holds its run's {sum x, sum x^2}, the output is the one
+    of the default 256-pixel partition bit for bit, and a partition the kernel cannot serve leaves the statistics to the caller."""
+    from stedm_amd import ops
+    pr = ops.Precision.parse("bf16")
+    x = torch.randn(B, H, W, cin, device=dev)
+    w = torch.randn(cout, cin, 3, 3, device=dev) / math.sqrt(cin * 9)
+    h16 = torch.empty((B, H, W, cin), dtype=torch.int16, device=dev)
+    ops.gn_apply16(x, None, h16, None, pr)
+    whi, wlo = ops.pack_conv_weight(w, pr); wf = ops.pack_conv_weight_frag(w, pr)
+    HW = H * W
+    ref = torch.empty(B, H, W, cout, device=dev)
+    cs0 = torch.empty((B, ops.gn_chan_nslab(HW), cout, 2), device=dev)
+    ops.conv_igemm(None, whi, wlo, ref, prec=pr, src16=(h16, None), w_frag=wf, chan_stats=cs0, ws=torch.empty(16 * ref.numel(), device=dev))
+    out = torch.full_like(ref, float("nan"))
+    cs = torch.full((B, HW // run, cout, 2), float("nan"), device=dev)
+    ops.conv_igemm(None, whi, wlo, out, prec=pr, src16=(h16, None), w_frag=wf, chan_stats=cs, ws=torch.empty(16 * out.numel(), device=dev))
+    assert torch.equal(out, ref)
+    flat = out.view(B, HW // run, run, cout).double()
+    assert torch.allclose(cs[..., 0].double(), flat.sum(2), rtol=1e-4, atol=2e-3)
+    assert torch.allclose(cs[..., 1].double(), (flat * flat).sum(2), rtol=1e-4, atol=2e-3)
+    assert torch.allclose(cs.sum(1).double(), cs0.sum(1).double(), rtol=1e-4, atol=2e-3)
+
+
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
 @pytest.mark.parametrize("B,H,W,cin,cout,groups,emb,res", [
     (2, 8, 8, 1024, 1024, 32, True, False),      # batch-1 CFG step: split 16, one group per block of the reduce pass
