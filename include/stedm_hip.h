@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STEDM_ABI_VERSION 8
+#define STEDM_ABI_VERSION 9
 
 #define STEDM_F16 0
 #define STEDM_BF16 1
@@ -225,6 +225,18 @@ typedef struct stedm_conv_args {
                       * still be a valid buffer, the other forms fill it. chan_stats is always written. */
   void* gn_out16_lo; /* npass == 3 (round 4): the lo planes of that GroupNorm output (value - hi, rounded): with it the 3-product modes get the
                       * same epilogue / reduce-pass GroupNorm as the single-product ones. NULL otherwise. */
+  /* Optional (round 4, ABI 9): the LSA attention's operand planes straight from the to_qkv GEMM's epilogue (vit_set.py:52-57: to_qkv, chunk(3),
+   * 'b n (h d) -> b h n d', q * temperature.exp()). qkv_q != NULL: the launch is a 1x1 GEMM over M = nb * qkv_T rows (B = 1, Hin = 1,
+   * Win = M) with cout = 3 * qkv_heads * 64; column block s of heads * 64 is q (s = 0), k (1), v (2). Instead of `out` / `out16_*` (both NULL)
+   * the epilogue writes q * qkv_qscale -> qkv_q [nb * heads][qkv_Tp][64], k -> qkv_k (same shape), v TRANSPOSED -> qkv_vt
+   * [nb * heads][64][qkv_Tp], all 16-bit of mm_dtype; rows / columns t >= qkv_T are never written (the caller zeroed them once). Needs a
+   * single-product mode, fragment-order weights (the register-streamed kernel is the only one with this epilogue: stedm_conv_rs_ok tells),
+   * qkv_T and qkv_Tp even, heads even. Replaces the [M][3 * heads * 64] 16-bit output + stedm_qkv_pack16. */
+  void* qkv_q;
+  void* qkv_k;
+  void* qkv_vt;
+  int32_t qkv_T, qkv_Tp, qkv_heads;
+  float qkv_qscale;
 } stedm_conv_args;
 /* Replaces: GN->SiLU->conv3x3(+bias)(+emb)(+skip) of ResBlock._forward openaimodel.py:268-288,
  * Downsample/Upsample convs (:122-132,:156-173), 1x1 skip_connection (:254), and the 1x1

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STEDM_HIP_LIB") or os.path.join(_HERE, "libstedm_hip.so")     # STEDM_HIP_LIB: A/B timing of another build
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 F16, BF16 = 0, 1
 CONV_S1, CONV_DOWN, CONV_UP, CONV_UP_SUBPIXEL, CONV_S2D = 0, 1, 2, 3, 4
 
@@ -39,6 +39,8 @@ class ConvArgs(C.Structure):
         ("ws", C.c_void_p), ("ws_floats", C.c_int64), ("chan_nslab", C.c_int32), ("w_frag16", C.c_void_p), ("w_frag_b16", C.c_void_p), ("pad_br", C.c_int32),
         ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p), ("gn_eps", C.c_float), ("gn_groups", C.c_int32), ("gn_act", C.c_int32), ("gn_out16", C.c_void_p), ("gn_mr", C.c_void_p), ("gn_only", C.c_int32),
         ("gn_out16_lo", C.c_void_p),
+        ("qkv_q", C.c_void_p), ("qkv_k", C.c_void_p), ("qkv_vt", C.c_void_p),
+        ("qkv_T", C.c_int32), ("qkv_Tp", C.c_int32), ("qkv_heads", C.c_int32), ("qkv_qscale", C.c_float),
     ]
 
 

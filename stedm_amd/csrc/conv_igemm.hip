@@ -374,7 +374,13 @@ extern "C" int stedm_conv_igemm(const stedm_conv_args* args, void* stream) {
 // validates the arguments and fills the derived sizes of `p`
 static int conv_setup(ConvParams& p) {
   const stedm_conv_args& a = p.a;
-  STEDM_CHECK_ARG((a.src1 || a.src16_hi) && (a.w_hi || (a.mode == STEDM_CONV_S2D && a.w_frag)) && (a.out || a.out16_hi), "conv_igemm: null src/w_hi/out");
+  STEDM_CHECK_ARG((a.src1 || a.src16_hi) && (a.w_hi || (a.mode == STEDM_CONV_S2D && a.w_frag)) && (a.out || a.out16_hi || a.qkv_q), "conv_igemm: null src/w_hi/out");
+  STEDM_CHECK_ARG(!a.qkv_q || (a.qkv_k && a.qkv_vt && !a.out && !a.out16_hi && !a.res && !a.emb && !a.chan_stats && !a.gn_out16 && !a.act_out && a.src16_hi && !a.src1 &&
+                               !a.src16b_hi && a.w_frag && a.ks == 1 && a.mode == STEDM_CONV_S1 && a.npass == 1 && a.B == 1 && a.Hin == 1 && a.qkv_heads > 0 &&
+                               a.qkv_heads % 2 == 0 && a.cout == 3 * a.qkv_heads * 64 && a.qkv_T > 0 && a.qkv_T % 2 == 0 && a.qkv_Tp >= a.qkv_T &&
+                               a.qkv_Tp % 2 == 0 && a.Win % a.qkv_T == 0),
+                  "conv_igemm: the qkv epilogue needs a flat 1x1 GEMM (B = Hin = 1, Win = nb * T rows), cout = 3 * heads * 64 with an even head count, even T / Tp, "
+                  "src16 + w_frag, a single-product mode and no other output or epilogue extra");
   STEDM_CHECK_ARG(a.pad_br == 0 || a.mode == STEDM_CONV_S2D, "conv_igemm: pad_br belongs to the space-to-depth form");
   STEDM_CHECK_ARG(a.mode != STEDM_CONV_S2D || (a.src16_hi && !a.src1 && a.w_frag && a.ks == 3 && a.npass == 1 && !a.src16b_hi),
                   "conv_igemm: the space-to-depth form needs src16 planes, w_frag, ks=3, single product");

@@ -397,9 +397,11 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
                chan_stats: Optional[torch.Tensor] = None,
                skip: Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = None, query_fused: bool = False, query_rs: bool = False,
                ws: Optional[torch.Tensor] = None, pad_br: bool = False, w_frag16: Optional[torch.Tensor] = None,
-               gn_next: Optional[tuple] = None):
+               gn_next: Optional[tuple] = None, qkv_planes: Optional[tuple] = None):
     """src1 [B,Hin,Win,c1] NHWC fp32 (fused path) and/or src16 = (hi, lo) 16-bit NHWC planes [B,Hin,Win,Cin] from
-    gn_apply16 (DMA path) -> out [B,Hout,Wout,cout] NHWC fp32 (see stedm_conv_igemm)."""
+    gn_apply16 (DMA path) -> out [B,Hout,Wout,cout] NHWC fp32 (see stedm_conv_igemm).
+    qkv_planes = (q, k, vt, T, Tp, heads, qscale): the LSA attention's operand planes as the only output of a flat to_qkv GEMM
+    (stedm_conv_args.qkv_*; out and out16 None)."""
     if out is not None:
         _chk(out, name="out")
     a = ConvArgs()
@@ -443,7 +445,17 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
     if out16 is not None:
         a.out16_hi = out16[0].data_ptr()
         a.out16_lo = _ptr(out16[1]) if prec.npass == 3 else None
-    oshape = out.shape if out is not None else out16[0].shape
+    if qkv_planes is not None:
+        qq, qk, qv, qT, qTp, qH, qs = qkv_planes
+        assert out is None and out16 is None and prec.npass == 1 and src16 is not None
+        nb = src16[0].shape[2] // int(qT)
+        for t_, shp in ((qq, (nb * qH, qTp, 64)), (qk, (nb * qH, qTp, 64)), (qv, (nb * qH, 64, qTp))):
+            assert t_.dtype == torch.int16 and t_.is_contiguous() and tuple(t_.shape) == shp, (tuple(t_.shape), shp)
+        a.qkv_q, a.qkv_k, a.qkv_vt = qq.data_ptr(), qk.data_ptr(), qv.data_ptr()
+        a.qkv_T, a.qkv_Tp, a.qkv_heads, a.qkv_qscale = int(qT), int(qTp), int(qH), float(qs)
+        oshape = (1, 1, src16[0].shape[2], 3 * int(qH) * 64)
+    else:
+        oshape = out.shape if out is not None else out16[0].shape
     if src1 is not None:
         _chk(src1, name="src1")
         B, Hin, Win, c1 = src1.shape

@@ -11,6 +11,7 @@ stedm_amd/swin.py (third-party torchvision arithmetic, SURVEY.md §8c: parity un
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -105,6 +106,8 @@ class sViT(nn.Module):
         # `last_dropout_seed` is what the last forward used (tests rebuild the masks from it)
         self.dropout_seed: Optional[int] = None
         self.last_dropout_seed = 0
+        # to_qkv's epilogue writes the attention's operand planes (single-product modes, no dropout); STEDM_SVIT_FUSE_QKV=0: the separate pack pass
+        self.fuse_qkv = os.environ.get("STEDM_SVIT_FUSE_QKV", "1") != "0"
 
     # mask stream ids of the dropout sites (include/stedm_hip.h, "train-mode dropout"): site = 8 * layer + kind, the embedding site alone
     SITE_EMB, SITE_ATTN, SITE_OUT, SITE_FF1, SITE_FF2 = 0x10000, 1, 2, 3, 4
@@ -152,12 +155,13 @@ class sViT(nn.Module):
         self._packed = P
         self._pack_key = key
 
-    def _gemm(self, a16, w, M, N, bias=None, res=None, out=None, act_out=0, out16=None):
+    def _gemm(self, a16, w, M, N, bias=None, res=None, out=None, act_out=0, out16=None, qkv_planes=None, query_rs=False):
         """[M, K] 16-bit planes x packed [N][1][K] weights on the DMA conv kernel (1x1 conv view [1, 1, M, K])."""
         K = a16[0].shape[-1]
         v = lambda t: None if t is None else t.view(1, 1, M, -1)
-        ops.conv_igemm(None, w[0], w[1], v(out), prec=self.precision, ks=1, src16=(v(a16[0]), v(a16[1])), bias=bias, res=v(res),
-                       act_out=act_out, out16=None if out16 is None else (v(out16[0]), v(out16[1])), w_frag=w[2])
+        return ops.conv_igemm(None, w[0], w[1], v(out), prec=self.precision, ks=1, src16=(v(a16[0]), v(a16[1])), bias=bias, res=v(res),
+                              act_out=act_out, out16=None if out16 is None else (v(out16[0]), v(out16[1])), w_frag=w[2],
+                              qkv_planes=qkv_planes, query_rs=query_rs)
 
     @torch.no_grad()
     def forward(self, img, t_emb=None, c_old=None):
@@ -201,14 +205,21 @@ class sViT(nn.Module):
         ln = (self._buf("ln.hi", (M, dim), i16), self._buf("ln.lo", (M, dim), i16) if lo_ok else None)
         # single-product modes: to_qkv writes its 16-bit output only (the attention's operands are 16-bit — or MX-fp8 packed from them — anyway)
         q16 = prec.npass == 1
-        qkv = self._buf("qkv16", (M, 3 * heads * 64), i16) if q16 else self._buf("qkv", (M, 3 * heads * 64))
         mk = lambda nm, shp: (self._buf(nm + ".hi", shp, i16, zero=True), self._buf(nm + ".lo", shp, i16, zero=True) if lo_ok else None)
         q, k, vt = mk("q", (B * heads, Tp, 64)), mk("k", (B * heads, Tp, 64)), mk("vt", (B * heads, 64, Tp))
         att = (self._buf("att.hi", (M, heads * 64), i16), self._buf("att.lo", (M, heads * 64), i16) if lo_ok else None)
+        # ... and, 16-bit operands without dropout: the GEMM's epilogue writes the attention's q / k / v^T planes itself (stedm_conv_args.qkv_*:
+        # no [M][3 * heads * 64] tensor, no qkv_pack pass), where the register-streamed kernel runs the problem
+        planes = lambda l: (q[0], k[0], vt[0], T, Tp, heads, P[f"tau{l}"])
+        fused_qkv = (q16 and not prec.attn_fp8 and p_drop == 0 and self.fuse_qkv and self.depth > 0 and T % 2 == 0 and heads % 2 == 0
+                     and bool(self._gemm(ln, P["qkv0"], M, 3 * heads * 64, qkv_planes=planes(0), query_rs=True)))
+        qkv = None if fused_qkv else (self._buf("qkv16", (M, 3 * heads * 64), i16) if q16 else self._buf("qkv", (M, 3 * heads * 64)))
         for l, (attn, ff) in enumerate(self.transformer.layers):
             mlp = ff.fn.net[0].out_features
             ops.ln_apply16(x, attn.norm.weight, attn.norm.bias, attn.norm.eps, ln[0], ln[1], prec)
-            if q16:
+            if fused_qkv:
+                self._gemm(ln, P[f"qkv{l}"], M, 3 * heads * 64, qkv_planes=planes(l))
+            elif q16:
                 self._gemm(ln, P[f"qkv{l}"], M, 3 * heads * 64, out16=(qkv, None))
             else:
                 self._gemm(ln, P[f"qkv{l}"], M, 3 * heads * 64, out=qkv)
@@ -222,7 +233,8 @@ class sViT(nn.Module):
                 ops.qkv_pack(qkv, P[f"tau{l}"], q, k, vt, B, T, Tp, heads, prec)
                 ops.lsa_flash_drop(q, k, vt, att, B, T, Tp, heads, prec, p_drop, seed, 8 * l + self.SITE_ATTN)
             else:
-                ops.qkv_pack(qkv, P[f"tau{l}"], q, k, vt, B, T, Tp, heads, prec)
+                if not fused_qkv:
+                    ops.qkv_pack(qkv, P[f"tau{l}"], q, k, vt, B, T, Tp, heads, prec)
                 ops.lsa_flash(q, k, vt, att, B, T, Tp, heads, prec)
             h16 = (self._buf("h.hi", (M, mlp), i16), self._buf("h.lo", (M, mlp), i16) if lo_ok else None)
             if p_drop > 0:

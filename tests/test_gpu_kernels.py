@@ -817,6 +817,23 @@ def test_conv_s2d_downsample(dev, prec, tol, B, H, W, cin, cout, ws):
         assert torch.allclose(cs[:, k, :, 0].double(), flat[:, k * 256:(k + 1) * 256].sum(1), rtol=1e-4, atol=2e-3)
 
 
+@pytest.mark.parametrize("prec", ["bf16", "f16", "parity"])
+@pytest.mark.parametrize("rows,dim", [(4098 * 2 + 3, 256), (1031, 512), (517, 768), (259, 1024), (66, 2048), (131, 320), (37, 64)])
+def test_ln_apply16(dev, prec, rows, dim):
+    """LayerNorm -> operand planes (vit_set.py:14-20 PreNorm, attention.py BasicTransformerBlock norms): the one-pass register form for
+    dim = 256 k (rows per wave 4 / 2 / 1, ragged last wave) and the scalar form for any other width, against torch's layer_norm."""
+    from stedm_amd import ops
+    pr = ops.Precision.parse(prec)
+    x = (torch.randn(rows, dim, device=dev) * 1.7 + 0.3)
+    g = torch.randn(dim, device=dev) * 0.2 + 1.0; b = torch.randn(dim, device=dev) * 0.1
+    hi = torch.full((rows, dim), 0x7FFF, dtype=torch.int16, device=dev)
+    lo = torch.full((rows, dim), 0x7FFF, dtype=torch.int16, device=dev) if pr.npass == 3 else None
+    ops.ln_apply16(x, g, b, 1e-5, hi, lo, pr)
+    ref = F.layer_norm(x.double(), (dim,), g.double(), b.double(), 1e-5)
+    got = _as_float(hi, pr).double() + (_as_float(lo, pr).double() if lo is not None else 0.0)
+    assert rel_err(got, ref) < (2e-6 if pr.npass == 3 else (2e-2 if prec == "bf16" else 2.5e-3))     # max error / spread: half an ulp of a 6-sigma value
+
+
 def test_chan_stats_any_partition(dev):
     """The statistics slots may cut a sample's pixels any way (256-pixel runs, row pairs from conv_in, run x parity from the
     sub-pixel upsample): producers with different partitions feed one GroupNorm over their concat."""

@@ -79,6 +79,57 @@ def test_svit_fast_modes_reported(dev, golden, precision, tol):
     assert err < tol
 
 
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+@pytest.mark.parametrize("nb,T,heads,dim,bias", [(2, 1026, 12, 256, False), (3, 4098, 12, 256, False), (5, 514, 4, 128, True), (1, 2050, 12, 256, True)])
+def test_to_qkv_epilogue_writes_the_attention_planes(dev, precision, nb, T, heads, dim, bias):
+    """to_qkv with the qkv epilogue (stedm_conv_args.qkv_*; vit_set.py:52-57) against the same GEMM with its fp32 output: q = round(out * scale),
+    k = round(out), v^T = round(out) transposed — bit for bit (same accumulation order), rows / columns t >= T untouched; tiles that
+    straddle two samples (T is no multiple of 256) and a ragged last tile included."""
+    from stedm_amd import ops
+    from stedm_amd._lib import F16
+    prec = ops.Precision.parse(precision)
+    ft = torch.float16 if prec.mm_dtype == F16 else torch.bfloat16
+    M, N, Tp = nb * T, 3 * heads * 64, (T + 127) // 128 * 128
+    x16 = (torch.randn(M, dim, device=dev) * 0.8).to(ft).view(torch.int16)
+    w = torch.randn(N, dim, 1, 1, device=dev) / math.sqrt(dim)
+    bs = torch.randn(N, device=dev) * 0.2 if bias else None
+    whi, wlo = ops.pack_conv_weight(w, prec); wf = ops.pack_conv_weight_frag(w, prec)
+    v4 = lambda t: t.view(1, 1, M, -1)
+    out = torch.empty(M, N, device=dev)
+    ops.conv_igemm(None, whi, wlo, v4(out), prec=prec, ks=1, src16=(v4(x16), None), w_frag=wf, bias=bs)
+    i16 = torch.int16
+    fill = 0x1234
+    q, k = (torch.full((nb * heads, Tp, 64), fill, dtype=i16, device=dev) for _ in range(2))
+    vt = torch.full((nb * heads, 64, Tp), fill, dtype=i16, device=dev)
+    scale = 0.1375
+    kw = dict(prec=prec, ks=1, src16=(v4(x16), None), w_frag=wf, bias=bs, qkv_planes=(q, k, vt, T, Tp, heads, scale))
+    assert ops.conv_igemm(None, whi, wlo, None, query_rs=True, **kw), "the register-streamed kernel should take this problem"
+    ops.conv_igemm(None, whi, wlo, None, **kw)
+    o = out.view(nb, T, 3, heads, 64)
+    planes = lambda s_, sc: (o[:, :, s_] * sc).to(ft).permute(0, 2, 1, 3).reshape(nb * heads, T, 64)      # [nb * heads][T][64]
+    assert torch.equal(q[:, :T].view(ft), planes(0, scale))
+    assert torch.equal(k[:, :T].view(ft), planes(1, 1.0))
+    assert torch.equal(vt[:, :, :T].view(ft), planes(2, 1.0).transpose(1, 2))
+    assert bool((q[:, T:] == fill).all()) and bool((k[:, T:] == fill).all()) and bool((vt[:, :, T:] == fill).all())
+
+
+@pytest.mark.parametrize("precision,tol", [("f16", 1e-2), ("bf16", 8e-2)])
+def test_svit_512_fused_qkv_vs_reference_golden(dev, golden, precision, tol):
+    """The full-size encoder (T = 4098) in the single-product modes: the to_qkv GEMMs run with the qkv epilogue (the small fixtures fall back to
+    the pack pass: too few tiles for the register-streamed kernel); against the reference golden and against the unfused path."""
+    fx = golden("f7_svit")
+    m = make_svit(dev, 512, 4, precision)
+    x = prng.uniform(7, "svit.i512_ns4.img", (1, 4, 512, 512, 3)).to(dev)
+    assert m.fuse_qkv
+    y = m(x).clone()
+    assert not any(k_[0] in ("qkv16", "qkv") for k_ in m._bufs), "the fused path allocates no [M][3 * heads * 64] tensor"
+    m.fuse_qkv = False
+    y0 = m(x).clone()
+    err, err0 = rel(y, fx["i512_ns4"]), rel(y0, fx["i512_ns4"])
+    print(f"[sViT 512 ns4 {precision}] rel err vs reference golden: fused qkv epilogue {err:.3e}, pack pass {err0:.3e}")
+    assert err < tol and err0 < tol
+
+
 @pytest.mark.parametrize("B,T,heads", [(2, 66, 12), (1, 130, 2), (1, 300, 3)])
 def test_lsa_flash_vs_oracle(dev, B, T, heads):
     """LSA core (vit_set.py:56-66) alone: logits * exp(tau), diagonal masked, softmax, @ v."""
