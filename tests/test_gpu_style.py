@@ -80,10 +80,11 @@ def test_svit_fast_modes_reported(dev, golden, precision, tol):
 
 
 @pytest.mark.parametrize("precision", ["bf16", "f16"])
-@pytest.mark.parametrize("nb,T,heads,dim,bias", [(2, 1026, 12, 256, False), (3, 4098, 12, 256, False), (5, 514, 4, 128, True), (1, 2050, 12, 256, True)])
+@pytest.mark.parametrize("nb,T,heads,dim,bias", [(2, 1026, 12, 256, False), (3, 4098, 12, 256, False), (11, 514, 4, 128, True), (1, 2050, 12, 256, True),
+                                                 (12, 4098, 12, 256, False), (13, 4098, 2, 128, True)])      # the last two: enough M-tiles for the N-persistent form
 def test_to_qkv_epilogue_writes_the_attention_planes(dev, precision, nb, T, heads, dim, bias):
     """to_qkv with the qkv epilogue (stedm_conv_args.qkv_*; vit_set.py:52-57) against the same GEMM with its fp32 output: q = round(out * scale),
-    k = round(out), v^T = round(out) transposed — bit for bit (same accumulation order), rows / columns t >= T untouched; tiles that
+    k = round(out), v^T = round(out) transposed — bit for bit (same accumulation order; q in fp16 to one ulp), rows / columns t >= T untouched; tiles that
     straddle two samples (T is no multiple of 256) and a ragged last tile included."""
     from stedm_amd import ops
     from stedm_amd._lib import F16
@@ -107,10 +108,54 @@ def test_to_qkv_epilogue_writes_the_attention_planes(dev, precision, nb, T, head
     ops.conv_igemm(None, whi, wlo, None, **kw)
     o = out.view(nb, T, 3, heads, 64)
     planes = lambda s_, sc: (o[:, :, s_] * sc).to(ft).permute(0, 2, 1, 3).reshape(nb * heads, T, 64)      # [nb * heads][T][64]
-    assert torch.equal(q[:, :T].view(ft), planes(0, scale))
+    # (fp16: the scale and the conversion may be one fused multiply-convert, i.e. a single rounding of out * scale: at most one ulp from the two-step value)
+    assert torch.allclose(q[:, :T].view(ft).float(), planes(0, scale).float(), rtol=1.1e-3, atol=1e-7) if ft == torch.float16 else \
+        torch.equal(q[:, :T].view(ft), planes(0, scale))
     assert torch.equal(k[:, :T].view(ft), planes(1, 1.0))
     assert torch.equal(vt[:, :, :T].view(ft), planes(2, 1.0).transpose(1, 2))
     assert bool((q[:, T:] == fill).all()) and bool((k[:, T:] == fill).all()) and bool((vt[:, :, T:] == fill).all())
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+@pytest.mark.parametrize("M,K,N,form", [(50000, 256, 256, "out"), (50000, 256, 384, "res"), (49153, 128, 256, "o16"), (50000, 256, 256, "gelu"),
+                                        (65536, 192, 128 * 5, "res")])
+def test_short_k_gemm_n_persistent_form_is_the_tiled_one_bit_for_bit(dev, precision, M, K, N, form):
+    """The set-ViT's FeedForward / to_out style GEMMs (vit_set.py:23-31): with K <= 256 and enough M-tiles one block per M-tile walks all
+    N-tiles and stores from the accumulators (conv_rs.inc, RS_1X1N) — same sums, same epilogue order as the tile-per-block form
+    (STEDM_CONV_NO_NPERS=1), ragged last M-tile included; and both against a float64 product."""
+    import os
+    from stedm_amd import ops
+    from stedm_amd._lib import F16
+    prec = ops.Precision.parse(precision)
+    ft = torch.float16 if prec.mm_dtype == F16 else torch.bfloat16
+    x = (torch.randn(M, K, device=dev) * 0.7).to(ft)
+    w = (torch.randn(N, K, 1, 1, device=dev) / math.sqrt(K)).to(ft).float()
+    bs = torch.randn(N, device=dev) * 0.3
+    res0 = torch.randn(M, N, device=dev)
+    whi, wlo = ops.pack_conv_weight(w, prec); wf = ops.pack_conv_weight_frag(w, prec)
+    v4 = lambda t: t.view(1, 1, M, -1)
+
+    def run():
+        out = res0.clone() if form == "res" else (torch.full((M, N), float("nan"), device=dev) if form == "out" else None)
+        o16 = torch.full((M, N), 0x7FFF, dtype=torch.int16, device=dev) if form in ("o16", "gelu") else None
+        ops.conv_igemm(None, whi, wlo, None if out is None else v4(out), prec=prec, ks=1, src16=(v4(x.view(torch.int16)), None), w_frag=wf, bias=bs,
+                       res=v4(out) if form == "res" else None, act_out=2 if form == "gelu" else 0, out16=None if o16 is None else (v4(o16), None))
+        return out if out is not None else o16.view(ft).float()
+
+    got = run()
+    os.environ["STEDM_CONV_NO_NPERS"] = "1"
+    try:
+        ref_tiled = run()
+    finally:
+        del os.environ["STEDM_CONV_NO_NPERS"]
+    if form == "gelu" and ft == torch.float16:     # the last multiply of the GELU and the fp16 conversion may fuse into one rounding: one ulp
+        assert torch.allclose(got, ref_tiled, rtol=1.1e-3, atol=1e-7)
+    else:
+        assert torch.equal(got, ref_tiled)
+    ref = x.double() @ w.view(N, K).double().t() + bs.double()
+    if form == "res": ref = ref + res0.double()
+    if form == "gelu": ref = F.gelu(ref)
+    assert rel(got, ref.cpu().numpy()) < (1e-5 if form in ("out", "res") else (5e-2 if precision == "bf16" else 6e-3))     # 16-bit forms: half an ulp of the largest output over the spread
 
 
 @pytest.mark.parametrize("precision,tol", [("f16", 1e-2), ("bf16", 8e-2)])
