@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(512) wgrad3x3_kernel(WgradArgs a) {
 __global__ void __launch_bounds__(256) sum_planes_kernel(const float4* __restrict__ part, float4* __restrict__ out, long n4, int nsplit, int accumulate) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     float4 v = accumulate ? out[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
+#pragma unroll 16      // (loads of 16 slices in flight, added in slice order: small filters have few columns and up to 128 slices)
     for (int z = 0; z < nsplit; ++z) {
       const float4 w = part[(long)z * n4 + i];
       v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
@@ -315,8 +315,9 @@ extern "C" int stedm_wgrad3x3_plan(int B, int H, int W, int Cin, int Cout, int* 
   const int tiles = (Cin / 128) * (Cout / 64), nunits = B * (H / (64 / W));
   int ks = cus / tiles;                          // whole slices that fit ONE round of the chip (one workgroup is resident per CU)
   const long wbytes = 9L * Cin * Cout * 4;       // every slice costs a partial of this size in HBM (written here, read by the reduce):
-  int cap = (int)((64L << 20) / wbytes);         // <= 64 MB of partials, between 16 and 32 slices (the reduce walks them serially)
-  cap = cap < 16 ? 16 : (cap > 32 ? 32 : cap);
+  int cap = (int)((64L << 20) / wbytes);         // <= 64 MB of partials, between 16 and 128 slices (the reduce walks them serially). Small filters
+  cap = cap < 16 ? 16 : (cap > 128 ? 128 : cap); // (128 -> 128 at 32 x 32: 2 tiles) were capped at 32 slices = 64 workgroups: 100 us for 19 GFLOP
+
   if (ks > cap) ks = cap;
   if (ks > nunits / 4) ks = nunits / 4;          // and >= 4 units per slice
   if (ks < 1) ks = 1;
