@@ -62,6 +62,14 @@ class UNetTrainer:
         self._touched: Optional[list] = None
         self.bucket_mb = 256            # gradient all-reduce bucket (xGMI rings are per-link bound: few, large collectives)
         self.overlap_all_reduce = True
+        # single rank, no accumulation: the optimizer of a run of parameters may start on a side stream the moment the backward has written the
+        # last of their gradients (the HBM-bound AdamW / EMA / re-pack pass then runs beside the dgrad / wgrad kernels of the layers below);
+        # same kernels on the same values as the pass after the backward (bitwise: tests/test_gpu_train.py). OFF by default — measured on
+        # MI355X (B = 64, runs of 8 .. 512 MB): 94 % of the optimizer's kernel time ran beside backward kernels, but it doubled (1.8 -> 3.9 ms
+        # per step) and the backward's kernels slowed with it: 18.96 - 19.12 ms against 18.75 ms in order. opt_bucket_mb: the run length
+        self.overlap_optimizer = os.environ.get("STEDM_TRAIN_OVERLAP_OPT", "0") != "0"
+        self.opt_bucket_mb = int(os.environ.get("STEDM_TRAIN_OPT_BUCKET_MB", "32"))
+        self.overlap_opt_fires = 0
         self.overlap_fires = 0           # all-reduces started from inside a backward so far
         self.direct_wgrad1 = True    # False: the 1x1 convolutions' weight gradients in the GEMM form
         self.wgrad_oihw = True       # the direct 3x3 kernel writes its slices in the parameter's order (False: [tap][ci][co] partials + transposing reduce)
@@ -347,7 +355,7 @@ class UNetTrainer:
 
     # ------------------------------------------------------------------------------------------------ backward
     @torch.no_grad()
-    def backward(self, d_eps: torch.Tensor, on_bucket=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    def backward(self, d_eps: torch.Tensor, on_bucket=None, sched=None) -> Tuple[torch.Tensor, torch.Tensor]:
         """d_eps [B,out,H,W] = dL/d(eps prediction). Fills `.grad` of every parameter; returns (dL/dx [B,in,H,W] over the
         concatenated [x | c_concat] input, dL/dcontext [B, 4*model_channels]). on_bucket(b): called as soon as every gradient of
         bucket b of the arena (self._sched.bounds[b]) is final — the walk runs from the output to the input, so the arena's buckets
@@ -368,8 +376,9 @@ class UNetTrainer:
             self._dpacks = {}
             self._dplan, self._dplan_key = ops.PackPlan(self.bprec), dkey
         self.internal_grads()
+        sched = self._sched if sched is None else sched       # (the all-reduce buckets, or the overlapped optimizer's shorter runs)
         if on_bucket is not None:
-            self._sched.reset()
+            sched.reset()
         B = d_eps.shape[0]
         ted = m.model_channels * 4
         self.dE = self._buf("dE", (B, m._emb_ntot))
@@ -378,7 +387,7 @@ class UNetTrainer:
         def flush():
             if on_bucket is not None:
                 for p in self._touched:
-                    b = self._sched.done(self._pidx[id(p)])
+                    b = sched.done(self._pidx[id(p)])
                     if b is not None:
                         on_bucket(b)
                 self._touched = []
@@ -665,13 +674,13 @@ class UNetTrainer:
 
     # ------------------------------------------------------------------------------------------------ loss + optimizer
     @torch.no_grad()
-    def loss_and_backward(self, x, c_concat, t, context, target, on_bucket=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    def loss_and_backward(self, x, c_concat, t, context, target, on_bucket=None, sched=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """L1 loss of ddpm.py:1030-1040 on the eps prediction, then the full backward. -> (loss [1] device tensor, dx, dcontext)"""
         pred = self.forward(x, c_concat, t, context)
         loss = self._buf("loss", (1,))
         dpred = self._buf(f"dpred.{tuple(pred.shape)}", tuple(pred.shape))
         ops.l1_loss(pred, target.float().contiguous(), dpred, self._buf("loss.ws", (1024,), torch.float64), loss)
-        dx, dctx = self.backward(dpred, on_bucket=on_bucket)
+        dx, dctx = self.backward(dpred, on_bucket=on_bucket, sched=sched)
         return loss, dx, dctx
 
     def _chunks(self, params, dev):
@@ -741,6 +750,7 @@ class UNetTrainer:
             for j, (w, sn, sc, flip, cout, cin, taps, m16, out) in enumerate(pl.items):
                 by_ptr.setdefault(w.data_ptr(), []).append((pl, j, sn, sc, flip, cout, cin, taps, m16, out))
         rec, blk, fused_idx, used = [], 0, set(), {id(pl): [] for pl in plans}
+        rec_parts = []
         prow, pciw = ops.adamw_ema_pack_piece()
         for i, p in enumerate(params):
             its = by_ptr.get(p.data_ptr())
@@ -763,6 +773,7 @@ class UNetTrainer:
             body = b"".join(o[2] for o in outs) + b"\0" * (24 * (4 - len(outs)))
             rec.append(struct.pack("<QQQQQiiiiii", int(tab[i, 0]), int(tab[i, 1]), int(tab[i, 2]), int(tab[i, 3]), int(tab[i, 4]), co, ci, taps, blk,
                                    len(outs), 0) + body)
+            rec_parts.append((i, tuple(int(tab[i, c_]) for c_ in range(5)), co, ci, taps, len(outs), body, (co // prow) * (ci // pciw)))
             blk += (co // prow) * (ci // pciw)
             fused_idx.add(i)
             for (pl, j, _) in outs:
@@ -780,6 +791,22 @@ class UNetTrainer:
             fu["co"] = torch.tensor(co_, dtype=torch.int64, device=dev)
             for pl in plans:
                 pl.set_fused(used[id(pl)])
+            # the same two launches per run of the overlapped optimizer's schedule (own tables, block offsets from 0)
+            osched = self._opt_sched()
+            fu["runs"] = []
+            for b in range(len(osched.bounds)):
+                mine = [r for r in rec_parts if osched.param_bucket[r[0]] == b]
+                rb, nb_ = [], 0
+                for (i, t5, co, ci, taps, nouts, body, nblk) in mine:
+                    rb.append(struct.pack("<QQQQQiiiiii", *t5, co, ci, taps, nb_, nouts, 0) + body)
+                    nb_ += nblk
+                cti, coi = [], []
+                for i, p in rest:
+                    if osched.param_bucket[i] == b:
+                        for o in range(0, p.numel(), 4096):
+                            cti.append(i); coi.append(o)
+                fu["runs"].append({"descs": torch.frombuffer(bytearray(b"".join(rb)), dtype=torch.uint8).to(dev) if rb else None, "n": len(rb), "blocks": nb_,
+                                   "ct": torch.tensor(cti, dtype=torch.int32, device=dev), "co": torch.tensor(coi, dtype=torch.int64, device=dev)})
         self._fused = fu
         return fu if fu["n"] else None
 
@@ -797,6 +824,33 @@ class UNetTrainer:
         """ema.py:28-31: the counter is incremented first, decay = min(decay, (1 + n) / (10 + n))."""
         self.ema_updates += 1
         return min(self.ema_decay, (1 + self.ema_updates) / (10 + self.ema_updates))
+
+    def _opt_sched(self):
+        """Runs of the arena (cut at parameter boundaries, about opt_bucket_mb each) whose optimizer pass starts inside the backward."""
+        if getattr(self, "_osched", None) is None:
+            from .parallel import BucketSchedule
+            order = self._arena_params
+            self._osched = BucketSchedule(self._arena_off, [p.numel() for p in order], self.opt_bucket_mb * (1 << 20) // 4, tail_from=self._n_unet_params,
+                                          align=4, total=self.grad_arena.numel())
+        return self._osched
+
+    def _opt_run(self, fu, b: int, decay: float, gs: float) -> None:
+        """the optimizer pass of run b of _opt_sched() on the current stream"""
+        st, r = self._opt, fu["runs"][b]
+        if r["n"]:
+            ops.adamw_ema_pack(r["descs"], r["n"], r["blocks"], self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, decay, gs)
+        if r["ct"].numel():
+            ops.adamw_ema(st["table"], r["ct"], r["co"], self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, decay, grad_scale=gs)
+
+    def _after_optimizer(self, fu) -> None:
+        self.m.invalidate()      # parameters changed through raw pointers: repack on the next forward
+        if fu is not None:
+            # ... except what this pass wrote itself: valid while neither a parameter's version nor the model's value generation
+            # (UNetModel.invalidate(): EMA swap, checkpoint load, edits through .data / raw pointers) moves
+            token = self.m.freshness_token()
+            for plan in fu["plans"]:
+                plan.mark_fresh(token)
+        self._grads_ready = False
 
     @torch.no_grad()
     def optimizer_step(self) -> None:
@@ -818,14 +872,7 @@ class UNetTrainer:
             if fu["ct"].numel():
                 ops.adamw_ema(st["table"], fu["ct"], fu["co"], self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, decay,
                               grad_scale=gs)
-        self.m.invalidate()      # parameters changed through raw pointers: repack on the next forward
-        if fu is not None:
-            # ... except what this pass wrote itself: valid while neither a parameter's version nor the model's value generation
-            # (UNetModel.invalidate(): EMA swap, checkpoint load, edits through .data / raw pointers) moves
-            token = self.m.freshness_token()
-            for plan in fu["plans"]:
-                plan.mark_fresh(token)
-        self._grads_ready = False
+        self._after_optimizer(fu)
 
     @torch.no_grad()
     def ema_step(self) -> None:
@@ -976,6 +1023,36 @@ class UNetTrainer:
                 self.overlap_fires += 1          # collectives issued from inside the backward (tests assert the overlap path really ran)
         if k > 1 and getattr(self, "_acc_arena", None) is None:
             self._acc_arena = torch.empty_like(self.grad_arena)
+        fu = None
+        if self.overlap_optimizer and not multi and k == 1 and self.fuse_packs and self._opt is not None:
+            fu = self._fused_opt()      # (None until the forward's and the backward's pack plans exist: the first steps run the plain order)
+        if fu is not None and fu.get("runs"):
+            osched = self._opt_sched()
+            self.step_count += 1
+            decay = self._next_ema_decay() if self.ema_decay is not None else 0.0
+            gs = getattr(self, "_grad_scale", 1.0)
+            if getattr(self, "_opt_stream", None) is None:
+                self._opt_stream = torch.cuda.Stream()
+            side, main = self._opt_stream, torch.cuda.current_stream()
+
+            def on_run(b):
+                ev = torch.cuda.Event()
+                ev.record(main)              # every gradient of run b has been written by kernels queued so far
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    self._opt_run(fu, b, decay, gs)
+                self.overlap_opt_fires += 1
+
+            loss, dx, dctx = self.loss_and_backward(x, c_concat, t, context, target, on_bucket=on_run, sched=osched)
+            if after_backward is not None:
+                after_backward(dx, dctx)
+            self._grads_ready = True
+            main.wait_stream(side)
+            for b in range(len(osched.bounds)):      # runs that did not complete inside the backward (the cond stage's tail, untouched parameters)
+                if not osched.fired[b]:
+                    self._opt_run(fu, b, decay, gs)
+            self._after_optimizer(fu)
+            return loss
         loss, dx, dctx = self.loss_and_backward(x, c_concat, t, context, target, on_bucket=on_bucket)
         if after_backward is not None:
             after_backward(dx, dctx)

@@ -194,6 +194,42 @@ def test_optimizer_writes_the_weight_packs_itself(dev, precision):
     assert len(ka) == len(kb) and all(torch.equal(a, b) for a, b in zip(ka, kb))
 
 
+@pytest.mark.parametrize("bucket_mb", [1, 32])
+def test_optimizer_inside_the_backward_equals_the_pass_after_it(dev, bucket_mb):
+    """Single rank, no accumulation: the optimizer pass of a run of parameters starts on a side stream as soon as the backward has written
+    the last of their gradients (UNetTrainer.overlap_optimizer). Same kernels on the same values: losses of five steps, parameters, EMA
+    shadows, optimizer moments and every weight pack bit for bit against the pass after the backward; short runs (1 MB) fire many times."""
+    from stedm_amd.train import UNetTrainer
+    cfg = dict(image_size=16, in_channels=7, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=[32, 16, 8], channel_mult=[1, 4, 8],
+               num_heads=4)
+    runs = []
+    for overlap in (True, False):
+        m = build(cfg, 6, dev, "bf16")
+        tr = UNetTrainer(m, lr=2e-4, weight_decay=0.01)
+        tr.overlap_optimizer = overlap
+        tr.opt_bucket_mb = bucket_mb
+        x, ctx, target = _inputs("fuse", cfg, 2, 16, 6, dev)
+        t = torch.tensor([951, 21], device=dev)
+        losses = [float(tr.train_step(x[:, :4].contiguous(), x[:, 4:].contiguous(), t, ctx, target)) for _ in range(5)]
+        torch.cuda.synchronize()
+        if overlap:
+            nruns = len(tr._opt_sched().bounds)
+            assert tr.overlap_opt_fires > 0 and nruns >= (8 if bucket_mb == 1 else 1), (tr.overlap_opt_fires, nruns)
+            print(f"optimizer runs per step: {nruns}, started inside the backward over 5 steps: {tr.overlap_opt_fires}")
+        else:
+            assert tr.overlap_opt_fires == 0
+        m._prepare()
+        packs = [it[8].clone() for pl in (m._plan, tr._dplan) for it in pl.items]
+        runs.append((losses, [p.detach().clone() for p in m.parameters()], [e.clone() for e in tr.ema_parameters()],
+                     [v.clone() for v in tr._opt["m"]] + [v.clone() for v in tr._opt["v"]], packs))
+    (la, pa, ea, ma, ka), (lb, pb, eb, mb, kb) = runs
+    assert la == lb, (la, lb)
+    for name, xa, xb in (("parameter", pa, pb), ("ema", ea, eb), ("moment", ma, mb), ("pack", ka, kb)):
+        assert len(xa) == len(xb)
+        for i, (a, b) in enumerate(zip(xa, xb)):
+            assert torch.equal(a, b), f"{name} {i}"
+
+
 def test_spatial_rescaler_weight_gradient_vs_oracle(dev):
     """cond_stage_trainable: channel_mapper.weight gradient from the c_concat slice of the U-Net's input gradient, against autograd
     over the oracle's restatement of SpatialRescaler.forward (encoders/modules.py:123-130)."""
