@@ -237,6 +237,15 @@ typedef struct stedm_conv_args {
   void* qkv_vt;
   int32_t qkv_T, qkv_Tp, qkv_heads;
   float qkv_qscale;
+  /* Optional (round 4, ABI 9): a LayerNorm over the output ROW in the epilogue of a 1x1 GEMM whose rows fit one N-tile (cout <= 128) — Swin-V2's
+   * res-post-norm `x = x + norm(proj(attn))` / `x + norm(mlp)` at 96 channels and the patch embedding's norm. ln_gamma != NULL:
+   * out = LayerNorm(conv + bias; ln_gamma, ln_beta, ln_eps) (+ ln_res, fp32 [M][cout], may alias `out`), written as fp32 `out` and / or 16-bit
+   * `out16_hi`. Needs a single-product mode, no res / emb / chan_stats / act_out / out16_lo, cout %% 4 == 0; only the register-streamed kernel has
+   * this epilogue (stedm_conv_rs_ok tells). Replaces the GEMM's fp32 output + stedm_swin_ln. */
+  const float* ln_gamma;
+  const float* ln_beta;
+  const float* ln_res;
+  float ln_eps;
 } stedm_conv_args;
 /* Replaces: GN->SiLU->conv3x3(+bias)(+emb)(+skip) of ResBlock._forward openaimodel.py:268-288,
  * Downsample/Upsample convs (:122-132,:156-173), 1x1 skip_connection (:254), and the 1x1

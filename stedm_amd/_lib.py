@@ -41,6 +41,7 @@ class ConvArgs(C.Structure):
         ("gn_out16_lo", C.c_void_p),
         ("qkv_q", C.c_void_p), ("qkv_k", C.c_void_p), ("qkv_vt", C.c_void_p),
         ("qkv_T", C.c_int32), ("qkv_Tp", C.c_int32), ("qkv_heads", C.c_int32), ("qkv_qscale", C.c_float),
+        ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_res", C.c_void_p), ("ln_eps", C.c_float),
     ]
 
 

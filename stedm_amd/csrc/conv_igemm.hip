@@ -375,6 +375,10 @@ extern "C" int stedm_conv_igemm(const stedm_conv_args* args, void* stream) {
 static int conv_setup(ConvParams& p) {
   const stedm_conv_args& a = p.a;
   STEDM_CHECK_ARG((a.src1 || a.src16_hi) && (a.w_hi || (a.mode == STEDM_CONV_S2D && a.w_frag)) && (a.out || a.out16_hi || a.qkv_q), "conv_igemm: null src/w_hi/out");
+  STEDM_CHECK_ARG(!a.ln_gamma || (a.ln_beta && (a.out || a.out16_hi) && !a.out16_lo && !a.res && !a.emb && !a.chan_stats && !a.gn_out16 && !a.act_out && !a.qkv_q &&
+                                  a.src16_hi && !a.src1 && !a.src16b_hi && a.w_frag && a.ks == 1 && a.mode == STEDM_CONV_S1 && a.npass == 1 && a.cout <= 128 &&
+                                  a.cout % 4 == 0),
+                  "conv_igemm: the LayerNorm epilogue needs a 1x1 GEMM with cout <= 128 (a multiple of 4), src16 + w_frag, a single-product mode and no other epilogue extra");
   STEDM_CHECK_ARG(!a.qkv_q || (a.qkv_k && a.qkv_vt && !a.out && !a.out16_hi && !a.res && !a.emb && !a.chan_stats && !a.gn_out16 && !a.act_out && a.src16_hi && !a.src1 &&
                                !a.src16b_hi && a.w_frag && a.ks == 1 && a.mode == STEDM_CONV_S1 && a.npass == 1 && a.B == 1 && a.Hin == 1 && a.qkv_heads > 0 &&
                                a.qkv_heads % 2 == 0 && a.cout == 3 * a.qkv_heads * 64 && a.qkv_T > 0 && a.qkv_T % 2 == 0 && a.qkv_Tp >= a.qkv_T &&

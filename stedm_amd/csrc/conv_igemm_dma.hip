@@ -27,6 +27,7 @@ int stedm::conv_launch_dma(ConvParams& p, hipStream_t st, bool dry) {
   int rc = a.npass == 3 ? (f16 ? conv_dma_pick_f16_p3(p, st, dry) : conv_dma_pick_bf16_p3(p, st, dry))
                         : (f16 ? conv_dma_pick_f16_p1(p, st, dry) : conv_dma_pick_bf16_p1(p, st, dry));
   if (dry) return rc < 0 ? 1 : 0;
+  if (rc < 0 && a.ln_gamma) { set_error("conv_igemm(dma): the register-streamed kernel does not run this LayerNorm-epilogue problem (see stedm_conv_rs_ok)"); return 1; }
   if (rc < 0 && a.qkv_q) { set_error("conv_igemm(dma): the register-streamed kernel does not run this qkv-epilogue problem (see stedm_conv_rs_ok)"); return 1; }
   if (rc < 0 && a.src16b_hi) { set_error("conv_igemm(dma): no kernel runs this fused skip problem (see stedm_conv_fused_skip_ok)"); return 1; }
   if (rc < 0) { set_error("conv_igemm(dma): no tile configuration fits (Hin=%d Win=%d mode=%d Cin=%d)", a.Hin, a.Win, a.mode, p.Cin); return 1; }

@@ -397,11 +397,13 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
                chan_stats: Optional[torch.Tensor] = None,
                skip: Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = None, query_fused: bool = False, query_rs: bool = False,
                ws: Optional[torch.Tensor] = None, pad_br: bool = False, w_frag16: Optional[torch.Tensor] = None,
-               gn_next: Optional[tuple] = None, qkv_planes: Optional[tuple] = None):
+               gn_next: Optional[tuple] = None, qkv_planes: Optional[tuple] = None, ln_after: Optional[tuple] = None):
     """src1 [B,Hin,Win,c1] NHWC fp32 (fused path) and/or src16 = (hi, lo) 16-bit NHWC planes [B,Hin,Win,Cin] from
     gn_apply16 (DMA path) -> out [B,Hout,Wout,cout] NHWC fp32 (see stedm_conv_igemm).
     qkv_planes = (q, k, vt, T, Tp, heads, qscale): the LSA attention's operand planes as the only output of a flat to_qkv GEMM
-    (stedm_conv_args.qkv_*; out and out16 None)."""
+    (stedm_conv_args.qkv_*; out and out16 None).
+    ln_after = (gamma, beta, eps, res): LayerNorm over the output row (cout <= 128) + optional fp32 residual in the epilogue
+    (stedm_conv_args.ln_*): out / out16 receive LayerNorm(conv + bias) + res."""
     if out is not None:
         _chk(out, name="out")
     a = ConvArgs()
@@ -445,6 +447,14 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
     if out16 is not None:
         a.out16_hi = out16[0].data_ptr()
         a.out16_lo = _ptr(out16[1]) if prec.npass == 3 else None
+    if ln_after is not None:
+        l_g, l_b, l_eps, l_res = ln_after
+        _chk(l_g, name="ln gamma"); _chk(l_b, name="ln beta")
+        assert res is None and prec.npass == 1 and (out is not None or out16 is not None)
+        a.ln_gamma, a.ln_beta, a.ln_eps = l_g.data_ptr(), l_b.data_ptr(), float(l_eps)
+        if l_res is not None:
+            _chk(l_res, name="ln residual")
+            a.ln_res = l_res.data_ptr()
     if qkv_planes is not None:
         qq, qk, qv, qT, qTp, qH, qs = qkv_planes
         assert out is None and out16 is None and prec.npass == 1 and src16 is not None

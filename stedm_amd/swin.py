@@ -15,6 +15,7 @@ torch.nn modules are parameter containers; `forward` launches HIP kernels throug
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -115,6 +116,8 @@ class SwinTransformerV2(nn.Module):
                     nn.init.zeros_(m.bias)
         self.precision = Precision.parse(precision) if isinstance(precision, str) else precision
         self.chunk_images = chunk_images
+        # rows of <= 128 channels: the post-norm LayerNorm (+ residual) runs in the producing GEMM's epilogue; STEDM_SWIN_FUSE_LN=0: its own pass
+        self.fuse_ln = os.environ.get("STEDM_SWIN_FUSE_LN", "1") != "0"
         # train-mode stochastic depth (torchvision: StochasticDepth(p_i, "row") on both residual branches of block i, p_i rising linearly to
         # stochastic_depth_prob over all blocks). `sd_gates` ([blocks, 2, N] fp32, = bernoulli(1 - p_i) / (1 - p_i)) overrides the draw (tests).
         nb = sum(depths)
@@ -211,11 +214,25 @@ class SwinTransformerV2(nn.Module):
         self._packed = P
         self._pack_key = key
 
-    def _gemm(self, a16, w, M, bias=None, res=None, out=None, act_out=0, out16=None):
+    def _gemm(self, a16, w, M, bias=None, res=None, out=None, act_out=0, out16=None, ln_after=None, query_rs=False):
         """[M, K] 16-bit planes x packed [N][1][K] weights on the DMA conv kernels (1x1 conv view [1, 1, M, K])."""
         v = lambda t: None if t is None else t.view(1, 1, M, -1)
-        ops.conv_igemm(None, w[0], w[1], v(out), prec=self.precision, ks=1, src16=(v(a16[0]), v(a16[1])), bias=bias, res=v(res),
-                       act_out=act_out, out16=None if out16 is None else (v(out16[0]), v(out16[1])), w_frag=w[2])
+        return ops.conv_igemm(None, w[0], w[1], v(out), prec=self.precision, ks=1, src16=(v(a16[0]), v(a16[1])), bias=bias, res=v(res),
+                              act_out=act_out, out16=None if out16 is None else (v(out16[0]), v(out16[1])), w_frag=w[2], ln_after=ln_after,
+                              query_rs=query_rs)
+
+    def _gemm_ln(self, a16, w, M, bias, norm, res, xc, x16, y, gate=None, rows_per_gate=1):
+        """x = (res +) norm(a16 @ w^T + bias) -> fp32 xc and the operand planes x16. Rows of up to 128 channels (stage 1, the patch embedding)
+        without a stochastic-depth gate: the GEMM's epilogue normalises the row itself (stedm_conv_args.ln_*: no fp32 GEMM output, no LayerNorm
+        pass); otherwise the GEMM writes y and stedm_swin_ln follows."""
+        prec = self.precision
+        ln = (norm.weight, norm.bias, norm.eps, res)
+        if (self.fuse_ln and gate is None and prec.npass == 1 and xc.shape[-1] <= 128 and xc.shape[-1] % 4 == 0
+                and self._gemm(a16, w, M, bias=bias, out=xc, out16=(x16[0], None), ln_after=ln, query_rs=True)):
+            self._gemm(a16, w, M, bias=bias, out=xc, out16=(x16[0], None), ln_after=ln)
+            return
+        self._gemm(a16, w, M, bias=bias, out=y)
+        ops.swin_ln(y, norm.weight, norm.bias, norm.eps, res, xc, x16[0], x16[1], prec, gate=gate, rows_per_gate=rows_per_gate)
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -251,10 +268,9 @@ class SwinTransformerV2(nn.Module):
         ops.swin_patch16(x, pe16[0], pe16[1], prec)
         y = self._buf("y0", (M, dim))
         conv, ln0 = self.features[0][0], self.features[0][2]
-        self._gemm(pe16, P["pe"], M, bias=conv.bias, out=y)
         xc = self._buf("x0", (M, dim))
         x16 = self._planes("x16.0", (M, dim))
-        ops.swin_ln(y, ln0.weight, ln0.bias, ln0.eps, None, xc, x16[0], x16[1], prec)
+        self._gemm_ln(pe16, P["pe"], M, conv.bias, ln0, None, xc, x16, y)
         bi = 0          # block index over all stages (stochastic-depth gate row)
         for s, (blocks, merge) in enumerate(self._stages()):
             heads = self.heads[s]
@@ -272,17 +288,15 @@ class SwinTransformerV2(nn.Module):
                 else:
                     self._gemm(x16, P["qkv" + nm], M, bias=P["qkvb" + nm], out=qkv)
                 ops.swin_window_attn(qkv, P["qkvb" + nm], P["scale" + nm], P["rpb" + nm], att[0], att[1], N, H, W, heads, at.shift_size[0], prec)
-                self._gemm(att, P["proj" + nm], M, bias=at.proj.bias, out=y)
                 g1 = g2 = None
                 if self._gates is not None and self.sd_probs[bi] > 0:
                     g1, g2 = (self._gates[bi, j, n0:n0 + N].contiguous() for j in (0, 1))
                 bi += 1
-                ops.swin_ln(y, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, xc, xc, x16[0], x16[1], prec, gate=g1, rows_per_gate=H * W)     # x = x + sd(norm1(attn(x)))
+                self._gemm_ln(att, P["proj" + nm], M, at.proj.bias, blk.norm1, xc, xc, x16, y, gate=g1, rows_per_gate=H * W)     # x = x + sd(norm1(attn(x)))
                 hid = blk.mlp[0].out_features
                 h16 = self._planes(f"h{s}", (M, hid))
                 self._gemm(x16, P["fc1" + nm], M, bias=blk.mlp[0].bias, act_out=2, out16=h16)                      # GELU(Linear)
-                self._gemm(h16, P["fc2" + nm], M, bias=blk.mlp[3].bias, out=y)
-                ops.swin_ln(y, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, xc, xc, x16[0], x16[1], prec, gate=g2, rows_per_gate=H * W)     # x = x + sd(norm2(mlp(x)))
+                self._gemm_ln(h16, P["fc2" + nm], M, blk.mlp[3].bias, blk.norm2, xc, xc, x16, y, gate=g2, rows_per_gate=H * W)                   # x = x + sd(norm2(mlp(x)))
             if merge is not None:
                 Ho, Wo = (H + 1) // 2, (W + 1) // 2
                 Mo = N * Ho * Wo

@@ -118,7 +118,7 @@ def test_to_qkv_epilogue_writes_the_attention_planes(dev, precision, nb, T, head
 
 @pytest.mark.parametrize("precision", ["bf16", "f16"])
 @pytest.mark.parametrize("M,K,N,form", [(50000, 256, 256, "out"), (50000, 256, 384, "res"), (49153, 128, 256, "o16"), (50000, 256, 256, "gelu"),
-                                        (65536, 192, 128 * 5, "res")])
+                                        (65536, 192, 128 * 5, "res"), (50000, 128, 288, "o16"), (50000, 192, 576, "gelu"), (49999, 256, 200, "res")])      # ragged last N-tile
 def test_short_k_gemm_n_persistent_form_is_the_tiled_one_bit_for_bit(dev, precision, M, K, N, form):
     """The set-ViT's FeedForward / to_out style GEMMs (vit_set.py:23-31): with K <= 256 and enough M-tiles one block per M-tile walks all
     N-tiles and stores from the accumulators (conv_rs.inc, RS_1X1N) — same sums, same epilogue order as the tile-per-block form

@@ -54,6 +54,37 @@ def make_swin(dev, precision="parity", classes=512, **kw):
     return m.to(dev), params
 
 
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+@pytest.mark.parametrize("M,K,N,res", [(70000, 128, 96, True), (70000, 384, 96, True), (33333, 64, 96, False), (40000, 128, 128, True), (50001, 192, 64, False)])
+def test_gemm_with_layernorm_epilogue(dev, precision, M, K, N, res):
+    """x = (res +) LayerNorm(a @ w^T + bias) in the 1x1 GEMM's epilogue (stedm_conv_args.ln_*; Swin-V2's res-post-norm at 96 channels,
+    torchvision swin_transformer.py SwinTransformerBlockV2.forward) against the GEMM's fp32 output + torch's layer_norm; in place on the
+    residual stream as the embedder calls it; ragged last M-tile."""
+    from stedm_amd import ops
+    from stedm_amd._lib import F16
+    prec = ops.Precision.parse(precision)
+    ft = torch.float16 if prec.mm_dtype == F16 else torch.bfloat16
+    x16 = (torch.randn(M, K, device=dev) * 0.7).to(ft).view(torch.int16)
+    w = torch.randn(N, K, 1, 1, device=dev) / math.sqrt(K)
+    bs = torch.randn(N, device=dev) * 0.3
+    g = torch.randn(N, device=dev) * 0.2 + 1.0; b = torch.randn(N, device=dev) * 0.1
+    r0 = torch.randn(M, N, device=dev) if res else None
+    whi, wlo = ops.pack_conv_weight(w, prec); wf = ops.pack_conv_weight_frag(w, prec)
+    v4 = lambda t: t.view(1, 1, M, -1)
+    y = torch.empty(M, N, device=dev)
+    ops.conv_igemm(None, whi, wlo, v4(y), prec=prec, ks=1, src16=(v4(x16), None), w_frag=wf, bias=bs)
+    ref = torch.nn.functional.layer_norm(y.double(), (N,), g.double(), b.double(), 1e-5)
+    if res: ref = ref + r0.double()
+    xc = r0.clone() if res else torch.full((M, N), float("nan"), device=dev)
+    h16 = torch.full((M, N), 0x7FFF, dtype=torch.int16, device=dev)
+    kw = dict(prec=prec, ks=1, src16=(v4(x16), None), w_frag=wf, bias=bs, out16=(v4(h16), None), ln_after=(g, b, 1e-5, xc if res else None))
+    assert ops.conv_igemm(None, whi, wlo, v4(xc), query_rs=True, **kw)
+    ops.conv_igemm(None, whi, wlo, v4(xc), **kw)
+    err = float((xc.double() - ref).abs().max()) / float(ref.std())
+    assert err < 1e-5, err
+    assert torch.equal(h16.view(ft), xc.to(ft))
+
+
 def test_swin_rpb_and_buffers_match_oracle(dev):
     from oracle import swin as osw
     from stedm_amd import ops
