@@ -896,7 +896,8 @@ __global__ void axpby_kernel(const float* __restrict__ x, float* __restrict__ y,
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   const float4 a = reinterpret_cast<const float4*>(x)[i];
-  float4 b = reinterpret_cast<float4*>(y)[i];
+  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (beta != 0.f) b = reinterpret_cast<float4*>(y)[i];      // beta = 0 starts an accumulation window: y may hold anything (NaN included), as in BLAS
   b.x = alpha * a.x + beta * b.x; b.y = alpha * a.y + beta * b.y; b.z = alpha * a.z + beta * b.z; b.w = alpha * a.w + beta * b.w;
   reinterpret_cast<float4*>(y)[i] = b;
 }

@@ -248,6 +248,18 @@ def test_spatial_rescaler_weight_gradient_vs_oracle(dev):
     assert torch.allclose(g2.cpu(), 2 * w.grad, rtol=1e-5, atol=1e-5)
 
 
+def test_axpby_with_beta_zero_does_not_read_the_destination(dev):
+    """stedm_axpby_f32 opens an accumulation window with beta = 0 on a torch.empty arena: whatever the memory held (a NaN from a freed test
+    tensor turned every gradient of the window into NaN) must not enter the result."""
+    from stedm_amd import ops
+    x = torch.randn(4096, device=dev)
+    y = torch.full((4096,), float("nan"), device=dev)
+    ops.axpby(x, y, 0.5, 0.0)
+    assert torch.equal(y, 0.5 * x)
+    ops.axpby(x, y, 0.25, 1.0)
+    assert torch.allclose(y, 0.75 * x, rtol=1e-6, atol=0)
+
+
 def test_gradient_accumulation_equals_the_full_batch(dev, golden):
     """accumulate_grad_batches = 2 over the two samples of the F14 case reproduces the full-batch gradient of the reference (the L1 loss is a
     mean of per-sample means); the optimizer runs only on the second micro-batch."""
