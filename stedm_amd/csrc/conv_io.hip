@@ -159,23 +159,79 @@ __global__ void __launch_bounds__(256) conv_out_kernel(const float* __restrict__
   const int y0 = (t / tc) * CO_TR, x0 = (t % tc) * CO_TC;
   const int cpg = c / groups;
   const int HW = H * W;
-  for (int ch = threadIdx.x; ch < c; ch += 256) {
-    const int g = ch / cpg;
-    double su = 0.0, sq = 0.0;
-    for (int k = 0; k < nslab; ++k)          // fixed order: slab, then channel of the group
-      for (int cc = g * cpg; cc < (g + 1) * cpg; ++cc) {
-        const float* p = cs + (((long)b * nslab + k) * c + cc) * 2;
-        su += (double)p[0];
-        sq += (double)p[1];
+  // The patch chunks are software-pipelined through registers: chunk k + 1 is requested before chunk k is multiplied, and chunk 0 before the
+  // statistics are folded (a workgroup used to walk statistics -> chunk load -> products -> next chunk load strictly in sequence: 40 us per
+  // launch at any batch size, all of it memory latency — every workgroup of the grid is resident at once)
+  constexpr int NPRE = (PR * PC * (CO_CH / 4) + 255) / 256;
+  float4 pre[NPRE];
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+      const int i = threadIdx.x + j * 256;
+      const int q = i % (CO_CH / 4);
+      const int pc = (i / (CO_CH / 4)) % PC;
+      const int pr = i / ((CO_CH / 4) * PC);
+      const int sy = y0 + pr - 1, sxx = x0 + pc - 1;
+      pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < PR * PC * (CO_CH / 4) && sy >= 0 && sy < H && sxx >= 0 && sxx < W && c0 + q * 4 < c)
+        pre[j] = *reinterpret_cast<const float4*>(src + (((long)b * H + sy) * W + sxx) * c + c0 + q * 4);
+    }
+  };
+  auto stash = [&](int c0) {      // GroupNorm + SiLU on the way into LDS; halo / padding positions stay exactly zero
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+      const int i = threadIdx.x + j * 256;
+      if (i >= PR * PC * (CO_CH / 4)) continue;
+      const int q = i % (CO_CH / 4);
+      const int pc = (i / (CO_CH / 4)) % PC;
+      const int pr = i / ((CO_CH / 4) * PC);
+      const int sy = y0 + pr - 1, sxx = x0 + pc - 1;
+      float4 v = pre[j];
+      if (sy >= 0 && sy < H && sxx >= 0 && sxx < W && c0 + q * 4 < c) {
+        const int cc = c0 + q * 4;
+        v.x = silu_f(fmaf(v.x, sscale[cc], sshift[cc])); v.y = silu_f(fmaf(v.y, sscale[cc + 1], sshift[cc + 1]));
+        v.z = silu_f(fmaf(v.z, sscale[cc + 2], sshift[cc + 2])); v.w = silu_f(fmaf(v.w, sscale[cc + 3], sshift[cc + 3]));
       }
-    const double inv_n = 1.0 / ((double)cpg * HW);
-    const double mean = su * inv_n;
-    double var = sq * inv_n - mean * mean;
-    var = var > 0.0 ? var : 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float gm = gamma[ch] * rstd;
-    sscale[ch] = gm;
-    sshift[ch] = beta[ch] - (float)mean * gm;
+      *reinterpret_cast<float4*>(sx + (pr * PC + pc) * PST + q * 4) = v;
+    }
+  };
+  fetch(0);
+  // statistics: a thread sums the slab partials of ONE channel (independent loads), the group totals are folded from LDS in channel order
+  double* dsum = reinterpret_cast<double*>(sx);     // [c][2] (the patch area is not in use yet)
+  for (int ch = threadIdx.x; ch < c; ch += 256) {
+    double su = 0.0, sq = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < nslab; ++k) {
+      const float2 pp = *reinterpret_cast<const float2*>(cs + (((long)b * nslab + k) * c + ch) * 2);
+      su += (double)pp.x;
+      sq += (double)pp.y;
+    }
+    dsum[ch * 2] = su; dsum[ch * 2 + 1] = sq;
+  }
+  __syncthreads();
+  float my_scale[4], my_shift[4];                   // (c <= 1024 on this path: the LDS check of the launcher)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ch = threadIdx.x + j * 256;
+    my_scale[j] = 0.f; my_shift[j] = 0.f;
+    if (ch < c) {
+      const int g = ch / cpg;
+      double su = 0.0, sq = 0.0;
+      for (int cc = g * cpg; cc < (g + 1) * cpg; ++cc) { su += dsum[cc * 2]; sq += dsum[cc * 2 + 1]; }      // fixed order
+      const double inv_n = 1.0 / ((double)cpg * HW);
+      const double mean = su * inv_n;
+      double var = sq * inv_n - mean * mean;
+      var = var > 0.0 ? var : 0.0;
+      const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+      my_scale[j] = gamma[ch] * rstd;
+      my_shift[j] = beta[ch] - (float)mean * my_scale[j];
+    }
+  }
+  __syncthreads();                                  // every thread is done reading dsum (it aliases the patch area)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ch = threadIdx.x + j * 256;
+    if (ch < c) { sscale[ch] = my_scale[j]; sshift[ch] = my_shift[j]; }
   }
   const int pix = threadIdx.x & 127;
   const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);   // wave-uniform: keeps the weight index scalar
@@ -184,21 +240,9 @@ __global__ void __launch_bounds__(256) conv_out_kernel(const float* __restrict__
 #pragma unroll
   for (int o = 0; o < COUTP; ++o) acc[o] = 0.f;
   for (int c0 = 0; c0 < c; c0 += CO_CH) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < PR * PC * (CO_CH / 4); i += 256) {
-      const int q = i % (CO_CH / 4);
-      const int pc = (i / (CO_CH / 4)) % PC;
-      const int pr = i / ((CO_CH / 4) * PC);
-      const int sy = y0 + pr - 1, sxx = x0 + pc - 1;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (sy >= 0 && sy < H && sxx >= 0 && sxx < W && c0 + q * 4 < c) {
-        v = *reinterpret_cast<const float4*>(src + (((long)b * H + sy) * W + sxx) * c + c0 + q * 4);
-        const int cc = c0 + q * 4;
-        v.x = silu_f(fmaf(v.x, sscale[cc], sshift[cc])); v.y = silu_f(fmaf(v.y, sscale[cc + 1], sshift[cc + 1]));
-        v.z = silu_f(fmaf(v.z, sscale[cc + 2], sshift[cc + 2])); v.w = silu_f(fmaf(v.w, sscale[cc + 3], sshift[cc + 3]));
-      }
-      *reinterpret_cast<float4*>(sx + (pr * PC + pc) * PST + q * 4) = v;
-    }
+    __syncthreads();                                // scale / shift visible (first chunk); the previous chunk's products are done with sx
+    stash(c0);
+    if (c0 + CO_CH < c) fetch(c0 + CO_CH);
     __syncthreads();
     const int cb = c0 + half * (CO_CH / 2);          // first channel of this half (uniform)
 #pragma unroll
@@ -237,8 +281,8 @@ extern "C" int stedm_conv_out(const float* src, int c, const float* chan_stats, 
                               float eps, int groups, const float* w, const float* bias, float* out, int B, int H, int W,
                               int cout, void* stream) {
   STEDM_CHECK_ARG(src && chan_stats && gamma && beta && w && out && nslab > 0, "conv_out: null pointer / nslab");
-  STEDM_CHECK_ARG(c % 32 == 0 && cout >= 1 && cout <= CO_MAXOUT && groups > 0 && c % groups == 0,
-                  "conv_out: need c %% 32 == 0, c %% groups == 0 and cout <= %d (c=%d cout=%d)", CO_MAXOUT, c, cout);
+  STEDM_CHECK_ARG(c % 32 == 0 && c <= 1024 && cout >= 1 && cout <= CO_MAXOUT && groups > 0 && c % groups == 0,
+                  "conv_out: need c %% 32 == 0, c <= 1024, c %% groups == 0 and cout <= %d (c=%d cout=%d)", CO_MAXOUT, c, cout);
   const int coutp = cout <= 4 ? 4 : 8;
   const size_t lds = ((size_t)2 * c + (size_t)(CO_TR + 2) * (CO_TC + 2) * (CO_CH + 4) + 128 * coutp) * sizeof(float);
   STEDM_CHECK_ARG(lds <= 64 * 1024, "conv_out: needs %zu B LDS", lds);
