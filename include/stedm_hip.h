@@ -99,6 +99,9 @@ int stedm_pack_conv_weight_frag16(const float* w, long sn, long sc, int flip, vo
  * stride-1 3x3 problems from 128 input channels run on the register-streamed kernel (three MFMAs per fragment pair); w_hi / w_lo must still be
  * given: every other problem takes the LDS-operand kernels as before. */
 int stedm_pack_conv_weight_frag16_hl(const float* w, long sn, long sc, int flip, void* out, int cout, int cin, int mm_dtype, void* stream);
+/* ... of a 1x1 filter (ABI 9; the 3-product modes' skip_connection openaimodel.py:254, qkv / proj_out :343-346 on the register-streamed kernel):
+ * out = [2][ceil(cout / 128)][cin / 32][1][8][512] 16-bit (hi stream, then lo stream), passed as stedm_conv_args.w_frag16 with ks = 1. */
+int stedm_pack_conv_weight_frag16_hl1(const float* w, long sn, long sc, int flip, void* out, int cout, int cin, int mm_dtype, void* stream);
 int stedm_pack_conv_weight_s2d_frag(const float* w_oihw, void* out, int cout, int cin, int mm_dtype, int pad_br, void* stream);
 /* [rows][cols] fp32 -> [cols][rows] fp32 (Linear weights are consumed K-major). */
 int stedm_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);

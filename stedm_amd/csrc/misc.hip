@@ -352,6 +352,21 @@ extern "C" int stedm_pack_conv_weight_frag16_hl(const float* w, long sn, long sc
   return 0;
 }
 
+// ... of a 1x1 filter (skip_connection, qkv, proj_out in the 3-product modes): out = [2][ceil(cout / 128)][cin / 32][1][8][512]
+extern "C" int stedm_pack_conv_weight_frag16_hl1(const float* w, long sn, long sc, int flip, void* out, int cout, int cin, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(w && out && cin % 32 == 0 && cout > 0, "pack_conv_weight_frag16_hl1: bad args (cin %% 32)");
+  STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "pack_conv_weight_frag16_hl1: bad mm_dtype %d", mm_dtype);
+  const long total = (long)((cout + 127) / 128) * (cin / 32) * 8 * 64 * 8;
+  const int grid = ((cout + 127) / 128) * (cin / 32) * 4;
+  hipStream_t st = as_stream(stream);
+  if (mm_dtype == STEDM_F16)
+    pack_conv_weight_frag_kernel<_Float16, 1, true><<<grid, 256, 0, st>>>(w, (_Float16*)out, cout, cin, total, sn, sc, flip, (_Float16*)out + total);
+  else
+    pack_conv_weight_frag_kernel<__bf16, 1, true><<<grid, 256, 0, st>>>(w, (__bf16*)out, cout, cin, total, sn, sc, flip, (__bf16*)out + total);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
 // STEDM_CONV_S2D weights: the stride-2 3x3 as a 2x2 conv over the 4 parity blocks of the space-to-depth planes, fragment order
 template <typename T>
 __global__ void pack_conv_weight_s2d_frag_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, long total, int pad_br) {

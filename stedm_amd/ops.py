@@ -149,11 +149,10 @@ def pack_conv_weight_frag16(w: torch.Tensor, prec: Precision, sn: Optional[int] 
         sn, sc = cin * ks * ks, ks * ks
     _chk(w, name="conv weight")
     assert cin % 32 == 0
-    if prec.npass == 3:      # 3-product mode: [2] = the hi stream, then the lo stream (3x3 only)
-        assert ks == 3
-        out = torch.empty((2, (cout + 127) // 128, cin // 32, 9, 8, 64, 8), dtype=torch.int16, device=w.device)
-        check(lib().stedm_pack_conv_weight_frag16_hl(w.data_ptr(), sn, sc, int(flip), out.data_ptr(), cout, cin, prec.mm_dtype, _stream()),
-              "stedm_pack_conv_weight_frag16_hl")
+    if prec.npass == 3:      # 3-product mode: [2] = the hi stream, then the lo stream
+        out = torch.empty((2, (cout + 127) // 128, cin // 32, ks * ks, 8, 64, 8), dtype=torch.int16, device=w.device)
+        fn = lib().stedm_pack_conv_weight_frag16_hl if ks == 3 else lib().stedm_pack_conv_weight_frag16_hl1
+        check(fn(w.data_ptr(), sn, sc, int(flip), out.data_ptr(), cout, cin, prec.mm_dtype, _stream()), "stedm_pack_conv_weight_frag16_hl")
         return out
     out = torch.empty(((cout + 127) // 128, cin // 32, ks * ks, 8, 64, 8), dtype=torch.int16, device=w.device)
     check(lib().stedm_pack_conv_weight_frag16(w.data_ptr(), sn, sc, int(flip), out.data_ptr(), cout, cin, ks, prec.mm_dtype, _stream()),

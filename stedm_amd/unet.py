@@ -319,7 +319,8 @@ class UNetModel(nn.Module):
                 else:
                     pk.hi, pk.lo = ops.pack_conv_weight(conv.weight.float(), prec)
                     if pk.frag16 is not None:     # 3-product mode: the hi + lo fragment streams
-                        pk.frag16 = ops.pack_conv_weight_frag16(conv.weight.detach().float(), prec)
+                        wf = conv.weight.detach().float()
+                        pk.frag16 = ops.pack_conv_weight_frag16((wf.unsqueeze(-1) if wf.dim() == 3 else wf).contiguous(), prec)
                 return
             hi = lo = frag = None
             w4 = conv.weight.detach().float()
@@ -347,10 +348,11 @@ class UNetModel(nn.Module):
                 hi = ops.LazyPlanes(lambda w=conv.weight: ops.pack_conv_weight(w.float(), prec))
             else:
                 hi, lo = ops.pack_conv_weight(conv.weight.float(), prec)
-                if self.conv_path == "dma" and prec.npass == 3 and k3 and self._m16 and conv.in_channels % 32 == 0 and conv.in_channels >= 128:
-                    # 3-product mode on the register-streamed kernel (conv_rs.inc P3): hi + lo fragment streams; the planes above stay for
-                    # the problems it does not take
-                    frag16 = ops.pack_conv_weight_frag16(w4, prec)
+                if self.conv_path == "dma" and prec.npass == 3 and self._m16 and conv.in_channels % 32 == 0 and (
+                        (k3 and conv.in_channels >= 128) or (tuple(w4.shape[2:]) == (1, 1) and conv.in_channels >= 64)):
+                    # 3-product mode on the register-streamed kernel (conv_rs.inc P3: 3x3, and 1x1 = RS_1X1M): hi + lo fragment streams; the
+                    # planes above stay for the problems it does not take
+                    frag16 = ops.pack_conv_weight_frag16(w4.contiguous(), prec)
             self._packed[id(conv)] = _Packed(hi, lo, None if conv.bias is None else conv.bias.detach().float().contiguous(), frag, frag16)
 
         for m in self.modules():
@@ -545,7 +547,8 @@ class UNetModel(nn.Module):
             elif fused:
                 ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias, ps.frag16), **kw)
             else:
-                ops.conv_igemm(None, ps.hi, ps.lo, out, prec=prec, ks=1, src16=x16, bias=ps.bias, w_frag=ps.frag, ws=ws)
+                ops.conv_igemm(None, ps.hi, ps.lo, out, prec=prec, ks=1, src16=x16, bias=ps.bias, w_frag=ps.frag, ws=ws,
+                               w_frag16=ps.frag16 if prec.npass == 3 else None)
                 ops.conv_igemm(None, pk2.hi, pk2.lo, out, res=out, **kw)
             return out
         if not has_skip:
@@ -587,7 +590,8 @@ class UNetModel(nn.Module):
             return out
         qkv = self._buf(tag + ".qkv", (B, H, W, 3 * Cc))
         if dma:
-            ops.conv_igemm(None, pq.hi, pq.lo, qkv, prec=prec, ks=1, src16=self._norm16(ab.norm, 0, x), bias=pq.bias, w_frag=pq.frag)
+            ops.conv_igemm(None, pq.hi, pq.lo, qkv, prec=prec, ks=1, src16=self._norm16(ab.norm, 0, x), bias=pq.bias, w_frag=pq.frag,
+                           w_frag16=pq.frag16 if prec.npass == 3 else None)
         else:
             sc, sh = self._gn(tag + ".gn", ab.norm, x)
             ops.conv_igemm(x, pq.hi, pq.lo, qkv, prec=prec, ks=1, scale=sc, shift=sh, act=0, bias=pq.bias)
@@ -597,7 +601,7 @@ class UNetModel(nn.Module):
             self._tape.append(("attn", ab, x, qkv, a, out))
         if dma:
             ops.conv_igemm(None, pp.hi, pp.lo, out, prec=prec, ks=1, src16=self._norm16(None, 0, a), bias=pp.bias, res=x, w_frag=pp.frag,
-                           chan_stats=self._cs_new(out))
+                           chan_stats=self._cs_new(out), w_frag16=pp.frag16 if prec.npass == 3 else None)
         else:
             ops.conv_igemm(a, pp.hi, pp.lo, out, prec=prec, ks=1, bias=pp.bias, res=x)
         return out

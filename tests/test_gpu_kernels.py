@@ -489,6 +489,20 @@ def test_conv_dma_3x3(dev, prec, tol, B, H, W, cin, cout):
     _conv_dma_case(dev, prec, tol, B, H, W, cin, cout, "s1", 3)
 
 
+@pytest.mark.parametrize("prec", ["parity", "parity_bf16"])
+@pytest.mark.parametrize("B,H,W,cin,cout,emb,res,ws", [
+    (128, 8, 8, 2048, 1024, False, False, False),     # a decoder skip_connection of the NS32 step
+    (128, 16, 16, 640, 512, True, True, False), (200, 16, 16, 64, 160, False, True, False), (801, 8, 8, 96, 32, True, False, False),
+    (3, 128, 128, 64, 64, False, True, False), (130, 8, 8, 1024, 3072, False, False, False),     # an AttentionBlock's qkv
+    (2, 16, 16, 512, 512, False, True, True), (4, 8, 8, 1024, 256, True, True, True)])          # small grids: K split over the workspace
+def test_conv_1x1_three_product_register_streamed(dev, prec, B, H, W, cin, cout, emb, res, ws):
+    """1x1 convolutions of the 3-product modes (skip_connection openaimodel.py:254, qkv / proj_out :343-346) on the register-streamed
+    kernel (conv_rs.inc RS_1X1M: 16x16x32 MFMA, hi + lo activation planes and fragment streams): against fp64 at the split-product
+    tolerance; ragged sample counts, cout not a multiple of 128, K split."""
+    tol = {"parity": 2e-5, "parity_bf16": 3e-4}[prec]        # max error over the output's spread: 22- / 16-bit operand products, K up to 2048
+    _conv_dma_case(dev, prec, tol, B, H, W, cin, cout, "s1", 1, use_emb=emb, use_res=res, ws=ws, m16=True, want_rs=True)
+
+
 @pytest.mark.parametrize("prec,tol", PRECS[1:])
 @pytest.mark.parametrize("B,H,W,cin,cout,emb,res", [
     (50, 32, 32, 32, 96, True, True), (200, 16, 16, 64, 128, True, False), (801, 8, 8, 32, 32, False, True), (3, 128, 128, 32, 64, True, True),
