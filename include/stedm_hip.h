@@ -102,6 +102,12 @@ int stedm_pack_conv_weight_frag16_hl(const float* w, long sn, long sc, int flip,
 /* ... of a 1x1 filter (ABI 9; the 3-product modes' skip_connection openaimodel.py:254, qkv / proj_out :343-346 on the register-streamed kernel):
  * out = [2][ceil(cout / 128)][cin / 32][1][8][512] 16-bit (hi stream, then lo stream), passed as stedm_conv_args.w_frag16 with ks = 1. */
 int stedm_pack_conv_weight_frag16_hl1(const float* w, long sn, long sc, int flip, void* out, int cout, int cin, int mm_dtype, void* stream);
+/* ... of the Upsample's sub-pixel form (openaimodel.py:122-132; 4 output parities x 2x2 pre-summed taps, as stedm_pack_conv_weight_up_frag) and of
+ * the Downsample's space-to-depth form (:156-173; as stedm_pack_conv_weight_s2d_frag), w OIHW 3x3 fp32 (ABI 9):
+ * out = [2][4 parities][ceil(cout / 128)][cin / 32][4][8][512] resp. [2][ceil(cout / 128)][4 cin / 32][4][8][512] 16-bit (hi stream, then lo),
+ * passed as stedm_conv_args.w_frag16 with mode STEDM_CONV_UP_SUBPIXEL resp. STEDM_CONV_S2D and npass = 3. */
+int stedm_pack_conv_weight_up_frag16_hl(const float* w, void* out, int cout, int cin, int mm_dtype, void* stream);
+int stedm_pack_conv_weight_s2d_frag16_hl(const float* w, void* out, int cout, int cin, int mm_dtype, int pad_br, void* stream);
 int stedm_pack_conv_weight_s2d_frag(const float* w_oihw, void* out, int cout, int cin, int mm_dtype, int pad_br, void* stream);
 /* [rows][cols] fp32 -> [cols][rows] fp32 (Linear weights are consumed K-major). */
 int stedm_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);

@@ -59,6 +59,8 @@ SIGNATURES = {
     "stedm_pack_conv_weight_frag16": (_I, [_P, C.c_long, C.c_long, _I, _P, _I, _I, _I, _I, _P]),
     "stedm_pack_conv_weight_frag16_hl": (_I, [_P, C.c_long, C.c_long, _I, _P, _I, _I, _I, _P]),
     "stedm_pack_conv_weight_frag16_hl1": (_I, [_P, C.c_long, C.c_long, _I, _P, _I, _I, _I, _P]),
+    "stedm_pack_conv_weight_up_frag16_hl": (_I, [_P, _P, _I, _I, _I, _P]),
+    "stedm_pack_conv_weight_s2d_frag16_hl": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "stedm_pack_conv_weight_s2d_frag": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "stedm_space_to_depth16": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P]),
     "stedm_transpose_f32": (_I, [_P, _P, _I, _I, _P]),

@@ -374,7 +374,8 @@ extern "C" int stedm_conv_igemm(const stedm_conv_args* args, void* stream) {
 // validates the arguments and fills the derived sizes of `p`
 static int conv_setup(ConvParams& p) {
   const stedm_conv_args& a = p.a;
-  STEDM_CHECK_ARG((a.src1 || a.src16_hi) && (a.w_hi || (a.mode == STEDM_CONV_S2D && a.w_frag)) && (a.out || a.out16_hi || a.qkv_q), "conv_igemm: null src/w_hi/out");
+  STEDM_CHECK_ARG((a.src1 || a.src16_hi) && (a.w_hi || (a.mode == STEDM_CONV_S2D && (a.w_frag || (a.npass == 3 && a.w_frag16)))) && (a.out || a.out16_hi || a.qkv_q),
+                  "conv_igemm: null src/w_hi/out");
   STEDM_CHECK_ARG(!a.ln_gamma || (a.ln_beta && (a.out || a.out16_hi) && !a.out16_lo && !a.res && !a.emb && !a.chan_stats && !a.gn_out16 && !a.act_out && !a.qkv_q &&
                                   a.src16_hi && !a.src1 && !a.src16b_hi && a.w_frag && a.ks == 1 && a.mode == STEDM_CONV_S1 && a.npass == 1 && a.cout <= 128 &&
                                   a.cout % 4 == 0),
@@ -386,8 +387,9 @@ static int conv_setup(ConvParams& p) {
                   "conv_igemm: the qkv epilogue needs a flat 1x1 GEMM (B = Hin = 1, Win = nb * T rows), cout = 3 * heads * 64 with an even head count, even T / Tp, "
                   "src16 + w_frag, a single-product mode and no other output or epilogue extra");
   STEDM_CHECK_ARG(a.pad_br == 0 || a.mode == STEDM_CONV_S2D, "conv_igemm: pad_br belongs to the space-to-depth form");
-  STEDM_CHECK_ARG(a.mode != STEDM_CONV_S2D || (a.src16_hi && !a.src1 && a.w_frag && a.ks == 3 && a.npass == 1 && !a.src16b_hi),
-                  "conv_igemm: the space-to-depth form needs src16 planes, w_frag, ks=3, single product");
+  STEDM_CHECK_ARG(a.mode != STEDM_CONV_S2D || (a.src16_hi && !a.src1 && a.ks == 3 && !a.src16b_hi &&
+                                                ((a.npass == 1 && a.w_frag) || (a.npass == 3 && a.w_frag16 && a.src16_lo))),
+                  "conv_igemm: the space-to-depth form needs src16 planes, ks=3 and w_frag (single product) or w_frag16 + src16_lo (3 products)");
   STEDM_CHECK_ARG((!a.act_out && !a.out16_hi) || (a.src16_hi && !a.src1), "conv_igemm: act_out/out16 need the DMA path (src16 only)");
   STEDM_CHECK_ARG(!a.src1 || (a.src2 != nullptr) == (a.c2 > 0), "conv_igemm: src2/c2 mismatch");
   STEDM_CHECK_ARG(!a.src16_hi || a.npass == 1 || a.src16_lo, "conv_igemm: npass=3 needs src16_lo");
@@ -396,7 +398,7 @@ static int conv_setup(ConvParams& p) {
   STEDM_CHECK_ARG(a.mode != STEDM_CONV_UP_SUBPIXEL || (a.src16_hi && !a.src1 && a.ks == 3), "conv_igemm: sub-pixel upsample needs the DMA path (src16) and ks=3");
   STEDM_CHECK_ARG(a.ks == 3 || a.mode == STEDM_CONV_S1, "conv_igemm: 1x1 supports stride 1 only");
   STEDM_CHECK_ARG(a.npass == 1 || a.npass == 3, "conv_igemm: npass must be 1 or 3");
-  STEDM_CHECK_ARG(a.npass == 1 || a.w_lo, "conv_igemm: npass=3 needs w_lo");
+  STEDM_CHECK_ARG(a.npass == 1 || a.w_lo || (a.mode == STEDM_CONV_S2D && a.w_frag16), "conv_igemm: npass=3 needs w_lo");
   STEDM_CHECK_ARG((a.scale != nullptr) == (a.shift != nullptr), "conv_igemm: scale/shift must come together");
   STEDM_CHECK_ARG(a.B > 0 && a.Hin > 0 && a.Win > 0 && a.cout > 0, "conv_igemm: bad sizes");
   STEDM_CHECK_ARG(a.mm_dtype == STEDM_F16 || a.mm_dtype == STEDM_BF16, "conv_igemm: bad mm_dtype %d", a.mm_dtype);

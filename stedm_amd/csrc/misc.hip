@@ -402,6 +402,72 @@ extern "C" int stedm_pack_conv_weight_s2d_frag(const float* w, void* out, int co
   return 0;
 }
 
+// The same two derived filters for the 3-product modes on the 16x16x32 MFMA kind (conv_rs.inc RS_SUBM): fragment order of
+// stedm_pack_conv_weight_frag16 with 4 taps — out[parity][tn][chunk32][tap][c][lane][e] = W'[n = tn*128 + 16 c + (lane & 15)][ci = 32 chunk +
+// 16 (g & 1) + 8 (g >> 1) + e][tap], g = lane >> 4 — as a hi stream followed by a lo stream (value - hi, rounded).
+// UP: the four parity filters with pre-summed taps (pack_conv_weight_up_frag_kernel); else: the space-to-depth filter over 4 * cin channels.
+template <typename T, bool UP>
+__global__ void pack_conv_weight_sub_frag16_hl_kernel(const float* __restrict__ w, T* __restrict__ out, int cout, int cin, long per_parity, long total,
+                                                      int pad_br) {
+  const int nch = (UP ? cin : 4 * cin) / 32;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int par = UP ? (int)(i / per_parity) : 0;
+    const long ii = i - par * per_parity;
+    const int e = (int)(ii & 7);
+    const int lane = (int)((ii >> 3) & 63);
+    const int c = (int)((ii >> 9) & 7);
+    long r = ii >> 12;
+    const int tap = (int)(r & 3); r >>= 2;
+    const int chunk = (int)(r % nch);
+    const int tn = (int)(r / nch);
+    const int g = lane >> 4;
+    const int n = tn * 128 + c * 16 + (lane & 15);
+    const int cc = chunk * 32 + 16 * (g & 1) + 8 * (g >> 1) + e;
+    const int a = tap >> 1, b = tap & 1;
+    float v = 0.f;
+    if (n < cout) {
+      if (UP) {
+        const int py = par >> 1, px = par & 1;
+        const int dy0 = py == 0 ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), dy1 = py == 0 ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
+        const int dx0 = px == 0 ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), dx1 = px == 0 ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
+        for (int dy = dy0; dy <= dy1; ++dy)
+          for (int dx = dx0; dx <= dx1; ++dx) v += w[((long)n * cin + cc) * 9 + dy * 3 + dx];
+      } else {
+        const int pb = cc / cin, ci = cc - pb * cin;          // parity block of the space-to-depth planes, channel inside it
+        const int py = pb >> 1, px = pb & 1;
+        const int dy = pad_br ? (a == 0 ? py : (py == 0 ? 2 : -1)) : (a == 0 ? (py == 1 ? 0 : -1) : (py == 0 ? 1 : 2));
+        const int dx = pad_br ? (b == 0 ? px : (px == 0 ? 2 : -1)) : (b == 0 ? (px == 1 ? 0 : -1) : (px == 0 ? 1 : 2));
+        if (dy >= 0 && dx >= 0) v = w[((long)n * cin + ci) * 9 + dy * 3 + dx];
+      }
+    }
+    const T hv = (T)v;
+    out[i] = hv;
+    out[total + i] = (T)(v - (float)hv);
+  }
+}
+
+extern "C" int stedm_pack_conv_weight_up_frag16_hl(const float* w, void* out, int cout, int cin, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(w && out && cin % 32 == 0 && cout > 0, "pack_conv_weight_up_frag16_hl: bad args (cin %% 32)");
+  STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "pack_conv_weight_up_frag16_hl: bad mm_dtype %d", mm_dtype);
+  const long per = (long)((cout + 127) / 128) * (cin / 32) * 4 * 8 * 64 * 8, total = 4 * per;
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (mm_dtype == STEDM_F16) pack_conv_weight_sub_frag16_hl_kernel<_Float16, true><<<grid, 256, 0, as_stream(stream)>>>(w, (_Float16*)out, cout, cin, per, total, 0);
+  else pack_conv_weight_sub_frag16_hl_kernel<__bf16, true><<<grid, 256, 0, as_stream(stream)>>>(w, (__bf16*)out, cout, cin, per, total, 0);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int stedm_pack_conv_weight_s2d_frag16_hl(const float* w, void* out, int cout, int cin, int mm_dtype, int pad_br, void* stream) {
+  STEDM_CHECK_ARG(w && out && cin % 8 == 0 && cout > 0, "pack_conv_weight_s2d_frag16_hl: bad args (cin %% 8)");
+  STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "pack_conv_weight_s2d_frag16_hl: bad mm_dtype %d", mm_dtype);
+  const long total = (long)((cout + 127) / 128) * (4 * cin / 32) * 4 * 8 * 64 * 8;
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (mm_dtype == STEDM_F16) pack_conv_weight_sub_frag16_hl_kernel<_Float16, false><<<grid, 256, 0, as_stream(stream)>>>(w, (_Float16*)out, cout, cin, total, total, pad_br);
+  else pack_conv_weight_sub_frag16_hl_kernel<__bf16, false><<<grid, 256, 0, as_stream(stream)>>>(w, (__bf16*)out, cout, cin, total, total, pad_br);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
 // NHWC fp32 -> space-to-depth 16-bit planes [B][H/2][W/2][4C]; thread = one channel quad of one input pixel
 template <typename T>
 __global__ void __launch_bounds__(256) space_to_depth16_kernel(const float* __restrict__ x, T* __restrict__ hi, T* __restrict__ lo, int C, int H, int W,

@@ -367,6 +367,10 @@ class UNetModel(nn.Module):
                     # stride-2 conv as a stride-1 2x2 conv over space-to-depth planes (register-streamed kernel)
                     self._packed[(id(m.op), "s2d")] = _Packed(None, None, self._packed[id(m.op)].bias,
                                                               ops.pack_conv_weight_s2d_frag(m.op.weight.float(), prec))
+                elif self.conv_path == "dma" and prec.npass == 3 and self._m16 and m.op.in_channels % 32 == 0:
+                    # ... in the 3-product modes with hi + lo planes and fragment streams (conv_rs.inc RS_SUBM)
+                    self._packed[(id(m.op), "s2d")] = _Packed(None, None, self._packed[id(m.op)].bias, None,
+                                                              ops.pack_conv_weight_s2d_frag16_hl(m.op.weight.float(), prec))
             elif isinstance(m, Upsample):
                 pack(m.conv)
                 if self.conv_path == "dma":   # sub-pixel form: 4 parity 2x2 convs with pre-summed taps
@@ -375,7 +379,9 @@ class UNetModel(nn.Module):
                         hi, lo = ops.LazyPlanes(lambda w=m.conv.weight: ops.pack_conv_weight_up(w.float(), prec)), None
                     else:
                         hi, lo = ops.pack_conv_weight_up(m.conv.weight.float(), prec)
-                    self._packed[(id(m.conv), "up")] = _Packed(hi, lo, self._packed[id(m.conv)].bias, frag)
+                    frag16 = (ops.pack_conv_weight_up_frag16_hl(m.conv.weight.float(), prec)
+                              if prec.npass == 3 and self._m16 and m.conv.in_channels % 32 == 0 and m.conv.in_channels >= 128 else None)
+                    self._packed[(id(m.conv), "up")] = _Packed(hi, lo, self._packed[id(m.conv)].bias, frag, frag16)
             elif isinstance(m, AttentionBlock):
                 pack(m.qkv)
                 pack(m.proj_out)
@@ -645,10 +651,15 @@ class UNetModel(nn.Module):
                 if ps2 is not None and H % 2 == 0 and W % 2 == 0 and (H // 2) * (W // 2) >= 16:
                     C = h.shape[-1]
                     planes = self._buf(f"s2d16.{B}x{H}x{W}x{C}", (B, H // 2, W // 2, 4 * C), torch.int16)
-                    ops.space_to_depth16(h, planes, None, self.precision)
+                    planes_lo = self._buf(f"s2d16lo.{B}x{H}x{W}x{C}", (B, H // 2, W // 2, 4 * C), torch.int16) if self.precision.npass == 3 else None
                     ws = self._buf("conv_ws", ((16 if out.numel() <= (1 << 20) else 2) * out.numel(),))
-                    h = ops.conv_igemm(None, None, None, out, prec=self.precision, mode=CONV_S2D, src16=(planes, None), bias=ps2.bias,
-                                       w_frag=ps2.frag, chan_stats=self._cs_new(out), ws=ws)
+                    kw2 = dict(prec=self.precision, mode=CONV_S2D, src16=(planes, planes_lo), bias=ps2.bias, w_frag=ps2.frag, w_frag16=ps2.frag16, ws=ws)
+                    if self.precision.npass == 3 and not ops.conv_igemm(None, None, None, out, query_rs=True, **kw2):
+                        # (a problem the register-streamed 3-product kernel does not take: the fused fp32-source kernel, as before)
+                        h = ops.conv_igemm(h, pk.hi, pk.lo, out, prec=self.precision, mode=CONV_DOWN, bias=pk.bias)
+                    else:
+                        ops.space_to_depth16(h, planes, planes_lo, self.precision)
+                        h = ops.conv_igemm(None, None, None, out, chan_stats=self._cs_new(out), **kw2)
                 else:
                     # fused fp32-source kernel (parity mode / odd sizes)
                     h = ops.conv_igemm(h, pk.hi, pk.lo, out, prec=self.precision, mode=CONV_DOWN, bias=pk.bias)
@@ -663,7 +674,8 @@ class UNetModel(nn.Module):
                     src16 = self._raw16.get(h.data_ptr()) or self._norm16(None, 0, h)
                     # statistics slots of the sub-pixel form: (256-pixel run of the low-res grid) x (output parity)
                     h = ops.conv_igemm(None, pu.hi, pu.lo, out, prec=self.precision, mode=CONV_UP_SUBPIXEL,
-                                       src16=src16, bias=pu.bias, w_frag=pu.frag, chan_stats=self._cs_new(out, 4 * ops.gn_chan_nslab(H * W)))
+                                       src16=src16, bias=pu.bias, w_frag=pu.frag, chan_stats=self._cs_new(out, 4 * ops.gn_chan_nslab(H * W)),
+                                       w_frag16=pu.frag16 if self.precision.npass == 3 else None)
                 else:
                     h = ops.conv_igemm(h, pk.hi, pk.lo, out, prec=self.precision, mode=CONV_UP, bias=pk.bias)
             else:

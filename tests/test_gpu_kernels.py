@@ -472,7 +472,8 @@ def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_em
               res=None if res is None else nhwc(res).to(dev),
               w_frag=None if not frag else (ops.pack_conv_weight_up_frag(w.to(dev), prec) if mode == "up2" else ops.pack_conv_weight_frag(w.to(dev), prec)),
               ws=torch.empty(16 * out.numel(), device=dev) if ws else None,
-              w_frag16=ops.pack_conv_weight_frag16(w.to(dev), prec) if m16 else None)
+              w_frag16=None if not m16 else (ops.pack_conv_weight_up_frag16_hl(w.to(dev), prec) if mode == "up2" and prec.npass == 3
+                                             else ops.pack_conv_weight_frag16(w.to(dev), prec)))
     if want_rs is not None:     # the register-streamed kernel must (not) be the one that runs
         assert ops.conv_igemm(src1, whi, wlo, out, query_rs=True, **kw) == want_rs
     ops.conv_igemm(src1, whi, wlo, out, **kw)
@@ -823,6 +824,47 @@ def test_conv_s2d_downsample(dev, prec, tol, B, H, W, cin, cout, ws):
     cs = torch.full((B, ops.gn_chan_nslab(H * W // 4), cout, 2), float("nan"), device=dev)
     ops.conv_igemm(None, None, None, out, prec=pr, mode=CONV_S2D, src16=(planes, None), bias=bias.to(dev),
                    w_frag=ops.pack_conv_weight_s2d_frag(w.to(dev), pr), chan_stats=cs, ws=torch.empty(2 * out.numel(), device=dev) if ws else None)
+    torch.cuda.synchronize()
+    err = rel_err(nchw(out), ref)
+    assert err < tol, f"{prec}: rel err {err:.3e} >= {tol}"
+    flat = out.view(B, -1, cout).double()
+    for k in range(cs.shape[1]):
+        assert torch.allclose(cs[:, k, :, 0].double(), flat[:, k * 256:(k + 1) * 256].sum(1), rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("prec", ["parity", "parity_bf16"])
+@pytest.mark.parametrize("B,H,W,cin,cout,emb,res", [(128, 8, 8, 1024, 1024, False, False), (128, 16, 16, 512, 512, False, False),     # the NS32 step's two Upsamples
+                                                    (50, 16, 16, 128, 96, True, True), (7, 32, 32, 160, 200, False, True), (130, 8, 8, 256, 64, True, False)])
+def test_conv_subpixel_upsample_three_product_register_streamed(dev, prec, B, H, W, cin, cout, emb, res):
+    """Upsample (nearest x2 + 3x3, openaimodel.py:122-132) in the 3-product modes on the register-streamed kernel (conv_rs.inc RS_SUBM: four
+    output parities with pre-summed 2x2 taps, 16x16x32 MFMA, hi + lo planes and fragment streams) against fp64; ragged batches / cout."""
+    tol = {"parity": 2e-5, "parity_bf16": 3e-4}[prec]
+    _conv_dma_case(dev, prec, tol, B, H, W, cin, cout, "up2", 3, use_emb=emb, use_res=res, m16=True, want_rs=True)
+
+
+@pytest.mark.parametrize("prec", ["parity", "parity_bf16"])
+@pytest.mark.parametrize("B,H,W,cin,cout,ws", [(128, 32, 32, 128, 128, False), (128, 16, 16, 512, 512, False), (64, 16, 16, 512, 512, True), (5, 16, 16, 64, 96, True),
+                                                (40, 64, 64, 32, 160, False), (9, 8, 8, 64, 64, True)])
+def test_conv_s2d_downsample_three_product(dev, prec, B, H, W, cin, cout, ws):
+    """Downsample.op in the 3-product modes: hi + lo space-to-depth planes, the RS_SUBM kind with the space-to-depth filter's hi + lo
+    fragment streams; K split over the workspace on small grids; statistics from the epilogue / reduce pass."""
+    from stedm_amd import ops
+    from stedm_amd._lib import CONV_S2D
+    pr = ops.Precision.parse(prec)
+    tol = {"parity": 2e-5, "parity_bf16": 3e-4}[prec]
+    x = prng.normal(33, "sd3.x", (B, cin, H, W))
+    w = prng.normal(33, "sd3.w", (cout, cin, 3, 3), 1.0 / math.sqrt(cin * 9))
+    bias = prng.normal(33, "sd3.b", (cout,), 0.05)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), stride=2, padding=1)
+    hi = torch.empty((B, H // 2, W // 2, 4 * cin), dtype=torch.int16, device=dev); lo = torch.empty_like(hi)
+    ops.space_to_depth16(nhwc(x).to(dev), hi, lo, pr)
+    out = torch.full((B, H // 2, W // 2, cout), float("nan"), device=dev)
+    cs = torch.full((B, ops.gn_chan_nslab(H * W // 4), cout, 2), float("nan"), device=dev)
+    kw = dict(prec=pr, mode=CONV_S2D, src16=(hi, lo), bias=bias.to(dev), w_frag16=ops.pack_conv_weight_s2d_frag16_hl(w.to(dev), pr),
+              ws=torch.empty(2 * out.numel(), device=dev) if ws else None)
+    if not ops.conv_igemm(None, None, None, out, query_rs=True, **kw):
+        pytest.skip("grid too small for the register-streamed kernel without a workspace: the module falls back to the fp32-source kernel")
+    ops.conv_igemm(None, None, None, out, chan_stats=cs, **kw)
     torch.cuda.synchronize()
     err = rel_err(nchw(out), ref)
     assert err < tol, f"{prec}: rel err {err:.3e} >= {tol}"
