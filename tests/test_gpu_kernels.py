@@ -863,7 +863,13 @@ def test_conv_s2d_downsample_three_product(dev, prec, B, H, W, cin, cout, ws):
     kw = dict(prec=pr, mode=CONV_S2D, src16=(hi, lo), bias=bias.to(dev), w_frag16=ops.pack_conv_weight_s2d_frag16_hl(w.to(dev), pr),
               ws=torch.empty(2 * out.numel(), device=dev) if ws else None)
     if not ops.conv_igemm(None, None, None, out, query_rs=True, **kw):
-        pytest.skip("grid too small for the register-streamed kernel without a workspace: the module falls back to the fp32-source kernel")
+        # a problem the register-streamed kernel declines (a single tile with too short a K walk per share): what UNetModel then runs is the
+        # fused fp32-source kernel (stedm_amd/unet.py, Downsample) — checked here the same way
+        from stedm_amd._lib import CONV_DOWN
+        whi, wlo = ops.pack_conv_weight(w.to(dev), pr)
+        ops.conv_igemm(nhwc(x).to(dev), whi, wlo, out, prec=pr, mode=CONV_DOWN, bias=bias.to(dev))
+        assert rel_err(nchw(out), ref) < tol
+        return
     ops.conv_igemm(None, None, None, out, chan_stats=cs, **kw)
     torch.cuda.synchronize()
     err = rel_err(nchw(out), ref)
