@@ -14,7 +14,7 @@ def main():
     prec = ops.Precision.parse(sys.argv[1] if len(sys.argv) > 1 else "bf16")
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     p = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
-    T, heads = 4098, 12
+    T, heads = int(os.environ.get("LSA_T", "4098")), 12      # LSA_T: another token count (4096: no 2-query tail tile)
     dev = torch.device("cuda:0")
     torch.set_grad_enabled(False)
     Tp = (T + 127) // 128 * 128
