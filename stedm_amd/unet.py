@@ -592,7 +592,7 @@ class UNetModel(nn.Module):
             a16 = self._planes(B, H, W, Cc, "attn16")
             ops.attn_legacy16(qkv16[0].view(B, H * W, 3 * Cc), a16[0], ab.num_heads, prec)
             ops.conv_igemm(None, pp.hi, pp.lo, out, prec=prec, ks=1, src16=a16, bias=pp.bias, res=x, w_frag=pp.frag,
-                           chan_stats=self._cs_new(out))
+                           chan_stats=self._cs_new(out), ws=self._buf("conv_ws", ((16 if out.numel() <= (1 << 20) else 2) * out.numel(),)))
             return out
         qkv = self._buf(tag + ".qkv", (B, H, W, 3 * Cc))
         if dma:
@@ -673,9 +673,11 @@ class UNetModel(nn.Module):
                     pu = self._packed[(id(layer.conv), "up")]
                     src16 = self._raw16.get(h.data_ptr()) or self._norm16(None, 0, h)
                     # statistics slots of the sub-pixel form: (256-pixel run of the low-res grid) x (output parity)
+                    # (small grids — a sampling batch of up to 8 — split K over the workspace like the other kinds)
+                    ws = self._buf("conv_ws", ((16 if out.numel() <= (1 << 20) else 2) * out.numel(),)) if self.precision.npass == 1 else None
                     h = ops.conv_igemm(None, pu.hi, pu.lo, out, prec=self.precision, mode=CONV_UP_SUBPIXEL,
                                        src16=src16, bias=pu.bias, w_frag=pu.frag, chan_stats=self._cs_new(out, 4 * ops.gn_chan_nslab(H * W)),
-                                       w_frag16=pu.frag16 if self.precision.npass == 3 else None)
+                                       w_frag16=pu.frag16 if self.precision.npass == 3 else None, ws=ws)
                 else:
                     h = ops.conv_igemm(h, pk.hi, pk.lo, out, prec=self.precision, mode=CONV_UP, bias=pk.bias)
             else:

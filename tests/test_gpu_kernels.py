@@ -832,6 +832,36 @@ def test_conv_s2d_downsample(dev, prec, tol, B, H, W, cin, cout, ws):
         assert torch.allclose(cs[:, k, :, 0].double(), flat[:, k * 256:(k + 1) * 256].sum(1), rtol=1e-4, atol=2e-3)
 
 
+@pytest.mark.parametrize("prec,tol", PRECS[1:])
+@pytest.mark.parametrize("B,H,W,cin,cout,res", [(2, 8, 8, 1024, 1024, False), (2, 16, 16, 512, 512, True), (16, 8, 8, 1024, 1024, False), (3, 16, 16, 256, 96, True),
+                                                (1, 32, 32, 128, 128, False)])
+def test_conv_subpixel_upsample_split_k(dev, prec, tol, B, H, W, cin, cout, res):
+    """The sub-pixel Upsample on grids that leave CUs idle (a sampling batch of 1 .. 8: 4 parities x a few tiles): K split over the workspace
+    on the register-streamed kernel — partial planes of the full-resolution output, summed in a fixed order by the reduce pass, which also
+    fills the caller's statistics partition (4 slots per 256 low-resolution pixels); bitwise reproducible, against fp64."""
+    from stedm_amd import ops
+    from stedm_amd._lib import CONV_UP_SUBPIXEL
+    pr = ops.Precision.parse(prec)
+    _conv_dma_case(dev, prec, tol, B, H, W, cin, cout, "up2", 3, use_emb=False, use_res=res, frag=True, ws=True, want_rs=True)
+    x = torch.randn(B, H, W, cin, device=dev)
+    w = torch.randn(cout, cin, 3, 3, device=dev) / math.sqrt(cin * 9)
+    h16 = torch.empty((B, H, W, cin), dtype=torch.int16, device=dev)
+    ops.gn_apply16(x, None, h16, None, pr)
+    whi, wlo = ops.pack_conv_weight_up(w, pr); wf = ops.pack_conv_weight_up_frag(w, pr)
+    runs = []
+    for _ in range(2):
+        out = torch.full((B, 2 * H, 2 * W, cout), float("nan"), device=dev)
+        cs = torch.full((B, 4 * ops.gn_chan_nslab(H * W), cout, 2), float("nan"), device=dev)
+        ops.conv_igemm(None, whi, wlo, out, prec=pr, mode=CONV_UP_SUBPIXEL, src16=(h16, None), w_frag=wf, chan_stats=cs, ws=torch.empty(16 * out.numel(), device=dev))
+        runs.append((out, cs))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    out, cs = runs[0]
+    assert bool(torch.isfinite(out).all()) and bool(torch.isfinite(cs).all())
+    flat = out.view(B, -1, cout).double()
+    assert torch.allclose(cs[..., 0].sum(1).double(), flat.sum(1), rtol=1e-4, atol=2e-3)
+    assert torch.allclose(cs[..., 1].sum(1).double(), (flat * flat).sum(1), rtol=1e-4, atol=2e-3)
+
+
 @pytest.mark.parametrize("prec", ["parity", "parity_bf16"])
 @pytest.mark.parametrize("B,H,W,cin,cout,emb,res", [(128, 8, 8, 1024, 1024, False, False), (128, 16, 16, 512, 512, False, False),     # the NS32 step's two Upsamples
                                                     (50, 16, 16, 128, 96, True, True), (7, 32, 32, 160, 200, False, True), (130, 8, 8, 256, 64, True, False)])
