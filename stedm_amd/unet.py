@@ -544,8 +544,17 @@ class UNetModel(nn.Module):
                 fused = bool((pk2.frag is not None or pk2.frag16 is not None) and ps.frag is not None and
                              ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias, ps.frag16), query_fused=True, **kw))
                 self._consts[fuse_key] = fused
+            only16 = False
             if fused and o16 is not None and self._tape is None and prec.npass == 1:
-                # inference: the Upsample that follows reads the 16-bit planes only — the fp32 tensor and its statistics are not written
+                # inference: the Upsample that follows reads the 16-bit planes only — the fp32 tensor and its statistics need not be written.
+                # A launch that splits K (small grids) has to write the fp32 tensor, though: asked once per shape
+                key16 = ("fuse16", id(rb), B, H, W)
+                only16 = self._consts.get(key16)
+                if only16 is None:
+                    only16 = bool(ops.conv_igemm(None, pk2.hi, pk2.lo, None, skip=(x16[0], ps.frag, ps.bias, ps.frag16), query_fused=True,
+                                                 **dict(kw, chan_stats=None)))
+                    self._consts[key16] = only16
+            if only16:
                 # (`out` stays the handle the planes are filed under)
                 kw.update(chan_stats=None)
                 self._cs.pop(out.data_ptr(), None)          # (no statistics are written for the handle: nothing may find a buffer for it)

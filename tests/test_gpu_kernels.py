@@ -655,6 +655,49 @@ def test_conv_fused_skip(dev, prec, tol, B, H, W, cin, cb, cout, emb, m16):
 
 
 @pytest.mark.parametrize("prec,tol", PRECS[1:])
+@pytest.mark.parametrize("m16", [False, True])
+@pytest.mark.parametrize("B,H,W,cin,cb,cout,emb", [(2, 8, 8, 1024, 2048, 1024, True), (2, 16, 16, 512, 1536, 512, False), (16, 8, 8, 1024, 2048, 1024, True),
+                                                   (2, 32, 32, 128, 640, 128, True), (4, 16, 16, 512, 640, 512, False), (3, 8, 8, 512, 1024, 768, True)])
+def test_conv_fused_skip_with_k_split(dev, prec, tol, B, H, W, cin, cb, cout, emb, m16):
+    """The fused ResBlock tail on grids that leave CUs idle (sampling batches of 1 .. 8): every K share of the 3x3 also takes its share of the
+    skip_connection's 64-channel chunks; the reduce pass adds both biases, the embedding row and emits the statistics. Against fp64; the
+    second run is the first bit for bit."""
+    from stedm_amd import ops
+    pr = ops.Precision.parse(prec)
+    hsrc = F.silu(prng.normal(23, "fsk.h", (B, cin, H, W)))
+    x = prng.normal(23, "fsk.x", (B, cb, H, W))
+    w3 = prng.normal(23, "fsk.w3", (cout, cin, 3, 3), 1.0 / math.sqrt(cin * 9))
+    w1 = prng.normal(23, "fsk.w1", (cout, cb, 1, 1), 1.0 / math.sqrt(cb))
+    b3 = prng.normal(23, "fsk.b3", (cout,), 0.05); b1 = prng.normal(23, "fsk.b1", (cout,), 0.05)
+    ref = F.conv2d(hsrc.double(), w3.double(), b3.double(), padding=1) + F.conv2d(x.double(), w1.double(), b1.double())
+    e = None
+    if emb:
+        e = prng.normal(23, "fsk.e", (B, cout)); ref = ref + e.double()[:, :, None, None]
+    h16 = torch.empty((B, H, W, cin), dtype=torch.int16, device=dev); x16 = torch.empty((B, H, W, cb), dtype=torch.int16, device=dev)
+    ops.gn_apply16(nhwc(hsrc).to(dev), None, h16, None, pr)
+    ops.gn_apply16(nhwc(x).to(dev), None, x16, None, pr)
+    whi, wlo = ops.pack_conv_weight(w3.to(dev), pr)
+    runs = []
+    for _ in range(2):
+        out = torch.full((B, H, W, cout), float("nan"), device=dev)
+        cs = torch.full((B, ops.gn_chan_nslab(H * W), cout, 2), float("nan"), device=dev)
+        kw = dict(prec=pr, src16=(h16, None), bias=b3.to(dev), emb=None if e is None else e.to(dev), emb_bstride=0 if e is None else cout,
+                  w_frag=ops.pack_conv_weight_frag(w3.to(dev), pr), chan_stats=cs, ws=torch.empty(16 * out.numel(), device=dev),
+                  w_frag16=ops.pack_conv_weight_frag16(w3.to(dev), pr) if m16 else None,
+                  skip=(x16, ops.pack_conv_weight_frag(w1.to(dev), pr), b1.to(dev)) + ((ops.pack_conv_weight_frag16(w1.to(dev), pr),) if m16 else ()))
+        assert ops.conv_igemm(None, whi, wlo, out, query_fused=True, **kw)
+        ops.conv_igemm(None, whi, wlo, out, **kw)
+        runs.append((out, cs))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    out, cs = runs[0]
+    err = rel_err(nchw(out), ref)
+    assert err < tol, f"{prec}: rel err {err:.3e} >= {tol}"
+    flat = out.view(B, H * W, cout).double()
+    for k in range(cs.shape[1]):
+        assert torch.allclose(cs[:, k, :, 0].double(), flat[:, k * 256:(k + 1) * 256].sum(1), rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("prec,tol", PRECS[1:])
 @pytest.mark.parametrize("B,H,W,cin,cout,mode,m16", [(8, 16, 512, 128, 128, "s1", False), (3, 17, 1024, 64, 96, "s1", False), (4, 24, 512, 256, 128, "s1", True),
                                                        (6, 32, 256, 256, 256, "s1", True), (4, 16, 128, 256, 128, "up2", False)])
 def test_conv_rows_wider_than_the_tile(dev, prec, tol, B, H, W, cin, cout, mode, m16):
