@@ -166,15 +166,19 @@ REF128 = dict(image_size=128, in_channels=6, model_channels=128, out_channels=3,
 GFLOP_PER_SAMPLE_FORWARD_REF128 = 872.37      # BASELINE.md §3 (hooks on the reference module, 128x128x3 latents)
 
 
-def ref128_leg(dev, precision, B, steps=6, warmup=2):
-    """The reference-native shape (conf/diffusion/unet_config/landscape.yaml:1-16, conf/diffusion/ldm_based.yaml:10-11: 128x128x3 latents,
+def ref128_leg(dev, precision, B, steps=6, warmup=2, spatial_transformer=False):
+    """spatial_transformer: the same U-Net with use_spatial_transformer=True, context_dim=1024 (openaimodel.py:486, 644-667: the middle block's
+    AttentionBlock becomes a SpatialTransformer, ldm/modules/attention.py:218-261, whose two CrossAttentions per block run as self-attentions
+    at T = 1024, 8 heads x 128) - the north_star's "SpatialTransformer attention on MFMA tiles" leg.
+    The reference-native shape (conf/diffusion/unet_config/landscape.yaml:1-16, conf/diffusion/ldm_based.yaml:10-11: 128x128x3 latents,
     Cin 6 / Cout 3; the only attention is the middle block's, T = 32 * 32 = 1024 tokens, openaimodel.py:644-649): the same DDIM-50 + CFG 1.5
     denoising step, hipGraph replay, at batch B per GPU; convolution roofline and the attention kernel's MFMA fraction from HIP events."""
     from stedm_amd.ddim import DDIMSampler, StepGraph
     from stedm_amd.latent_diffusion import LatentDiffusion
     from stedm_amd.unet import UNetModel
     from stedm_amd.utils import prng
-    unet = UNetModel(precision=precision, **REF128).eval()
+    cfg = dict(REF128, use_spatial_transformer=True, context_dim=1024) if spatial_transformer else REF128
+    unet = UNetModel(precision=precision, **cfg).eval()
     prng.fill_module_(unet, seed=0)
     ld = LatentDiffusion(unet, linear_start=0.0015, linear_end=0.0205, image_size=128, channels=3, conditioning_key="hybrid", loss_type="l1",
                          use_graph=True).to(dev)
@@ -203,12 +207,17 @@ def ref128_leg(dev, precision, B, steps=6, warmup=2):
            "roofline": {"bound": "mfma", "kernel": "all stedm_conv_igemm launches of a REF128 step (as issued)", "achieved": round(cs["tflops"], 2),
                         "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(cs["tflops"] / PEAK_MFMA_TFLOPS, 4),
                         "launches_per_step": cs["launches"] // 2, "conv_ms_per_step": round(cs["total_ms"] / 2, 3)},
-           "attention": {"kernel": "attn_mfma_tiles_kernel (middle block, one wave per 32 queries, 64-key tiles, online softmax)", "tokens": asum["tokens"],
+           "attention": {"kernel": "attn_flash_kernel (" + ("SpatialTransformer attn1 + attn2, self-attention" if spatial_transformer else "middle AttentionBlock") +
+                                   "; workgroup = 128 queries of a sample-head, K / V rows of 64-key tiles staged once in LDS, online softmax)", "tokens": asum["tokens"],
                          "launches_per_step": asum["launches"] // 2, "us_per_launch": round(1e3 * asum["total_ms"] / max(1, asum["launches"]), 1),
                          "achieved": round(asum["tflops"], 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(asum["tflops"] / PEAK_MFMA_TFLOPS, 4)},
            "what": "the reference-native U-Net (landscape.yaml: in 6 / out 3, 128^2 latents, 234.6 M parameters), one DDIM-50 + CFG 1.5 denoising step "
                    "per batch, hipGraph replay; 872.37 GFLOP per sample-forward"}
+    if spatial_transformer:
+        rec["what"] = ("the reference-native U-Net with use_spatial_transformer=True, context_dim=1024 (middle block: ResBlock, ResBlockStyle, "
+                       "SpatialTransformer depth 1, ResBlock), one DDIM-50 + CFG 1.5 denoising step per batch, hipGraph replay")
+        del rec["step_reference_equivalent_tflops"], rec["step_reference_equivalent_frac_of_mfma_peak"]     # (the 872.37 GFLOP count is the AttentionBlock net's)
     del sg, smp, ld, unet
     torch.cuda.empty_cache()
     return rec
@@ -658,6 +667,10 @@ def main():
                     out["ref128_step"] = ref128_leg(dev, args.precision, args.ref128_batch)
                 except Exception as e:          # never lose the headline over a side leg
                     out["ref128_step"] = {"error": str(e)[:200]}
+                try:
+                    out["st_step"] = ref128_leg(dev, args.precision, args.ref128_batch, spatial_transformer=True)
+                except Exception as e:
+                    out["st_step"] = {"error": str(e)[:200]}
         if not args.no_e2e_leg and world == 1:
             # BASELINE config 5's latent size (64x64x4, CATCH 512^2): the same denoising step on 4x the pixels, reported beside the headline
             ld.model.diffusion_model.set_precision(args.precision)

@@ -4,8 +4,10 @@ As wired by the reference U-Net (TimestepEmbedSequential calls `layer(x)`, opena
 a context: both attentions of a BasicTransformerBlock are self-attentions, and `attn2.to_k/to_v` (Linear(context_dim, inner))
 only accept the tokens when context_dim == inner_dim. The same restriction is enforced here.
 
-Kernels reused: gn_apply16 (GroupNorm eps 1e-6), ln_apply16, the 1x1 DMA GEMM, attn_legacy (the per-head q|k|v channel
-layout is produced by permuting the packed to_q/to_k/to_v rows once; scale d^-1/2 == (d^-1/4 on q) * (d^-1/4 on k)), geglu16.
+Kernels reused: gn_apply16 (GroupNorm eps 1e-6), ln_apply16, the register-streamed 1x1 GEMM, the attention kernels of the AttentionBlock
+(the per-head q|k|v channel layout is produced by permuting the packed to_q/to_k/to_v rows once; scale d^-1/2 == (d^-1/4 on q) *
+(d^-1/4 on k)): attn_flash_kernel on MFMA in the single-product modes (stedm_attn_legacy16), the fp32 kernel in the 3-product modes
+and under training; geglu16.
 """
 from __future__ import annotations
 
@@ -81,7 +83,16 @@ class SpatialTransformer(nn.Module):
     # ---- weight packing (called from UNetModel._prepare)
     def pack(self, prec) -> Dict:
         P = {}
-        cv = lambda w: ops.pack_conv_weight(w.detach().float().reshape(w.shape[0], -1, 1, 1).contiguous(), prec)
+
+        def cv(w):
+            """([cout][1][cin] hi, lo planes; fragment-order pack of the register-streamed 1x1 kind (single-product modes: 32x32x16 order,
+            3-product modes: the hi + lo 16x16x32 streams) or None when the width does not admit it)"""
+            w4 = w.detach().float().reshape(w.shape[0], -1, 1, 1).contiguous()
+            hi, lo = ops.pack_conv_weight(w4, prec)
+            cin = w4.shape[1]
+            frag = ops.pack_conv_weight_frag(w4, prec) if prec.npass == 1 and cin % 64 == 0 else None
+            frag16 = ops.pack_conv_weight_frag16(w4, prec) if prec.npass == 3 and cin % 32 == 0 and cin >= 64 else None
+            return hi, lo, frag, frag16
         P["proj_in"] = cv(self.proj_in.weight)
         P["proj_out"] = cv(self.proj_out.weight)
         h, d = self.n_heads, self.d_head
@@ -118,9 +129,16 @@ class SpatialTransformer(nn.Module):
         v4 = lambda t, width: None if t is None else t.view(1, 1, M, width)
         tag = f"st{id(self)}." if save is not None else "st."
 
-        def gemm(a16, w, N, bias=None, res=None, out=None):
+        def gemm(a16, w, N, bias=None, res=None, out=None, out16=None):
             K = a16[0].shape[-1]
-            ops.conv_igemm(None, w[0], w[1], v4(out, N), prec=prec, ks=1, src16=(v4(a16[0], K), v4(a16[1], K)), bias=bias, res=v4(res, N))
+            ops.conv_igemm(None, w[0], w[1], v4(out, N), prec=prec, ks=1, src16=(v4(a16[0], K), v4(a16[1], K)), bias=bias, res=v4(res, N),
+                           w_frag=w[2], w_frag16=w[3], out16=None if out16 is None else (v4(out16, N), None))
+
+        # single-product modes, inference: CrossAttention.forward (attention.py:170-193) on MFMA - the stacked to_q | to_k | to_v GEMM writes
+        # its rows as ONE 16-bit plane (no fp32 qkv), attn_flash_kernel reads K / V tiles from it and writes to_out's operand plane
+        # (same operand rounding as every other contraction of these modes; logits, softmax and normalisation fp32). The 3-product modes
+        # and the training forward (the backward re-reads fp32 qkv rows) keep the fp32 kernel.
+        mfma_attn = prec.npass == 1 and save is None and self.d_head in (16, 32, 64, 128)
 
         # GroupNorm (eps 1e-6, no activation) -> proj_in
         g16 = planes("gn", C)
@@ -138,9 +156,15 @@ class SpatialTransformer(nn.Module):
             for nm, norm in (("attn1", blk.norm1), ("attn2", blk.norm2)):
                 at = getattr(blk, nm)
                 sfx = f"{i}.{nm}.{M}" if save is not None else f"{M}"
+                ops.ln_apply16(y, norm.weight, norm.bias, norm.eps, ln[0], ln[1], prec)
+                if mfma_attn:
+                    qkv16 = buf(f"st.qkv16.{M}x{3 * inner}", (B, T, 3 * inner), i16)
+                    gemm(ln, P[f"{i}.{nm}.qkv"], 3 * inner, out16=qkv16)
+                    ops.attn_legacy16(qkv16, a16[0], self.n_heads, prec)
+                    gemm(a16, P[f"{i}.{nm}.out"], inner, bias=at.to_out[0].bias, res=y, out=y)
+                    continue
                 qkv = buf(f"{tag}qkv.{sfx}", (B, T, 3 * inner))
                 att = buf(f"{tag}att.{sfx}", (B, T, inner))
-                ops.ln_apply16(y, norm.weight, norm.bias, norm.eps, ln[0], ln[1], prec)
                 gemm(ln, P[f"{i}.{nm}.qkv"], 3 * inner, out=qkv)
                 ops.attn_legacy(qkv, att, self.n_heads)
                 ops.gn_apply16(att.view(1, 1, M, inner), None, a16[0].view(1, 1, M, inner), None if a16[1] is None else a16[1].view(1, 1, M, inner), prec)
@@ -163,7 +187,7 @@ class SpatialTransformer(nn.Module):
         ops.gn_apply16(y.view(1, 1, M, inner), None, a16[0].view(1, 1, M, inner), None if a16[1] is None else a16[1].view(1, 1, M, inner), prec)
         ops.conv_igemm(None, P["proj_out"][0], P["proj_out"][1], out.view(1, 1, M, C), prec=prec, ks=1,
                        src16=(a16[0].view(1, 1, M, inner), None if a16[1] is None else a16[1].view(1, 1, M, inner)),
-                       bias=self.proj_out.bias, res=x.view(1, 1, M, C))
+                       bias=self.proj_out.bias, res=x.view(1, 1, M, C), w_frag=P["proj_out"][2], w_frag16=P["proj_out"][3])
         if save is not None:
             save["yL"] = y
         return out

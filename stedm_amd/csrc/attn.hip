@@ -5,6 +5,8 @@
 //
 // v1: VALU fp32 (the U-Net's middle attention is 0.03 % of the forward's FLOPs at 32x32 latents);
 // one 256-thread block per (sample*head, 64-query tile); K/V tiles of 64 keys streamed through LDS.
+#include <stdlib.h>
+
 #include "common.hpp"
 using namespace stedm;
 
@@ -392,24 +394,227 @@ __global__ void __launch_bounds__(256) attn_mfma_tiles_kernel(const T* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Flash form of the same attention for any token count (the middle block at 128 x 128 latents: T = 1024, ch = 128; the SpatialTransformer's
+// CrossAttention, ldm/modules/attention.py:170-193, whose stacked to_q | to_k | to_v rows are packed in this head-major order): a workgroup
+// owns NW x 32 queries of one (sample, head) and streams the K and V rows of 64-key tiles ONCE through LDS for all its waves
+// (global_load_lds_dwordx4 straight from the token-major 16-bit qkv plane, ring of two 32-KB stages, one block barrier per tile) - round 4's
+// attn_mfma_tiles_kernel had every wave fetch its own K fragments from global memory and gather V with 2-byte loads (210 TFLOP/s, 8.4 % of
+// the MFMA peak at T = 1024). LDS image of a tile: [64 rows][256-B pitch], 16-B chunk ch of row r at chunk ch ^ (((r & 3) << 2) | ((r >> 2) & 3))
+// (cdna_hip_programming.md T10 image (b)): the K fragments are row reads (ds_read_b128), the V^T fragments of O^T += V^T P^T are
+// transposing reads (ds_read_b64_tr_b16) of the SAME token-major rows, both conflict-free - no V^T copy of the qkv plane exists anywhere.
+// S^T = K Q^T is computed swapped (keys on the accumulator rows, the wave's 32 queries on the lanes): the softmax statistics of a query are
+// lane-local plus one cross-half exchange, and the exponentiated tile is the B operand of the second product as it lies
+// (k-slot j of k-step (it, u) of lane half h is key 32 it + 16 u + 8 (j >> 2) + 4 h + (j & 3)).
+// Head widths 16 (zero-extended to one 32-wide MFMA k-step / d-tile), 32, 64, 128; keys beyond T are masked, query rows beyond T are not stored.
+// ------------------------------------------------------------------------------------------------
+#define GLDS16(gptr, lptr)                                                                                  \
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gptr),                   \
+                                   (void __attribute__((address_space(3)))*)(lptr), 16, 0, 0)
+
+static __device__ __attribute__((aligned(256))) unsigned char g_attn_zero[256];   // source of the zero extension (ch = 16)
+
+struct AttnFlashArgs {
+  const void* qkv;   // 16-bit plane [B][T][heads * 3 * ch], channel = head * 3 ch + {q: 0, k: ch, v: 2 ch} + c
+  void* out;         // 16-bit plane [B][T][heads * ch]
+  int T, heads, nbh, nq;
+  float c;           // logit scale x log2(e): p = exp2((s - m) c)
+};
+
+template <typename T, int CH, int NW>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_flash_kernel(const AttnFlashArgs a) {
+  using V8 = typename MM<T>::V8;
+  typedef T V4T __attribute__((ext_vector_type(4)));
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) s16x4* lp4;
+  constexpr int DP = CH < 32 ? 32 : CH;          // head width as the MFMAs see it
+  constexpr int KS = DP / 16, DT = DP / 32;
+  constexpr int NBUF = 2, TILE_B = 32768;        // K rows 16 KiB | V rows 16 KiB
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[NBUF * TILE_B];
+  // block -> (sample-head, query tile): all query tiles of a sample-head on one XCD (its K / V rows stay in that XCD's L2)
+  int bh, qtile;
+  {
+    const int L = blockIdx.x;
+    if ((a.nbh & 7) == 0) { const int x = L & 7, j = L >> 3; bh = x + 8 * (j / a.nq); qtile = j % a.nq; }
+    else { bh = L % a.nbh; qtile = L / a.nbh; }
+  }
+  const int b = bh / a.heads, hd = bh % a.heads;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int C3 = a.heads * 3 * CH, C = a.heads * CH;
+  const T* base = reinterpret_cast<const T*>(a.qkv) + (long)b * a.T * C3 + hd * 3 * CH;
+  const int q0 = qtile * (NW * 32) + wave * 32;
+  const bool live = q0 < a.T;                    // wave-uniform
+
+  V8 qf[KS];
+  {
+    const int row = min(q0 + r, a.T - 1);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (16 * s + 8 * h < CH) qf[s] = *reinterpret_cast<const V8*>(base + (long)row * C3 + 16 * s + 8 * h);
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[s][j] = (T)0.f;
+      }
+    }
+  }
+  // DMA: instruction j of a tile half fills rows 4 j .. 4 j + 3 (1 KiB): lane -> row 4 j + (lane >> 4), physical chunk lane & 15
+  constexpr int NI = 16 / NW;                    // instructions per wave, tile and operand
+  const int drow = 4 * wave + (lane >> 4);       // + 4 NW i
+  auto issue = [&](int kt) __attribute__((always_inline)) {
+    unsigned char* dst = ring + (kt % NBUF) * TILE_B + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int row = drow + 4 * NW * i;
+      const int ch = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));      // logical chunk held by this lane's slot
+      const T* src = base + (long)min(kt * 64 + row, a.T - 1) * C3 + ch * 8;
+      if (ch * 8 < CH) {
+        GLDS16(src + CH, dst + i * (NW * 1024));
+        GLDS16(src + 2 * CH, dst + 16384 + i * (NW * 1024));
+      } else if (ch * 8 < DP) {
+        GLDS16(g_attn_zero + (lane & 15) * 16, dst + i * (NW * 1024));      // zero extension of K (V's extension rows feed output channels that are never stored)
+      }
+    }
+  };
+  f32x16 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int ntiles = (a.T + 63) >> 6;
+  // fragment addresses inside a tile (bytes)
+  const int swz = ((r & 3) << 2) | ((r >> 2) & 3);
+  const unsigned kb = 256u * r + 16u * (unsigned)(h ^ swz);                      // K row read of k-step s: kb ^ (s << 5), + 8192 for rows 32 ..
+  const int g1 = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;          // transposed read: lane 4 q + p of its 16-lane group
+  const unsigned vlo = 16384u + 256u * (4 * h + tq) + 16u * (unsigned)((tq << 2) | (g1 << 1) | ((tp >> 1) ^ h)) + 8u * (tp & 1);
+  const unsigned vhi = 16384u + 256u * (4 * h + tq + 8) + 16u * (unsigned)((tq << 2) | ((g1 ^ 1) << 1) | ((tp >> 1) ^ h)) + 8u * (tp & 1);
+
+  issue(0);
+#pragma unroll 1
+  for (int kt = 0; kt < ntiles; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();        // tile kt is complete in LDS; every wave is done with tile kt - 1, whose stage takes tile kt + 1
+    if (kt + 1 < ntiles) issue(kt + 1);
+    if (!live) continue;                 // a wave without queries only feeds the ring
+    const unsigned char* tb = ring + (kt % NBUF) * TILE_B;
+    f32x16 st[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[it][e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const V8 ka = *reinterpret_cast<const V8*>(tb + it * 8192 + (kb ^ (unsigned)(s << 5)));
+        st[it] = MM<T>::mfma(ka, qf[s], st[it]);
+      }
+    if (kt * 64 + 64 > a.T) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (kt * 64 + 32 * it + (e & 3) + 8 * (e >> 2) + 4 * h >= a.T) st[it][e] = -INFINITY;
+    }
+    // online softmax over the keys of query column r: 32 values of this tile in this lane, 32 in lane ^ 32
+    float m = st[0][0];
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) m = fmaxf(m, st[it][e]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float m_new = fmaxf(m_run, m);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * a.c);
+    const float mc = m_new * a.c;
+    float sum = 0.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(st[it][e], a.c, -mc));
+        st[it][e] = pv;
+        sum += pv;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    l_run = l_run * alpha + sum;
+    m_run = m_new;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+    }
+    // O^T[d][q] += sum_k V[k][d] P[k][q] over this tile's keys
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        V8 pb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pb[j] = (T)st[it][8 * u + j];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const unsigned tofs = 4096u * (2 * it + u);
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(tb + tofs + (vlo ^ (unsigned)(dt << 6))));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(tb + tofs + (vhi ^ (unsigned)(dt << 6))));
+          const s16x8 v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          o[dt] = MM<T>::mfma(__builtin_bit_cast(V8, v8), pb, o[dt]);
+        }
+      }
+  }
+  // lane (query r) holds channels d = 32 dt + (e & 3) + 8 (e >> 2) + 4 h: 4 consecutive channels per e-quad -> 8-B stores
+  if (!live || q0 + r >= a.T) return;
+  const float inv = 1.0f / l_run;
+  T* orow = reinterpret_cast<T*>(a.out) + ((long)b * a.T + q0 + r) * C + hd * CH;
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int eq = 0; eq < 4; ++eq) {
+      if (32 * dt + 8 * eq + 4 * h >= CH) continue;
+      V4T v;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = (T)(o[dt][eq * 4 + k] * inv);
+      *reinterpret_cast<V4T*>(orow + 32 * dt + 8 * eq + 4 * h) = v;
+    }
+}
+
+template <typename T, int NW>
+static int attn_flash_launch(const AttnFlashArgs& a, int ch, hipStream_t st) {
+  const int grid = a.nbh * a.nq;
+  if (ch == 128) attn_flash_kernel<T, 128, NW><<<grid, NW * 64, 0, st>>>(a);
+  else if (ch == 64) attn_flash_kernel<T, 64, NW><<<grid, NW * 64, 0, st>>>(a);
+  else if (ch == 32) attn_flash_kernel<T, 32, NW><<<grid, NW * 64, 0, st>>>(a);
+  else attn_flash_kernel<T, 16, NW><<<grid, NW * 64, 0, st>>>(a);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int stedm_attn_legacy16(const void* qkv, int qkv_is16, void* out16, int B, int T, int heads, int ch, int mm_dtype, void* stream) {
   STEDM_CHECK_ARG(qkv && out16 && B > 0 && heads > 0, "attn_legacy16: bad args");
-  STEDM_CHECK_ARG(T > 0 && T % 64 == 0 && T <= 4096 && (ch == 128 || ch == 64 || ch == 32) && (T == 64 || (qkv_is16 && ch != 32)),
-                  "attn_legacy16: covers T == 64 (ch in {32, 64, 128}) and, from the 16-bit qkv plane, T = 64 n <= 4096 with ch in {64, 128} (T=%d ch=%d)", T, ch);
+  STEDM_CHECK_ARG(T > 0 && (ch == 128 || ch == 64 || ch == 32 || ch == 16) && ((T == 64 && ch != 16) || qkv_is16),
+                  "attn_legacy16: covers head widths 16 / 32 / 64 / 128 from the 16-bit qkv plane (any T) and T == 64 (ch >= 32) from fp32 rows (T=%d ch=%d is16=%d)", T, ch, qkv_is16);
   STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "attn_legacy16: bad mm_dtype");
-  if (T != 64) {
-    const int np = B * heads * (T / 32), g = (np + 3) / 4;
-    const float sc2 = 1.0f / sqrtf((float)ch);
+  if (T != 64 || ch == 16) {
+    // flash form: workgroups of 4 waves x 32 queries (two per CU)
     hipStream_t s_ = as_stream(stream);
-    if (mm_dtype == STEDM_F16) {
-      if (ch == 128) attn_mfma_tiles_kernel<_Float16, 128><<<g, 256, 0, s_>>>((const _Float16*)qkv, (_Float16*)out16, np, heads, T, sc2);
-      else attn_mfma_tiles_kernel<_Float16, 64><<<g, 256, 0, s_>>>((const _Float16*)qkv, (_Float16*)out16, np, heads, T, sc2);
-    } else {
-      if (ch == 128) attn_mfma_tiles_kernel<__bf16, 128><<<g, 256, 0, s_>>>((const __bf16*)qkv, (__bf16*)out16, np, heads, T, sc2);
-      else attn_mfma_tiles_kernel<__bf16, 64><<<g, 256, 0, s_>>>((const __bf16*)qkv, (__bf16*)out16, np, heads, T, sc2);
+    static const bool tiles_ab = getenv("STEDM_ATTN_TILES") != nullptr;      // round-4 kernel, kept for the A/B of profiles/r05_attn_flash.md
+    if (tiles_ab && T % 64 == 0 && ch >= 64) {
+      const int np = B * heads * (T / 32), g = (np + 3) / 4;
+      const float sc2 = 1.0f / sqrtf((float)ch);
+      if (mm_dtype == STEDM_F16) {
+        if (ch == 128) attn_mfma_tiles_kernel<_Float16, 128><<<g, 256, 0, s_>>>((const _Float16*)qkv, (_Float16*)out16, np, heads, T, sc2);
+        else attn_mfma_tiles_kernel<_Float16, 64><<<g, 256, 0, s_>>>((const _Float16*)qkv, (_Float16*)out16, np, heads, T, sc2);
+      } else {
+        if (ch == 128) attn_mfma_tiles_kernel<__bf16, 128><<<g, 256, 0, s_>>>((const __bf16*)qkv, (__bf16*)out16, np, heads, T, sc2);
+        else attn_mfma_tiles_kernel<__bf16, 64><<<g, 256, 0, s_>>>((const __bf16*)qkv, (__bf16*)out16, np, heads, T, sc2);
+      }
+      STEDM_LAUNCH_CHECK();
+      return 0;
     }
-    STEDM_LAUNCH_CHECK();
-    return 0;
+    AttnFlashArgs fa{qkv, out16, T, heads, B * heads, (T + 127) / 128, 1.4426950408889634f / sqrtf((float)ch)};
+    return mm_dtype == STEDM_F16 ? attn_flash_launch<_Float16, 4>(fa, ch, s_) : attn_flash_launch<__bf16, 4>(fa, ch, s_);
   }
   const int nprob = B * heads, grid = (nprob + 3) / 4;
   const float scale2 = 1.0f / sqrtf((float)ch);

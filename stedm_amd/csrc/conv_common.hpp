@@ -26,8 +26,17 @@ struct ConvParams {
   int xcd_m;       // register-streamed kernel: XCD-aware block -> tile order: 0 plain, else gm in {8, 4, 2} = the M-tiles are dealt over gm XCD groups, the N-tiles over 8 / gm (conv_rs_kernel)
   int npers;       // register-streamed 1x1 kind: N-persistent form (one block per M-tile walks all N-tiles; conv_rs_try)
   unsigned* ovf;   // fp16 operand range guard flag (common.hpp) or nullptr; set by the dispatcher for fp16 launches
-  int dbg;  // ablation bits (STEDM_CONV_DBG, timing experiments only): 1 no weight DMA, 2 no patch staging, 4 no MFMA, 8 no LDS frag reads
+  int dbg;  // ablation bits (STEDM_CONV_DBG; DIAGNOSTIC BUILDS ONLY, see STEDM_DBG below): 1 no weight DMA, 2 no patch staging, 4 no MFMA, 8 no LDS frag reads
 };
+
+// Run-time ablation switches and phase stamps (STEDM_CONV_DBG) exist only in diagnostic builds (-DSTEDM_CONV_DIAG=<bits>, tools/conv_diag.sh;
+// bits = 0 gives the run-time switches alone). In the shipped library STEDM_DBG(...) is the constant 0: no branch, no load of p.dbg, nothing
+// between the compiler and its exact s_waitcnt counts in the hot loops (a run-time branch around a load costs it those counts).
+#ifdef STEDM_CONV_DIAG
+#define STEDM_DBG(WORD, BITS) (((WORD) & (BITS)) != 0)
+#else
+#define STEDM_DBG(WORD, BITS) (0)
+#endif
 
 template <typename T>
 struct MM;

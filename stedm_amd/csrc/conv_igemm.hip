@@ -429,7 +429,12 @@ static int conv_dispatch(ConvParams& p, void* stream) {
   { const int rc = conv_setup(p); if (rc) return rc; }
   hipStream_t st = as_stream(stream);
   static const int dbg0 = getenv("STEDM_CONV_DBG") ? atoi(getenv("STEDM_CONV_DBG")) : 0;
+#ifdef STEDM_CONV_DIAG
   p.dbg = dbg0;
+#else
+  p.dbg = 0;
+  if (dbg0) { set_error("conv_igemm: STEDM_CONV_DBG=%d needs a diagnostic build (tools/conv_diag.sh, STEDM_HIP_LIB); the shipped kernels compile no ablation switch", dbg0); return 1; }
+#endif
   p.ovf = a.mm_dtype == STEDM_F16 ? f16_guard_flag() : nullptr;
   if (a.src16_hi) {   // v3: both operands by LDS-DMA from pre-normalised 16-bit planes
     const int rc = conv_launch_dma(p, st);

@@ -460,7 +460,8 @@ __global__ void __launch_bounds__(256) gn_apply16c_kernel(GnApplyCArgs a, int sl
     }
   };
   load_batch(threadIdx.x);
-  bool maybe_over = false;       // block-uniform: some channel partial of this block's groups admits |x| > 65504 (fp16 guard)
+  bool maybe_over = false;       // block-uniform: some channel partial of this block's groups admits |x| > 65504 (fp16 guard, raw planes)
+  bool norm_over = false;        // block-uniform: some channel's gamma / beta admits a normalised value beyond the fp16 range
   unsigned bad_raw = 0u, bad_norm = 0u;
   {
     const int L = 256 / a.groups;                 // lanes per group (groups <= 64)
@@ -492,7 +493,14 @@ __global__ void __launch_bounds__(256) gn_apply16c_kernel(GnApplyCArgs a, int sl
       lrstd[g] = (float)(1.0 / sqrt(var + (double)a.eps));
       if (a.mr && sl == 0) { a.mr[((long)b * a.groups + g) * 2] = lmean[g]; a.mr[((long)b * a.groups + g) * 2 + 1] = lrstd[g]; }
     }
-    __syncthreads();
+    // the normalised planes have their own switch: |x^| <= sqrt(n) whatever the raw values are, so a plane value can only leave the fp16
+    // range through gamma / beta (sqrt(n) |gamma| + |beta| > 65504) - small raw values do not rule that out
+    int nb = 0;
+    if (a.ovf != nullptr && __is_same(T, _Float16)) {
+      const float rn = sqrtf((float)cpg * (float)a.HW);
+      for (int c = threadIdx.x; c < C; c += 256) nb |= !(rn * fabsf(a.gamma[c]) + fabsf(a.beta[c]) < 65504.f);
+    }
+    norm_over = __syncthreads_or(nb) != 0;
   }
   for (int i = threadIdx.x; i < total; i += 256 * U) {
     if (i != (int)threadIdx.x) load_batch(i);
@@ -530,7 +538,7 @@ __global__ void __launch_bounds__(256) gn_apply16c_kernel(GnApplyCArgs a, int sl
         V4 hi;
         hi[0] = (T)w.x; hi[1] = (T)w.y; hi[2] = (T)w.z; hi[3] = (T)w.w;
         oh[o] = hi;
-        if (maybe_over) bad_norm |= f16_over_v4<T>(hi);
+        if (norm_over) bad_norm |= f16_over_v4<T>(hi);
         if (ol) {
           V4 lo;
           lo[0] = (T)(w.x - (float)hi[0]); lo[1] = (T)(w.y - (float)hi[1]);
@@ -542,7 +550,8 @@ __global__ void __launch_bounds__(256) gn_apply16c_kernel(GnApplyCArgs a, int sl
       if (qs[k] >= Q) { qs[k] -= Q; ++pixs[k]; }
     }
   }
-  if (maybe_over) { f16_guard_commit(a.ovf, bad_raw, STEDM_F16G_RAW); f16_guard_commit(a.ovf, bad_norm, STEDM_F16G_NORM); }
+  if (maybe_over) f16_guard_commit(a.ovf, bad_raw, STEDM_F16G_RAW);
+  if (norm_over) f16_guard_commit(a.ovf, bad_norm, STEDM_F16G_NORM);
 }
 
 
@@ -602,7 +611,8 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
   };
   load_adv(v, 0);
   load_adv(vn, 1);
-  bool maybe_over = false;       // block-uniform: some channel partial of this block's groups admits |x| > 65504 (fp16 guard)
+  bool maybe_over = false;       // block-uniform: some channel partial of this block's groups admits |x| > 65504 (fp16 guard, raw planes)
+  bool norm_over = false;        // block-uniform: some channel's gamma / beta admits a normalised value beyond the fp16 range
   unsigned bad_raw = 0u, bad_norm = 0u;
   {
     const int g_lo = c_lo / cpg, ng = c_n / cpg;  // this block's groups
@@ -637,13 +647,18 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
       if (a.mr && (cb > 0 || sl == 0)) { a.mr[((long)b * a.groups + g) * 2] = lmean[g]; a.mr[((long)b * a.groups + g) * 2 + 1] = lrstd[g]; }
     }
     __syncthreads();
+    int nb = 0;
+    const bool guard = a.ovf != nullptr && __is_same(T, _Float16);
+    const float rn = sqrtf((float)cpg * (float)a.HW);          // |x^| <= sqrt(n): the normalised planes' own switch (see gn_apply16c_kernel)
     for (int c = c_lo + threadIdx.x; c < c_lo + c_n; c += 256) {
       const int gc = c / cpg;
+      const float gmc = a.gamma[c], btc = a.beta[c];
       tab[c] = lmean[gc];
-      tab[C + c] = lrstd[gc] * a.gamma[c];
-      tab[2 * C + c] = a.beta[c];
+      tab[C + c] = lrstd[gc] * gmc;
+      tab[2 * C + c] = btc;
+      if (guard) nb |= !(rn * fabsf(gmc) + fabsf(btc) < 65504.f);
     }
-    __syncthreads();
+    norm_over = __syncthreads_or(nb) != 0;
   }
   const bool odd = threadIdx.x & 1;
   auto pack4 = [](float x0, float x1, float x2, float x3) {
@@ -689,7 +704,7 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
       w.x = (w.x - mn.x) * sc.x + bt.x; w.y = (w.y - mn.y) * sc.y + bt.y; w.z = (w.z - mn.z) * sc.z + bt.z; w.w = (w.w - mn.w) * sc.w + bt.w;
       if (a.act == 1) { w.x = silu_f(w.x); w.y = silu_f(w.y); w.z = silu_f(w.z); w.w = silu_f(w.w); }
       oq[k] = pack4(w.x, w.y, w.z, w.w);
-      if (maybe_over) bad_norm |= f16_over4<T>(oq[k]);
+      if (norm_over) bad_norm |= f16_over4<T>(oq[k]);
       if (ol) {
         V4 hq = *reinterpret_cast<V4*>(&oq[k]);
         olq[k] = pack4(w.x - (float)hq[0], w.y - (float)hq[1], w.z - (float)hq[2], w.w - (float)hq[3]);
@@ -713,7 +728,8 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
   };
   for (int it = 0; it < nfull; ++it) body(std::false_type{}, it);
   if (nfull * 256 * U < total) body(std::true_type{}, nfull);
-  if (maybe_over) { f16_guard_commit(a.ovf, bad_raw, STEDM_F16G_RAW); f16_guard_commit(a.ovf, bad_norm, STEDM_F16G_NORM); }
+  if (maybe_over) f16_guard_commit(a.ovf, bad_raw, STEDM_F16G_RAW);
+  if (norm_over) f16_guard_commit(a.ovf, bad_norm, STEDM_F16G_NORM);
 }
 
 extern "C" int stedm_gn_apply16c_mr(const float* x1, int c1, const float* cs1, int nslab1, const float* x2, int c2, const float* cs2, int nslab2, int x2_bmod,

@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(512) wgrad3x3_kernel(WgradArgs a) {
     const unsigned char* px = sX + buf * WG_XBUF;
     const unsigned char* py = sY + buf * WG_YBUF;
 #pragma unroll 1
-    for (int s = 0; s < ((a.dbg & 2) ? 0 : 4); ++s) {
+    for (int s = 0; s < (STEDM_DBG(a.dbg, 2) ? 0 : 4); ++s) {
       const int k_lo = 16 * s + 8 * h + q, k_hi = k_lo + 4;            // this lane's block rows (pixels of the unit)
       const bf16x8 bf = tr_pair(py, k_lo * WG_YS + colB, k_hi * WG_YS + colB);
       // patch row of tap (0, 0); tap (ky, kx) adds the compile-time constant (ky * PW + kx) rows
@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(512) wgrad3x3_kernel(WgradArgs a) {
       }
     }
   };
-  const bool ld_on = !(a.dbg & 1), st_on = !(a.dbg & 4);
+  const bool ld_on = !STEDM_DBG(a.dbg, 1), st_on = !STEDM_DBG(a.dbg, 4);
   if (u0 < u1) { load_unit(u0, rxA, ryA); store_unit(0, rxA, ryA); }
   if constexpr (DEEP) {
     // LDS holds unit u (computed) and u+1; registers hold u+1 / u+2 (sets A / B alternating)
@@ -366,7 +366,12 @@ static int wgrad3x3_launch(const void* x16, const void* dy16, float* part, int B
   a.ksplit = ks; a.tiles_n = Cout / 64;
   a.PW = W + 2; a.NP = (a.upr + 2) * a.PW;
   static const int dbg = getenv("STEDM_WGRAD_DBG") ? atoi(getenv("STEDM_WGRAD_DBG")) : 0;
+#ifdef STEDM_CONV_DIAG
   a.dbg = dbg;
+#else
+  a.dbg = 0;
+  if (dbg) { set_error("wgrad: STEDM_WGRAD_DBG=%d needs a diagnostic build (-DSTEDM_CONV_DIAG=0); the shipped kernels compile no ablation switch", dbg); return 1; }
+#endif
   a.oihw = oihw;
   const size_t lds = 2 * WG_XBUF + 2 * WG_YBUF;
   static bool attr = false;

@@ -717,8 +717,23 @@ def predict_latents_sharded(model: S_ZSS_DM, shard_batch: dict, global_batch: in
         from .schedule import make_ddim_timesteps
         n_iter = int(make_ddim_timesteps(int(ddim_steps), model.num_timesteps).shape[0])      # (S = 6 -> 7 iterations: ddim.py's uniform stride)
         noises = [par.per_sample_normal(seed, ids, shape, stream=1 + i).to(dev) for i in range(n_iter)]
-    lat = predict_latents(model, shard_batch, ddim_steps, eta=eta, cfg_scale=cfg_scale, x_T=x_T, noises=noises, **kw)
+    from ._lib import StedmHipError
+    err: Optional[StedmHipError] = None
+    lat = None
+    try:
+        lat = predict_latents(model, shard_batch, ddim_steps, eta=eta, cfg_scale=cfg_scale, x_T=x_T, noises=noises, **kw)
+    except StedmHipError as e:       # (the fp16 range guard raises at the end of the loop: ddim.py's f16_guard_check)
+        if not (gather and world > 1):
+            raise
+        err = e
     if gather and world > 1:
+        # a rank that raised must not leave the others waiting in the all-gather: agree on the outcome first (one 4-byte all-reduce)
+        flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if int(flag.item()):
+            if err is not None:
+                raise err
+            raise StedmHipError(f"rank {rank} of {world}: another rank's sampling loop raised (fp16 operand overflow there); no latents gathered")
         lat = par.all_gather_samples(lat, int(global_batch), group)
     return lat
 

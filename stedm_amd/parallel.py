@@ -19,10 +19,14 @@ def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def per_sample_normal(seed: int, sample_ids, shape, stream: int = 0) -> torch.Tensor:
-    """N(0,1) tensor [len(ids), *shape] whose row i depends only on (seed, stream, sample_ids[i])."""
+    """N(0,1) tensor [len(ids), *shape] whose row i depends only on (seed, stream, sample_ids[i]).
+    Key word 1 = sample id (high 32 bits) | stream (low 32 bits): 2^32 streams per sample, so the step index of any DDIM schedule
+    (ddim.py:139: up to 1000 iterations) never aliases x_T's stream 0."""
+    assert 0 <= stream < (1 << 32)
     rows = []
     for sid in sample_ids:
-        g = np.random.Generator(np.random.Philox(key=[seed & 0xFFFFFFFF, (int(sid) << 8 | (stream & 0xFF)) & 0xFFFFFFFFFFFFFFFF]))
+        assert 0 <= int(sid) < (1 << 32)
+        g = np.random.Generator(np.random.Philox(key=[seed & 0xFFFFFFFF, (int(sid) << 32) | stream]))
         rows.append(g.standard_normal(size=tuple(shape), dtype=np.float32))
     return torch.from_numpy(np.stack(rows)) if rows else torch.empty((0,) + tuple(shape))
 
