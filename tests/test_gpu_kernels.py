@@ -250,7 +250,7 @@ def test_attn_legacy16_mfma(dev, prec, tol, B, heads, ch):
     assert torch.equal(out, out2)
 
 
-@pytest.mark.parametrize("prec,tol,tol16", [("f16", 1.5e-2, 6e-3), ("bf16", 1e-1, 5e-2)])      # (max error over more keys per query than at T = 64; reported modes)
+@pytest.mark.parametrize("prec,tol,tol16", [("f16", 2.5e-2, 1.2e-2), ("bf16", 2e-1, 8e-2)])      # (max error over more keys per query than at T = 64; reported modes)
 @pytest.mark.parametrize("B,T,heads,ch", [(2, 256, 8, 128), (1, 1024, 8, 128), (3, 128, 4, 64), (66, 256, 8, 128),
                                           (2, 36, 8, 16), (1, 100, 2, 64), (2, 576, 8, 128), (3, 1000, 4, 32), (1, 4096, 2, 64), (5, 65, 3, 128), (2, 64, 8, 16)])
 def test_attn_legacy16_mfma_key_tiles(dev, prec, tol, tol16, B, T, heads, ch):
@@ -447,6 +447,42 @@ def test_conv_epilogue_chan_stats(dev, prec, B, H, W, cin, cout):
     ops.conv_igemm(None, whi, wlo, out, prec=pr, src16=(hi16, lo16), bias=bias, emb=emb, emb_bstride=cout, res=res,
                    w_frag=ops.pack_conv_weight_frag(w, pr) if pr.npass == 1 else None, chan_stats=cs2)
     assert torch.equal(cs, cs2)   # no atomics anywhere: bitwise reproducible
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16", "parity"])
+@pytest.mark.parametrize("B,H,W,cin,cout", [(1, 24, 24, 512, 512), (2, 24, 24, 256, 128), (1, 40, 40, 512, 256), (3, 10, 10, 1024, 1024)])
+def test_conv1x1_split_k_chan_stats_on_sizes_off_the_256_pixel_run(dev, prec, B, H, W, cin, cout):
+    """a 1x1 (the attention block's proj_out: chan_stats + residual + workspace) whose H * W neither divides nor is a
+    multiple of the 256-pixel statistics run, at a batch small enough for the K split (24 x 24 = 576 pixels, B = 1, 512 channels: 8 shares).
+    The reduce pass cannot fill the caller's slots in that case and must not claim it did: the dispatcher's statistics pass writes them.
+    Statistics are compared with the sums of the stored output; a stale buffer (the bug) leaves the NaN fill in place. (The U-Net classes
+    themselves only admit latent widths the 3x3 tiles divide - powers of two - so this is reachable through the C ABI only.)"""
+    from stedm_amd import ops
+    pr = ops.Precision.parse(prec)
+    x = torch.randn(B, H, W, cin, device=dev)
+    w = torch.randn(cout, cin, 1, 1, device=dev) / math.sqrt(cin)
+    bias = torch.randn(cout, device=dev); res = torch.randn(B, H, W, cout, device=dev)
+    hi16 = torch.empty((B, H, W, cin), dtype=torch.int16, device=dev); lo16 = torch.empty_like(hi16)
+    ops.gn_apply16(x, None, hi16, lo16, pr)
+    whi, wlo = ops.pack_conv_weight(w, pr)
+    ns = ops.gn_chan_nslab(H * W)
+    out = torch.full((B, H, W, cout), float("nan"), device=dev)
+    cs = torch.full((B, ns, cout, 2), float("nan"), device=dev)
+    ops.conv_igemm(None, whi, wlo, out, prec=pr, ks=1, src16=(hi16, lo16), bias=bias, res=res,
+                   w_frag=ops.pack_conv_weight_frag(w, pr) if pr.npass == 1 else None,
+                   w_frag16=ops.pack_conv_weight_frag16(w, pr) if pr.npass == 3 else None,
+                   chan_stats=cs, ws=torch.empty(16 * out.numel(), device=dev))
+    xr = _as_float(hi16, pr).double() + (_as_float(lo16, pr).double() if pr.npass == 3 else 0.0)
+    from stedm_amd._lib import F16
+    wr = w.double() if pr.npass == 3 else w.to(torch.float16 if pr.mm_dtype == F16 else torch.bfloat16).double()
+    ref = torch.einsum("bhwc,oc->bhwo", xr, wr.view(cout, cin)) + bias.double() + res.double()
+    assert rel_err(out, ref) < (1e-4 if pr.npass == 3 else 2e-3)
+    flat = out.view(B, H * W, cout).double()
+    assert bool(torch.isfinite(cs).all()), "statistics slots left unwritten"
+    for k in range(ns):
+        sl = flat[:, k * 256:(k + 1) * 256]
+        assert torch.allclose(cs[:, k, :, 0].double(), sl.sum(1), rtol=1e-4, atol=2e-3)
+        assert torch.allclose(cs[:, k, :, 1].double(), (sl * sl).sum(1), rtol=1e-4, atol=2e-3)
 
 
 def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_emb=True, use_res=True, seed=12, frag=False, ws=False, m16=False, want_rs=None):
