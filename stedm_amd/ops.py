@@ -184,22 +184,23 @@ def pack_conv_weight_s2d_frag(w: torch.Tensor, prec: Precision, pad_br: bool = F
 
 
 def pack_conv_weight_up_frag16_hl(w: torch.Tensor, prec: Precision) -> torch.Tensor:
-    """3-product modes: the sub-pixel upsample filters as hi + lo fragment streams of the 16x16x32 kind (stedm_pack_conv_weight_up_frag16_hl)."""
+    """The sub-pixel upsample filters as hi + lo fragment streams of the 16x16x32 kind (stedm_pack_conv_weight_up_frag16_hl): the 3-product
+    modes read both, the single-product modes the hi stream (RS_SUBM, conv_rs.inc)."""
     w = w.detach().contiguous()
     _chk(w, name="conv weight")
     cout, cin, ks, _ = w.shape
-    assert ks == 3 and cin % 32 == 0 and prec.npass == 3
+    assert ks == 3 and cin % 32 == 0
     out = torch.empty((2, 4, (cout + 127) // 128, cin // 32, 4, 8, 64, 8), dtype=torch.int16, device=w.device)
     check(lib().stedm_pack_conv_weight_up_frag16_hl(w.data_ptr(), out.data_ptr(), cout, cin, prec.mm_dtype, _stream()), "stedm_pack_conv_weight_up_frag16_hl")
     return out
 
 
 def pack_conv_weight_s2d_frag16_hl(w: torch.Tensor, prec: Precision, pad_br: bool = False) -> torch.Tensor:
-    """3-product modes: the space-to-depth Downsample filter as hi + lo fragment streams of the 16x16x32 kind."""
+    """The space-to-depth Downsample filter as hi + lo fragment streams of the 16x16x32 kind (3-product modes: both; single-product: hi)."""
     w = w.detach().contiguous()
     _chk(w, name="conv weight")
     cout, cin, ks, _ = w.shape
-    assert ks == 3 and cin % 8 == 0 and prec.npass == 3
+    assert ks == 3 and cin % 8 == 0
     out = torch.empty((2, (cout + 127) // 128, 4 * cin // 32, 4, 8, 64, 8), dtype=torch.int16, device=w.device)
     check(lib().stedm_pack_conv_weight_s2d_frag16_hl(w.data_ptr(), out.data_ptr(), cout, cin, prec.mm_dtype, int(pad_br), _stream()),
           "stedm_pack_conv_weight_s2d_frag16_hl")
@@ -523,7 +524,7 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
     elif mode == CONV_UP_SUBPIXEL:
         assert w_hi.shape == (4 * a.cout, 4, a.c1 + a.c2), (w_hi.shape, a.cout, a.c1, a.c2)
     elif mode == CONV_S2D:
-        assert w_hi is None and (w_frag is not None or (prec.npass == 3 and w_frag16 is not None)) and src1 is None, \
+        assert w_hi is None and (w_frag is not None or w_frag16 is not None) and src1 is None, \
             "the space-to-depth form runs on the register-streamed kernel only"
     else:
         assert w_hi.shape == (a.cout, ks * ks, a.c1 + a.c2), (w_hi.shape, a.cout, ks, a.c1, a.c2)

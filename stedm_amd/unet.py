@@ -379,6 +379,7 @@ class UNetModel(nn.Module):
                         hi, lo = ops.LazyPlanes(lambda w=m.conv.weight: ops.pack_conv_weight_up(w.float(), prec)), None
                     else:
                         hi, lo = ops.pack_conv_weight_up(m.conv.weight.float(), prec)
+                    # 16x16x32 fragment order (RS_SUBM): the 3-product modes (single product: the 32x32x16 RS_SUB form measured faster)
                     frag16 = (ops.pack_conv_weight_up_frag16_hl(m.conv.weight.float(), prec)
                               if prec.npass == 3 and self._m16 and m.conv.in_channels % 32 == 0 and m.conv.in_channels >= 128 else None)
                     self._packed[(id(m.conv), "up")] = _Packed(hi, lo, self._packed[id(m.conv)].bias, frag, frag16)
@@ -686,7 +687,7 @@ class UNetModel(nn.Module):
                     ws = self._buf("conv_ws", ((16 if out.numel() <= (1 << 20) else 2) * out.numel(),)) if self.precision.npass == 1 else None
                     h = ops.conv_igemm(None, pu.hi, pu.lo, out, prec=self.precision, mode=CONV_UP_SUBPIXEL,
                                        src16=src16, bias=pu.bias, w_frag=pu.frag, chan_stats=self._cs_new(out, 4 * ops.gn_chan_nslab(H * W)),
-                                       w_frag16=pu.frag16 if self.precision.npass == 3 else None, ws=ws)
+                                       w_frag16=pu.frag16, ws=ws)
                 else:
                     h = ops.conv_igemm(h, pk.hi, pk.lo, out, prec=self.precision, mode=CONV_UP, bias=pk.bias)
             else:
