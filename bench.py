@@ -98,9 +98,11 @@ class ConvTimer:
                     g_out, g_lo = g_out
                 ops.gn_apply16c(out, kw["chan_stats"], None, None, g_out, g_lo, kw["prec"], g_w, g_b, g_eps, g_groups, g_act,
                                 mean_rstd=gn_next[6] if len(gn_next) > 6 else None)
-            if out is None:    # 16-bit-plane output only (qkv of the attention block)
+            if out is None:    # 16-bit-plane output only (qkv of the attention block; a decoder tensor written into the next concat's raw plane)
                 out = kw["out16"][0]
             M = out.numel() // out.shape[-1]
+            if kw.get("cout"):  # (out16_stride form: the plane is wider than the convolution's output)
+                out = out[..., :kw["cout"]]
             if w_hi is None:   # space-to-depth Downsample: 9 taps x cin of the stride-2 conv (the 2x2 x 4cin form executes 16/9 of that)
                 flops = 2.0 * M * out.shape[-1] * 9 * kw["src16"][0].shape[-1] / 4
             elif isinstance(w_hi, ops.LazyPlanes):   # fragment-order weights in use: K = taps x cin from the call (sub-pixel upsample: 4 executed taps)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STEDM_ABI_VERSION 9
+#define STEDM_ABI_VERSION 10
 
 #define STEDM_F16 0
 #define STEDM_BF16 1
@@ -152,6 +152,14 @@ int stedm_gn_apply16c(const float* x1, int c1, const float* cs1, int nslab1, con
 int stedm_gn_apply16c_mr(const float* x1, int c1, const float* cs1, int nslab1, const float* x2, int c2, const float* cs2, int nslab2, int x2_bmod,
                          const float* gamma, const float* beta, float eps, int groups, int act, int B, int HW,
                          void* out_hi, void* out_lo, void* raw_hi, void* raw_lo, float* mean_rstd, int mm_dtype, void* stream);
+/* The same pass when the h half of the concat already sits in the raw plane as 16-bit values, written there by the producing convolution
+ * (stedm_conv_args.out16_hi + out16_stride; no fp32 tensor of it exists): raw_hi [B][HW][c1 + c2] holds x1 in channels [0, c1) on entry
+ * and receives the plain conversion of x2 (fp32, [B or x2_bmod][HW][c2]) in [c1, c1 + c2); out_hi receives act(GroupNorm([x1|x2])).
+ * 4 bytes per element of the h half instead of 8 (fp32 read + two 16-bit writes). cs1: the statistics the producer's epilogue left.
+ * Single-product modes; c1 and c1 + c2 multiples of 8. Replaces the same reference lines as stedm_gn_apply16c. */
+int stedm_gn_apply16c_x16(int c1, const float* cs1, int nslab1, const float* x2, int c2, const float* cs2, int nslab2, int x2_bmod,
+                          const float* gamma, const float* beta, float eps, int groups, int act, int B, int HW,
+                          void* out_hi, void* raw_hi, int mm_dtype, void* stream);
 int stedm_gn_stats(const float* x1, int c1, const float* x2, int c2, int x2_bmod, int groups, int B, int HW,
                    double* stats, void* stream);
 int stedm_gn_apply16(const float* x1, int c1, const float* x2, int c2, int x2_bmod, const float* gamma,
@@ -255,6 +263,13 @@ typedef struct stedm_conv_args {
   const float* ln_beta;
   const float* ln_res;
   float ln_eps;
+  /* Optional (round 5, ABI 10): elements per pixel row of the out16_hi plane (0: cout). With it a convolution writes its 16-bit output into
+   * channels [0, cout) of a WIDER plane - the raw plane [B][Hout][Wout][cout + c_skip] of the decoder's th.cat([h, hs.pop()])
+   * (openaimodel.py:800) that the next ResBlock's skip_connection reads and stedm_gn_apply16c_x16 normalises - and `out` may be NULL together
+   * with chan_stats != NULL (the statistics are those of the fp32 values before their rounding): in inference nothing but that GroupNorm and
+   * that 1x1 read the tensor, so no fp32 copy of it is ever stored. Register-streamed kernel, single-product modes, no out16_lo
+   * (stedm_conv_rs_ok tells; split-K launches take it too). */
+  int32_t out16_stride;
 } stedm_conv_args;
 /* Replaces: GN->SiLU->conv3x3(+bias)(+emb)(+skip) of ResBlock._forward openaimodel.py:268-288,
  * Downsample/Upsample convs (:122-132,:156-173), 1x1 skip_connection (:254), and the 1x1

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STEDM_HIP_LIB") or os.path.join(_HERE, "libstedm_hip.so")     # STEDM_HIP_LIB: A/B timing of another build
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 F16, BF16 = 0, 1
 CONV_S1, CONV_DOWN, CONV_UP, CONV_UP_SUBPIXEL, CONV_S2D = 0, 1, 2, 3, 4
 
@@ -42,6 +42,7 @@ class ConvArgs(C.Structure):
         ("qkv_q", C.c_void_p), ("qkv_k", C.c_void_p), ("qkv_vt", C.c_void_p),
         ("qkv_T", C.c_int32), ("qkv_Tp", C.c_int32), ("qkv_heads", C.c_int32), ("qkv_qscale", C.c_float),
         ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_res", C.c_void_p), ("ln_eps", C.c_float),
+        ("out16_stride", C.c_int32),
     ]
 
 
@@ -73,6 +74,7 @@ SIGNATURES = {
     "stedm_gn_chan_stats16": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "stedm_gn_apply16c": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _F, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "stedm_gn_apply16c_mr": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _F, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
+    "stedm_gn_apply16c_x16": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _F, _I, _I, _I, _I, _P, _P, _I, _P]),
     "stedm_conv_igemm": (_I, [C.POINTER(ConvArgs), _P]),
     "stedm_conv_fused_skip_ok": (_I, [C.POINTER(ConvArgs)]),
     "stedm_conv_rs_ok": (_I, [C.POINTER(ConvArgs)]),

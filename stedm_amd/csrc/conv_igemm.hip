@@ -349,13 +349,20 @@ extern "C" int stedm_conv_igemm(const stedm_conv_args* args, void* stream) {
   memset(&p, 0, sizeof(p));
   p.a = *args;
   const stedm_conv_args& a = p.a;
-  STEDM_CHECK_ARG(!a.chan_stats || a.out, "conv_igemm: chan_stats needs the fp32 output");
+  STEDM_CHECK_ARG(!a.chan_stats || a.out || (a.out16_hi && !a.out16_lo && a.npass == 1), "conv_igemm: chan_stats needs the fp32 output (or, single product, the 16-bit-only form)");
+  STEDM_CHECK_ARG(a.out16_stride == 0 || (a.out16_hi && !a.out16_lo && a.npass == 1 && a.out16_stride >= a.cout && a.out16_stride % 4 == 0 && a.cout % 4 == 0 &&
+                                          !a.ln_gamma && !a.qkv_q && !a.act_out),
+                  "conv_igemm: out16_stride needs out16_hi alone (single product), stride >= cout, both multiples of 4, plain epilogue");
   STEDM_CHECK_ARG(!a.gn_out16 || (a.out && a.chan_stats && a.gn_gamma && a.gn_beta && a.gn_groups > 0 && a.cout % a.gn_groups == 0 &&
                                   (a.npass == 1 || a.gn_out16_lo) && a.mode == STEDM_CONV_S1 && (a.gn_act == 0 || a.gn_act == 1)),
                   "conv_igemm: gn_out16 needs out, chan_stats, gamma / beta, groups dividing cout, stride 1 and a single-product mode (or gn_out16_lo)");
   STEDM_CHECK_ARG(!a.gn_out16_lo || a.gn_out16, "conv_igemm: gn_out16_lo without gn_out16");
   int rc = conv_dispatch(p, stream);
   if (rc != 0) return rc;
+  if (a.chan_stats && !p.stats_done && !a.out) {      // (cannot happen: conv_rs_try declines the 16-bit-only form when its epilogue would not write the statistics)
+    set_error("conv_igemm: the 16-bit-only form with chan_stats ran on a kernel without the statistics epilogue");
+    return 1;
+  }
   if (a.chan_stats && !p.stats_done) {
     // the kernel that ran has no statistics epilogue: one extra pass over the output
     const int up = (a.mode == STEDM_CONV_UP || a.mode == STEDM_CONV_UP_SUBPIXEL) ? 4 : 1, down = a.mode == STEDM_CONV_DOWN ? 4 : 1;

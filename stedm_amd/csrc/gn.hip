@@ -415,6 +415,8 @@ struct GnApplyCArgs {
   void* raw_lo;
   float* mr;     // optional [B][groups][2]: the {mean, rstd} this pass folds anyway, kept for the training backward
   unsigned* ovf; // fp16 range guard flag (common.hpp) or nullptr
+  const void* x16;  // v8 kernel, X16 form: the x1 channels arrive as the 16-bit values a convolution's epilogue already wrote into channels
+                    // [0, c1) of the raw plane [B][HW][c1 + c2] (= raw_hi): x1 is not read and that part of the raw plane not rewritten
 };
 
 // A value beyond the fp16 range (65 504) in a run of pixels makes that run's sum of squares exceed 65 504^2 = 4.29e9: a block whose channel
@@ -564,7 +566,7 @@ __global__ void __launch_bounds__(256) gn_apply16c_kernel(GnApplyCArgs a, int sl
 // cb > 0: the block takes a CHANNEL run of cb channels (whole groups, a multiple of 8) of every pixel of its sample instead of a pixel run
 // of all channels: it folds the statistics and builds the table of its own groups only (the samples of the 8 x 8 level are 64 pixels of
 // 1024 - 2048 channels: six pixel-run blocks per sample each built the whole table for 11 pixels of streaming).
-template <typename T>
+template <typename T, bool X16 = false>
 __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int slab, int cb) {
   typedef T V4 __attribute__((ext_vector_type(4)));
   __shared__ double dsu[256], dsq[256];
@@ -574,8 +576,9 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
   const int C = a.c1 + a.c2, Qall = C >> 2;
   const int cpg = C / a.groups;
   const int b2 = a.bmod > 0 ? b % a.bmod : b;
-  const float* p1 = a.x1 + (long)b * a.HW * a.c1;
+  const float* p1 = X16 ? nullptr : a.x1 + (long)b * a.HW * a.c1;
   const float* p2 = a.x2 ? a.x2 + (long)b2 * a.HW * a.c2 : nullptr;
+  const T* p16 = X16 ? reinterpret_cast<const T*>(a.x16) + (long)b * a.HW * C : nullptr;      // rows of C channels: the raw plane itself
   const int c_lo = cb > 0 ? sl * cb : 0, c_n = cb > 0 ? cb : C;       // this block's channels
   const int Q = c_n >> 2, q_lo = c_lo >> 2;                           // quads per pixel of this block, first quad
   const int px0 = cb > 0 ? 0 : sl * slab, px1 = cb > 0 ? a.HW : min(a.HW, px0 + slab);
@@ -603,8 +606,13 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
     for (int k = 0; k < U; ++k) {
       const bool ok = it * 256 * U + (int)threadIdx.x + k * 256 < total;
       const int px = ok ? lpx[k] : px0, c = (q_lo + (ok ? lqs[k] : 0)) * 4;
-      const float* src = c < a.c1 ? p1 + (long)px * a.c1 + c : p2 + (long)px * a.c2 + (c - a.c1);
-      dst[k] = *reinterpret_cast<const float4*>(src);
+      if (X16 && c < a.c1) {           // 8 B of the producer's 16-bit values
+        const V4 h4 = *reinterpret_cast<const V4*>(p16 + (long)px * C + c);
+        dst[k] = make_float4((float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]);
+      } else {
+        const float* src = (!X16 && c < a.c1) ? p1 + (long)px * a.c1 + c : p2 + (long)px * a.c2 + (c - a.c1);
+        dst[k] = *reinterpret_cast<const float4*>(src);
+      }
       lpx[k] += dpix; lqs[k] += dq;
       if (lqs[k] >= Q) { lqs[k] -= Q; ++lpx[k]; }
     }
@@ -717,8 +725,10 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
     const uint4 so = pair16(oq[0], oq[1]);
     if (!TAIL || mlive) *reinterpret_cast<uint4*>(oh + o) = so;
     if (ol) { const uint4 t4 = pair16(olq[0], olq[1]); if (!TAIL || mlive) *reinterpret_cast<uint4*>(ol + o) = t4; }
-    if (rh) { const uint4 t4 = pair16(rq[0], rq[1]); if (!TAIL || mlive) *reinterpret_cast<uint4*>(rh + o) = t4; }
-    if (rl) { const uint4 t4 = pair16(rlq[0], rlq[1]); if (!TAIL || mlive) *reinterpret_cast<uint4*>(rl + o) = t4; }
+    // (X16: the x1 part of the raw plane is the source itself; c1 % 8 == 0 keeps a lane pair on one side of the seam)
+    const bool rawst = !X16 || (q_lo + (qs[mk] & ~1)) * 4 >= a.c1;
+    if (rh) { const uint4 t4 = pair16(rq[0], rq[1]); if ((!TAIL || mlive) && rawst) *reinterpret_cast<uint4*>(rh + o) = t4; }
+    if (rl) { const uint4 t4 = pair16(rlq[0], rlq[1]); if ((!TAIL || mlive) && rawst) *reinterpret_cast<uint4*>(rl + o) = t4; }
 #pragma unroll
     for (int k = 0; k < U; ++k) {
       pixs[k] += dpix; qs[k] += dq;
@@ -732,9 +742,173 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
   if (norm_over) f16_guard_commit(a.ovf, bad_norm, STEDM_F16G_NORM);
 }
 
+// Round 5: the pass on OCTETS (8 channels per thread and iteration), single-product modes. A lane's unit is 8 contiguous channels of one
+// pixel: 16 B of 16-bit source (the h half of a decoder concat in its X16 form) or 32 B of fp32 source in, ONE 16-B store of the normalised
+// plane out (plus one of the raw plane for fp32-source channels when asked) - no lane exchange, half the table reads and address
+// arithmetic per byte of gn_apply16c_v8_kernel. (The quad kernel with 8-B loads for the 16-bit half ran the nine decoder concats at
+// 3.1 TB/s of 1.64 GB where the fp32 form had run 5.2 TB/s of 2.41 GB: the pass is bound by requests in flight, not by bytes.)
+// Same block partition as the quad kernel (pixel runs of all channels, or channel runs of whole groups: cb), same statistics fold.
+template <typename T, bool X16>
+__global__ void __launch_bounds__(256) gn_apply16c_o8_kernel(GnApplyCArgs a, int slab, int cb) {
+  typedef T V8 __attribute__((ext_vector_type(8)));
+  __shared__ double dsu[256], dsq[256];
+  __shared__ float lmean[64], lrstd[64];
+  extern __shared__ __attribute__((aligned(16))) float tab[];   // [3][C]: mean, rstd * gamma, beta per channel
+  const int b = blockIdx.x, sl = blockIdx.y;
+  const int C = a.c1 + a.c2, Oall = C >> 3;
+  const int cpg = C / a.groups;
+  const int b2 = a.bmod > 0 ? b % a.bmod : b;
+  const float* p1 = X16 ? nullptr : a.x1 + (long)b * a.HW * a.c1;
+  const float* p2 = a.x2 ? a.x2 + (long)b2 * a.HW * a.c2 : nullptr;
+  const T* p16 = X16 ? reinterpret_cast<const T*>(a.x16) + (long)b * a.HW * C : nullptr;      // rows of C channels: the raw plane itself
+  const int c_lo = cb > 0 ? sl * cb : 0, c_n = cb > 0 ? cb : C;       // this block's channels
+  const int O = c_n >> 3, o_lo = c_lo >> 3;                           // octets per pixel of this block, first octet
+  const int px0 = cb > 0 ? 0 : sl * slab, px1 = cb > 0 ? a.HW : min(a.HW, px0 + slab);
+  const int total = (px1 - px0) * O;             // octets of this block
+  uint4* oh = reinterpret_cast<uint4*>(a.out_hi) + (long)b * a.HW * Oall;      // 16-B units (one octet of 16-bit values)
+  uint4* rh = a.raw_hi ? reinterpret_cast<uint4*>(a.raw_hi) + (long)b * a.HW * Oall : nullptr;
+  int pix = px0 + (int)threadIdx.x / O, oc = (int)threadIdx.x % O;        // compute cursor
+  int lpx = pix, loc = oc;                                                // load cursor: two block iterations ahead
+  const int dpix = 256 / O, dq = 256 % O;
+  // three batches of loads in flight per thread, all unconditional (see gn_apply16c_v8_kernel): an out-of-range cursor re-reads the block's
+  // first octet; a 16-bit-source octet issues its one 16-B load twice (same address) instead of a branch around the second
+  float4 va[2], vb[2], vc[2];
+  const int nfull = total / 256;
+  auto load_adv = [&](float4 (&dst)[2], int it) {
+    const bool ok = it * 256 + (int)threadIdx.x < total;
+    const int px = ok ? lpx : px0, c = (o_lo + (ok ? loc : 0)) * 8;
+    // one address pair, selected without a branch: the loads themselves are unconditional
+    const bool h16 = X16 && c < a.c1;
+    const float* f32 = (!X16 && c < a.c1) ? p1 + (long)px * a.c1 + c : p2 + (long)px * a.c2 + (c - a.c1);
+    const char* s0 = h16 ? reinterpret_cast<const char*>(p16 + (long)px * C + c) : reinterpret_cast<const char*>(f32);
+    const char* s1 = h16 ? s0 : s0 + 16;
+    dst[0] = *reinterpret_cast<const float4*>(s0);
+    dst[1] = *reinterpret_cast<const float4*>(s1);
+    lpx += dpix; loc += dq;
+    if (loc >= O) { loc -= O; ++lpx; }
+  };
+  load_adv(va, 0);
+  load_adv(vb, 1);
+  bool maybe_over = false, norm_over = false;       // block-uniform fp16 guard switches (raw planes / normalised planes), as in the quad kernel
+  unsigned bad_raw = 0u, bad_norm = 0u;
+  {
+    const int g_lo = c_lo / cpg, ng = c_n / cpg;  // this block's groups
+    const int L = 256 / ng;                       // lanes per group (groups <= 64)
+    const int gl = threadIdx.x / L, l = threadIdx.x % L, g = g_lo + gl;
+    double su = 0.0, sq = 0.0;
+    int big = 0;
+    if (gl < ng) {
+      const int nmax = a.nslab1 > a.nslab2 ? a.nslab1 : a.nslab2;
+      const int n = cpg * nmax;
+      for (int e = l; e < n; e += L) {            // entry = (slab k, channel cc of the group); tensors may be partitioned differently
+        const int k = e / cpg, c = g * cpg + (e - k * cpg);
+        if (c < a.c1) {
+          if (k < a.nslab1) { const float* p = a.cs1 + (((long)b * a.nslab1 + k) * a.c1 + c) * 2; su += (double)p[0]; sq += (double)p[1]; big |= !(p[1] < STEDM_F16_SQ_SAFE); }
+        } else if (k < a.nslab2) {
+          const float* p = a.cs2 + (((long)b2 * a.nslab2 + k) * a.c2 + (c - a.c1)) * 2; su += (double)p[0]; sq += (double)p[1]; big |= !(p[1] < STEDM_F16_SQ_SAFE);
+        }
+      }
+    }
+    dsu[threadIdx.x] = su; dsq[threadIdx.x] = sq;
+    maybe_over = __syncthreads_or(big) != 0 && a.ovf != nullptr && __is_same(T, _Float16);
+    if (gl < ng && l == 0) {
+      double s_ = 0.0, q_ = 0.0;
+      for (int i = 0; i < L; ++i) { s_ += dsu[threadIdx.x + i]; q_ += dsq[threadIdx.x + i]; }   // fixed order
+      const double inv_n = 1.0 / ((double)cpg * a.HW);
+      const double mean = s_ * inv_n;
+      double var = q_ * inv_n - mean * mean;
+      var = var > 0.0 ? var : 0.0;
+      lmean[g] = (float)mean;
+      lrstd[g] = (float)(1.0 / sqrt(var + (double)a.eps));
+      if (a.mr && (cb > 0 || sl == 0)) { a.mr[((long)b * a.groups + g) * 2] = lmean[g]; a.mr[((long)b * a.groups + g) * 2 + 1] = lrstd[g]; }
+    }
+    __syncthreads();
+    int nb = 0;
+    const bool guard = a.ovf != nullptr && __is_same(T, _Float16);
+    const float rn = sqrtf((float)cpg * (float)a.HW);
+    for (int c = c_lo + threadIdx.x; c < c_lo + c_n; c += 256) {
+      const int gc = c / cpg;
+      const float gmc = a.gamma[c], btc = a.beta[c];
+      tab[c] = lmean[gc];
+      tab[C + c] = lrstd[gc] * gmc;
+      tab[2 * C + c] = btc;
+      if (guard) nb |= !(rn * fabsf(gmc) + fabsf(btc) < 65504.f);
+    }
+    norm_over = __syncthreads_or(nb) != 0;
+  }
+  auto pack8 = [](const float (&x)[8]) {
+    V8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (T)x[j];
+    return __builtin_bit_cast(uint4, h);
+  };
+  auto over8 = [](uint4 q) { return f16_over2<T>(q.x) | f16_over2<T>(q.y) | f16_over2<T>(q.z) | f16_over2<T>(q.w); };
+  auto body = [&](auto tail_c, const int it) {
+    constexpr bool TAIL = decltype(tail_c)::value;
+    load_adv(vc, it + 2);
+    const bool live = !TAIL || it * 256 + (int)threadIdx.x < total;
+    const int c = (o_lo + (live ? oc : 0)) * 8;
+    float w[8];
+    const bool from16 = X16 && c < a.c1;
+    if (from16) {
+      const V8 h8 = __builtin_bit_cast(V8, va[0]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = (float)h8[j];
+    } else {
+      w[0] = va[0].x; w[1] = va[0].y; w[2] = va[0].z; w[3] = va[0].w; w[4] = va[1].x; w[5] = va[1].y; w[6] = va[1].z; w[7] = va[1].w;
+    }
+    const long o = (long)pix * Oall + o_lo + oc;
+    if (rh && !from16) {          // (X16: the 16-bit half of the raw plane is the source itself)
+      const uint4 rq = pack8(w);
+      if (maybe_over) bad_raw |= over8(rq);
+      if (live) rh[o] = rq;
+    }
+    const float4 m0 = *reinterpret_cast<const float4*>(tab + c), m1 = *reinterpret_cast<const float4*>(tab + c + 4);
+    const float4 s0 = *reinterpret_cast<const float4*>(tab + C + c), s1 = *reinterpret_cast<const float4*>(tab + C + c + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(tab + 2 * C + c), b1 = *reinterpret_cast<const float4*>(tab + 2 * C + c + 4);
+    w[0] = (w[0] - m0.x) * s0.x + b0.x; w[1] = (w[1] - m0.y) * s0.y + b0.y; w[2] = (w[2] - m0.z) * s0.z + b0.z; w[3] = (w[3] - m0.w) * s0.w + b0.w;
+    w[4] = (w[4] - m1.x) * s1.x + b1.x; w[5] = (w[5] - m1.y) * s1.y + b1.y; w[6] = (w[6] - m1.z) * s1.z + b1.z; w[7] = (w[7] - m1.w) * s1.w + b1.w;
+    if (a.act == 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = silu_f(w[j]);
+    }
+    const uint4 oq = pack8(w);
+    if (norm_over) bad_norm |= over8(oq);
+    if (live) oh[o] = oq;
+    pix += dpix; oc += dq;
+    if (oc >= O) { oc -= O; ++pix; }
+    va[0] = vb[0]; va[1] = vb[1]; vb[0] = vc[0]; vb[1] = vc[1];
+  };
+  for (int it = 0; it < nfull; ++it) body(std::false_type{}, it);
+  if (nfull * 256 < total) body(std::true_type{}, nfull);
+  if (maybe_over) f16_guard_commit(a.ovf, bad_raw, STEDM_F16G_RAW);
+  if (norm_over) f16_guard_commit(a.ovf, bad_norm, STEDM_F16G_NORM);
+}
+
 extern "C" int stedm_gn_apply16c_mr(const float* x1, int c1, const float* cs1, int nslab1, const float* x2, int c2, const float* cs2, int nslab2, int x2_bmod,
                                     const float* gamma, const float* beta, float eps, int groups, int act, int B, int HW,
                                     void* out_hi, void* out_lo, void* raw_hi, void* raw_lo, float* mean_rstd, int mm_dtype, void* stream);
+
+static int gn_apply16c_launch(GnApplyCArgs a, int B, int mm_dtype, void* stream);
+
+// The same pass when the x1 half of the concat already sits in the raw plane as 16-bit values (written there by the producing convolution's
+// epilogue: stedm_conv_args.out16_hi + out16_stride, no fp32 tensor of it exists): reads 2 B instead of 4 for those channels and writes
+// their normalised plane only. raw_hi [B][HW][c1 + c2] holds x1 in channels [0, c1) on entry and receives the plain conversion of x2 in
+// [c1, c1 + c2). cs1: the channel statistics the producer's epilogue left (of the fp32 values before their rounding). Single-product modes.
+extern "C" int stedm_gn_apply16c_x16(int c1, const float* cs1, int nslab1, const float* x2, int c2, const float* cs2, int nslab2, int x2_bmod,
+                                     const float* gamma, const float* beta, float eps, int groups, int act, int B, int HW,
+                                     void* out_hi, void* raw_hi, int mm_dtype, void* stream) {
+  STEDM_CHECK_ARG(cs1 && out_hi && raw_hi && gamma && beta, "gn_apply16c_x16: null pointer");
+  STEDM_CHECK_ARG((x2 != nullptr) == (c2 > 0) && (x2 == nullptr || cs2 != nullptr), "gn_apply16c_x16: x2/c2/cs2 mismatch");
+  const int C = c1 + c2;
+  STEDM_CHECK_ARG(C % 8 == 0 && c1 % 8 == 0 && c1 > 0 && (size_t)3 * C * sizeof(float) <= 48 * 1024, "gn_apply16c_x16: need c1, c1 + c2 multiples of 8, C <= 4096");
+  STEDM_CHECK_ARG(groups > 0 && groups <= 64 && C % groups == 0, "gn_apply16c_x16: need groups <= 64 and C %% groups == 0");
+  STEDM_CHECK_ARG(mm_dtype == STEDM_F16 || mm_dtype == STEDM_BF16, "gn_apply16c_x16: bad mm_dtype");
+  STEDM_CHECK_ARG(nslab1 > 0 && (x2 == nullptr || nslab2 > 0), "gn_apply16c_x16: nslab1 / nslab2 must be the slot counts of cs1 / cs2");
+  GnApplyCArgs a{nullptr, x2, cs1, cs2, c1, c2, x2_bmod, groups, HW, act, nslab1, x2 ? nslab2 : 0, gamma, beta, eps, out_hi, nullptr, raw_hi, nullptr, nullptr,
+                 mm_dtype == STEDM_F16 ? f16_guard_flag() : nullptr, raw_hi};
+  return gn_apply16c_launch(a, B, mm_dtype, stream);
+}
 
 extern "C" int stedm_gn_apply16c(const float* x1, int c1, const float* cs1, int nslab1, const float* x2, int c2, const float* cs2, int nslab2, int x2_bmod,
                                  const float* gamma, const float* beta, float eps, int groups, int act, int B, int HW,
@@ -755,7 +929,12 @@ extern "C" int stedm_gn_apply16c_mr(const float* x1, int c1, const float* cs1, i
   STEDM_CHECK_ARG(raw_hi || !raw_lo, "gn_apply16c: raw_lo without raw_hi");
   STEDM_CHECK_ARG(nslab1 > 0 && (x2 == nullptr || nslab2 > 0), "gn_apply16c: nslab1 / nslab2 must be the slot counts of cs1 / cs2");
   GnApplyCArgs a{x1, x2, cs1, cs2, c1, c2, x2_bmod, groups, HW, act, nslab1, x2 ? nslab2 : 0, gamma, beta, eps, out_hi, out_lo, raw_hi, raw_lo, mean_rstd,
-                 mm_dtype == STEDM_F16 ? f16_guard_flag() : nullptr};
+                 mm_dtype == STEDM_F16 ? f16_guard_flag() : nullptr, nullptr};
+  return gn_apply16c_launch(a, B, mm_dtype, stream);
+}
+
+static int gn_apply16c_launch(GnApplyCArgs a, int B, int mm_dtype, void* stream) {
+  const int C = a.c1 + a.c2, HW = a.HW, groups = a.groups, c1 = a.c1;
   // Pixels per block. Every block folds the group statistics and builds its per-channel table first, a cost that grows with C, so wide
   // tensors want long runs (128 KiB of fp32 input: 21 pixels of the 1536-channel decoder concat; at a fixed 32 KiB that shape ran at 4.3
   // TB/s, now 5.3) — as long as the grid keeps >= 768 blocks (3 per CU), which the 64-pixel samples of the 8x8 level need (12 pixels per
@@ -787,11 +966,28 @@ extern "C" int stedm_gn_apply16c_mr(const float* x1, int c1, const float* cs1, i
       if (cb > 0 && (C % cb != 0 || c1 % cb != 0 || cb % unit != 0 || cb / cpg > 64)) cb = 0;
     }
     if (cb > 0) grid = dim3(B, C / cb);
-    if (mm_dtype == STEDM_F16) gn_apply16c_v8_kernel<_Float16><<<grid, 256, lds, as_stream(stream)>>>(a, slab, cb);
+    static const int o8_mode = getenv("STEDM_GN_O8") ? atoi(getenv("STEDM_GN_O8")) : 1;      // A/B timing only: 0 quad kernel everywhere, 1 octets for the X16 form, 2 octets wherever they apply
+    const bool o8_ok = !a.out_lo && !a.raw_lo && (cb == 0 || cb % 8 == 0);
+    if (o8_ok && ((a.x16 && o8_mode >= 1) || o8_mode >= 2)) {
+      if (a.x16) {
+        if (mm_dtype == STEDM_F16) gn_apply16c_o8_kernel<_Float16, true><<<grid, 256, lds, as_stream(stream)>>>(a, slab, cb);
+        else gn_apply16c_o8_kernel<__bf16, true><<<grid, 256, lds, as_stream(stream)>>>(a, slab, cb);
+      } else {
+        if (mm_dtype == STEDM_F16) gn_apply16c_o8_kernel<_Float16, false><<<grid, 256, lds, as_stream(stream)>>>(a, slab, cb);
+        else gn_apply16c_o8_kernel<__bf16, false><<<grid, 256, lds, as_stream(stream)>>>(a, slab, cb);
+      }
+      STEDM_LAUNCH_CHECK();
+      return 0;
+    }
+    if (a.x16) {
+      if (mm_dtype == STEDM_F16) gn_apply16c_v8_kernel<_Float16, true><<<grid, 256, lds, as_stream(stream)>>>(a, slab, cb);
+      else gn_apply16c_v8_kernel<__bf16, true><<<grid, 256, lds, as_stream(stream)>>>(a, slab, cb);
+    } else if (mm_dtype == STEDM_F16) gn_apply16c_v8_kernel<_Float16><<<grid, 256, lds, as_stream(stream)>>>(a, slab, cb);
     else gn_apply16c_v8_kernel<__bf16><<<grid, 256, lds, as_stream(stream)>>>(a, slab, cb);
     STEDM_LAUNCH_CHECK();
     return 0;
   }
+  STEDM_CHECK_ARG(!a.x16, "gn_apply16c_x16: the 16-bit source form belongs to the vector kernel");
   if (mm_dtype == STEDM_F16)
     gn_apply16c_kernel<_Float16><<<grid, 256, 0, as_stream(stream)>>>(a, slab);
   else

@@ -315,6 +315,26 @@ def gn_apply16c(x1: torch.Tensor, cs1: torch.Tensor, x2: Optional[torch.Tensor],
                                      _ptr(mean_rstd), prec.mm_dtype, _stream()), "stedm_gn_apply16c_mr")
 
 
+def gn_apply16c_x16(c1: int, cs1: torch.Tensor, x2: Optional[torch.Tensor], cs2: Optional[torch.Tensor], out_hi: torch.Tensor, raw_hi: torch.Tensor,
+                    prec: Precision, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, groups: int = 32, act: int = 0, x2_bmod: int = 0) -> None:
+    """act(GroupNorm([x1|x2])) where x1 (c1 channels) already sits as 16-bit values in channels [0, c1) of raw_hi [B,H,W,c1+c2] (written there by
+    the producing convolution: conv_igemm(out=None, out16=..., out16_stride=c1+c2)); x2 fp32 as in gn_apply16c. out_hi receives the
+    normalised planes, raw_hi the plain conversion of x2. Single-product modes (stedm_gn_apply16c_x16)."""
+    assert prec.npass == 1 and raw_hi.dtype == torch.int16 and out_hi.dtype == torch.int16 and raw_hi.is_contiguous() and out_hi.is_contiguous()
+    B, C = raw_hi.shape[0], raw_hi.shape[-1]
+    HW = raw_hi.numel() // (B * C)
+    c2 = 0 if x2 is None else x2.shape[-1]
+    assert C == c1 + c2 and tuple(out_hi.shape) == tuple(raw_hi.shape)
+    check(lib().stedm_gn_apply16c_x16(int(c1), cs1.data_ptr(), cs1.shape[1], _ptr(x2), c2, _ptr(cs2), 0 if cs2 is None else cs2.shape[1], x2_bmod,
+                                      gamma.data_ptr(), beta.data_ptr(), float(eps), groups, act, B, HW, out_hi.data_ptr(), raw_hi.data_ptr(),
+                                      prec.mm_dtype, _stream()), "stedm_gn_apply16c_x16")
+
+
+def gn_apply16c_x16_ok(c1: int, c2: int, groups: int = 32) -> bool:
+    C = c1 + c2
+    return C % 8 == 0 and c1 % 8 == 0 and c1 > 0 and 3 * C * 4 <= 48 * 1024 and 0 < groups <= 64 and C % groups == 0
+
+
 # ------------------------------------------------------------------------------------------- conv
 class LazyPlanes:
     """[cout][tap][cin] hi (/lo) weight planes packed on first need. The register-streamed kernel reads only the fragment-order
@@ -420,7 +440,8 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
                chan_stats: Optional[torch.Tensor] = None,
                skip: Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = None, query_fused: bool = False, query_rs: bool = False,
                ws: Optional[torch.Tensor] = None, pad_br: bool = False, w_frag16: Optional[torch.Tensor] = None,
-               gn_next: Optional[tuple] = None, qkv_planes: Optional[tuple] = None, ln_after: Optional[tuple] = None):
+               gn_next: Optional[tuple] = None, qkv_planes: Optional[tuple] = None, ln_after: Optional[tuple] = None,
+               out16_stride: int = 0, cout: Optional[int] = None):
     """src1 [B,Hin,Win,c1] NHWC fp32 (fused path) and/or src16 = (hi, lo) 16-bit NHWC planes [B,Hin,Win,Cin] from
     gn_apply16 (DMA path) -> out [B,Hout,Wout,cout] NHWC fp32 (see stedm_conv_igemm).
     qkv_planes = (q, k, vt, T, Tp, heads, qscale): the LSA attention's operand planes as the only output of a flat to_qkv GEMM
@@ -470,6 +491,10 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
     if out16 is not None:
         a.out16_hi = out16[0].data_ptr()
         a.out16_lo = _ptr(out16[1]) if prec.npass == 3 else None
+        if out16_stride:
+            # the 16-bit output goes into channels [0, cout) of a wider plane (stedm_conv_args.out16_stride): `cout` names the convolution's width
+            assert cout is not None and out is None and prec.npass == 1 and out16[0].shape[-1] == out16_stride and out16[0].is_contiguous()
+            a.out16_stride = int(out16_stride)
     if ln_after is not None:
         l_g, l_b, l_eps, l_res = ln_after
         _chk(l_g, name="ln gamma"); _chk(l_b, name="ln beta")
@@ -489,6 +514,8 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
         oshape = (1, 1, src16[0].shape[2], 3 * int(qH) * 64)
     else:
         oshape = out.shape if out is not None else out16[0].shape
+        if cout is not None:
+            oshape = tuple(oshape[:-1]) + (int(cout),)
     if src1 is not None:
         _chk(src1, name="src1")
         B, Hin, Win, c1 = src1.shape

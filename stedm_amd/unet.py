@@ -455,6 +455,16 @@ class UNetModel(nn.Module):
         plain conversion of [x1|x2] (operand of the 1x1 skip_connection) produced by the same pass."""
         B, H, W, _ = x1.shape
         C = x1.shape[-1] + (0 if x2 is None else x2.shape[-1])
+        x16 = self._x16.pop(x1.data_ptr(), None)
+        if x16 is not None:
+            # x1 was never stored in fp32: its producer wrote the 16-bit values into channels [0, c1) of this block's raw plane and left the
+            # channel statistics (conv_igemm out16_stride); the pass reads 2 B per element of that half and writes its normalised plane only
+            rawp, c1 = x16
+            assert norm is not None and want_raw and tuple(rawp.shape) == (B, H, W, C) and c1 == x1.shape[-1]
+            hi = self._planes(B, H, W, C)[0]
+            ops.gn_apply16c_x16(c1, self._cs[x1.data_ptr()], x2, None if x2 is None else self._chan_stats(x2), hi, rawp, self.precision,
+                                norm.weight, norm.bias, norm.eps, norm.num_groups, act, x2_bmod)
+            return (hi, None), (rawp, None)
         # training forward in the backward's operand format (bf16 single product): each normalised plane gets its own buffer and is kept
         # for the weight-gradient pass instead of being recomputed there
         keep = self._tape is not None and norm is not None and self.precision.npass == 1 and self.precision.mm_dtype == BF16
@@ -481,8 +491,17 @@ class UNetModel(nn.Module):
                         norm.weight, norm.bias, norm.eps, norm.num_groups, act, x2_bmod, raw, mean_rstd=mr)
         return ((hi, lo), raw) if want_raw else (hi, lo)
 
-    def _res(self, tag: str, rb: ResBlock, x1, x2, emb_all, emb_off, emb_bstride, x2_bmod=0, want16=False):
-        """ResBlock._forward openaimodel.py:268-288 on NHWC tensors; [x1|x2] is the virtual concat input."""
+    def _cat_plane(self, B, H, W, co, next_cat):
+        """The raw plane [B,H,W,next_cat] of the NEXT block's concat input, whose channels [0, co) a producer fills (two buffers per shape in
+        turn: the block that writes the next one's plane is still reading its own through the fused skip_connection)."""
+        self._catpp ^= 1
+        return self._buf(f"cat16.{self._catpp}.{B}x{H}x{W}x{next_cat}", (B, H, W, next_cat), torch.int16)
+
+    def _res(self, tag: str, rb: ResBlock, x1, x2, emb_all, emb_off, emb_bstride, x2_bmod=0, want16=False, next_cat=None):
+        """ResBlock._forward openaimodel.py:268-288 on NHWC tensors; [x1|x2] is the virtual concat input.
+        next_cat (inference, single product): the channel count of the NEXT block's th.cat([h, hs.pop()]) input (openaimodel.py:800) when nothing
+        but that block's GroupNorm and skip_connection read this block's output: the tail convolution then writes it as 16-bit values straight
+        into that concat's raw plane and stores no fp32 tensor (the returned tensor is only the handle the statistics are filed under)."""
         prec = self.precision
         B, H, W, _ = x1.shape
         co = rb.out_channels
@@ -522,6 +541,9 @@ class UNetModel(nn.Module):
                 # (inference: nothing but that GroupNorm reads h — an epilogue that writes the planes itself skips h's fp32 store)
                 # (3-product modes, round 4: the (hi, lo) pair; single-product: the hi plane)
                 gn_next = (gn2.weight, gn2.bias, gn2.eps, gn2.num_groups, 1, h16_next if prec.npass == 3 else h16_next[0], mr2, self._tape is None)
+            # (round 5, measured and left out: at the 32 x 32 level, where out_layers' GroupNorm cannot ride on the epilogue, storing h as 16-bit
+            #  values only + the 2-byte GroupNorm pass saved 21 us of passes and cost 57 us of epilogues - the generic row loop looks the
+            #  embedding row up per row, the fp32 fast path once per sample)
             ops.conv_igemm(None, pk.hi, pk.lo, h, prec=prec, src16=a16, bias=pk.bias, emb=emb_all, emb_offset=emb_off,
                            emb_bstride=emb_bstride, w_frag=pk.frag, chan_stats=self._cs_new(h), ws=ws, w_frag16=pk.frag16, gn_next=gn_next)
         else:
@@ -545,6 +567,18 @@ class UNetModel(nn.Module):
                 fused = bool((pk2.frag is not None or pk2.frag16 is not None) and ps.frag is not None and
                              ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias, ps.frag16), query_fused=True, **kw))
                 self._consts[fuse_key] = fused
+            if fused and next_cat is not None and o16 is None:
+                keyc = ("fusecat", id(rb), B, H, W, next_cat)
+                okc = self._consts.get(keyc)
+                rawn = self._cat_plane(B, H, W, co, next_cat)
+                kwc = dict(kw, out16=(rawn, None), out16_stride=next_cat, cout=co)
+                if okc is None:
+                    okc = bool(ops.conv_igemm(None, pk2.hi, pk2.lo, None, skip=(x16[0], ps.frag, ps.bias, ps.frag16), query_fused=True, **kwc))
+                    self._consts[keyc] = okc
+                if okc:
+                    ops.conv_igemm(None, pk2.hi, pk2.lo, None, skip=(x16[0], ps.frag, ps.bias, ps.frag16), **kwc)
+                    self._x16[out.data_ptr()] = (rawn, co)
+                    return out
             only16 = False
             if fused and o16 is not None and self._tape is None and prec.npass == 1:
                 # inference: the Upsample that follows reads the 16-bit planes only — the fp32 tensor and its statistics need not be written.
@@ -576,6 +610,19 @@ class UNetModel(nn.Module):
             res = out
         if dma:
             h16 = h16_next if h16_next is not None else self._norm16(rb.out_layers[0], 1, h)
+            if next_cat is not None and o16 is None:
+                rawn = self._cat_plane(B, H, W, co, next_cat)
+                kwc = dict(prec=prec, src16=h16, bias=pk2.bias, res=res, w_frag=pk2.frag, chan_stats=self._cs_new(out), ws=ws, w_frag16=pk2.frag16,
+                           out16=(rawn, None), out16_stride=next_cat, cout=co)
+                keyc = ("rescat", id(rb), B, H, W, next_cat)
+                okc = self._consts.get(keyc)
+                if okc is None:
+                    okc = bool(ops.conv_igemm(None, pk2.hi, pk2.lo, None, query_rs=True, **kwc))
+                    self._consts[keyc] = okc
+                if okc:
+                    ops.conv_igemm(None, pk2.hi, pk2.lo, None, **kwc)
+                    self._x16[out.data_ptr()] = (rawn, co)
+                    return out
             ops.conv_igemm(None, pk2.hi, pk2.lo, out, prec=prec, src16=h16, bias=pk2.bias, res=res, w_frag=pk2.frag,
                            chan_stats=self._cs_new(out), ws=ws, out16=o16, w_frag16=pk2.frag16)
         else:
@@ -622,22 +669,30 @@ class UNetModel(nn.Module):
             ops.conv_igemm(a, pp.hi, pp.lo, out, prec=prec, ks=1, bias=pp.bias, res=x)
         return out
 
-    def _run_block(self, tag: str, blk, h, skip, emb_all, emb_bstride, style_all, skip_bmod=0, li0=0):
-        """TimestepEmbedSequential.forward openaimodel.py:93-101 (+ the th.cat of :800 folded into the first layer)."""
+    def _run_block(self, tag: str, blk, h, skip, emb_all, emb_bstride, style_all, skip_bmod=0, li0=0, next_skip_c=None):
+        """TimestepEmbedSequential.forward openaimodel.py:93-101 (+ the th.cat of :800 folded into the first layer).
+        next_skip_c: channels of the skip tensor the NEXT block concatenates to this block's output (decoder), when that block starts with a
+        ResBlock that has a skip_connection convolution: the last layer here may then write its output as 16-bit values into that concat's
+        raw plane instead of an fp32 tensor (_res / Upsample below)."""
         layers = list(blk)
+        cat_ok = (next_skip_c is not None and self._tape is None and self.conv_path == "dma" and self.precision.npass == 1 and
+                  not os.environ.get("STEDM_NO_CAT16"))
         for li, layer in enumerate(layers, start=li0):
             ltag = f"{tag}.{li}"
             nxt = layers[li - li0 + 1] if li - li0 + 1 < len(layers) else None
             if isinstance(layer, ResBlock):
                 x1 = h
+                ncat = None
+                if cat_ok and nxt is None and ops.gn_apply16c_x16_ok(layer.out_channels, next_skip_c):
+                    ncat = layer.out_channels + next_skip_c
                 h = self._res(ltag, layer, h, skip, emb_all, self._emb_off[id(layer)], emb_bstride, x2_bmod=skip_bmod,
-                              want16=isinstance(nxt, Upsample))
+                              want16=isinstance(nxt, Upsample), next_cat=ncat)
                 if self._tape is not None:
                     self._tape.append(("res", layer, x1, skip, self._last_h, h, self._emb_off[id(layer)]))
                 skip = None
             elif isinstance(layer, ResBlockStyle):
                 x1 = h
-                h = self._res(ltag, layer.block, h, None, style_all, 0, style_all.shape[1])
+                h = self._res(ltag, layer.block, h, None, style_all, 0, style_all.shape[1])      # (never the last layer of its block: no next_cat)
                 if self._tape is not None:
                     self._tape.append(("res", layer.block, x1, None, self._last_h, h, None))
             elif isinstance(layer, AttentionBlock):
@@ -685,9 +740,25 @@ class UNetModel(nn.Module):
                     # statistics slots of the sub-pixel form: (256-pixel run of the low-res grid) x (output parity)
                     # (small grids — a sampling batch of up to 8 — split K over the workspace like the other kinds)
                     ws = self._buf("conv_ws", ((16 if out.numel() <= (1 << 20) else 2) * out.numel(),)) if self.precision.npass == 1 else None
-                    h = ops.conv_igemm(None, pu.hi, pu.lo, out, prec=self.precision, mode=CONV_UP_SUBPIXEL,
-                                       src16=src16, bias=pu.bias, w_frag=pu.frag, chan_stats=self._cs_new(out, 4 * ops.gn_chan_nslab(H * W)),
-                                       w_frag16=pu.frag16, ws=ws)
+                    kwu = dict(prec=self.precision, mode=CONV_UP_SUBPIXEL, src16=src16, bias=pu.bias, w_frag=pu.frag,
+                               chan_stats=self._cs_new(out, 4 * ops.gn_chan_nslab(H * W)), w_frag16=pu.frag16, ws=ws)
+                    done = False
+                    if cat_ok and nxt is None and ops.gn_apply16c_x16_ok(layer.out_channels, next_skip_c):
+                        # the next block's GroupNorm and skip_connection are this tensor's only readers: 16-bit values into its concat's raw plane
+                        ncat = layer.out_channels + next_skip_c
+                        rawn = self._cat_plane(B, 2 * H, 2 * W, layer.out_channels, ncat)
+                        kwc = dict(kwu, out16=(rawn, None), out16_stride=ncat, cout=layer.out_channels)
+                        keyc = ("upcat", id(layer), B, H, W, ncat)
+                        okc = self._consts.get(keyc)
+                        if okc is None:
+                            okc = bool(ops.conv_igemm(None, pu.hi, pu.lo, None, query_rs=True, **kwc))
+                            self._consts[keyc] = okc
+                        if okc:
+                            ops.conv_igemm(None, pu.hi, pu.lo, None, **kwc)
+                            self._x16[out.data_ptr()] = (rawn, layer.out_channels)
+                            h, done = out, True
+                    if not done:
+                        h = ops.conv_igemm(None, pu.hi, pu.lo, out, **kwu)
                 else:
                     h = ops.conv_igemm(h, pk.hi, pk.lo, out, prec=self.precision, mode=CONV_UP, bias=pk.bias)
             else:
@@ -749,6 +820,8 @@ class UNetModel(nn.Module):
         self._prepare()
         self._cs = {}
         self._raw16 = {}
+        self._x16 = {}          # fp32 handle -> (raw plane of the next block's concat, channels): tensors that exist in 16 bits only
+        self._catpp = 0
         self._saved16 = {}
         self._saved_mr = {}
         self._plane_ctr = 0
@@ -810,10 +883,18 @@ class UNetModel(nn.Module):
                 if cs2 is not None:      # the replicas share the statistics of the shared-encoder tensor
                     cs2[r * B:(r + 1) * B].copy_(cs1)
             h = h2
-        h = self._run_block("mid.b", mid[1:], h, None, emb_d, emb_stride, style_all, li0=1)
+        def first_takes_cat(blk):      # a decoder block whose first layer is a ResBlock with a skip_connection convolution (always, in this net)
+            l0 = list(blk)[0]
+            return isinstance(l0, ResBlock) and not isinstance(l0.skip_connection, nn.Identity)
+
+        ob = list(self.output_blocks)
+        h = self._run_block("mid.b", mid[1:], h, None, emb_d, emb_stride, style_all, li0=1,
+                            next_skip_c=hs[-1].shape[-1] if ob and first_takes_cat(ob[0]) else None)
         bmod = B if nrep > 1 else 0
-        for i, blk in enumerate(self.output_blocks):
-            h = self._run_block(f"out{i}", blk, h, hs.pop(), emb_d, emb_stride, style_all, skip_bmod=bmod)
+        for i, blk in enumerate(ob):
+            skip = hs.pop()
+            nsc = hs[-1].shape[-1] if (i + 1 < len(ob) and first_takes_cat(ob[i + 1])) else None
+            h = self._run_block(f"out{i}", blk, h, skip, emb_d, emb_stride, style_all, skip_bmod=bmod, next_skip_c=nsc)
         if out is None:
             out = torch.empty((Bd, self.out_channels, H, W), dtype=torch.float32, device=x.device)
         gn = self.out[0]

@@ -485,6 +485,79 @@ def test_conv1x1_split_k_chan_stats_on_sizes_off_the_256_pixel_run(dev, prec, B,
         assert torch.allclose(cs[:, k, :, 1].double(), (sl * sl).sum(1), rtol=1e-4, atol=2e-3)
 
 
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+@pytest.mark.parametrize("B,H,W,c1,c2,bmod", [(128, 8, 8, 1024, 1024, 64), (128, 16, 16, 1024, 512, 64), (64, 32, 32, 512, 128, 0), (6, 16, 16, 512, 128, 3), (3, 8, 8, 1024, 512, 0),
+                                              (2, 32, 32, 128, 128, 0)])
+def test_gn_apply16c_x16_equals_the_fp32_source_pass_on_the_rounded_values(dev, prec, B, H, W, c1, c2, bmod):
+    """stedm_gn_apply16c_x16 (round 5): the decoder concat's GroupNorm when the h half already sits in the raw plane as 16-bit values (no fp32
+    tensor of it exists). Against stedm_gn_apply16c fed the SAME rounded values as fp32 and the same channel statistics: bitwise the same
+    normalised planes; the raw plane keeps the h half and receives the plain conversion of the skip half. Straddling groups (1536, 640
+    channels), CFG batch sharing (bmod), the channel-cut block form of small samples."""
+    from stedm_amd import ops
+    pr = ops.Precision.parse(prec)
+    tdt = torch.float16 if prec == "f16" else torch.bfloat16
+    C = c1 + c2
+    x1 = torch.randn(B, H, W, c1, device=dev) * 1.7 + 0.2
+    B2 = bmod if bmod else B
+    x2 = torch.randn(B2, H, W, c2, device=dev) * 0.8 - 0.1
+    gamma = torch.randn(C, device=dev) * 0.3 + 1.0; beta = torch.randn(C, device=dev) * 0.2
+    cs1 = torch.empty((B, ops.gn_chan_nslab(H * W), c1, 2), device=dev); ops.gn_chan_stats(x1, cs1)
+    cs2 = torch.empty((B2, ops.gn_chan_nslab(H * W), c2, 2), device=dev); ops.gn_chan_stats(x2, cs2)
+    x1r = x1.to(tdt)                                                 # what the producing convolution's epilogue stores
+    raw = torch.full((B, H, W, C), 0x7e7e, dtype=torch.int16, device=dev)
+    raw.view(tdt)[..., :c1] = x1r
+    out = torch.full((B, H, W, C), 0x7e7e, dtype=torch.int16, device=dev)
+    ops.gn_apply16c_x16(c1, cs1, x2, cs2, out, raw, pr, gamma, beta, 1e-5, 32, 1, bmod)
+    ref_out = torch.empty_like(out); ref_raw = torch.empty_like(raw)
+    ops.gn_apply16c(x1r.float().contiguous(), cs1, x2, cs2, ref_out, None, pr, gamma, beta, 1e-5, 32, 1, bmod, (ref_raw, None))
+    assert torch.equal(out, ref_out)
+    assert torch.equal(raw, ref_raw)
+    assert torch.equal(raw.view(tdt)[..., :c1], x1r)
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+@pytest.mark.parametrize("B,H,W,cin,cout,extra,mode,res,ws", [
+    (128, 16, 16, 512, 512, 512, "s1", True, False),      # a decoder ResBlock tail at the 16 x 16 level (identity-skip form)
+    (2, 8, 8, 1024, 1024, 1024, "s1", True, True),        # K split: the reduce pass writes the 16-bit values and the statistics
+    (128, 8, 8, 1024, 1024, 1024, "s1", False, True),     # the headline step's 8 x 8 level (two-way K split)
+    (128, 8, 8, 512, 256, 64, "up2", False, False),       # Upsample into the next concat's plane (sub-pixel form, scattered rows)
+    (3, 8, 8, 256, 128, 128, "up2", False, True)])
+def test_conv_16bit_only_output_with_statistics_into_a_wider_plane(dev, prec, B, H, W, cin, cout, extra, mode, res, ws):
+    """stedm_conv_args.out16_stride (round 5): out == NULL, the 16-bit output goes into channels [0, cout) of a [.., cout + extra] plane, the
+    statistics are still written. Against the same launch with an fp32 output and a contiguous out16 plane: the same 16-bit values and
+    the same statistics, bit for bit; the other channels of the wide plane untouched."""
+    from stedm_amd import ops
+    from stedm_amd._lib import CONV_S1, CONV_UP_SUBPIXEL
+    pr = ops.Precision.parse(prec)
+    up = mode == "up2"
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    x = torch.randn(B, H, W, cin, device=dev)
+    w = torch.randn(cout, cin, 3, 3, device=dev) / math.sqrt(cin * 9)
+    bias = torch.randn(cout, device=dev)
+    r = torch.randn(B, Ho, Wo, cout, device=dev) if res else None
+    h16 = torch.empty((B, H, W, cin), dtype=torch.int16, device=dev)
+    ops.gn_apply16(x, None, h16, None, pr)
+    if up:
+        whi, wlo = ops.pack_conv_weight_up(w, pr); wf = ops.pack_conv_weight_up_frag(w, pr)
+        ns = 4 * ops.gn_chan_nslab(H * W)
+    else:
+        whi, wlo = ops.pack_conv_weight(w, pr); wf = ops.pack_conv_weight_frag(w, pr)
+        ns = ops.gn_chan_nslab(H * W)
+    kw = dict(prec=pr, mode=CONV_UP_SUBPIXEL if up else CONV_S1, src16=(h16, None), bias=bias, res=r, w_frag=wf)
+    mk_ws = lambda: torch.empty(16 * B * Ho * Wo * cout, device=dev) if ws else None
+    out = torch.empty(B, Ho, Wo, cout, device=dev); o16 = torch.zeros((B, Ho, Wo, cout), dtype=torch.int16, device=dev)
+    cs = torch.full((B, ns, cout, 2), float("nan"), device=dev)
+    ops.conv_igemm(None, whi, wlo, out, chan_stats=cs, out16=(o16, None), ws=mk_ws(), **kw)
+    wide = torch.full((B, Ho, Wo, cout + extra), 0x7e7e, dtype=torch.int16, device=dev)
+    cs2 = torch.full_like(cs, float("nan"))
+    kwc = dict(kw, chan_stats=cs2, out16=(wide, None), out16_stride=cout + extra, cout=cout, ws=mk_ws())
+    assert ops.conv_igemm(None, whi, wlo, None, query_rs=True, **kwc)
+    ops.conv_igemm(None, whi, wlo, None, **kwc)
+    assert torch.equal(wide[..., :cout], o16)
+    assert bool((wide[..., cout:] == 0x7e7e).all())
+    assert torch.equal(cs, cs2)
+
+
 def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_emb=True, use_res=True, seed=12, frag=False, ws=False, m16=False, want_rs=None):
     from stedm_amd import ops
     from stedm_amd._lib import CONV_DOWN, CONV_S1, CONV_UP, CONV_UP_SUBPIXEL
