@@ -748,7 +748,10 @@ __global__ void __launch_bounds__(256) gn_apply16c_v8_kernel(GnApplyCArgs a, int
 // arithmetic per byte of gn_apply16c_v8_kernel. (The quad kernel with 8-B loads for the 16-bit half ran the nine decoder concats at
 // 3.1 TB/s of 1.64 GB where the fp32 form had run 5.2 TB/s of 2.41 GB: the pass is bound by requests in flight, not by bytes.)
 // Same block partition as the quad kernel (pixel runs of all channels, or channel runs of whole groups: cb), same statistics fold.
-template <typename T, bool X16>
+// PAIR (C and c1 multiples of 16): the fp32 half is loaded with a 16-B lane stride - lanes 2k / 2k + 1 own octets e / e + 1 = quads 4 of one
+// 64-B run; load 0 takes quads (0, 1) of the run, load 1 quads (2, 3), and the pair trades one quad each way (4 DPP moves) - instead of two
+// 16-B loads at a 32-B lane stride, which request every cache line twice (3.4 TB/s on that half against 5.2 for coalesced loads).
+template <typename T, bool X16, bool PAIR>
 __global__ void __launch_bounds__(256) gn_apply16c_o8_kernel(GnApplyCArgs a, int slab, int cb) {
   typedef T V8 __attribute__((ext_vector_type(8)));
   __shared__ double dsu[256], dsq[256];
@@ -780,8 +783,10 @@ __global__ void __launch_bounds__(256) gn_apply16c_o8_kernel(GnApplyCArgs a, int
     // one address pair, selected without a branch: the loads themselves are unconditional
     const bool h16 = X16 && c < a.c1;
     const float* f32 = (!X16 && c < a.c1) ? p1 + (long)px * a.c1 + c : p2 + (long)px * a.c2 + (c - a.c1);
-    const char* s0 = h16 ? reinterpret_cast<const char*>(p16 + (long)px * C + c) : reinterpret_cast<const char*>(f32);
-    const char* s1 = h16 ? s0 : s0 + 16;
+    // (PAIR: the even lane of a pair starts at its own octet, the odd lane 16 B before its own: together 32 contiguous bytes per load)
+    const char* s0 = h16 ? reinterpret_cast<const char*>(p16 + (long)px * C + c)
+                         : reinterpret_cast<const char*>(f32) - ((PAIR && ok && (threadIdx.x & 1)) ? 16 : 0);
+    const char* s1 = h16 ? s0 : s0 + ((PAIR && ok) ? 32 : 16);      // (a dead cursor re-reads the block's first octet: never before the tensor)
     dst[0] = *reinterpret_cast<const float4*>(s0);
     dst[1] = *reinterpret_cast<const float4*>(s1);
     lpx += dpix; loc += dq;
@@ -854,6 +859,14 @@ __global__ void __launch_bounds__(256) gn_apply16c_o8_kernel(GnApplyCArgs a, int
       const V8 h8 = __builtin_bit_cast(V8, va[0]);
 #pragma unroll
       for (int j = 0; j < 8; ++j) w[j] = (float)h8[j];
+    } else if (PAIR) {
+      // even lane holds quads {0, 2} of the pair's 64-B run and owns {0, 1}; odd lane holds {1, 3} and owns {2, 3}
+      const bool odd = threadIdx.x & 1;
+      const float4 give = odd ? va[0] : va[1];
+      float4 got;
+      got.x = __shfl_xor(give.x, 1, 64); got.y = __shfl_xor(give.y, 1, 64); got.z = __shfl_xor(give.z, 1, 64); got.w = __shfl_xor(give.w, 1, 64);
+      const float4 q0 = odd ? got : va[0], q1 = odd ? va[1] : got;
+      w[0] = q0.x; w[1] = q0.y; w[2] = q0.z; w[3] = q0.w; w[4] = q1.x; w[5] = q1.y; w[6] = q1.z; w[7] = q1.w;
     } else {
       w[0] = va[0].x; w[1] = va[0].y; w[2] = va[0].z; w[3] = va[0].w; w[4] = va[1].x; w[5] = va[1].y; w[6] = va[1].z; w[7] = va[1].w;
     }
@@ -969,13 +982,17 @@ static int gn_apply16c_launch(GnApplyCArgs a, int B, int mm_dtype, void* stream)
     static const int o8_mode = getenv("STEDM_GN_O8") ? atoi(getenv("STEDM_GN_O8")) : 1;      // A/B timing only: 0 quad kernel everywhere, 1 octets for the X16 form, 2 octets wherever they apply
     const bool o8_ok = !a.out_lo && !a.raw_lo && (cb == 0 || cb % 8 == 0);
     if (o8_ok && ((a.x16 && o8_mode >= 1) || o8_mode >= 2)) {
-      if (a.x16) {
-        if (mm_dtype == STEDM_F16) gn_apply16c_o8_kernel<_Float16, true><<<grid, 256, lds, as_stream(stream)>>>(a, slab, cb);
-        else gn_apply16c_o8_kernel<__bf16, true><<<grid, 256, lds, as_stream(stream)>>>(a, slab, cb);
+      static const bool no_pair = getenv("STEDM_GN_NOPAIR") != nullptr;      // A/B timing only
+      const bool pair = C % 16 == 0 && c1 % 16 == 0 && (cb == 0 || cb % 16 == 0) && !no_pair;
+#define GN_O8(TT, XX, PP) gn_apply16c_o8_kernel<TT, XX, PP><<<grid, 256, lds, as_stream(stream)>>>(a, slab, cb)
+      if (mm_dtype == STEDM_F16) {
+        if (a.x16) { if (pair) GN_O8(_Float16, true, true); else GN_O8(_Float16, true, false); }
+        else { if (pair) GN_O8(_Float16, false, true); else GN_O8(_Float16, false, false); }
       } else {
-        if (mm_dtype == STEDM_F16) gn_apply16c_o8_kernel<_Float16, false><<<grid, 256, lds, as_stream(stream)>>>(a, slab, cb);
-        else gn_apply16c_o8_kernel<__bf16, false><<<grid, 256, lds, as_stream(stream)>>>(a, slab, cb);
+        if (a.x16) { if (pair) GN_O8(__bf16, true, true); else GN_O8(__bf16, true, false); }
+        else { if (pair) GN_O8(__bf16, false, true); else GN_O8(__bf16, false, false); }
       }
+#undef GN_O8
       STEDM_LAUNCH_CHECK();
       return 0;
     }
