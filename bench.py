@@ -497,7 +497,8 @@ def dry_run(args, rank, world):
     from stedm_amd import parallel as par
     if world > 1:
         torch.distributed.init_process_group("gloo")
-    lo, hi = par.shard_range(args.batch * world, rank, world)
+    gb = int(os.environ.get("STEDM_BENCH_DRY_GLOBAL", args.batch * world))      # (a global batch the ranks do not divide: uneven shards)
+    lo, hi = par.shard_range(gb, rank, world)
     final = par.per_sample_normal(1, list(range(lo, hi)), (4, 32, 32))
     if world > 1:
         torch.distributed.barrier()
@@ -510,18 +511,19 @@ def dry_run(args, rank, world):
     ranks_seen = 1
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        gathered = par.all_gather_samples(final, args.batch * world)
-        assert gathered.shape[0] == args.batch * world
+        gathered = par.all_gather_samples(final, gb)
+        assert gathered.shape[0] == gb
         ranks_seen = torch.distributed.get_world_size()
-        ref = par.per_sample_normal(1, list(range(args.batch * world)), (4, 32, 32))
+        ref = par.per_sample_normal(1, list(range(gb)), (4, 32, 32))
         assert torch.equal(gathered, ref), "gathered samples differ from the single-rank stream"
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank == 0:
         print(json.dumps({"metric": "U-Net denoising steps/sec (32x32x4 latent, bs=64)", "value": None, "unit": "steps/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "dry_run": True, "rccl_ranks": ranks_seen, "scaling": "weak",
+                          "cpu_baseline": None if world == 1 else "n/a (world > 1): the CPU oracle is timed on rank 0 of the N = 1 run only",
                           "config": {"workload": "launcher rehearsal only (no HIP work)", "batch_per_gpu": args.batch,
-                                     "global_batch": args.batch * world}}), flush=True)
+                                     "global_batch": gb, "shard_sizes": [par.shard_range(gb, r, world)[1] - par.shard_range(gb, r, world)[0] for r in range(world)]}}), flush=True)
 
 
 def main():
@@ -934,6 +936,8 @@ def main():
                                                      "workload, batch, graph, steps and warm-up as `value`"}
         elif world == 1:
             out["cpu_baseline"] = None
+        else:
+            out["cpu_baseline"] = "n/a (world > 1): the CPU oracle is timed on rank 0 of the N = 1 run only"
     if world > 1 and not args.no_train_leg:
         # the training half of north_star on N ranks (train_diff.py:75-76: DDP over the ranks, one process per GPU): BASELINE config 2's step
         # at the per-GPU batch — forward + L1 + backward with the gradient buckets all-reduced over RCCL while the backward still runs, then

@@ -540,6 +540,13 @@ int stedm_silu(const float* x, const float* dy, float* out, long n, int mode, vo
  * (tables: the fp32 buffers sqrt_alphas_cumprod / sqrt_one_minus_alphas_cumprod of ddpm.py:155-156). Bit-exact vs the fp32 reference. */
 int stedm_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac,
                    float* out, int B, long n, void* stream);
+/* Per-sample normal noise on the device: out [rows][n] fp32, row i ~ N(0, 1) depending only on (seed, stream, sample id of row i) - x_T
+ * (ddim.py:122) and the per-step noise of eta > 0 (ddim.py:206) of a rank's shard in a data-parallel prediction run, identical for any
+ * world size (the reference's batch-shaped draw from the global generator is not). sample_ids: device int64 [rows], or NULL for
+ * first_id + row. Philox4x32-10, counter {element / 4, stream, 0x4E524D4C, 0}, key {seed (low 32 bits), sample id}; Box-Muller on word
+ * pairs (the parity tests hold a numpy restatement of this definition). */
+int stedm_philox_normal(float* out, int rows, int n, const long* sample_ids, int first_id, unsigned long long seed, unsigned stream, void* stream_);
+
 /* loss = mean|target - pred| (ddpm.py:282-295 'l1' + :1030-1040), d_pred = grad_scale * sign(pred - target) / n (NULL: skip).
  * ws: 1024 doubles. */
 int stedm_l1_loss(const float* pred, const float* target, long n, float grad_scale, float* d_pred, double* ws, float* loss,

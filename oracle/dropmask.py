@@ -93,3 +93,23 @@ def keep_attention(nbh: int, T: int, p: float, seed: int, site: int) -> np.ndarr
 # Random123 known-answer vectors of philox4x32-10 (kat_vectors: counter words, key words -> output words)
 KAT = [((0, 0, 0, 0), (0, 0), (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
        ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0), (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1))]
+
+
+def normal_rows(seed: int, sample_ids, n: int, stream: int) -> np.ndarray:
+    """numpy restatement of stedm_philox_normal (include/stedm_hip.h): [len(ids), n] float32. Group g of four consecutive elements of a row =
+    philox4x32_10(counter {g, stream, 0x4E524D4C, 0}, key {seed & 0xFFFFFFFF, sample id}); Box-Muller on the word pairs with
+    u = (w + 0.5) 2^-32 in float32 (the device uses the hardware log / sin / cos: equal to a few float32 ulps, not bitwise)."""
+    ng = (n + 3) // 4
+    g = np.arange(ng, dtype=np.uint64)
+    rows = []
+    for sid in sample_ids:
+        r = philox4x32_10(g & MASK32, np.uint64(stream), np.uint64(0x4E524D4C), np.uint64(0), seed & 0xFFFFFFFF, int(sid) & 0xFFFFFFFF)
+        w = [np.asarray(x, dtype=np.uint64).astype(np.float32) for x in r]
+        k = np.float32(2.3283064365386963e-10)
+        u = [np.clip((x + np.float32(0.5)) * k, np.float32(1.1641532e-10), np.float32(0.99999994)) if i in (0, 2) else (x + np.float32(0.5)) * k
+             for i, x in enumerate(w)]
+        ra = np.sqrt(np.float32(-2.0) * np.log(u[0])); rb = np.sqrt(np.float32(-2.0) * np.log(u[2]))
+        two_pi = np.float32(6.283185307179586)
+        z = np.stack([ra * np.cos(two_pi * u[1]), ra * np.sin(two_pi * u[1]), rb * np.cos(two_pi * u[3]), rb * np.sin(two_pi * u[3])], axis=1)
+        rows.append(z.reshape(-1)[:n].astype(np.float32))
+    return np.stack(rows)

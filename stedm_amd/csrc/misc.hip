@@ -2,6 +2,7 @@
 #include <stdarg.h>
 
 #include "common.hpp"
+#include "dropmask.hpp"
 
 namespace stedm {
 static thread_local char g_err[512] = "";
@@ -831,5 +832,40 @@ extern "C" int stedm_graph_launch(void* graph_exec, void* stream) {
 }
 extern "C" int stedm_graph_destroy(void* graph_exec) {
   if (graph_exec) STEDM_HIP_TRY(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------ per-sample normal noise
+// x_T (ddim.py:122) and the per-step noise of eta > 0 (ddim.py:206) for a rank's shard of a data-parallel prediction run: row i depends only
+// on (seed, stream, global sample id), so a sample is the same under any world size (the reference draws batch-shaped from the global
+// generator, which cannot give that). Definition (the parity tests restate it in numpy): group g of four consecutive elements of a
+// row = Philox4x32-10(counter {g, stream, 0x4E524D4C, 0}, key {seed, sample id}); words (w0, w1) and (w2, w3) give two Box-Muller pairs with
+// u = (w + 0.5) 2^-32: z0 = sqrt(-2 ln u0) cos(2 pi u1), z1 = sqrt(-2 ln u0) sin(2 pi u1). fp32 arithmetic with the hardware log / sin / cos.
+__global__ void __launch_bounds__(256) philox_normal_kernel(float* __restrict__ out, const long* __restrict__ ids, int id0, int n, unsigned seed, unsigned stream) {
+  const int row = blockIdx.y;
+  const unsigned sid = ids ? (unsigned)ids[row] : (unsigned)(id0 + row);
+  const int ngroups = (n + 3) >> 2;
+  for (int g = blockIdx.x * 256 + threadIdx.x; g < ngroups; g += gridDim.x * 256) {
+    const U4 r = philox4x32_10(U4{(unsigned)g, stream, 0x4E524D4Cu, 0u}, seed, sid);
+    float z[4];
+    const float k = 2.3283064365386963e-10f;     // 2^-32
+    const float u0 = ((float)r.x + 0.5f) * k, u1 = ((float)r.y + 0.5f) * k, u2 = ((float)r.z + 0.5f) * k, u3 = ((float)r.w + 0.5f) * k;
+    const float ra = sqrtf(-2.0f * __logf(fminf(fmaxf(u0, 1.1641532e-10f), 0.99999994f))), rb = sqrtf(-2.0f * __logf(fminf(fmaxf(u2, 1.1641532e-10f), 0.99999994f)));
+    z[0] = ra * __cosf(6.283185307179586f * u1); z[1] = ra * __sinf(6.283185307179586f * u1);
+    z[2] = rb * __cosf(6.283185307179586f * u3); z[3] = rb * __sinf(6.283185307179586f * u3);
+    float* o = out + (long)row * n + 4 * g;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (4 * g + j < n) o[j] = z[j];
+  }
+}
+
+extern "C" int stedm_philox_normal(float* out, int rows, int n, const long* sample_ids, int first_id, unsigned long long seed, unsigned stream, void* stream_) {
+  STEDM_CHECK_ARG(out && rows > 0 && n > 0, "philox_normal: bad arguments");
+  const int ngroups = (n + 3) / 4;
+  dim3 grid((ngroups + 255) / 256 < 64 ? (ngroups + 255) / 256 : 64, rows);
+  philox_normal_kernel<<<grid, 256, 0, as_stream(stream_)>>>(out, sample_ids, first_id, n, (unsigned)(seed & 0xFFFFFFFFull), stream);
+  STEDM_LAUNCH_CHECK();
   return 0;
 }

@@ -711,12 +711,16 @@ def predict_latents_sharded(model: S_ZSS_DM, shard_batch: dict, global_batch: in
         raise ValueError(f"rank {rank} of {world}: the shard holds {n} samples, shard_range({global_batch}) gives {hi - lo}")
     shape = (model.channels, model.image_size, model.image_size)
     dev = model.device
-    x_T = par.per_sample_normal(seed, ids, shape, stream=0).to(dev)
+    on_gpu = torch.device(dev).type == "cuda"
+    # (GPU: drawn on the device from the per-sample Philox key - one launch per tensor; the numpy streams remain for CPU tensors)
+    draw = (lambda st: par.per_sample_normal_device(seed, lo, hi - lo, shape, st, dev)) if on_gpu else \
+           (lambda st: par.per_sample_normal(seed, ids, shape, stream=st).to(dev))
+    x_T = draw(0)
     noises = None
     if eta != 0.0:
         from .schedule import make_ddim_timesteps
         n_iter = int(make_ddim_timesteps(int(ddim_steps), model.num_timesteps).shape[0])      # (S = 6 -> 7 iterations: ddim.py's uniform stride)
-        noises = [par.per_sample_normal(seed, ids, shape, stream=1 + i).to(dev) for i in range(n_iter)]
+        noises = [draw(1 + i) for i in range(n_iter)]
     from ._lib import StedmHipError
     err: Optional[StedmHipError] = None
     lat = None

@@ -852,6 +852,19 @@ def attn_legacy16(qkv: torch.Tensor, out16: torch.Tensor, heads: int, prec: Prec
     return out16
 
 
+def philox_normal(rows: int, shape, seed: int, stream: int, device, sample_ids: Optional[torch.Tensor] = None, first_id: int = 0) -> torch.Tensor:
+    """[rows, *shape] fp32 N(0, 1) on the device; row i depends only on (seed, stream, its sample id) (stedm_philox_normal)."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    out = torch.empty((rows,) + tuple(int(d) for d in shape), dtype=torch.float32, device=device)
+    if sample_ids is not None:
+        assert sample_ids.dtype == torch.int64 and sample_ids.is_cuda and sample_ids.numel() == rows and sample_ids.is_contiguous()
+    check(lib().stedm_philox_normal(out.data_ptr(), int(rows), n, _ptr(sample_ids), int(first_id), int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream) & 0xFFFFFFFF,
+                                    _stream()), "stedm_philox_normal")
+    return out
+
+
 # ------------------------------------------------------------------------------------------- DDIM
 def ddim_step(x: torch.Tensor, e_c: torch.Tensor, e_u: Optional[torch.Tensor], coefs: torch.Tensor, x_prev: torch.Tensor,
               pred_x0: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,

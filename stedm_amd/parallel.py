@@ -31,6 +31,18 @@ def per_sample_normal(seed: int, sample_ids, shape, stream: int = 0) -> torch.Te
     return torch.from_numpy(np.stack(rows)) if rows else torch.empty((0,) + tuple(shape))
 
 
+def per_sample_normal_device(seed: int, first_id: int, count: int, shape, stream: int, device) -> torch.Tensor:
+    """The same contract on the GPU (stedm_philox_normal: Philox4x32-10 keyed by (seed, global sample id), counter = (element group, stream),
+    Box-Muller): row i of the result belongs to sample first_id + i whatever the world size. What predict_latents_sharded draws x_T and,
+    for eta > 0, every step's noise from (ddim.py:122, 206) - one launch per tensor instead of a host loop over numpy generators per sample
+    and step. (A different generator than per_sample_normal: a run uses one or the other, never a mix.)"""
+    from . import ops
+    assert 0 <= stream < (1 << 32) and 0 <= first_id and first_id + count <= (1 << 32)
+    if count == 0:
+        return torch.empty((0,) + tuple(shape), dtype=torch.float32, device=device)
+    return ops.philox_normal(count, shape, seed, stream, device, None, first_id)
+
+
 def all_gather_samples(local: torch.Tensor, global_batch: int, group=None) -> torch.Tensor:
     """Concatenate the per-rank shards (possibly of unequal length) in rank order -> [global_batch, ...] on every rank."""
     import torch.distributed as dist

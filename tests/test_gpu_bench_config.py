@@ -68,7 +68,9 @@ def test_batch64_cfg_rows_vs_cpu_oracle(dev, oracle_ns32):
         out[precision] = dev2(torch.cat([ec[rows], eu[rows]]), ref)
         print(f"[NS32 B=64 CFG, rows {rows}, {precision}] vs CPU oracle: rel-L2 {out[precision][0]:.3e}, max/std {out[precision][1]:.3e}")
     assert out["parity"][0] < 1e-3 and out["parity"][1] < 1e-3
-    assert out["f16"][0] < 1e-3 and out["f16"][1] < 1e-2
+    # f16 (the bench headline's mode): inside north_star's 1e-3 as rel-L2 (measured 7.5e-4 .. 7.9e-4, round 5); the max-norm reading is
+    # bounded at what is measured (4.0e-3 .. 4.5e-3) + margin, so a regression shows - the mode that meets 1e-3 on BOTH readings is `parity`
+    assert out["f16"][0] < 1e-3 and out["f16"][1] < 5.5e-3
     assert out["bf16"][0] < 1.5e-2 and out["bf16"][1] < 8e-2
 
 
@@ -106,7 +108,9 @@ def test_batch256_cfg_rows_vs_cpu_oracle(dev, oracle_ns32):
         # bf16 4.6e-3: of the size of the mode's own deviation from the oracle, as it must be), bounded by twice that deviation
         assert d64[0] < {"parity": 1e-5, "f16": 2e-3, "bf16": 1.5e-2}[precision], (precision, d64)
     assert out["parity"][0] < 1e-3 and out["parity"][1] < 1e-3
-    assert out["f16"][0] < 1e-3 and out["f16"][1] < 1e-2
+    # f16 (the bench headline's mode): inside north_star's 1e-3 as rel-L2 (measured 7.5e-4 .. 7.9e-4, round 5); the max-norm reading is
+    # bounded at what is measured (4.0e-3 .. 4.5e-3) + margin, so a regression shows - the mode that meets 1e-3 on BOTH readings is `parity`
+    assert out["f16"][0] < 1e-3 and out["f16"][1] < 5.5e-3
     assert out["bf16"][0] < 1.5e-2 and out["bf16"][1] < 8e-2
 
 
@@ -132,7 +136,9 @@ def test_config5_latent64_batch64_cfg_rows_vs_cpu_oracle(dev, oracle_ns32):
         out[precision] = dev2(torch.cat([ec[rows], eu[rows]]), ref)
         print(f"[NS32 U-Net on 64x64x4 latents, B=64 CFG, rows {rows}, {precision}] vs CPU oracle: rel-L2 {out[precision][0]:.3e}, max/std {out[precision][1]:.3e}")
     assert out["parity"][0] < 1e-3 and out["parity"][1] < 1e-3
-    assert out["f16"][0] < 1e-3 and out["f16"][1] < 1e-2
+    # f16 (the bench headline's mode): inside north_star's 1e-3 as rel-L2 (measured 7.5e-4 .. 7.9e-4, round 5); the max-norm reading is
+    # bounded at what is measured (4.0e-3 .. 4.5e-3) + margin, so a regression shows - the mode that meets 1e-3 on BOTH readings is `parity`
+    assert out["f16"][0] < 1e-3 and out["f16"][1] < 5.5e-3
     assert out["bf16"][0] < 1.5e-2 and out["bf16"][1] < 8e-2
 
 

@@ -265,3 +265,28 @@ def test_batch_prefetcher_overlaps_and_preserves_data(dev):
     for d, hst in zip((d0, d1, d2), hosts):
         assert d["tag"] == hst["tag"] and torch.equal(d["a"].cpu(), hst["a"]) and torch.equal(d["b"].cpu(), hst["b"])
     assert d0["a"].data_ptr() != d1["a"].data_ptr()
+
+
+def test_device_per_sample_normal_matches_its_numpy_restatement_and_is_shard_invariant(dev):
+    """stedm_philox_normal: x_T / per-step noise of a rank's shard drawn on the device. Against the numpy restatement
+    of its definition (oracle/dropmask.py normal_rows: Philox4x32-10 words are integers and must agree exactly, the Box-Muller arithmetic
+    to a few float32 ulps); N(0, 1) moments; the rows of a shard are the rows of the whole batch (any world size gives the same samples);
+    distinct streams and seeds give distinct rows."""
+    from oracle import dropmask as od
+    from stedm_amd import parallel as par
+    shape = (4, 32, 32)
+    n = 4 * 32 * 32
+    full = par.per_sample_normal_device(1234, 0, 10, shape, 3, dev)
+    ref = torch.from_numpy(od.normal_rows(1234, range(10), n, 3)).view(10, *shape)
+    d = (full.cpu() - ref).abs().max()
+    print(f"[device normal] max |device - numpy restatement| = {float(d):.2e}; mean {float(full.mean()):+.4f}, std {float(full.std()):.4f}")
+    assert float(d) < 2e-5
+    assert abs(float(full.mean())) < 0.02 and abs(float(full.std()) - 1.0) < 0.02
+    for world in (2, 3, 8):
+        parts = [par.per_sample_normal_device(1234, *(lambda lo, hi: (lo, hi - lo))(*par.shard_range(10, r, world)), shape, 3, dev) for r in range(world)]
+        assert torch.equal(torch.cat(parts), full)
+    assert not torch.equal(par.per_sample_normal_device(1234, 0, 10, shape, 4, dev), full)
+    assert not torch.equal(par.per_sample_normal_device(1235, 0, 10, shape, 3, dev), full)
+    odd = par.per_sample_normal_device(7, 5, 3, (13,), 0, dev)          # a row length that is not a multiple of 4
+    ref2 = torch.from_numpy(od.normal_rows(7, range(5, 8), 13, 0))
+    assert float((odd.cpu() - ref2).abs().max()) < 2e-5

@@ -113,6 +113,18 @@ def test_bench_gpus_flag_launches_the_ranks_itself():
     assert sum(ln.startswith("{") for ln in r.stdout.splitlines()) == 1          # ONE line, from rank 0
 
 
+def test_bench_eight_ranks_uneven_shards_rehearsal():
+    """the N = 8 line the driver will ask for, rehearsed on CPU tensors over gloo: eight ranks started by bench.py
+    itself, a global batch the ranks do not divide (510 = 6 x 64 + 2 x 63), shard_range / all_gather of unequal shards / max-over-ranks at
+    world 8, ONE line from rank 0 that says why it carries no cpu_baseline."""
+    r, line = _bench(["--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "64"], {"STEDM_BENCH_DRY": "1", "STEDM_BENCH_DRY_GLOBAL": "510"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 8 and line["rccl_ranks"] == 8 and line["dry_run"] is True
+    assert line["config"]["global_batch"] == 510 and line["config"]["shard_sizes"] == [64] * 6 + [63] * 2
+    assert isinstance(line["cpu_baseline"], str) and "world > 1" in line["cpu_baseline"]
+    assert sum(ln.startswith("{") for ln in r.stdout.splitlines()) == 1
+
+
 def test_bench_under_torch_distributed_run_as_the_driver_launches_it():
     """The driver's N > 1 command line, verbatim: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
     --master-port P bench.py --gpus N --steps K --warmup W`. bench.py must take RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher
