@@ -277,6 +277,14 @@ typedef struct stedm_conv_args {
 int stedm_conv_igemm(const stedm_conv_args* args, void* stream);
 /* 1 when stedm_conv_igemm would run `args` (with src16b_hi / w_frag_b / cb set) as one fused kernel, else 0. No launch. */
 int stedm_conv_fused_skip_ok(const stedm_conv_args* args);
+/* 1 when the tiled 3x3 kernels of stedm_conv_igemm have a tiling for an Hout x Wout output grid (runs of 128 / 256 pixels aligned with the
+ * image rows: power-of-two widths, in practice), else 0: the host then runs the convolution as stedm_im2col_rows16 + the 1x1 kind. */
+int stedm_conv3x3_tiles_ok(int Hout, int Wout);
+/* Row-major im2col of 16-bit NHWC planes for the generic-shape form of a 3x3 convolution (any H, W: what UNetModel.forward of the reference
+ * accepts, openaimodel.py:761-806): dst [B][Ho][Wo][9 C], column tap * C + c = src [b][sy][sx][c] or 0 outside. mode 0: stride 1 pad 1
+ * (Ho = Hs); 1: stride 2 pad 1 (Downsample.op :164-166, Ho = (Hs - 1) / 2 + 1); 2: nearest x2 then stride 1 pad 1 (Upsample :129-131,
+ * Ho = 2 Hs). The GEMM over K = 9 C then reads the ordinary [cout][tap][cin] planes of stedm_pack_conv_weight. C %% 8 == 0. */
+int stedm_im2col_rows16(const void* src16, void* dst16, int B, int Hs, int Ws, int C, int mode, void* stream);
 /* 1 when the register-streamed kernel (w_frag) takes this problem: w_hi / w_lo are then never read, so the caller may skip packing
  * them and pass any non-NULL w_hi. Same decision path as stedm_conv_igemm; nothing is launched. */
 int stedm_conv_rs_ok(const stedm_conv_args* args);

@@ -74,6 +74,8 @@ SIGNATURES = {
     "stedm_gn_chan_stats16": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "stedm_gn_apply16c": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _F, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "stedm_gn_apply16c_mr": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _F, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
+    "stedm_conv3x3_tiles_ok": (_I, [_I, _I]),
+    "stedm_im2col_rows16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "stedm_philox_normal": (_I, [_P, _I, _I, _P, _I, C.c_ulonglong, C.c_uint, _P]),
     "stedm_gn_apply16c_x16": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _F, _I, _I, _I, _I, _P, _P, _I, _P]),
     "stedm_conv_igemm": (_I, [C.POINTER(ConvArgs), _P]),

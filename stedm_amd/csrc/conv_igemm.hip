@@ -322,6 +322,19 @@ bool stedm::conv_geometry(ConvParams& p, int bm, bool allow_wsplit) {
 static int conv_dispatch(ConvParams& p, void* stream);
 static int conv_setup(ConvParams& p);
 
+// 1 when the tiled 3x3 kernels have a tiling for an Hout x Wout output grid (conv_geometry: runs of 128 or 256 pixels aligned with the image
+// rows), 0 otherwise - the caller then takes the im2col + flat GEMM form (stedm_im2col_rows16). No launch, no error message.
+extern "C" int stedm_conv3x3_tiles_ok(int Hout, int Wout) {
+  if (Hout <= 0 || Wout <= 0) return 0;
+  if (Wout > 256 && Wout % 256 == 0) return 1;      // rows wider than a tile (the register-streamed kernel's row-run form)
+  for (int bm = 256; bm >= 128; bm >>= 1) {
+    const int HW = Hout * Wout;
+    if (HW <= bm) { if (bm % HW == 0) return 1; continue; }
+    if (bm % Wout == 0 && HW % bm == 0) return 1;
+  }
+  return 0;
+}
+
 extern "C" int stedm_conv_fused_skip_ok(const stedm_conv_args* args) {
   if (!args || !args->src16b_hi || !args->src16_hi) return 0;
   ConvParams p;

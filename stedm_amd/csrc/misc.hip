@@ -869,3 +869,40 @@ extern "C" int stedm_philox_normal(float* out, int rows, int n, const long* samp
   STEDM_LAUNCH_CHECK();
   return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------ row-major im2col (16-bit), generic-shape fallback
+// The implicit-GEMM kernels tile the output grid in runs of 128 / 256 pixels that must align with image rows (conv_geometry): latent widths
+// that are not powers of two (96 x 96, 40 x 40, 24 x 24: anything UNetModel of the reference accepts, openaimodel.py:761-806 only needs
+// H, W divisible by 4) have no such tiling. For those a 3x3 convolution runs as im2col + flat GEMM: dst [B][Ho][Wo][9 C] with column
+// tap * C + c = src [b][sy][sx][c] (0 outside), then the 1x1 kind over K = 9 C with the ordinary [cout][tap][cin] weight planes (same
+// contraction order as the tiled kernels' planes; every epilogue of the 1x1 kind applies). 9x the activation bytes: a correctness path.
+// mode 0: stride 1 pad 1; 1: stride 2 pad 1 (Downsample.op, openaimodel.py:164-166); 2: nearest x2 then stride 1 pad 1 (Upsample, :129-131).
+__global__ void __launch_bounds__(256) im2col_rows16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int B, int Hs, int Ws, int C8, int Ho, int Wo, int mode) {
+  const long total = (long)B * Ho * Wo * 9 * C8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    long r = i / C8;
+    const int tap = (int)(r % 9); r /= 9;
+    const int x = (int)(r % Wo); r /= Wo;
+    const int y = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    int sy, sx;
+    bool ok;
+    if (mode == 1) { sy = 2 * y + dy; sx = 2 * x + dx; ok = sy >= 0 && sy < Hs && sx >= 0 && sx < Ws; }
+    else if (mode == 2) { const int uy = y + dy, ux = x + dx; ok = uy >= 0 && uy < Ho && ux >= 0 && ux < Wo; sy = uy >> 1; sx = ux >> 1; }
+    else { sy = y + dy; sx = x + dx; ok = sy >= 0 && sy < Hs && sx >= 0 && sx < Ws; }
+    dst[i] = ok ? src[(((long)b * Hs + sy) * Ws + sx) * C8 + c8] : make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
+extern "C" int stedm_im2col_rows16(const void* src16, void* dst16, int B, int Hs, int Ws, int C, int mode, void* stream) {
+  STEDM_CHECK_ARG(src16 && dst16 && B > 0 && Hs > 0 && Ws > 0 && C > 0 && C % 8 == 0 && mode >= 0 && mode <= 2, "im2col_rows16: bad arguments (C %% 8 == 0)");
+  const int Ho = mode == 1 ? (Hs - 1) / 2 + 1 : (mode == 2 ? 2 * Hs : Hs), Wo = mode == 1 ? (Ws - 1) / 2 + 1 : (mode == 2 ? 2 * Ws : Ws);
+  const long total = (long)B * Ho * Wo * 9 * (C / 8);
+  const long blocks = (total + 255) / 256;
+  im2col_rows16_kernel<<<(int)(blocks < 65536 ? blocks : 65536), 256, 0, as_stream(stream)>>>((const uint4*)src16, (uint4*)dst16, B, Hs, Ws, C / 8, Ho, Wo, mode);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}

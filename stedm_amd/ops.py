@@ -430,6 +430,45 @@ class PackPlan:
         check(lib().stedm_pack_frag_multi(self._table.data_ptr(), len(self.items), self._blocks, self.prec.mm_dtype, _stream()), "stedm_pack_frag_multi")
 
 
+def conv3x3_tiles_ok(Hout: int, Wout: int) -> bool:
+    """Do the tiled 3x3 kernels have a tiling for this output grid (stedm_conv3x3_tiles_ok)? Otherwise conv_igemm takes the im2col form."""
+    return bool(lib().stedm_conv3x3_tiles_ok(int(Hout), int(Wout)))
+
+
+_GENERIC_COLS: dict = {}      # (device, shape) -> im2col planes of the generic-shape path (reused: one convolution at a time on a stream)
+
+
+def _conv3x3_generic(src16, w_hi, w_lo, out, *, prec: Precision, mode: int, **kw):
+    """A 3x3 convolution on an output grid the tiled kernels cannot tile (latent widths that are not powers of two): row-major im2col of the
+    16-bit planes (stedm_im2col_rows16) + the 1x1 kind over K = 9 C with the ordinary [cout][tap][cin] weight planes. Same epilogues
+    (bias / embedding / residual / statistics / the riding GroupNorm), 9x the activation bytes: a correctness path, not a fast one."""
+    assert kw.get("skip") is None, "the fused skip phase belongs to the tiled kernels (stedm_conv_fused_skip_ok says so)"
+    B, H, W, C = src16[0].shape
+    Ho, Wo = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if mode == CONV_DOWN else ((2 * H, 2 * W) if mode == CONV_UP else (H, W))
+    cols = []
+    for i, pl in enumerate(src16):
+        if pl is None or (i == 1 and prec.npass != 3):
+            cols.append(None)
+            continue
+        key = (pl.device, i, B, Ho, Wo, 9 * C)
+        col = _GENERIC_COLS.get(key)
+        if col is None:
+            if len(_GENERIC_COLS) > 16:
+                _GENERIC_COLS.clear()
+            col = _GENERIC_COLS[key] = torch.empty((B, Ho, Wo, 9 * C), dtype=torch.int16, device=pl.device)
+        check(lib().stedm_im2col_rows16(pl.data_ptr(), col.data_ptr(), B, H, W, C, {CONV_S1: 0, CONV_DOWN: 1, CONV_UP: 2}[mode], _stream()),
+              "stedm_im2col_rows16")
+        cols.append(col)
+    if isinstance(w_hi, LazyPlanes):
+        w_hi, w_lo = w_hi.get()
+    cout = w_hi.shape[0]
+    assert tuple(w_hi.shape) == (cout, 9, C), (tuple(w_hi.shape), cout, C)
+    for k in ("w_frag", "w_frag16", "ks", "out16_stride", "cout"):
+        kw.pop(k, None)
+    return conv_igemm(None, w_hi.view(cout, 1, 9 * C), None if w_lo is None else w_lo.view(cout, 1, 9 * C), out, prec=prec, ks=1, mode=CONV_S1,
+                      src16=(cols[0], cols[1]), **kw)
+
+
 def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[torch.Tensor], out: torch.Tensor, *, prec: Precision,
                ks: int = 3, mode: int = CONV_S1, src2: Optional[torch.Tensor] = None, src2_bmod: int = 0,
                scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, act: int = 0,
@@ -448,6 +487,15 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
     (stedm_conv_args.qkv_*; out and out16 None).
     ln_after = (gamma, beta, eps, res): LayerNorm over the output row (cout <= 128) + optional fp32 residual in the epilogue
     (stedm_conv_args.ln_*): out / out16 receive LayerNorm(conv + bias) + res."""
+    if src16 is not None and src1 is None and ks == 3 and mode in (CONV_S1, CONV_DOWN, CONV_UP) and not out16_stride:
+        _, H_, W_, _ = src16[0].shape
+        Ho_, Wo_ = ((H_ - 1) // 2 + 1, (W_ - 1) // 2 + 1) if mode == CONV_DOWN else ((2 * H_, 2 * W_) if mode == CONV_UP else (H_, W_))
+        if not conv3x3_tiles_ok(Ho_, Wo_):
+            if query_fused or query_rs:
+                return False
+            return _conv3x3_generic(src16, w_hi, w_lo, out, prec=prec, mode=mode, scale=scale, shift=shift, act=act, bias=bias, emb=emb,
+                                    emb_offset=emb_offset, emb_bstride=emb_bstride, res=res, act_out=act_out, out16=out16, chan_stats=chan_stats,
+                                    skip=skip, ws=ws, gn_next=gn_next)
     if out is not None:
         _chk(out, name="out")
     a = ConvArgs()

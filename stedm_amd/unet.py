@@ -639,8 +639,7 @@ class UNetModel(nn.Module):
         pp = self._packed[id(ab.proj_out)]
         out = self._buf(tag + ".out", (B, H, W, Cc))
         ch = Cc // ab.num_heads
-        if dma and prec.npass == 1 and self._tape is None and ((H * W == 64 and ch in (32, 64, 128)) or
-                                                                 ((H * W) % 64 == 0 and H * W <= 4096 and ch in (64, 128))):
+        if dma and prec.npass == 1 and self._tape is None and ch in (16, 32, 64, 128):
             # 64 tokens (64 n tokens: key tiles with an online softmax around the same products): the qkv conv writes its result as a 16-bit plane, the whole attention of a (sample, head) runs on one wave's
             # MFMAs and is written as proj_out's 16-bit operand plane (same operand rounding as everywhere in these modes)
             qkv16 = self._planes(B, H, W, 3 * Cc, "qkv16")
@@ -715,7 +714,11 @@ class UNetModel(nn.Module):
                 if self._tape is not None:
                     self._tape.append(("down", layer, h, out))
                 ps2 = self._packed.get((id(layer.op), "s2d"))
-                if ps2 is not None and H % 2 == 0 and W % 2 == 0 and (H // 2) * (W // 2) >= 16:
+                if self.conv_path == "dma" and H % 2 == 0 and W % 2 == 0 and not ops.conv3x3_tiles_ok(H // 2, W // 2):
+                    # an output grid the tiled kernels cannot tile (latent widths that are not powers of two): im2col + flat GEMM (ops.conv_igemm)
+                    h = ops.conv_igemm(None, pk.hi, pk.lo, out, prec=self.precision, mode=CONV_DOWN, src16=self._norm16(None, 0, h), bias=pk.bias,
+                                       chan_stats=self._cs_new(out))
+                elif ps2 is not None and H % 2 == 0 and W % 2 == 0 and (H // 2) * (W // 2) >= 16:
                     C = h.shape[-1]
                     planes = self._buf(f"s2d16.{B}x{H}x{W}x{C}", (B, H // 2, W // 2, 4 * C), torch.int16)
                     planes_lo = self._buf(f"s2d16lo.{B}x{H}x{W}x{C}", (B, H // 2, W // 2, 4 * C), torch.int16) if self.precision.npass == 3 else None
@@ -739,6 +742,11 @@ class UNetModel(nn.Module):
                 if self.conv_path == "dma":
                     pu = self._packed[(id(layer.conv), "up")]
                     src16 = self._raw16.get(h.data_ptr()) or self._norm16(None, 0, h)
+                    if not ops.conv3x3_tiles_ok(H, W):
+                        # (the sub-pixel form tiles the low-resolution grid) generic shapes: nearest x2 + 3x3 as im2col + flat GEMM from the plain filter
+                        h = ops.conv_igemm(None, pk.hi, pk.lo, out, prec=self.precision, mode=CONV_UP, src16=src16, bias=pk.bias,
+                                           chan_stats=self._cs_new(out))
+                        continue
                     # statistics slots of the sub-pixel form: (256-pixel run of the low-res grid) x (output parity)
                     # (small grids — a sampling batch of up to 8 — split K over the workspace like the other kinds)
                     ws = self._buf("conv_ws", ((16 if out.numel() <= (1 << 20) else 2) * out.numel(),)) if self.precision.npass == 1 else None

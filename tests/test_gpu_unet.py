@@ -213,6 +213,31 @@ def test_unet_with_spatial_transformer_vs_oracle(dev):
         bad(x.to(dev), t.to(dev), context=ctx.to(dev))
 
 
+@pytest.mark.parametrize("size,mult,heads,B", [(96, (1, 2, 4), 4, 1), (40, (1, 4), 4, 2), (24, (1, 4, 8), 4, 3), (12, (1, 2, 4), 4, 2)])
+def test_unet_latent_sizes_off_the_tile_grid_vs_oracle(dev, size, mult, heads, B):
+    """Latent widths that are not powers of two (anything divisible by 4 is legal for the reference's UNetModel, openaimodel.py:761-806): the
+    tiled 3x3 kernels have no tiling for them, the convolutions run as im2col + flat GEMM (stedm_im2col_rows16 + the 1x1 kind: stride 1,
+    the stride-2 Downsample, nearest-x2 Upsample), the 1x1 tiles are ragged (a tile's rows span samples unevenly), the attention sees
+    576 / 100 / 36 / 9 tokens (key mask, dead query rows). Against the fp32 CPU oracle in the tolerance mode and both single-product modes."""
+    from oracle import unet as ou
+    kw = dict(image_size=size, in_channels=7, model_channels=32, out_channels=4, num_res_blocks=1, attention_resolutions=[32, 16, 8],
+              channel_mult=list(mult), num_heads=heads)
+    m = build(kw, 41, dev, "parity")
+    cfg = ou.UNetConfig(image_size=size, in_channels=7, model_channels=32, out_channels=4, num_res_blocks=1, channel_mult=tuple(mult), num_heads=heads)
+    plan = ou.build_plan(cfg)
+    P = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    x = prng.normal(41, "np2.x", (B, 7, size, size)); ctx = prng.normal(41, "np2.ctx", (B, 128))
+    t = torch.tensor([617, 3, 999][:B], dtype=torch.long)
+    ref = ou.unet_forward(P, cfg, x, t, ctx, plan=plan)
+    for mode, tol in (("parity", 1e-3), ("f16", 8e-3), ("bf16", 6e-2)):
+        m.set_precision(mode)
+        y = m(x.to(dev), t.to(dev), context=ctx.to(dev))
+        m.check_f16_range()
+        err = rel(y, ref)
+        print(f"[U-Net {size}x{size} levels x{mult} B={B}, {mode}] rel err vs fp32 oracle: {err:.3e}")
+        assert err < tol, mode
+
+
 @pytest.mark.parametrize("B", [64, 50])
 def test_unet_bench_config_single_product_vs_parity(dev, golden, B):
     """BASELINE metric configuration (NS32, batch 64, CFG pass = 128 decoder rows): at this size the single-product modes run the
