@@ -28,7 +28,10 @@ struct WgradArgs {
   int nunits;             // B * upi
   int ksplit, tiles_n;    // tiles_n = Cout / 64
   int NP, PW;             // patch positions (upr + 2) * (W + 2), patch width W + 2
-  int dbg;                // timing experiments (STEDM_WGRAD_DBG): 1 no global loads, 2 no MFMA phase, 4 no LDS stores
+  int dbg;                // timing experiments (STEDM_WGRAD_DBG, diagnostic builds only): 1 no global loads, 2 no MFMA phase, 4 no LDS stores
+  int nks;                // k-steps of 16 pixels per 64-pixel unit (= 4). A RUN-TIME bound on purpose: with the literal 4 the compiler restructures
+                          // the k loop of the W <= 16 forms and spills 337 - 369 registers (554 instead of 89 us per launch: found by the round-5
+                          // bench after the ablation switch in this bound had become a compile-time constant)
   int oihw;               // 1: part is [ksplit][Cout][Cin][9] (the parameter's own OIHW order: with ksplit == 1 it IS the gradient)
 };
 
@@ -118,7 +121,7 @@ __global__ void __launch_bounds__(512) wgrad3x3_kernel(WgradArgs a) {
     const unsigned char* px = sX + buf * WG_XBUF;
     const unsigned char* py = sY + buf * WG_YBUF;
 #pragma unroll 1
-    for (int s = 0; s < (STEDM_DBG(a.dbg, 2) ? 0 : 4); ++s) {
+    for (int s = 0; s < (STEDM_DBG(a.dbg, 2) ? 0 : a.nks); ++s) {
       const int k_lo = 16 * s + 8 * h + q, k_hi = k_lo + 4;            // this lane's block rows (pixels of the unit)
       const bf16x8 bf = tr_pair(py, k_lo * WG_YS + colB, k_hi * WG_YS + colB);
       // patch row of tap (0, 0); tap (ky, kx) adds the compile-time constant (ky * PW + kx) rows
@@ -373,6 +376,7 @@ static int wgrad3x3_launch(const void* x16, const void* dy16, float* part, int B
   if (dbg) { set_error("wgrad: STEDM_WGRAD_DBG=%d needs a diagnostic build (-DSTEDM_CONV_DIAG=0); the shipped kernels compile no ablation switch", dbg); return 1; }
 #endif
   a.oihw = oihw;
+  a.nks = 4;
   const size_t lds = 2 * WG_XBUF + 2 * WG_YBUF;
   static bool attr = false;
   if (!attr) {
