@@ -72,6 +72,38 @@ def test_ddim_cfg_loop_vs_oracle(dev, use_graph):
     assert len(inter["x_inter"]) == 3   # initial, index 4 (== total-1), index 0
 
 
+@pytest.mark.parametrize("size", [24, 40])
+def test_ddim_cfg_loop_on_a_latent_size_off_the_tile_grid_vs_oracle(dev, size):
+    """The whole sampling loop (shared-encoder CFG pass, fused DDIM update, hipGraph replay) on latents whose width is not a power of two: the
+    3x3 convolutions run as im2col + flat GEMM (stedm_im2col_rows16), the attention sees 36 / 100 tokens. Final latents vs the CPU oracle loop."""
+    from oracle import ddim as od
+    from oracle import unet as ou
+    from stedm_amd.latent_diffusion import LatentDiffusion
+    from stedm_amd.unet import UNetModel
+    kw = dict(TINY, image_size=size, num_res_blocks=1)
+    unet = UNetModel(precision="parity", **kw).eval()
+    prng.fill_module_(unet, seed=9)
+    ld = LatentDiffusion(unet, linear_start=0.0015, linear_end=0.0205, image_size=size, channels=4, conditioning_key="hybrid", loss_type="l1",
+                         use_graph=True).to(dev)
+    cfg = ou.UNetConfig(image_size=size, in_channels=7, model_channels=32, out_channels=4, num_res_blocks=1, channel_mult=(1, 2, 4), num_heads=4)
+    plan = ou.build_plan(cfg)
+    P = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
+    B = 2
+    xT = prng.normal(32, "sg.xT", (B, 4, size, size)); cc = prng.normal(32, "sg.cc", (B, 3, size, size)) * 0.5
+    ctx = prng.normal(32, "sg.ctx", (B, 128)); ctx_u = prng.normal(32, "sg.ctxu", (B, 128))
+    apply_model = lambda x, t, c: ou.unet_forward(P, cfg, torch.cat([x, c["c_concat"][0]], 1), t, c["c_crossattn"][0], plan=plan)
+    ref = od.ddim_sample(apply_model, od.Schedule(), xT, {"c_concat": [cc], "c_crossattn": [ctx]}, 4, 0.0,
+                         uncond={"c_concat": [cc], "c_crossattn": [ctx_u]}, scale=1.5)
+    cond = {"c_concat": [cc.to(dev)], "c_crossattn": [ctx.to(dev)]}
+    unc = {"c_concat": [cc.to(dev)], "c_crossattn": [ctx_u.to(dev)]}
+    for mode, tol in (("parity", 1e-3), ("f16", 1e-2)):
+        unet.set_precision(mode)
+        s, _ = ld.sample_log(cond, B, True, 4, eta=0.0, x_T=xT.to(dev), unconditional_conditioning=unc, unconditional_guidance_scale=1.5, log_every_t=1000)
+        err = rel(s, ref)
+        print(f"[ddim cfg x4 on {size}x{size} latents, graph replay, {mode}] rel err vs oracle loop: {err:.3e}")
+        assert err < tol, mode
+
+
 def test_graph_equals_eager_bits(dev):
     xT, cc, ctx, ctx_u = inputs()
     outs = []

@@ -378,8 +378,8 @@ def test_svit_fp8_attention_mode_reported(dev, golden):
 def test_svit_fp8_attention_at_config5_size_vs_reference_golden(dev, golden):
     """BASELINE config 5's style half at its own size: 8 style images of 512 x 512 -> T = 4098 tokens, 12 heads x 64,
     the LSA attention (vit_set.py:52-67) on v_mfma_scale_f32_32x32x64_f8f6f4 with MX-fp8 operands, everything else bf16 single product -
-    against the reference's own output (F7 `i512_ns8`, tests/golden/make_golden_ns8.py). Bounds: the fp8 mode within 5e-2 rel-L2 of the
-    golden and within 2.5x of the bf16 mode's own deviation + 1e-2 (e4m3 operands: 3 mantissa bits, block scales of 32); both finite.
+    against the reference's own output (F7 `i512_ns8`, tests/golden/make_golden_ns8.py). Measured (round 5): bf16 3.2e-3, MX-fp8 4.0e-3 rel-L2
+    (averaging over 4098 keys hides most of e4m3's 3 mantissa bits). Bounds: bf16 < 1e-2, fp8 < 1.5e-2 and within 2x of bf16's + 5e-3; finite.
     A reported mode - the tolerance mode of the encoder is `parity` (test_svit_ns8_vs_reference_golden)."""
     fx = golden("f7_svit_ns8")
     x = prng.uniform(7, "svit.i512_ns8.img", (1, 8, 512, 512, 3)).to(dev)
@@ -391,7 +391,7 @@ def test_svit_fp8_attention_at_config5_size_vs_reference_golden(dev, golden):
         assert bool(torch.isfinite(y).all())
         res[precision] = float((y.double().cpu() - ref).norm() / ref.norm())
     print(f"[sViT ns=8, 512^2, T=4098] rel-L2 vs reference golden: bf16 {res['bf16']:.3e}, bf16 + MX-fp8 attention {res['fp8']:.3e}")
-    assert res["bf16"] < 2e-2 and res["fp8"] < 5e-2 and res["fp8"] < 2.5 * res["bf16"] + 1e-2
+    assert res["bf16"] < 1e-2 and res["fp8"] < 1.5e-2 and res["fp8"] < 2 * res["bf16"] + 5e-3
 
 
 # ------------------------------------------------------------------------------------------------ train-mode dropout (vit_set.py:28-30, 43/62, 49, 187)
