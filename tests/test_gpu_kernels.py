@@ -280,6 +280,42 @@ def test_attn_legacy16_mfma_key_tiles(dev, prec, tol, tol16, B, T, heads, ch):
     assert err < tol and err16 < tol16
 
 
+def test_attn_flash_eight_wave_form_equals_the_four_wave_form(dev, tmp_path):
+    """attn_flash_kernel has two workgroup forms: 4 waves / two-stage rings (128 queries) and 8 waves / four-stage rings (256 queries; chosen
+    for T >= 1024 at 128-wide heads when the grid fills the chip, i.e. only at bench-sized batches). A wave does the same arithmetic in both, so
+    the outputs must be bitwise equal: each form is forced through STEDM_ATTN_FORM in its own process (the switch is read once) on shapes that
+    give the 8-wave form dead waves, a partial last key tile and every head width; the 4-wave results are the ones the tests above pin."""
+    import subprocess
+    import sys
+    import os
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from stedm_amd import ops\n"
+        "from stedm_amd.utils import prng\n"
+        "dev = torch.device('cuda:0'); outs = {}\n"
+        "for prec in ('f16', 'bf16'):\n"
+        "    pr = ops.Precision.parse(prec)\n"
+        "    for (B, T, H, ch) in [(2, 1100, 2, 128), (1, 1024, 3, 128), (3, 300, 2, 64), (2, 77, 4, 32), (2, 513, 2, 16)]:\n"
+        "        qkv = (prng.normal(9, f'af.{T}.{ch}', (B, T, 3 * H * ch)) * 1.5).to(dev)\n"
+        "        q16 = torch.empty(qkv.shape, dtype=torch.int16, device=dev)\n"
+        "        ops.gn_apply16(qkv.view(B, 1, T, -1), None, q16.view(B, 1, T, -1), None, pr)\n"
+        "        out = torch.full((B, T, H * ch), 0x7e7e, dtype=torch.int16, device=dev)\n"
+        "        ops.attn_legacy16(q16, out, H, pr)\n"
+        "        outs[f'{prec}.{T}.{ch}'] = out.cpu()\n"
+        "torch.save(outs, sys.argv[1])\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for form in ("4", "8"):
+        path = str(tmp_path / f"form{form}.pt")
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, STEDM_ATTN_FORM=form), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[form] = torch.load(path, weights_only=True)
+    assert set(res["4"]) == set(res["8"]) and len(res["4"]) == 10
+    for k in res["4"]:
+        assert torch.equal(res["4"][k], res["8"][k]), k
+        assert bool((res["4"][k] != 0x7e7e).any())
+
+
 # ------------------------------------------------------------------------------------------------ DDIM
 @pytest.mark.parametrize("B,C,H,W,cfg,eta", [(2, 4, 32, 32, True, 0.0), (3, 3, 16, 16, True, 1.0), (2, 4, 8, 8, False, 1.0),
                                              (1, 3, 128, 128, True, 0.0), (2, 4, 12, 24, True, 0.5)])
