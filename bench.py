@@ -852,8 +852,22 @@ def main():
             for _ in range(4):
                 loss = tr.train_step(xs, ccs, tt, ctxs, tgt)
             torch.cuda.synchronize()
-            dtt = (time.perf_counter() - t0) / 4
+            dte = (time.perf_counter() - t0) / 4
+            # the same step captured once and replayed as one hipGraph launch (UNetTrainer.train_step_graphed: bitwise the eager step,
+            # tests/test_gpu_train.py); the capture happens on the first call after GRAPH_WARMUP eager ones
+            for _ in range(tr.GRAPH_WARMUP + 2):
+                tr.train_step_graphed(xs, ccs, tt, ctxs, tgt)
+            assert tr._graph is not None
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(6):
+                loss = tr.train_step_graphed(xs, ccs, tt, ctxs, tgt)
+            t_issue = (time.perf_counter() - t0) / 6
+            torch.cuda.synchronize()
+            dtt = (time.perf_counter() - t0) / 6
             out["train_step"] = {"ms": round(dtt * 1e3, 2), "steps_per_s": round(1 / dtt, 2), "samples_per_s": round(B / dtt, 1),
+                                 "launch": "hipGraph replay (one launch per step)", "host_ms_per_step": round(t_issue * 1e3, 2),
+                                 "eager_ms": round(dte * 1e3, 2),
                                  "dtype": unet.precision.label + " forward, bf16 backward operands, fp32 master/optimizer", "batch": B,
                                  "algorithmic_tflops": round(3 * B * GFLOP_PER_SAMPLE_FORWARD / 1e3 / dtt, 1),
                                  "what": "forward + L1 loss + backward (dgrad on the forward's MFMA conv kernels, direct 3x3 wgrad kernel) + fused AdamW + EMA, 234.6M params; "

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STEDM_ABI_VERSION 10
+#define STEDM_ABI_VERSION 11
 
 #define STEDM_F16 0
 #define STEDM_BF16 1
@@ -581,6 +581,14 @@ int stedm_adamw_ema(const void* table, const int* chunk_tensor, const long* chun
 int stedm_adamw_ema_pack_piece(int* rows, int* ciw);   /* the piece a block owns: a tensor takes (cout / rows) * (cin / ciw) blocks */
 int stedm_adamw_ema_pack(const void* descs, int ndesc, int total_blocks, float lr, float beta1, float beta2, float eps,
                          float weight_decay, int step, float ema_decay, float grad_scale, void* stream);
+/* The two passes above for a CAPTURED training step (hipGraph replay; the step of modules/ldm_diffusion.py:224-234 / ddpm.py:345-371 is
+ * shape-static): the step-dependent scalars come from the device. sched [n][4] = { 1 - beta1^s, sqrtf(1 - beta2^s), LitEma decay of step s,
+ * learning rate of step s } for a window of steps (built by the host with the arithmetic of the two calls above), *sched_idx = the row of the
+ * step being run (advanced inside the captured step by stedm_step_advance). */
+int stedm_adamw_ema_sched(const void* table, const int* chunk_tensor, const long* chunk_off, int nchunks, float beta1, float beta2, float eps,
+                          float weight_decay, const float* sched, const int* sched_idx, float grad_scale, void* stream);
+int stedm_adamw_ema_pack_sched(const void* descs, int ndesc, int total_blocks, float beta1, float beta2, float eps, float weight_decay,
+                               const float* sched, const int* sched_idx, float grad_scale, void* stream);
 /* LitEma.forward alone (ldm/modules/ema.py:25-44; on_train_batch_end, ddpm.py:369-371, runs it once per micro-batch, also on the
  * micro-batches of an accumulation window that do not step the optimizer): ema -= (1 - ema_decay) * (ema - p) over the same table
  * (entries without a shadow are skipped; g / m / v are not read). */

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STEDM_HIP_LIB") or os.path.join(_HERE, "libstedm_hip.so")     # STEDM_HIP_LIB: A/B timing of another build
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 F16, BF16 = 0, 1
 CONV_S1, CONV_DOWN, CONV_UP, CONV_UP_SUBPIXEL, CONV_S2D = 0, 1, 2, 3, 4
 
@@ -143,6 +143,8 @@ SIGNATURES = {
     "stedm_adamw_ema": (_I, [_P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _F, _F, _P]),
     "stedm_adamw_ema_pack": (_I, [_P, _I, _I, _F, _F, _F, _F, _F, _I, _F, _F, _P]),
     "stedm_adamw_ema_pack_piece": (_I, [_P, _P]),
+    "stedm_adamw_ema_sched": (_I, [_P, _P, _P, _I, _F, _F, _F, _F, _P, _P, _F, _P]),
+    "stedm_adamw_ema_pack_sched": (_I, [_P, _I, _I, _F, _F, _F, _F, _P, _P, _F, _P]),
     "stedm_ema_update": (_I, [_P, _P, _P, _I, _F, _P]),
     "stedm_vq_nearest": (_I, [_P, _P, _I, _I, _I, C.c_long, _P, _P, _P]),
     "stedm_conv1x1_nchw": (_I, [_P, _P, _P, _P, _I, _I, _I, C.c_long, _P]),

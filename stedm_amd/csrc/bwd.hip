@@ -952,7 +952,12 @@ __device__ __forceinline__ void adamw_one(float& p, float g_raw, float& m, float
 }
 __global__ void __launch_bounds__(256) adamw_ema_kernel(const OptTensor* __restrict__ table, const int* __restrict__ chunk_tensor,
                                                         const long* __restrict__ chunk_off, float lr, float beta1, float beta2, float eps, float wd, float bc1,
-                                                        float bc2_sqrt, float ema_decay, float grad_scale) {
+                                                        float bc2_sqrt, float ema_decay, float grad_scale, const float* __restrict__ sched,
+                                                        const int* __restrict__ sched_idx) {
+  if (sched) {      // graph replay: this step's row of the host-built schedule {bc1, sqrt(bc2), ema_decay, lr} (stedm_adamw_ema_sched)
+    const float* r = sched + 4 * (long)*sched_idx;
+    bc1 = r[0]; bc2_sqrt = r[1]; ema_decay = r[2]; lr = r[3];
+  }
   const OptTensor t = table[chunk_tensor[blockIdx.x]];
   const long o0 = chunk_off[blockIdx.x];
   const uintptr_t al = reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.g) | reinterpret_cast<uintptr_t>(t.m) |
@@ -1007,8 +1012,13 @@ static_assert(sizeof(FusedPackOut) == 24 && sizeof(FusedOptDesc) == 160, "FusedO
 
 template <int ROWS, int CIW>
 __global__ void __launch_bounds__(256) adamw_ema_pack_kernel(const FusedOptDesc* __restrict__ descs, const int nd, float lr, float beta1, float beta2,
-                                                             float eps, float wd, float bc1, float bc2_sqrt, float ema_decay, float grad_scale) {
+                                                             float eps, float wd, float bc1, float bc2_sqrt, float ema_decay, float grad_scale,
+                                                             const float* __restrict__ sched, const int* __restrict__ sched_idx) {
   extern __shared__ float ftile[];        // [ROWS][CIW * taps + 1]
+  if (sched) {
+    const float* r = sched + 4 * (long)*sched_idx;
+    bc1 = r[0]; bc2_sqrt = r[1]; ema_decay = r[2]; lr = r[3];
+  }
   int lo = 0, hi = nd - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -1341,7 +1351,19 @@ extern "C" int stedm_adamw_ema(const void* table, const int* chunk_tensor, const
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   const float bc2 = (float)(1.0 - pow((double)beta2, (double)step));
   adamw_ema_kernel<<<nchunks, 256, 0, as_stream(stream)>>>((const OptTensor*)table, chunk_tensor, chunk_off, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2),
-                                                          ema_decay, grad_scale);
+                                                          ema_decay, grad_scale, nullptr, nullptr);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+// The two optimizer passes with the step-dependent scalars read on the device: sched [n][4] = {1 - beta1^s, sqrt(1 - beta2^s), ema decay of step s,
+// learning rate of step s} built by the host for a window of steps, *sched_idx = the row of the step being replayed (advanced by stedm_step_advance
+// inside the captured step). A captured training step (UNetTrainer.capture_step) replays with nothing but that index changing.
+extern "C" int stedm_adamw_ema_sched(const void* table, const int* chunk_tensor, const long* chunk_off, int nchunks, float beta1, float beta2, float eps,
+                                     float weight_decay, const float* sched, const int* sched_idx, float grad_scale, void* stream) {
+  STEDM_CHECK_ARG(table && chunk_tensor && chunk_off && nchunks > 0 && sched && sched_idx, "adamw_ema_sched: bad args");
+  adamw_ema_kernel<<<nchunks, 256, 0, as_stream(stream)>>>((const OptTensor*)table, chunk_tensor, chunk_off, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, 0.f,
+                                                          grad_scale, sched, sched_idx);
   STEDM_LAUNCH_CHECK();
   return 0;
 }
@@ -1363,7 +1385,17 @@ extern "C" int stedm_adamw_ema_pack(const void* descs, int ndesc, int total_bloc
   const float bc2 = (float)(1.0 - pow((double)beta2, (double)step));
   const size_t lds = (size_t)kOptRows * (kOptCiw * 9 + 1) * sizeof(float);
   adamw_ema_pack_kernel<kOptRows, kOptCiw><<<total_blocks, 256, lds, as_stream(stream)>>>((const FusedOptDesc*)descs, ndesc, lr, beta1, beta2, eps, weight_decay,
-                                                                                          bc1, sqrtf(bc2), ema_decay, grad_scale);
+                                                                                          bc1, sqrtf(bc2), ema_decay, grad_scale, nullptr, nullptr);
+  STEDM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int stedm_adamw_ema_pack_sched(const void* descs, int ndesc, int total_blocks, float beta1, float beta2, float eps, float weight_decay,
+                                          const float* sched, const int* sched_idx, float grad_scale, void* stream) {
+  STEDM_CHECK_ARG(descs && ndesc > 0 && total_blocks > 0 && sched && sched_idx, "adamw_ema_pack_sched: bad args");
+  const size_t lds = (size_t)kOptRows * (kOptCiw * 9 + 1) * sizeof(float);
+  adamw_ema_pack_kernel<kOptRows, kOptCiw><<<total_blocks, 256, lds, as_stream(stream)>>>((const FusedOptDesc*)descs, ndesc, 0.f, beta1, beta2, eps, weight_decay,
+                                                                                          1.f, 1.f, 0.f, grad_scale, sched, sched_idx);
   STEDM_LAUNCH_CHECK();
   return 0;
 }

@@ -467,11 +467,13 @@ class LatentDiffusion(nn.Module):
         return (cc[0] if len(cc) == 1 else torch.cat(cc, 1)), (ca[0] if len(ca) == 1 else torch.cat(ca, 1))
 
     @torch.no_grad()
-    def training_step_hip(self, x_start, cond, t=None, noise=None, cond_input=None, group=None):
+    def training_step_hip(self, x_start, cond, t=None, noise=None, cond_input=None, group=None, graph=False):
         """One micro-batch on the fused path (latents + conditioning as `get_input` returns them): t ~ U{0..T-1} (ddpm.py:878),
         p_losses + backward; every `accumulate_grad_batches`-th call averages the accumulated gradients over the ranks (bucketed
         all-reduce when torch.distributed is initialised — what DDP does for train_diff.py:75) and runs AdamW; LitEma's update runs
-        after every micro-batch (ddpm.py:369-371). Returns the loss (device tensor)."""
+        after every micro-batch (ddpm.py:369-371). Returns the loss (device tensor). graph=True: the U-Net's part of the step (forward, loss,
+        backward, AdamW + EMA) is captured once and replayed as one hipGraph launch (UNetTrainer.train_step_graphed) when the step is
+        shape-static and self-contained — one rank, no accumulation, no trainable cond stage; the eager step runs otherwise."""
         if self.loss_type != 'l1':
             raise NotImplementedError("the training step is built for loss_type 'l1' (conf/diffusion/ldm_based.yaml)")
         tr = self._trainer_or_default()
@@ -489,6 +491,10 @@ class LatentDiffusion(nn.Module):
         if cond_input is not None and hasattr(self.cond_stage_model, "backward"):
             nx = x_noisy.shape[1]
             after = lambda dx, dctx: self.cond_stage_model.backward(cond_input, dx[:, nx:].contiguous())
+        if graph and after is None and not tr.extra_params and tr.accumulate_grad_batches == 1 and x_noisy.is_cuda:
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+                return tr.train_step_graphed(x_noisy, xc, t, ctx, noise)
         return tr.train_step(x_noisy, xc, t, ctx, noise, group=group, after_backward=after)
 
     # ------------------------------------------------------------------------------------------ checkpoints (reference key layout)

@@ -1164,6 +1164,25 @@ def adamw_ema_pack(descs: torch.Tensor, ndesc: int, total_blocks: int, lr: float
     note_raw_write()
 
 
+def adamw_ema_sched(table: torch.Tensor, chunk_tensor: torch.Tensor, chunk_off: torch.Tensor, beta1: float, beta2: float, eps: float, weight_decay: float,
+                    sched: torch.Tensor, sched_idx: torch.Tensor, grad_scale: float = 1.0) -> None:
+    """stedm_adamw_ema with {bias corrections, EMA decay, learning rate} read from row *sched_idx of sched [n][4] on the device (captured step)"""
+    assert sched.dtype == torch.float32 and sched.is_contiguous() and sched.shape[-1] == 4 and sched_idx.dtype == torch.int32
+    check(lib().stedm_adamw_ema_sched(table.data_ptr(), chunk_tensor.data_ptr(), chunk_off.data_ptr(), chunk_tensor.numel(), float(beta1), float(beta2),
+                                      float(eps), float(weight_decay), sched.data_ptr(), sched_idx.data_ptr(), float(grad_scale), _stream()),
+          "stedm_adamw_ema_sched")
+    note_raw_write()
+
+
+def adamw_ema_pack_sched(descs: torch.Tensor, ndesc: int, total_blocks: int, beta1: float, beta2: float, eps: float, weight_decay: float,
+                         sched: torch.Tensor, sched_idx: torch.Tensor, grad_scale: float = 1.0) -> None:
+    """stedm_adamw_ema_pack with the step-dependent scalars read on the device (see adamw_ema_sched)"""
+    assert sched.dtype == torch.float32 and sched.is_contiguous() and sched.shape[-1] == 4 and sched_idx.dtype == torch.int32
+    check(lib().stedm_adamw_ema_pack_sched(descs.data_ptr(), int(ndesc), int(total_blocks), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                           sched.data_ptr(), sched_idx.data_ptr(), float(grad_scale), _stream()), "stedm_adamw_ema_pack_sched")
+    note_raw_write()
+
+
 def ema_update(table: torch.Tensor, chunk_tensor: torch.Tensor, chunk_off: torch.Tensor, ema_decay: float) -> None:
     """LitEma.forward (ema.py:25-44) over the optimizer's pointer table: shadow -= (1 - decay) * (shadow - p)."""
     check(lib().stedm_ema_update(table.data_ptr(), chunk_tensor.data_ptr(), chunk_off.data_ptr(), chunk_tensor.numel(), float(ema_decay), _stream()),

@@ -838,9 +838,23 @@ class UNetTrainer:
         """the optimizer pass of run b of _opt_sched() on the current stream"""
         st, r = self._opt, fu["runs"][b]
         if r["n"]:
-            ops.adamw_ema_pack(r["descs"], r["n"], r["blocks"], self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, decay, gs)
+            self._adamw_pack(r["descs"], r["n"], r["blocks"], decay, gs)
         if r["ct"].numel():
-            ops.adamw_ema(st["table"], r["ct"], r["co"], self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, decay, grad_scale=gs)
+            self._adamw(st["table"], r["ct"], r["co"], decay, gs)
+
+    def _adamw(self, table, ct, co, decay: float, gs: float) -> None:
+        cs = getattr(self, "_cap_sched", None)
+        if cs is not None:       # inside capture_step(): bias corrections / EMA decay / lr of the replayed step come from the device schedule
+            ops.adamw_ema_sched(table, ct, co, self.betas[0], self.betas[1], self.eps, self.wd, cs[0], cs[1], grad_scale=gs)
+        else:
+            ops.adamw_ema(table, ct, co, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, decay, grad_scale=gs)
+
+    def _adamw_pack(self, descs, n: int, blocks: int, decay: float, gs: float) -> None:
+        cs = getattr(self, "_cap_sched", None)
+        if cs is not None:
+            ops.adamw_ema_pack_sched(descs, n, blocks, self.betas[0], self.betas[1], self.eps, self.wd, cs[0], cs[1], grad_scale=gs)
+        else:
+            ops.adamw_ema_pack(descs, n, blocks, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, decay, gs)
 
     def _after_optimizer(self, fu) -> None:
         self.m.invalidate()      # parameters changed through raw pointers: repack on the next forward
@@ -865,13 +879,12 @@ class UNetTrainer:
         gs = getattr(self, "_grad_scale", 1.0)
         fu = self._fused_opt() if self.fuse_packs else None
         if fu is None:
-            ops.adamw_ema(st["table"], st["ct"], st["co"], self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, decay, grad_scale=gs)
+            self._adamw(st["table"], st["ct"], st["co"], decay, gs)
         else:
             # convolution weights with fragment-order packs: the optimizer pass writes the packs of the next forward / backward itself
-            ops.adamw_ema_pack(fu["descs"], fu["n"], fu["blocks"], self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, decay, gs)
+            self._adamw_pack(fu["descs"], fu["n"], fu["blocks"], decay, gs)
             if fu["ct"].numel():
-                ops.adamw_ema(st["table"], fu["ct"], fu["co"], self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, decay,
-                              grad_scale=gs)
+                self._adamw(st["table"], fu["ct"], fu["co"], decay, gs)
         self._after_optimizer(fu)
 
     @torch.no_grad()
@@ -1089,3 +1102,104 @@ class UNetTrainer:
             self.all_reduce_grads(group)
         self.optimizer_step()
         return loss
+
+    # ------------------------------------------------------------------------------------------------ captured step (hipGraph replay)
+    GRAPH_WARMUP = 3          # eager steps before the capture: the forward's and the backward's pack plans and the fused optimizer table exist from the 3rd
+    GRAPH_WINDOW = 4096       # steps per upload of the device schedule
+
+    def _sched_rows(self, first_step: int, first_ema: int, n: int):
+        """{1 - beta1^s, sqrtf(1 - beta2^s), LitEma decay, lr} for steps first_step .. first_step + n - 1 with the arithmetic of stedm_adamw_ema
+        (bwd.hip: betas arrive as C floats, the powers are taken in double) and of _next_ema_decay — a replayed step uses the very scalars the
+        eager step would have been launched with"""
+        import numpy as np
+        b1, b2 = float(np.float32(self.betas[0])), float(np.float32(self.betas[1]))
+        rows = np.empty((n, 4), np.float32)
+        for i in range(n):
+            s_ = first_step + i
+            rows[i, 0] = np.float32(1.0 - b1 ** s_)
+            rows[i, 1] = np.sqrt(np.float32(1.0 - b2 ** s_))
+            e = first_ema + i
+            rows[i, 2] = np.float32(min(self.ema_decay, (1 + e) / (10 + e))) if self.ema_decay is not None else 0.0
+            rows[i, 3] = np.float32(self.lr)
+        return rows
+
+    def _graph_window(self, g) -> None:
+        """(re)fill the device schedule so that row 1 is the NEXT step (the captured step advances the index first) and rewind the index"""
+        n = self.GRAPH_WINDOW
+        rows = self._sched_rows(self.step_count, self.ema_updates, n)      # row 0 = the step already taken (never read), row k = step_count + k
+        g["sched"].copy_(torch.from_numpy(rows), non_blocking=False)
+        g["idx"].zero_()
+        g["base"], g["lr"] = self.step_count, self.lr
+
+    @torch.no_grad()
+    def train_step_graphed(self, x, c_concat, t, context, target) -> torch.Tensor:
+        """train_step() of one rank without gradient accumulation as ONE hipGraph launch (ddpm.py:345-371: training_step, optimizer.step,
+        on_train_batch_end — shape-static). The first GRAPH_WARMUP calls run eagerly (pack plans and the fused optimizer table are built by
+        them), the next call captures the step — forward, L1 loss, backward, AdamW + EMA + re-pack, about 790 launches — and every call from
+        then on copies the batch into the captured input buffers and replays it. What changes between steps (AdamW's bias corrections,
+        LitEma's decay, the learning rate) is read by the optimizer kernels from a device schedule the host fills for GRAPH_WINDOW steps at
+        a time (stedm_adamw_ema_sched); the step index advances inside the graph. Same kernels on the same values as the eager step: the
+        parameters after k replayed steps equal those after k eager steps bit for bit (tests/test_gpu_train.py). The graph is dropped (and
+        re-captured after GRAPH_WARMUP eager steps) when the shapes change or anything outside this method touched the parameters (EMA swap,
+        checkpoint load, an eager step). Returns the loss [1] (device tensor, overwritten by the next step)."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise NotImplementedError("train_step_graphed: one rank only (the bucketed all-reduce of train_step() is issued by the host)")
+        if self.accumulate_grad_batches != 1 or self.extra_params:
+            raise NotImplementedError("train_step_graphed: no gradient accumulation, no parameters outside the U-Net (their gradients are filled by a "
+                                      "host callback between the backward and the optimizer)")
+        if x.device.type != "cuda":
+            raise RuntimeError("train_step_graphed needs the HIP path (a CUDA/HIP device tensor)")
+        args = (x, c_concat, t, context, target)
+        key = tuple(None if a is None else (tuple(a.shape), a.dtype) for a in args)
+        g = getattr(self, "_graph", None)
+        if g is not None and (g["key"] != key or g["token"] != self.m.freshness_token() or g["host_step"] != self.step_count):
+            g = self._graph = None                    # someone else moved the parameters or the counters: the captured plan is stale
+            self._graph_eager = 0
+        if g is None:
+            if getattr(self, "_graph_eager", 0) < self.GRAPH_WARMUP or getattr(self, "_graph_key", None) != key:
+                if getattr(self, "_graph_key", None) != key:
+                    self._graph_key, self._graph_eager = key, 0
+                self._graph_eager += 1
+                return self.train_step(x, c_concat, t, context, target)
+            g = self._capture(args, key)
+        if self.step_count + 1 - g["base"] >= self.GRAPH_WINDOW or g["lr"] != self.lr:
+            self._graph_window(g)
+        for dst, src in zip(g["inputs"], args):
+            if dst is not None:
+                dst.copy_(src, non_blocking=True)
+        g["graph"].replay()
+        # the host's mirror of what the replay did on the device
+        self.step_count += 1
+        if self.ema_decay is not None:
+            self.ema_updates += 1
+        ops.note_raw_write()                 # (the replayed optimizer wrote the parameters through raw pointers, like the eager launches it stands for)
+        self._after_optimizer(g["fu"])
+        g["token"], g["host_step"] = self.m.freshness_token(), self.step_count
+        return g["loss"]
+
+    def _capture(self, args, key):
+        dev = args[0].device
+        inputs = [None if a is None else torch.empty_like(a) for a in args]
+        for dst, src in zip(inputs, args):
+            if dst is not None:
+                dst.copy_(src)
+        g = {"key": key, "inputs": inputs, "sched": torch.empty((self.GRAPH_WINDOW, 4), dtype=torch.float32, device=dev),
+             "idx": torch.zeros((1,), dtype=torch.int32, device=dev)}
+        self._graph_window(g)
+        # the capture pass runs the host side of one step without running its kernels: counters and flags are put back afterwards
+        keep = (self.step_count, self.ema_updates, self.overlap_opt_fires, self.overlap_fires)
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        self._cap_sched = (g["sched"], g["idx"])
+        try:
+            with torch.cuda.graph(graph):
+                ops.step_advance(g["idx"], 1)
+                loss = self.train_step(*inputs)
+        finally:
+            self._cap_sched = None
+            self.step_count, self.ema_updates, self.overlap_opt_fires, self.overlap_fires = keep
+        fu = self._fused_opt() if self.fuse_packs else None
+        g.update(graph=graph, loss=loss, fu=fu, token=self.m.freshness_token(), host_step=self.step_count)
+        self._graph = g
+        return g

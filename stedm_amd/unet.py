@@ -393,7 +393,10 @@ class UNetModel(nn.Module):
         c = self._consts
         half = self.model_channels // 2
         # host-built frequency table (util.py:162-164 builds it on the CPU in fp32)
-        c["freqs"] = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(dev)
+        fq = getattr(self, "_freqs", None)        # (kept across re-packs: a host-to-device copy has no place in a captured training step)
+        if fq is None or fq.device != dev or fq.numel() != half:
+            fq = self._freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(dev)
+        c["freqs"] = fq
         c["te_w0t"] = ops.transpose(self.time_embed[0].weight.float())
         c["te_b0"] = self.time_embed[0].bias.detach().float().contiguous()
         c["te_w2t"] = ops.transpose(self.time_embed[2].weight.float())

@@ -230,6 +230,77 @@ def test_optimizer_inside_the_backward_equals_the_pass_after_it(dev, bucket_mb):
             assert torch.equal(a, b), f"{name} {i}"
 
 
+@pytest.mark.parametrize("precision,overlap", [("bf16", False), ("f16", False), ("bf16", True), ("parity", False)])
+def test_captured_train_step_equals_the_eager_step_bitwise(dev, precision, overlap):
+    """UNetTrainer.train_step_graphed: three eager steps, then the whole step (forward, L1, backward, AdamW + EMA + re-pack) captured once and
+    replayed as one hipGraph launch with a different batch every step. Against train_step() on a second copy of the model: the loss of each
+    of nine steps, every parameter, EMA shadow, optimizer moment and weight pack bit for bit (the optimizer kernels read this step's bias
+    corrections / EMA decay / learning rate from the device schedule, built with the host arithmetic of the eager launch); a learning-rate
+    change between two replays reaches the device schedule; an eager step in between (a stranger moving the parameters) drops the graph and
+    the following calls re-capture; with the optimizer overlapped on a side stream the fork / join is part of the graph."""
+    from stedm_amd.train import UNetTrainer
+    cfg = dict(image_size=16, in_channels=7, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=[32, 16, 8], channel_mult=[1, 4, 8],
+               num_heads=4)
+    runs = []
+    for graphed in (True, False):
+        m = build(cfg, 6, dev, precision)
+        tr = UNetTrainer(m, lr=2e-4, weight_decay=0.01)
+        tr.overlap_optimizer = overlap
+        tr.opt_bucket_mb = 1
+        losses, replays = [], 0
+        for step in range(9):
+            x, ctx, target = _inputs(f"cap{step}", cfg, 2, 16, 6 + step, dev)
+            t = torch.tensor([951 - 7 * step, 21 + step], device=dev)
+            if step == 5:
+                tr.lr = 1e-4
+            a = (x[:, :4].contiguous(), x[:, 4:].contiguous(), t, ctx, target)
+            if graphed and step != 6:
+                losses.append(float(tr.train_step_graphed(*a)))
+                replays += int(getattr(tr, "_graph", None) is not None)
+            else:
+                losses.append(float(tr.train_step(*a)))      # step 6 of the graphed run: eager, behind the graph's back
+        torch.cuda.synchronize()
+        if graphed:
+            # steps 0-2 eager, 3-5 replayed, 6 eager (drops the graph), 7-8 eager again (warm-up of the re-capture)
+            assert replays == 3 and tr._graph is None and tr.step_count == 9 and tr.ema_updates == 9, (replays, tr.step_count, tr.ema_updates)
+            for step in range(9, 13):
+                x, ctx, target = _inputs(f"cap{step}", cfg, 2, 16, 6 + step, dev)
+                losses.append(float(tr.train_step_graphed(x[:, :4].contiguous(), x[:, 4:].contiguous(), torch.tensor([5 + step, 700], device=dev), ctx, target)))
+            assert tr._graph is not None and tr.step_count == 13
+        else:
+            for step in range(9, 13):
+                x, ctx, target = _inputs(f"cap{step}", cfg, 2, 16, 6 + step, dev)
+                losses.append(float(tr.train_step(x[:, :4].contiguous(), x[:, 4:].contiguous(), torch.tensor([5 + step, 700], device=dev), ctx, target)))
+        m._prepare()
+        packs = [it[8].clone() for pl in (m._plan, tr._dplan) for it in pl.items] if precision != "parity" else []
+        runs.append((losses, [p.detach().clone() for p in m.parameters()], [e.clone() for e in tr.ema_parameters()],
+                     [v.clone() for v in tr._opt["m"]] + [v.clone() for v in tr._opt["v"]], packs))
+    (la, pa, ea, ma, ka), (lb, pb, eb, mb, kb) = runs
+    print("losses", ["%.5f" % v for v in la])
+    assert la == lb, (la, lb)
+    for name, xa, xb in (("parameter", pa, pb), ("ema", ea, eb), ("moment", ma, mb), ("pack", ka, kb)):
+        assert len(xa) == len(xb)
+        for i, (a, b) in enumerate(zip(xa, xb)):
+            assert torch.equal(a, b), f"{name} {i}"
+
+
+def test_captured_train_step_device_schedule_rows_are_the_eager_scalars(dev):
+    """the rows of the device schedule against the scalars stedm_adamw_ema computes on the host (C float betas, double powers, sqrtf)"""
+    import ctypes
+    from stedm_amd.train import UNetTrainer
+    tr = UNetTrainer(build(TINY, 6, dev, "bf16"), lr=3e-4, betas=(0.9, 0.999), ema_decay=0.9999)
+    rows = tr._sched_rows(1, 1, 3000)
+    libm = ctypes.CDLL("libm.so.6")
+    libm.pow.restype = ctypes.c_double
+    libm.pow.argtypes = [ctypes.c_double, ctypes.c_double]
+    b1, b2 = ctypes.c_float(0.9).value, ctypes.c_float(0.999).value
+    for i in (0, 1, 2, 9, 10, 99, 1000, 2999):
+        s = 1 + i
+        assert rows[i, 0] == np.float32(1.0 - libm.pow(b1, float(s)))
+        assert rows[i, 1] == np.sqrt(np.float32(1.0 - libm.pow(b2, float(s))))
+        assert rows[i, 2] == np.float32(min(0.9999, (1 + s) / (10 + s))) and rows[i, 3] == np.float32(3e-4)
+
+
 def test_spatial_rescaler_weight_gradient_vs_oracle(dev):
     """cond_stage_trainable: channel_mapper.weight gradient from the c_concat slice of the U-Net's input gradient, against autograd
     over the oracle's restatement of SpatialRescaler.forward (encoders/modules.py:123-130)."""
@@ -665,6 +736,34 @@ def _seam_inputs(dev, B=2, seed=21):
     layout = prng.uniform(seed, "ld.layout", (B, 2, 64, 64)); ctx = prng.normal(seed, "ld.ctx", (B, 128))
     t = torch.tensor(([951, 21, 500, 3] * B)[:B], dtype=torch.long)
     return x0, noise, layout, ctx, t
+
+
+def test_training_step_hip_with_graph_replay_equals_the_eager_surface(dev):
+    """LatentDiffusion.training_step_hip(graph=True) with a frozen cond stage (q_sample and the conditioning stay eager, the U-Net's step is the
+    captured graph): losses of seven steps, the U-Net's parameters and the EMA shadows bit for bit against graph=False; with a trainable cond
+    stage (its gradient is a host callback between backward and optimizer) the same flag runs the eager step."""
+    res = []
+    for graph in (True, False):
+        ld, unet, resc = _tiny_ld(dev, trainable=False)
+        ld.train()
+        losses = []
+        for step in range(7):
+            x0, noise, layout, ctx, t = _seam_inputs(dev, seed=21 + step)
+            cond = {"c_concat": [ld.get_learned_conditioning(layout.to(dev))], "c_crossattn": [ctx.to(dev)]}
+            losses.append(float(ld.training_step_hip(x0.to(dev), cond, t.to(dev), noise.to(dev), graph=graph)))
+        tr = ld._trainer_or_default()
+        assert (getattr(tr, "_graph", None) is not None) == graph
+        res.append((losses, [p.detach().clone() for p in unet.parameters()], [e.clone() for e in tr.ema_parameters()]))
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    for a, b in zip(res[0][1] + res[0][2], res[1][1] + res[1][2]):
+        assert torch.equal(a, b)
+    ld, unet, resc = _tiny_ld(dev, trainable=True)
+    ld.train()
+    x0, noise, layout, ctx, t = _seam_inputs(dev)
+    cond = {"c_concat": [ld.get_learned_conditioning(layout.to(dev))], "c_crossattn": [ctx.to(dev)]}
+    for _ in range(5):
+        ld.training_step_hip(x0.to(dev), cond, t.to(dev), noise.to(dev), cond_input=layout.to(dev), graph=True)
+    assert getattr(ld._trainer_or_default(), "_graph", None) is None
 
 
 def test_p_losses_autograd_bridge_with_torch_adamw(dev):
