@@ -19,6 +19,8 @@ def main():
     prec = ops.Precision.parse("bf16"); dev = torch.device("cuda:0")
     small = bool(os.environ.get("PHASES_SMALL"))
     for name, B, H, W, cin, cout in (SMALL if small else SHAPES):
+        if os.environ.get("PHASES_B"):       # fewer tiles than CUs: is the epilogue's store burst bound per CU or by the fabric / HBM?
+            B = int(os.environ["PHASES_B"]); name += f" (B -> {B})"
         x = torch.randn(B, H, W, cin, device=dev)
         w = torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
         hi, lo = ops.pack_conv_weight(w, prec); wf = ops.pack_conv_weight_frag(w, prec)
