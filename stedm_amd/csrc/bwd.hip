@@ -5,6 +5,7 @@
 // (GroupNorm+SiLU backward, attention backward, reductions, loss, optimizer) is HBM-bound fp32 work in this file.
 // No atomics: every reduction has a fixed order, gradients are bitwise reproducible.
 #include "common.hpp"
+#include "sgemm.hpp"
 
 using namespace stedm;
 
@@ -832,49 +833,7 @@ __global__ void __launch_bounds__(256) attn_bwd_cols_kernel(const float* __restr
 
 // ------------------------------------------------------------------------------------------------ small fp32 GEMM
 // C[M][N] = alpha * op(A) op(B) + beta * C; op(A)[m][k] = ta ? A[k*lda + m] : A[m*lda + k]; op(B)[k][n] = tb ? B[n*ldb + k] : B[k*ldb + n]
-__global__ void __launch_bounds__(256) gemm_f32_kernel(const float* __restrict__ A, long lda, int ta, const float* __restrict__ Bm, long ldb, int tb,
-                                                       float* __restrict__ Cm, long ldc, int M, int N, int K, float alpha, float beta, int kchunk,
-                                                       float* __restrict__ part) {
-  __shared__ float sa[32][33], sb[32][33];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 16 x 16 threads, 2 x 2 outputs each
-  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-  const int kbeg = blockIdx.z * kchunk;                     // split-K: slice z accumulates K range [kbeg, kend) into part[z]
-  if (gridDim.z > 1) K = min(K, kbeg + kchunk);
-  for (int k0 = kbeg; k0 < K; k0 += 32) {
-    for (int e = threadIdx.x; e < 1024; e += 256) {
-      const int r = e >> 5, cidx = e & 31;
-      {  // sa[m][k]
-        const int m = ta ? m0 + cidx : m0 + r, kk = ta ? k0 + r : k0 + cidx;
-        const float val = (m < M && kk < K) ? (ta ? A[(long)kk * lda + m] : A[(long)m * lda + kk]) : 0.f;
-        if (ta) sa[cidx][r] = val; else sa[r][cidx] = val;
-      }
-      {  // sb[k][n]
-        const int kk = tb ? k0 + cidx : k0 + r, n = tb ? n0 + r : n0 + cidx;
-        const float val = (kk < K && n < N) ? (tb ? Bm[(long)n * ldb + kk] : Bm[(long)kk * ldb + n]) : 0.f;
-        if (tb) sb[cidx][r] = val; else sb[r][cidx] = val;
-      }
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (int kk = 0; kk < 32; ++kk) {
-      const float a0 = sa[ty * 2][kk], a1 = sa[ty * 2 + 1][kk], b0 = sb[kk][tx * 2], b1 = sb[kk][tx * 2 + 1];
-      acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int m = m0 + ty * 2 + i, n = n0 + tx * 2 + j;
-      if (m < M && n < N) {
-        if (gridDim.z > 1) part[((long)blockIdx.z * M + m) * N + n] = acc[i][j];
-        else Cm[(long)m * ldc + n] = alpha * acc[i][j] + (beta != 0.f ? beta * Cm[(long)m * ldc + n] : 0.f);
-      }
-    }
-}
-
+// (the tiled kernel is sgemm.hpp's; this unit holds the fixed-order reduce of its split-K slices)
 __global__ void gemm_f32_reduce_kernel(const float* __restrict__ part, int ks, float* __restrict__ Cm, long ldc, int M, int N, float alpha, float beta) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)M * N) return;
@@ -1299,7 +1258,7 @@ extern "C" int stedm_attn_legacy_bwd(const float* qkv, const float* d_out, float
 extern "C" int stedm_gemm_f32(const float* A, long lda, int trans_a, const float* Bm, long ldb, int trans_b, float* Cm, long ldc, int M, int N, int K, float alpha,
                               float beta, float* ws, long ws_floats, void* stream) {
   STEDM_CHECK_ARG(A && Bm && Cm && M > 0 && N > 0 && K > 0, "gemm_f32: bad args");
-  const int tiles = ((N + 31) / 32) * ((M + 31) / 32);
+  const int tiles = ((N + 63) / 64) * ((M + 63) / 64);
   int ks = 1;
   if (ws && tiles < 128 && K >= 1024) {          // few output tiles, long K: slices of K on separate blocks, fixed-order reduce
     ks = K / 256 < 64 ? K / 256 : 64;
@@ -1307,7 +1266,8 @@ extern "C" int stedm_gemm_f32(const float* A, long lda, int trans_a, const float
   }
   const int kchunk = ks > 1 ? ((K + ks - 1) / ks + 31) / 32 * 32 : K;
   if (ks > 1) ks = (K + kchunk - 1) / kchunk;
-  gemm_f32_kernel<<<dim3((N + 31) / 32, (M + 31) / 32, ks), 256, 0, as_stream(stream)>>>(A, lda, trans_a, Bm, ldb, trans_b, Cm, ldc, M, N, K, alpha, beta, kchunk, ws);
+  stedm::SgemmArgs g{A, lda, trans_a, Bm, ldb, trans_b, Cm, ldc, M, N, K, alpha, beta, kchunk, ws, nullptr, 0, 0};
+  stedm::sgemm_launch(g, ks, as_stream(stream));
   if (ks > 1) gemm_f32_reduce_kernel<<<(unsigned)(((long)M * N + 255) / 256), 256, 0, as_stream(stream)>>>(ws, ks, Cm, ldc, M, N, alpha, beta);
   STEDM_LAUNCH_CHECK();
   return 0;

@@ -3,6 +3,7 @@
 
 #include "common.hpp"
 #include "dropmask.hpp"
+#include "sgemm.hpp"
 
 namespace stedm {
 static thread_local char g_err[512] = "";
@@ -642,6 +643,12 @@ static int launch_linear(const float* x, const float* wt, const float* bias, flo
   if (N % 4 == 0 && B <= 2 && (size_t)(2 * K + 16 * 2 * 64) * sizeof(float) <= 64 * 1024) {
     const size_t lds = (size_t)(2 * K + 16 * 2 * 64) * sizeof(float);
     linear_rows_kernel<2><<<(N + 63) / 64, 256, lds, st>>>(x, wt, bias, out, B, K, N, act_in, act_out);
+    STEDM_LAUNCH_CHECK();
+    return 0;
+  }
+  if (B > LIN_ROWS) {      // more rows than one block of the row-streaming kernel holds: the tiled GEMM (sgemm.hpp), x read once per column tile
+    stedm::SgemmArgs g{x, (long)K, 0, wt, (long)N, 0, out, (long)N, B, N, K, 1.0f, 0.0f, K, nullptr, bias, act_in, act_out};
+    stedm::sgemm_launch(g, 1, st);
     STEDM_LAUNCH_CHECK();
     return 0;
   }

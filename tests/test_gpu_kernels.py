@@ -280,6 +280,53 @@ def test_attn_legacy16_mfma_key_tiles(dev, prec, tol, tol16, B, T, heads, ch):
     assert err < tol and err16 < tol16
 
 
+@pytest.mark.parametrize("M,N,K,ta,tb", [(64, 512, 512, False, False), (64, 10368, 512, False, False), (10368, 512, 64, True, False), (64, 512, 10368, False, False),
+                                         (512, 512, 64, True, False), (64, 512, 512, False, True), (225, 3, 512, False, False), (9, 512, 128, False, False),
+                                         (100, 77, 45, True, True), (33, 130, 1500, False, True), (1, 64, 2048, False, False), (300, 20, 31, True, False)])
+def test_gemm_f32_tiled_kernel_all_layouts(dev, M, N, K, ta, tb):
+    """stedm_gemm_f32 (sgemm.hpp: 64x64 / 64x16 / 16x64 / 16x16 tiles, K step 32 with register prefetch, split K with a fixed-order reduce) in
+    the four operand layouts, on the embedding path's shapes, on sizes that are multiples of nothing, with alpha / beta and through strided row
+    views, against fp64 (fp32 products and sums: 2e-6 of the row scale); bitwise the same on a second run."""
+    from stedm_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g).to(dev)
+    Bm = torch.randn((N, K) if tb else (K, N), generator=g).to(dev)
+    wide = torch.randn((M, N + 5), generator=g).to(dev)
+    C0 = wide[:, 2:2 + N]                                  # a strided view (ldc = N + 5)
+    ref = 0.5 * ((A.double().t() if ta else A.double()) @ (Bm.double().t() if tb else Bm.double())) + 0.25 * C0.double()
+    ws = torch.empty((1 << 22,), device=dev)
+    outs = []
+    for rep in range(2):
+        C = wide.clone()[:, 2:2 + N]
+        ops.gemm_f32(A, ta, Bm, tb, C, alpha=0.5, beta=0.25, ws=ws)
+        outs.append(C.clone())
+    err = float((outs[0].double() - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
+    assert err < 2e-6 * max(1.0, (K / 512) ** 0.5), err
+    assert torch.equal(outs[0], outs[1])
+    C = torch.full((M, N), float("nan"), device=dev)           # beta = 0 never reads the destination
+    ops.gemm_f32(A, ta, Bm, tb, C)
+    assert bool(torch.isfinite(C).all())
+
+
+@pytest.mark.parametrize("B,K,N,act_in,act_out,bias", [(64, 512, 10368, 1, 0, True), (64, 128, 512, 0, 1, True), (64, 512, 512, 0, 0, True), (256, 768, 512, 2, 2, True),
+                                                       (9, 100, 77, 1, 2, False), (225, 2, 512, 0, 2, True), (225, 512, 3, 0, 0, False), (17, 33, 4, 0, 0, True),
+                                                       (2, 512, 10368, 1, 0, True), (8, 512, 512, 0, 1, True)])
+def test_linear_kernel_forms_vs_fp64(dev, B, K, N, act_in, act_out, bias):
+    """stedm_linear: act_out(bias + act_in(x) wt) with wt K-major. Up to 2 rows / up to 8 rows per block: the row-streaming kernels; more rows: the
+    tiled GEMM of sgemm.hpp with the activations and the bias in its load / store paths (the time_embed and emb_layers Linears at a training
+    batch, Agg_Linear, the Swin position-bias MLP). Against fp64 on the same activations."""
+    from stedm_amd import ops
+    g = torch.Generator().manual_seed(B + 3 * K + 7 * N)
+    x = torch.randn((B, K), generator=g).to(dev)
+    wt = (torch.randn((K, N), generator=g) / K ** 0.5).to(dev)
+    b = torch.randn((N,), generator=g).to(dev) if bias else None
+    act = lambda v, a: torch.nn.functional.silu(v) if a == 1 else (torch.relu(v) if a == 2 else v)
+    ref = act(act(x.double(), act_in) @ wt.double() + (0 if b is None else b.double()), act_out)
+    out = ops.linear(x, wt, b, torch.full((B, N), float("nan"), device=dev), act_in=act_in, act_out=act_out)
+    err = float((out.double() - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
+    assert err < 3e-6, err
+
+
 def test_attn_flash_eight_wave_form_equals_the_four_wave_form(dev, tmp_path):
     """attn_flash_kernel has two workgroup forms: 4 waves / two-stage rings (128 queries) and 8 waves / four-stage rings (256 queries; chosen
     for T >= 1024 at 128-wide heads when the grid fills the chip, i.e. only at bench-sized batches). A wave does the same arithmetic in both, so
