@@ -595,11 +595,16 @@ __global__ void __launch_bounds__(256) linear_rows_kernel(const float* __restric
   extern __shared__ float lsm[];
   float* sx = lsm;                         // [ROWS][K]
   float* part = lsm + ROWS * K;            // [16][ROWS][64]
+  x += (long)blockIdx.y * ROWS * K;        // blockIdx.y: block of ROWS rows
+  out += (long)blockIdx.y * ROWS * N;
+  B = min(ROWS, B - (int)blockIdx.y * ROWS);
   const int q = threadIdx.x & 15, ks = threadIdx.x >> 4;
   const int n = blockIdx.x * 64 + q * 4;
+#pragma unroll 4      // (unconditional loads from a clamped row, several in flight: a load inside the bounds branch is waited for at its join)
   for (int i = threadIdx.x; i < ROWS * K; i += 256) {
     const int r = i / K, k = i - r * K;
-    float v = r < B ? x[(long)r * K + k] : 0.f;
+    float v = x[(long)min(r, B - 1) * K + k];
+    v = r < B ? v : 0.f;
     sx[i] = act_in == 1 ? silu_f(v) : (act_in == 2 ? fmaxf(v, 0.f) : v);
   }
   __syncthreads();
@@ -646,7 +651,16 @@ static int launch_linear(const float* x, const float* wt, const float* bias, flo
     STEDM_LAUNCH_CHECK();
     return 0;
   }
-  if (B > LIN_ROWS) {      // more rows than one block of the row-streaming kernel holds: the tiled GEMM (sgemm.hpp), x read once per column tile
+  // 3 rows and more: the same weight stream in blocks of 8 rows (blockIdx.y), x rows resident in LDS — while the weights are re-read by few
+  // enough row blocks (measured on MI355X, tools/bench_linear.py: B = 64: 7.7 / 9.9 / 38.8 us for 128 -> 512, 512 -> 512, 512 -> 10368 against
+  // 9.4 / 25.9 / 53.8 us on the tiled GEMM below; B = 256, N = 10368: 136 against 85 us)
+  if (N % 4 == 0 && (long)((B + 7) / 8) * ((N + 63) / 64) <= 2048 && (size_t)(8 * K + 16 * 8 * 64) * sizeof(float) <= 64 * 1024) {
+    const size_t lds = (size_t)(8 * K + 16 * 8 * 64) * sizeof(float);
+    linear_rows_kernel<8><<<dim3((N + 63) / 64, (B + 7) / 8), 256, lds, st>>>(x, wt, bias, out, B, K, N, act_in, act_out);
+    STEDM_LAUNCH_CHECK();
+    return 0;
+  }
+  if (B > LIN_ROWS) {      // many rows and a wide output: the tiled GEMM (sgemm.hpp), x read once per column tile
     stedm::SgemmArgs g{x, (long)K, 0, wt, (long)N, 0, out, (long)N, B, N, K, 1.0f, 0.0f, K, nullptr, bias, act_in, act_out};
     stedm::sgemm_launch(g, 1, st);
     STEDM_LAUNCH_CHECK();

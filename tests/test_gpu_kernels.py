@@ -310,11 +310,12 @@ def test_gemm_f32_tiled_kernel_all_layouts(dev, M, N, K, ta, tb):
 
 @pytest.mark.parametrize("B,K,N,act_in,act_out,bias", [(64, 512, 10368, 1, 0, True), (64, 128, 512, 0, 1, True), (64, 512, 512, 0, 0, True), (256, 768, 512, 2, 2, True),
                                                        (9, 100, 77, 1, 2, False), (225, 2, 512, 0, 2, True), (225, 512, 3, 0, 0, False), (17, 33, 4, 0, 0, True),
-                                                       (2, 512, 10368, 1, 0, True), (8, 512, 512, 0, 1, True)])
+                                                       (2, 512, 10368, 1, 0, True), (8, 512, 512, 0, 1, True), (300, 512, 10368, 1, 0, True), (70, 3000, 516, 2, 1, True)])
 def test_linear_kernel_forms_vs_fp64(dev, B, K, N, act_in, act_out, bias):
-    """stedm_linear: act_out(bias + act_in(x) wt) with wt K-major. Up to 2 rows / up to 8 rows per block: the row-streaming kernels; more rows: the
-    tiled GEMM of sgemm.hpp with the activations and the bias in its load / store paths (the time_embed and emb_layers Linears at a training
-    batch, Agg_Linear, the Swin position-bias MLP). Against fp64 on the same activations."""
+    """stedm_linear: act_out(bias + act_in(x) wt) with wt K-major. The weight-stream kernels (2 rows; blocks of 8 rows with x resident in LDS)
+    while few row blocks re-read the weights, the tiled GEMM of sgemm.hpp (activations and bias in its load / store paths) for many rows x wide
+    outputs, odd N or long K: the time_embed and emb_layers Linears at sampling / training batches, Agg_Linear, the Swin position-bias MLP.
+    Against fp64 on the same activations."""
     from stedm_amd import ops
     g = torch.Generator().manual_seed(B + 3 * K + 7 * N)
     x = torch.randn((B, K), generator=g).to(dev)
