@@ -794,14 +794,110 @@ __global__ void __launch_bounds__(256) ddim_step_kernel(const float* __restrict_
     }
 }
 
+// The same update with a thread's R = C H / (256 / W) elements of every operand held in registers: one round of independent loads instead of
+// three dependent passes over e_c / e_u (the kernel above is one block per sample, i.e. 64 busy CUs at the bench batch: all latency, 24 us per
+// step). Same operations in the same order as above (the sums run over r = part, part + parts, ...), so the results are the same bits.
+template <int R>
+__global__ void __launch_bounds__(256) ddim_step_reg_kernel(const float* __restrict__ x, const float* __restrict__ e_c, const float* __restrict__ e_u,
+                                                            const float* __restrict__ noise, const float* __restrict__ coefs,
+                                                            const int32_t* __restrict__ step_idx, float s, float phi, float* __restrict__ x_prev,
+                                                            float* __restrict__ pred_x0, int C, int H, int W) {
+  __shared__ float red[2][256];
+  __shared__ float ratio_w[256];
+  const int b = blockIdx.x;
+  const int idx = step_idx ? *step_idx : 0;
+  const float a_t = coefs[idx * 4 + 0], a_prev = coefs[idx * 4 + 1], sigma = coefs[idx * 4 + 2], sq1m = coefs[idx * 4 + 3];
+  const int CH = C * H;
+  const long base = (long)b * CH * W;
+  const int parts = 256 / W;               // host: 256 % W == 0 and CH == R * parts, every thread active
+  const int w = threadIdx.x % W, part = threadIdx.x / W;
+  float ec[R], eu[R], xv[R], nz[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) ec[j] = e_c[base + (long)(part + j * parts) * W + w];
+#pragma unroll
+  for (int j = 0; j < R; ++j) xv[j] = x[base + (long)(part + j * parts) * W + w];
+  if (e_u) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) eu[j] = e_u[base + (long)(part + j * parts) * W + w];
+  }
+  if (noise) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) nz[j] = noise[base + (long)(part + j * parts) * W + w];
+  }
+  if (e_u) {
+    float sc = 0.f, sw = 0.f;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      sc += ec[j];
+      sw += eu[j] + s * (ec[j] - eu[j]);
+    }
+    red[0][threadIdx.x] = sc;
+    red[1][threadIdx.x] = sw;
+    __syncthreads();
+    float mc = 0.f, mw = 0.f;
+    for (int p = 0; p < parts; ++p) {
+      mc += red[0][p * W + w];
+      mw += red[1][p * W + w];
+    }
+    mc /= (float)CH;
+    mw /= (float)CH;
+    __syncthreads();
+    float qc = 0.f, qw = 0.f;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const float ew = eu[j] + s * (ec[j] - eu[j]);
+      qc += (ec[j] - mc) * (ec[j] - mc);
+      qw += (ew - mw) * (ew - mw);
+    }
+    red[0][threadIdx.x] = qc;
+    red[1][threadIdx.x] = qw;
+    __syncthreads();
+    if (threadIdx.x < W) {
+      float vc = 0.f, vw = 0.f;
+      for (int p = 0; p < parts; ++p) {
+        vc += red[0][p * W + threadIdx.x];
+        vw += red[1][p * W + threadIdx.x];
+      }
+      ratio_w[threadIdx.x] = sqrtf(vc / (float)(CH - 1)) / sqrtf(vw / (float)(CH - 1));
+    }
+    __syncthreads();
+  }
+  const float sqrt_at = sqrtf(a_t);
+  const float dir_c = sqrtf(1.0f - a_prev - sigma * sigma);
+  const float sqrt_ap = sqrtf(a_prev);
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const long o = base + (long)(part + j * parts) * W + w;
+    float e = ec[j];
+    if (e_u) {
+      const float ew = eu[j] + s * (e - eu[j]);
+      e = (ew * ratio_w[w]) * phi + (1.0f - phi) * e;
+    }
+    const float x0 = (xv[j] - sq1m * e) / sqrt_at;
+    float xp = sqrt_ap * x0 + dir_c * e;
+    if (noise) xp += sigma * nz[j];
+    x_prev[o] = xp;
+    if (pred_x0) pred_x0[o] = x0;
+  }
+}
+
 extern "C" int stedm_ddim_step(const float* x, const float* e_c, const float* e_u, const float* noise, const float* coefs,
                                const int32_t* step_idx, float cfg_scale, float rescale_phi, float* x_prev, float* pred_x0,
                                int B, int C, int H, int W, void* stream) {
   STEDM_CHECK_ARG(x && e_c && coefs && x_prev, "ddim_step: null pointer");
   STEDM_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && W <= 256, "ddim_step: bad shape B=%d C=%d H=%d W=%d (W <= 256)", B, C, H, W);
   STEDM_CHECK_ARG(!e_u || C * H > 1, "ddim_step: std over (C,H) needs C*H > 1");
-  ddim_step_kernel<<<B, 256, 0, as_stream(stream)>>>(x, e_c, e_u, noise, coefs, step_idx, cfg_scale, rescale_phi, x_prev,
-                                                     pred_x0, C, H, W);
+  const int parts = 256 / W;
+  const bool reg = 256 % W == 0 && (C * H) % parts == 0;
+  const int per = reg ? C * H / parts : 0;
+#define DDIM_REG(RR) ddim_step_reg_kernel<RR><<<B, 256, 0, as_stream(stream)>>>(x, e_c, e_u, noise, coefs, step_idx, cfg_scale, rescale_phi, x_prev, pred_x0, C, H, W)
+  if (per == 16) DDIM_REG(16);          // 32 x 32 x 4 latents (the bench's)
+  else if (per == 4) DDIM_REG(4);       // 16 x 16 x 4
+  else if (per == 8) DDIM_REG(8);
+  else
+    ddim_step_kernel<<<B, 256, 0, as_stream(stream)>>>(x, e_c, e_u, noise, coefs, step_idx, cfg_scale, rescale_phi, x_prev,
+                                                       pred_x0, C, H, W);
+#undef DDIM_REG
   STEDM_LAUNCH_CHECK();
   return 0;
 }

@@ -882,8 +882,7 @@ class UNetModel(nn.Module):
             emb_d = emb_e
         else:  # decoder rows b and b+B share timestep row b
             emb_d = self._buf("emb_all_d", (Bd, self._emb_ntot))
-            for r in range(nrep):
-                emb_d[r * B:(r + 1) * B].copy_(emb_e)
+            emb_d.view(nrep, B, self._emb_ntot).copy_(emb_e.unsqueeze(0).expand(nrep, B, self._emb_ntot))
         style_all = self._style_proj(contexts, B, ted)
 
         conv0 = self.input_blocks[0][0]
@@ -908,10 +907,10 @@ class UNetModel(nn.Module):
             h2 = self._buf("mid.rep", (Bd,) + tuple(h.shape[1:]))
             cs1 = self._cs.get(h.data_ptr())
             cs2 = self._cs_new(h2, nslab=cs1.shape[1]) if cs1 is not None else None
-            for r in range(nrep):
-                h2[r * B:(r + 1) * B].copy_(h)
-                if cs2 is not None:      # the replicas share the statistics of the shared-encoder tensor
-                    cs2[r * B:(r + 1) * B].copy_(cs1)
+            # (one broadcast copy per tensor instead of nrep device-to-device memcpys: four launches of ~5 us were 0.4 % of the bench step)
+            h2.view((nrep,) + tuple(h.shape)).copy_(h.unsqueeze(0).expand((nrep,) + tuple(h.shape)))
+            if cs2 is not None:      # the replicas share the statistics of the shared-encoder tensor
+                cs2.view((nrep,) + tuple(cs1.shape)).copy_(cs1.unsqueeze(0).expand((nrep,) + tuple(cs1.shape)))
             h = h2
         def first_takes_cat(blk):      # a decoder block whose first layer is a ResBlock with a skip_connection convolution (always, in this net)
             l0 = list(blk)[0]

@@ -366,7 +366,8 @@ def test_attn_flash_eight_wave_form_equals_the_four_wave_form(dev, tmp_path):
 
 # ------------------------------------------------------------------------------------------------ DDIM
 @pytest.mark.parametrize("B,C,H,W,cfg,eta", [(2, 4, 32, 32, True, 0.0), (3, 3, 16, 16, True, 1.0), (2, 4, 8, 8, False, 1.0),
-                                             (1, 3, 128, 128, True, 0.0), (2, 4, 12, 24, True, 0.5)])
+                                             (1, 3, 128, 128, True, 0.0), (2, 4, 12, 24, True, 0.5),
+                                             (2, 4, 16, 16, True, 1.0), (3, 8, 8, 32, False, 0.5), (64, 4, 32, 32, True, 1.0)])   # (register-resident forms: 4 / 8 / 16 elements per thread)
 def test_ddim_step(dev, B, C, H, W, cfg, eta):
     from oracle import ddim as od
     from stedm_amd import ops
