@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STEDM_ABI_VERSION 11
+#define STEDM_ABI_VERSION 12
 
 #define STEDM_F16 0
 #define STEDM_BF16 1
@@ -270,6 +270,17 @@ typedef struct stedm_conv_args {
    * that 1x1 read the tensor, so no fp32 copy of it is ever stored. Register-streamed kernel, single-product modes, no out16_lo
    * (stedm_conv_rs_ok tells; split-K launches take it too). */
   int32_t out16_stride;
+  /* Optional (round 5, ABI 12): the GroupNorm of gn_* in the epilogue also where a sample spans 2 .. 4 tiles of 256 pixels (the 32 x 32 level at
+   * 128 channels: ResBlock.out_layers[0:2] behind in_layers' convolution, openaimodel.py:236-241). The tiles of a sample exchange their channel
+   * sums inside the launch: gn_coop [B][4][128][2] 8-byte words {tag, fp32 bits} that every tile stores write-through and its partners poll
+   * until the tag equals *gn_coop_epoch (a device word the caller advances once before every forward — never 0, frozen in no graph), then
+   * every tile normalises its own staged rows. gn_coop must be zero before its first use and belongs to ONE call site (a second launch of the
+   * same forward needs its own words); a spin that gives up ORs a code into *gn_coop_tmo (the caller checks it where it checks the fp16
+   * guard) and the planes of that launch are garbage. Taken when cout == 128 (one N-tile), no split K, single product; the call ends with
+   * the stedm_gn_apply16c pass as before otherwise. */
+  void* gn_coop;
+  const uint32_t* gn_coop_epoch;
+  uint32_t* gn_coop_tmo;
 } stedm_conv_args;
 /* Replaces: GN->SiLU->conv3x3(+bias)(+emb)(+skip) of ResBlock._forward openaimodel.py:268-288,
  * Downsample/Upsample convs (:122-132,:156-173), 1x1 skip_connection (:254), and the 1x1

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STEDM_HIP_LIB") or os.path.join(_HERE, "libstedm_hip.so")     # STEDM_HIP_LIB: A/B timing of another build
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 F16, BF16 = 0, 1
 CONV_S1, CONV_DOWN, CONV_UP, CONV_UP_SUBPIXEL, CONV_S2D = 0, 1, 2, 3, 4
 
@@ -43,6 +43,7 @@ class ConvArgs(C.Structure):
         ("qkv_T", C.c_int32), ("qkv_Tp", C.c_int32), ("qkv_heads", C.c_int32), ("qkv_qscale", C.c_float),
         ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_res", C.c_void_p), ("ln_eps", C.c_float),
         ("out16_stride", C.c_int32),
+        ("gn_coop", C.c_void_p), ("gn_coop_epoch", C.c_void_p), ("gn_coop_tmo", C.c_void_p),
     ]
 
 

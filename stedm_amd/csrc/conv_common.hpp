@@ -23,6 +23,7 @@ struct ConvParams {
   int stats_done;  // set by a launcher whose epilogue wrote a.chan_stats (otherwise the dispatcher runs gn_chan_stats)
   int gn_done;     // set by a launcher that wrote a.gn_out16 itself (otherwise the dispatcher runs gn_apply16c)
   int gn_tile;     // register-streamed kernel: its tiles hold whole samples x whole groups -> the epilogue writes a.gn_out16 (conv_rs_try)
+  int gn_coop;     // ... or 2 .. 4: tiles per sample that exchange their channel sums inside the launch (a.gn_coop, conv_rs.inc) and then do the same
   int xcd_m;       // register-streamed kernel: XCD-aware block -> tile order: 0 plain, else gm in {8, 4, 2} = the M-tiles are dealt over gm XCD groups, the N-tiles over 8 / gm (conv_rs_kernel)
   int npers;       // register-streamed 1x1 kind: N-persistent form (one block per M-tile walks all N-tiles; conv_rs_try)
   unsigned* ovf;   // fp16 operand range guard flag (common.hpp) or nullptr; set by the dispatcher for fp16 launches

@@ -84,6 +84,7 @@ def f16_guard_enable() -> torch.Tensor:
 def f16_guard_check(where: str = "") -> None:
     """Read (synchronising) and clear the flag of the current device; raise StedmHipError when an fp16 operand overflowed since the last
     check. A no-op when no fp16-mode model ever enabled the guard on this device."""
+    coop_check(where)
     w = _F16_GUARD.get(torch.cuda.current_device()) if torch.cuda.is_available() else None
     if w is None:
         return
@@ -95,6 +96,33 @@ def f16_guard_check(where: str = "") -> None:
             f"fp16 operand overflow{' in ' + where if where else ''}: a value beyond the fp16 range (|x| > 65504) or a NaN was rounded into "
             f"an MFMA operand plane [{sites}]. The reference computes in fp32; run this checkpoint with precision='bf16', or 'parity_bf16' for the 1e-3 tolerance (fp32 exponent "
             f"range) — the 'f16' and 'parity' modes cannot represent its activations.")
+
+
+# ------------------------------------------------------------------------------------------- in-launch GroupNorm hand-off (stedm_conv_args.gn_coop)
+_COOP: dict = {}               # device index -> [int32[4] per model]: word 0 = the epoch of the model's current forward, word 1 = the give-up flag of the bounded spins
+
+
+def coop_words_new() -> torch.Tensor:
+    """Two device words for the cooperative GroupNorm epilogue of ONE model on the current device (a model's forwards are serial; two models
+    may run on two streams). Registered for coop_check(); kept for the life of the process (captured graphs hold the addresses). Not inside a
+    graph capture."""
+    dev = torch.cuda.current_device()
+    w = torch.zeros((4,), dtype=torch.int32, device=torch.device("cuda", dev))
+    _COOP.setdefault(dev, []).append(w)
+    return w
+
+
+def coop_check(where: str = "") -> None:
+    """Read (synchronising) and clear the give-up flags; raise when a tile stopped waiting for its sample's other tiles (their planes are wrong)."""
+    ws = _COOP.get(torch.cuda.current_device(), []) if torch.cuda.is_available() else []
+    bad = False
+    for w in ws:
+        if int(w[1].item()):
+            w[1:2].zero_()
+            bad = True
+    if bad:
+        raise _lib.StedmHipError(f"cooperative GroupNorm epilogue{' in ' + where if where else ''}: a tile gave up waiting for the channel sums of its sample's other "
+                                 f"tiles (stedm_conv_args.gn_coop); the GroupNorm planes of that launch are invalid. STEDM_NO_GN_COOP=1 runs the separate pass instead.")
 
 
 # ------------------------------------------------------------------------------------------- weights
@@ -479,7 +507,7 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
                chan_stats: Optional[torch.Tensor] = None,
                skip: Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = None, query_fused: bool = False, query_rs: bool = False,
                ws: Optional[torch.Tensor] = None, pad_br: bool = False, w_frag16: Optional[torch.Tensor] = None,
-               gn_next: Optional[tuple] = None, qkv_planes: Optional[tuple] = None, ln_after: Optional[tuple] = None,
+               gn_next: Optional[tuple] = None, qkv_planes: Optional[tuple] = None, ln_after: Optional[tuple] = None, coop: Optional[tuple] = None,
                out16_stride: int = 0, cout: Optional[int] = None):
     """src1 [B,Hin,Win,c1] NHWC fp32 (fused path) and/or src16 = (hi, lo) 16-bit NHWC planes [B,Hin,Win,Cin] from
     gn_apply16 (DMA path) -> out [B,Hout,Wout,cout] NHWC fp32 (see stedm_conv_igemm).
@@ -522,6 +550,11 @@ def conv_igemm(src1: Optional[torch.Tensor], w_hi: torch.Tensor, w_lo: Optional[
             assert src16 is None or all(t is None or t.data_ptr() != g_lo.data_ptr() for t in src16), "gn_next lo planes alias the convolution's input planes"
             a.gn_out16_lo = g_lo.data_ptr()
         assert prec.npass == 1 or g_lo is not None, "gn_next in a 3-product mode needs the (hi, lo) planes"
+        if coop is not None:       # (words, state): [B][4][128][2] int64 words of this call site (zero before first use) + the model's coop_words_new()
+            cwd, cw = coop
+            assert cwd.dtype == torch.int64 and cwd.is_contiguous() and tuple(cwd.shape) == (out.shape[0], 4, 128, 2)
+            assert cw.dtype == torch.int32 and cw.numel() >= 2
+            a.gn_coop, a.gn_coop_epoch, a.gn_coop_tmo = cwd.data_ptr(), cw.data_ptr(), cw.data_ptr() + 4
     a.pad_br = int(pad_br)
     a.w_frag16 = _ptr(w_frag16)      # npass 3: the hi + lo streams of pack_conv_weight_frag16 in that mode
     a.w_frag = _ptr(w_frag) if prec.npass == 1 else None

@@ -564,8 +564,17 @@ class UNetModel(nn.Module):
                     ops.gn_apply16c_x16(co, self._cs[h.data_ptr()], None, None, h16_next[0], hraw, prec, gn2.weight, gn2.bias, gn2.eps, gn2.num_groups, 1)
                     done1 = True
             if not done1:
+                # (where a sample spans 2 .. 4 tiles - 32 x 32 pixels at 128 channels - the tiles exchange their channel sums inside the launch
+                #  and the GroupNorm still rides on the epilogue: stedm_conv_args.gn_coop; one word block per call site)
+                coop = None
+                if gn_next is not None and self._tape is None and prec.npass == 1 and co == 128 and 256 < H * W <= 1024:
+                    ck = (tag, B)
+                    coop = self._coop_bufs.get(ck)
+                    if coop is None:
+                        coop = self._coop_bufs[ck] = torch.zeros((B, 4, 128, 2), dtype=torch.int64, device=h.device)
                 ops.conv_igemm(None, pk.hi, pk.lo, h, prec=prec, src16=a16, bias=pk.bias, emb=emb_all, emb_offset=emb_off,
-                               emb_bstride=emb_bstride, w_frag=pk.frag, chan_stats=self._cs_new(h), ws=ws, w_frag16=pk.frag16, gn_next=gn_next)
+                               emb_bstride=emb_bstride, w_frag=pk.frag, chan_stats=self._cs_new(h), ws=ws, w_frag16=pk.frag16, gn_next=gn_next,
+                               coop=None if coop is None else (coop, self._coop_state))
         else:
             sc, sh = self._gn(tag + ".gn1", rb.in_layers[0], x1, x2, x2_bmod)
             ops.conv_igemm(x1, pk.hi, pk.lo, h, prec=prec, src2=x2, src2_bmod=x2_bmod, scale=sc, shift=sh, act=1, bias=pk.bias,
@@ -852,6 +861,9 @@ class UNetModel(nn.Module):
         self._raw16 = {}
         self._x16 = {}          # fp32 handle -> (raw plane of the next block's concat, channels): tensors that exist in 16 bits only
         self._catpp = 0
+        if getattr(self, "_coop_state", None) is None or self._coop_state.device != x.device:
+            self._coop_bufs, self._coop_state = {}, ops.coop_words_new()
+        ops.step_advance(self._coop_state, 1)      # the epoch of this forward's in-launch hand-offs (gn_coop): a device word, so that a replayed graph advances it too
         self._saved16 = {}
         self._saved_mr = {}
         self._plane_ctr = 0

@@ -643,6 +643,65 @@ def test_conv_16bit_only_output_with_statistics_into_a_wider_plane(dev, prec, B,
     assert torch.equal(cs, cs2)
 
 
+@pytest.mark.parametrize("prec,B,H,W,m16", [("f16", 64, 32, 32, False), ("bf16", 3, 32, 32, False), ("f16", 128, 32, 32, False), ("f16", 5, 16, 32, False),
+                                          ("bf16", 128, 16, 32, False), ("bf16", 7, 32, 24, False), ("bf16", 67, 32, 32, False)])
+def test_conv_group_norm_epilogue_across_the_tiles_of_a_sample(dev, prec, B, H, W, m16):
+    """stedm_conv_args.gn_coop (round 5): where a sample spans 2 .. 4 tiles of 256 pixels (32 x 32 and 16 x 32 pixels at 128 channels) the tiles
+    exchange their channel sums INSIDE the launch (8-byte {epoch, value} words, write-through, polled by one wave) and each normalises its own
+    rows: the GroupNorm + SiLU planes of ResBlock.out_layers come out of the convolution's epilogue and no fp32 tensor is stored. Against the
+    same convolution with an fp32 output followed by the stedm_gn_apply16c pass (same statistics, folded in the same order): the planes agree
+    to one unit of the 16-bit format, over eight forwards that reuse the word block under advancing epochs, with a second stream keeping
+    part of the chip busy (uneven arrival of a sample's tiles) and with the word block poisoned by a stale epoch; the give-up flag stays 0.
+    A 24-wide grid (the generic-shape form of the convolution) ends with the separate pass as before."""
+    from stedm_amd import ops
+    pr = ops.Precision.parse(prec)
+    c = 128
+    g = torch.Generator().manual_seed(B * 131 + H * 7 + W)
+    x = torch.randn(B, H, W, c, generator=g).to(dev)
+    w = (torch.randn(c, c, 3, 3, generator=g) / math.sqrt(c * 9)).to(dev)
+    bias = torch.randn(c, generator=g).to(dev)
+    emb = torch.randn(B, c, generator=g).to(dev)
+    gamma, beta = (1.0 + 0.3 * torch.randn(c, generator=g)).to(dev), (0.2 * torch.randn(c, generator=g)).to(dev)
+    h16 = torch.empty((B, H, W, c), dtype=torch.int16, device=dev)
+    ops.gn_apply16(x, None, h16, None, pr)
+    whi, wlo = ops.pack_conv_weight(w, pr); wf = ops.pack_conv_weight_frag(w, pr)
+    kw = dict(prec=pr, src16=(h16, None), bias=bias, emb=emb, emb_offset=0, emb_bstride=c, w_frag=wf)
+    ns = ops.gn_chan_nslab(H * W)
+    # reference: fp32 output + the separate pass
+    out = torch.empty(B, H, W, c, device=dev); cs = torch.empty(B, ns, c, 2, device=dev)
+    ops.conv_igemm(None, whi, wlo, out, chan_stats=cs, **kw)
+    ref = torch.empty((B, H, W, c), dtype=torch.int16, device=dev)
+    ops.gn_apply16c(out, cs, None, None, ref, None, pr, gamma, beta, 1e-5, 32, 1)
+    asf = lambda t: t.view(torch.float16 if prec == "f16" else torch.bfloat16).float()
+    unit = 2.0 ** (-10 if prec == "f16" else -7)
+    words = torch.zeros((B, 4, 128, 2), dtype=torch.int64, device=dev)
+    cw = ops.coop_words_new()
+    side = torch.cuda.Stream()
+    big = torch.randn(4096, 4096, device=dev)
+    for it in range(8):
+        ops.step_advance(cw, 1)
+        if it == 5:      # words of some other forward: tags that are not this epoch must be ignored like the zeros of a fresh block
+            words.fill_((int(cw[0].item()) + 1000) << 32 | 0x3f800000)
+        if it >= 3:      # uneven arrival: another stream holds part of the chip
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    big @ big
+        o2 = torch.full((B, H, W, c), float("nan"), device=dev); cs2 = torch.empty_like(cs)
+        planes = torch.full((B, H, W, c), 0x7e7e, dtype=torch.int16, device=dev)
+        ops.conv_igemm(None, whi, wlo, o2, chan_stats=cs2, gn_next=(gamma, beta, 1e-5, 32, 1, planes, None, True), coop=(words, cw), **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(cs, cs2)
+        d = (asf(planes) - asf(ref)).abs()
+        lim = unit * asf(ref).abs().clamp_min(2.0 ** -14) * 1.01
+        assert bool((d <= lim).all()), (it, float(d.max()))
+        assert float((planes != ref).float().mean()) < 2e-3, "more than rounding-boundary cases differ"
+        if W == 32 and B >= 64:      # (a grid that fills the chip: smaller ones take other kernels / split K and end with the pass)
+            assert bool(torch.isnan(o2).all()), "the epilogue form did not run (it stores no fp32 tensor: gn_only)"
+    assert int(cw[1].item()) == 0
+    ops.coop_check("test")
+
+
 def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_emb=True, use_res=True, seed=12, frag=False, ws=False, m16=False, want_rs=None):
     from stedm_amd import ops
     from stedm_amd._lib import CONV_DOWN, CONV_S1, CONV_UP, CONV_UP_SUBPIXEL
