@@ -545,7 +545,16 @@ class UNetModel(nn.Module):
                 # (3-product modes, round 4: the (hi, lo) pair; single-product: the hi plane)
                 gn_next = (gn2.weight, gn2.bias, gn2.eps, gn2.num_groups, 1, h16_next if prec.npass == 3 else h16_next[0], mr2, self._tape is None)
             done1 = False
-            if (gn_next is not None and self._tape is None and prec.npass == 1 and prec.mm_dtype == BF16 and H * W > 256 and B >= 8 and
+            # (where a sample spans 2 .. 4 tiles - 32 x 32 pixels at 128 channels - the tiles exchange their channel sums inside the launch
+            #  and the GroupNorm still rides on the epilogue: stedm_conv_args.gn_coop; one word block per call site)
+            coop = None
+            if gn_next is not None and self._tape is None and prec.npass == 1 and co == 128 and 256 < H * W <= 1024:
+                ck = (tag, B)
+                coop = self._coop_bufs.get(ck)
+                if coop is None:
+                    coop = self._coop_bufs[ck] = torch.zeros((B, 4, 128, 2), dtype=torch.int64, device=h.device)
+            coop_runs = coop is not None and B * H * W // 256 >= ops.device_cus() and not os.environ.get("STEDM_NO_GN_COOP")   # (a grid that fills the chip: no split K)
+            if (gn_next is not None and self._tape is None and prec.npass == 1 and prec.mm_dtype == BF16 and H * W > 256 and B >= 8 and not coop_runs and
                     not os.environ.get("STEDM_NO_H16ONLY") and ops.gn_apply16c_x16_ok(co, 0, gn2.num_groups)):
                 # Levels whose samples exceed a tile (32 x 32 and up): out_layers' GroupNorm cannot ride on the epilogue and nothing else reads h, so
                 # the convolution stores h as 16-bit values only (+ the channel statistics) and the GroupNorm pass reads 2 B per element.
@@ -564,14 +573,6 @@ class UNetModel(nn.Module):
                     ops.gn_apply16c_x16(co, self._cs[h.data_ptr()], None, None, h16_next[0], hraw, prec, gn2.weight, gn2.bias, gn2.eps, gn2.num_groups, 1)
                     done1 = True
             if not done1:
-                # (where a sample spans 2 .. 4 tiles - 32 x 32 pixels at 128 channels - the tiles exchange their channel sums inside the launch
-                #  and the GroupNorm still rides on the epilogue: stedm_conv_args.gn_coop; one word block per call site)
-                coop = None
-                if gn_next is not None and self._tape is None and prec.npass == 1 and co == 128 and 256 < H * W <= 1024:
-                    ck = (tag, B)
-                    coop = self._coop_bufs.get(ck)
-                    if coop is None:
-                        coop = self._coop_bufs[ck] = torch.zeros((B, 4, 128, 2), dtype=torch.int64, device=h.device)
                 ops.conv_igemm(None, pk.hi, pk.lo, h, prec=prec, src16=a16, bias=pk.bias, emb=emb_all, emb_offset=emb_off,
                                emb_bstride=emb_bstride, w_frag=pk.frag, chan_stats=self._cs_new(h), ws=ws, w_frag16=pk.frag16, gn_next=gn_next,
                                coop=None if coop is None else (coop, self._coop_state))
