@@ -11,5 +11,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_stepA -o 
 for kv in "$@"; do export "$kv"; done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_stepB -o run -- $B > $O/prof_${TAG}_stepB.log 2>&1 && echo B ok
 cd $R
-python3 tools/stats_md.py gpurun_out/prof_${TAG}_stepA ${TAG}_stepA "A" "$B" 4 "denoising step" ddim_step_kernel 5 | tail -1
-python3 tools/stats_md.py gpurun_out/prof_${TAG}_stepB ${TAG}_stepB "B: $*" "$B" 4 "denoising step" ddim_step_kernel 5 | tail -1
+python3 tools/stats_md.py gpurun_out/prof_${TAG}_stepA ${TAG}_stepA "A" "$B" 4 "denoising step" ddim_step 5 | tail -1
+python3 tools/stats_md.py gpurun_out/prof_${TAG}_stepB ${TAG}_stepB "B: $*" "$B" 4 "denoising step" ddim_step 5 | tail -1
