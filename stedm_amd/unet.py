@@ -548,12 +548,19 @@ class UNetModel(nn.Module):
             # (where a sample spans 2 .. 4 tiles - 32 x 32 pixels at 128 channels - the tiles exchange their channel sums inside the launch
             #  and the GroupNorm still rides on the epilogue: stedm_conv_args.gn_coop; one word block per call site)
             coop = None
-            if gn_next is not None and self._tape is None and prec.npass == 1 and co == 128 and 256 < H * W <= 1024:
+            # (only a grid that fills the chip: smaller ones split K or take other kernels and end with the pass anyway)
+            coop_runs = (gn_next is not None and self._tape is None and prec.npass == 1 and co == 128 and 256 < H * W <= 1024 and
+                         B * H * W // 256 >= ops.device_cus() and not os.environ.get("STEDM_NO_GN_COOP"))
+            if coop_runs:
                 ck = (tag, B)
                 coop = self._coop_bufs.get(ck)
                 if coop is None:
                     coop = self._coop_bufs[ck] = torch.zeros((B, 4, 128, 2), dtype=torch.int64, device=h.device)
-            coop_runs = coop is not None and B * H * W // 256 >= ops.device_cus() and not os.environ.get("STEDM_NO_GN_COOP")   # (a grid that fills the chip: no split K)
+                if not self._coop_advanced:
+                    # the epoch of this forward's hand-offs: a device word advanced by a one-thread launch (so that a replayed graph advances it
+                    # too), once per forward, in front of the first launch that uses it
+                    ops.step_advance(self._coop_state, 1)
+                    self._coop_advanced = True
             if (gn_next is not None and self._tape is None and prec.npass == 1 and prec.mm_dtype == BF16 and H * W > 256 and B >= 8 and not coop_runs and
                     not os.environ.get("STEDM_NO_H16ONLY") and ops.gn_apply16c_x16_ok(co, 0, gn2.num_groups)):
                 # Levels whose samples exceed a tile (32 x 32 and up): out_layers' GroupNorm cannot ride on the epilogue and nothing else reads h, so
@@ -864,7 +871,7 @@ class UNetModel(nn.Module):
         self._catpp = 0
         if getattr(self, "_coop_state", None) is None or self._coop_state.device != x.device:
             self._coop_bufs, self._coop_state = {}, ops.coop_words_new()
-        ops.step_advance(self._coop_state, 1)      # the epoch of this forward's in-launch hand-offs (gn_coop): a device word, so that a replayed graph advances it too
+        self._coop_advanced = False
         self._saved16 = {}
         self._saved_mr = {}
         self._plane_ctr = 0
