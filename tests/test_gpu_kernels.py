@@ -700,6 +700,12 @@ def test_conv_group_norm_epilogue_across_the_tiles_of_a_sample(dev, prec, B, H, 
             assert bool(torch.isnan(o2).all()), "the epilogue form did not run (it stores no fp32 tensor: gn_only)"
     assert int(cw[1].item()) == 0
     ops.coop_check("test")
+    if B == 64:      # the host side of a give-up: the flag a tile sets when its bounded spin ends raises at the next check and is cleared by it
+        from stedm_amd._lib import StedmHipError
+        cw[1:2].fill_(1)
+        with pytest.raises(StedmHipError, match="gave up waiting"):
+            ops.f16_guard_check("test")
+        ops.coop_check("test")
 
 
 def _conv_dma_case(dev, prec_name, tol, B, Hin, Win, cin, cout, mode, ks, use_emb=True, use_res=True, seed=12, frag=False, ws=False, m16=False, want_rs=None):
