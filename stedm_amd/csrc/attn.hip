@@ -343,7 +343,6 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) attn_flash_kernel(co
   typedef short s16x4 __attribute__((ext_vector_type(4)));
   typedef short s16x8 __attribute__((ext_vector_type(8)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  typedef __attribute__((address_space(3))) s16x4* lp4;
   constexpr int DP = CH < 32 ? 32 : CH;          // head width as the MFMAs see it
   constexpr int KS = DP / 16, DT = DP / 32;
   constexpr int NQK = 2 * KS, NPV = 4 * DT;      // MFMAs of a tile's two products (+ 2 reference steps in front of the first)

@@ -673,7 +673,6 @@ template <typename T, bool DROP = false>
 __global__ void __launch_bounds__(256, 2) lsa_flash64_kernel(FlashArgs a) {
   using V8 = typename MM<T>::V8;
   typedef T V4t __attribute__((ext_vector_type(4)));
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
   constexpr int NBUF = 3, TILE_B = 16384;          // K 8 KiB | V^T 8 KiB
   constexpr int O_BYTES = 4 * 32 * 65 * (int)sizeof(float);
   constexpr int LDS_B = NBUF * TILE_B > O_BYTES ? NBUF * TILE_B : O_BYTES;
