@@ -235,7 +235,8 @@ def test_captured_train_step_equals_the_eager_step_bitwise(dev, precision, overl
     """UNetTrainer.train_step_graphed: three eager steps, then the whole step (forward, L1, backward, AdamW + EMA + re-pack) captured once and
     replayed as one hipGraph launch with a different batch every step. Against train_step() on a second copy of the model: the loss of each
     of nine steps, every parameter, EMA shadow, optimizer moment and weight pack bit for bit (the optimizer kernels read this step's bias
-    corrections / EMA decay / learning rate from the device schedule, built with the host arithmetic of the eager launch); a learning-rate
+    corrections / EMA decay / learning rate from the device schedule, built with the host arithmetic of the eager launch — in bf16 with a
+    window of 3 rows, so that the schedule is re-filled between replays); a learning-rate
     change between two replays reaches the device schedule; an eager step in between (a stranger moving the parameters) drops the graph and
     the following calls re-capture; with the optimizer overlapped on a side stream the fork / join is part of the graph."""
     from stedm_amd.train import UNetTrainer
@@ -247,6 +248,8 @@ def test_captured_train_step_equals_the_eager_step_bitwise(dev, precision, overl
         tr = UNetTrainer(m, lr=2e-4, weight_decay=0.01)
         tr.overlap_optimizer = overlap
         tr.opt_bucket_mb = 1
+        if precision == "bf16":
+            tr.GRAPH_WINDOW = 3      # (the device schedule is re-filled every other replay: rows 1, 2 of a window, then the next window)
         losses, replays = [], 0
         for step in range(9):
             x, ctx, target = _inputs(f"cap{step}", cfg, 2, 16, 6 + step, dev)
