@@ -458,6 +458,9 @@ class UNetModel(nn.Module):
         plain conversion of [x1|x2] (operand of the 1x1 skip_connection) produced by the same pass."""
         B, H, W, _ = x1.shape
         C = x1.shape[-1] + (0 if x2 is None else x2.shape[-1])
+        pre = self._pre16.pop(x1.data_ptr(), None) if self._pre16 else None
+        if pre is not None and norm is not None and pre[0] == id(norm) and pre[1] == act and x2 is None and not want_raw and self._tape is None:
+            return pre[2]          # the producing convolution's call wrote this GroupNorm's planes already (_res: next_norm)
         x16 = self._x16.pop(x1.data_ptr(), None)
         if x16 is not None:
             # x1 was never stored in fp32: its producer wrote the 16-bit values into channels [0, c1) of this block's raw plane and left the
@@ -494,13 +497,28 @@ class UNetModel(nn.Module):
                         norm.weight, norm.bias, norm.eps, norm.num_groups, act, x2_bmod, raw, mean_rstd=mr)
         return ((hi, lo), raw) if want_raw else (hi, lo)
 
+    def _coop_for(self, site: str, B, H, W, co, prec):
+        """(words, state) for stedm_conv_args.gn_coop at call site `site`, or None: a sample of 2 .. 4 tiles at 128 channels on a grid that fills
+        the chip (smaller ones split K or take other kernels and end with the pass anyway), single product. The first use in a forward advances
+        the epoch: a device word, moved by a one-thread launch so that a replayed graph moves it too."""
+        if not (prec.npass == 1 and co == 128 and 256 < H * W <= 1024 and B * H * W // 256 >= ops.device_cus() and not os.environ.get("STEDM_NO_GN_COOP")):
+            return None
+        ck = (site, B)
+        words = self._coop_bufs.get(ck)
+        if words is None:
+            words = self._coop_bufs[ck] = torch.zeros((B, 4, 128, 2), dtype=torch.int64, device=self._coop_state.device)
+        if not self._coop_advanced:
+            ops.step_advance(self._coop_state, 1)
+            self._coop_advanced = True
+        return words, self._coop_state
+
     def _cat_plane(self, B, H, W, co, next_cat):
         """The raw plane [B,H,W,next_cat] of the NEXT block's concat input, whose channels [0, co) a producer fills (two buffers per shape in
         turn: the block that writes the next one's plane is still reading its own through the fused skip_connection)."""
         self._catpp ^= 1
         return self._buf(f"cat16.{self._catpp}.{B}x{H}x{W}x{next_cat}", (B, H, W, next_cat), torch.int16)
 
-    def _res(self, tag: str, rb: ResBlock, x1, x2, emb_all, emb_off, emb_bstride, x2_bmod=0, want16=False, next_cat=None):
+    def _res(self, tag: str, rb: ResBlock, x1, x2, emb_all, emb_off, emb_bstride, x2_bmod=0, want16=False, next_cat=None, next_norm=None):
         """ResBlock._forward openaimodel.py:268-288 on NHWC tensors; [x1|x2] is the virtual concat input.
         next_cat (inference, single product): the channel count of the NEXT block's th.cat([h, hs.pop()]) input (openaimodel.py:800) when nothing
         but that block's GroupNorm and skip_connection read this block's output: the tail convolution then writes it as 16-bit values straight
@@ -547,20 +565,8 @@ class UNetModel(nn.Module):
             done1 = False
             # (where a sample spans 2 .. 4 tiles - 32 x 32 pixels at 128 channels - the tiles exchange their channel sums inside the launch
             #  and the GroupNorm still rides on the epilogue: stedm_conv_args.gn_coop; one word block per call site)
-            coop = None
-            # (only a grid that fills the chip: smaller ones split K or take other kernels and end with the pass anyway)
-            coop_runs = (gn_next is not None and self._tape is None and prec.npass == 1 and co == 128 and 256 < H * W <= 1024 and
-                         B * H * W // 256 >= ops.device_cus() and not os.environ.get("STEDM_NO_GN_COOP"))
-            if coop_runs:
-                ck = (tag, B)
-                coop = self._coop_bufs.get(ck)
-                if coop is None:
-                    coop = self._coop_bufs[ck] = torch.zeros((B, 4, 128, 2), dtype=torch.int64, device=h.device)
-                if not self._coop_advanced:
-                    # the epoch of this forward's hand-offs: a device word advanced by a one-thread launch (so that a replayed graph advances it
-                    # too), once per forward, in front of the first launch that uses it
-                    ops.step_advance(self._coop_state, 1)
-                    self._coop_advanced = True
+            coop = self._coop_for(tag, B, H, W, co, prec) if gn_next is not None and self._tape is None else None
+            coop_runs = coop is not None
             if (gn_next is not None and self._tape is None and prec.npass == 1 and prec.mm_dtype == BF16 and H * W > 256 and B >= 8 and not coop_runs and
                     not os.environ.get("STEDM_NO_H16ONLY") and ops.gn_apply16c_x16_ok(co, 0, gn2.num_groups)):
                 # Levels whose samples exceed a tile (32 x 32 and up): out_layers' GroupNorm cannot ride on the epilogue and nothing else reads h, so
@@ -582,7 +588,7 @@ class UNetModel(nn.Module):
             if not done1:
                 ops.conv_igemm(None, pk.hi, pk.lo, h, prec=prec, src16=a16, bias=pk.bias, emb=emb_all, emb_offset=emb_off,
                                emb_bstride=emb_bstride, w_frag=pk.frag, chan_stats=self._cs_new(h), ws=ws, w_frag16=pk.frag16, gn_next=gn_next,
-                               coop=None if coop is None else (coop, self._coop_state))
+                               coop=coop)
         else:
             sc, sh = self._gn(tag + ".gn1", rb.in_layers[0], x1, x2, x2_bmod)
             ops.conv_igemm(x1, pk.hi, pk.lo, h, prec=prec, src2=x2, src2_bmod=x2_bmod, scale=sc, shift=sh, act=1, bias=pk.bias,
@@ -593,6 +599,21 @@ class UNetModel(nn.Module):
         if dma and want16:     # the consumer (Upsample) reads plain 16-bit planes: the conv epilogue writes them, no conversion pass
             o16 = self._planes(B, H, W, co, "up16")
             self._raw16[out.data_ptr()] = o16
+        # next_norm = (GroupNorm32, act) of the layer that reads this block's output alone (the next ResBlock's in_layers without a
+        # skip_connection convolution, an AttentionBlock's norm): the tail convolution's call writes that GroupNorm's planes too - in its
+        # epilogue / split-K reduce pass where a workgroup owns whole groups of whole samples, by the same trailing pass otherwise - and
+        # _norm16 hands them out instead of running its own pass (inference)
+        gnn, npl, coop2 = None, None, None
+        if next_norm is not None and dma and self._tape is None and o16 is None and next_cat is None and not os.environ.get("STEDM_NO_NEXT_GN"):
+            nn_, nact = next_norm
+            npl = self._planes(B, H, W, co)
+            gnn = (nn_.weight, nn_.bias, nn_.eps, nn_.num_groups, nact, npl if prec.npass == 3 else npl[0], None, False)
+            coop2 = self._coop_for(tag + ".c2", B, H, W, co, prec)     # (32 x 32 at 128 channels: the in-launch hand-off, as for out_layers' GroupNorm)
+
+        def filed():
+            if gnn is not None:
+                self._pre16[out.data_ptr()] = (id(next_norm[0]), next_norm[1], npl)
+            return out
         if dma and has_skip:
             # conv2 + skip_connection(x) in one kernel when the register-streamed kernel covers the problem (asked once per shape)
             ps = self._packed[id(rb.skip_connection)]
@@ -632,11 +653,13 @@ class UNetModel(nn.Module):
                 self._cs.pop(out.data_ptr(), None)          # (no statistics are written for the handle: nothing may find a buffer for it)
                 ops.conv_igemm(None, pk2.hi, pk2.lo, None, skip=(x16[0], ps.frag, ps.bias, ps.frag16), **kw)
             elif fused:
-                ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias, ps.frag16), **kw)
+                ops.conv_igemm(None, pk2.hi, pk2.lo, out, skip=(x16[0], ps.frag, ps.bias, ps.frag16), gn_next=gnn, **kw)
+                return filed()
             else:
                 ops.conv_igemm(None, ps.hi, ps.lo, out, prec=prec, ks=1, src16=x16, bias=ps.bias, w_frag=ps.frag, ws=ws,
                                w_frag16=ps.frag16 if prec.npass == 3 else None)
-                ops.conv_igemm(None, pk2.hi, pk2.lo, out, res=out, **kw)
+                ops.conv_igemm(None, pk2.hi, pk2.lo, out, res=out, gn_next=gnn, **kw)
+                return filed()
             return out
         if not has_skip:
             assert x2 is None
@@ -661,7 +684,8 @@ class UNetModel(nn.Module):
                     self._x16[out.data_ptr()] = (rawn, co)
                     return out
             ops.conv_igemm(None, pk2.hi, pk2.lo, out, prec=prec, src16=h16, bias=pk2.bias, res=res, w_frag=pk2.frag,
-                           chan_stats=self._cs_new(out), ws=ws, out16=o16, w_frag16=pk2.frag16)
+                           chan_stats=self._cs_new(out), ws=ws, out16=o16, w_frag16=pk2.frag16, gn_next=gnn, coop=coop2)
+            return filed()
         else:
             sc2, sh2 = self._gn(tag + ".gn2", rb.out_layers[0], h)
             ops.conv_igemm(h, pk2.hi, pk2.lo, out, prec=prec, scale=sc2, shift=sh2, act=1, bias=pk2.bias, res=res)
@@ -705,7 +729,18 @@ class UNetModel(nn.Module):
             ops.conv_igemm(a, pp.hi, pp.lo, out, prec=prec, ks=1, bias=pp.bias, res=x)
         return out
 
-    def _run_block(self, tag: str, blk, h, skip, emb_all, emb_bstride, style_all, skip_bmod=0, li0=0, next_skip_c=None):
+    @staticmethod
+    def _first_norm(layer):
+        """(GroupNorm32, act) of the first thing `layer` does with its input when it reads that tensor alone and needs no raw copy of it, else None"""
+        if isinstance(layer, ResBlockStyle):
+            layer = layer.block
+        if isinstance(layer, ResBlock):
+            return (layer.in_layers[0], 1) if isinstance(layer.skip_connection, nn.Identity) else None
+        if isinstance(layer, AttentionBlock):
+            return (layer.norm, 0)
+        return None
+
+    def _run_block(self, tag: str, blk, h, skip, emb_all, emb_bstride, style_all, skip_bmod=0, li0=0, next_skip_c=None, next_layer=None):
         """TimestepEmbedSequential.forward openaimodel.py:93-101 (+ the th.cat of :800 folded into the first layer).
         next_skip_c: channels of the skip tensor the NEXT block concatenates to this block's output (decoder), when that block starts with a
         ResBlock that has a skip_connection convolution: the last layer here may then write its output as 16-bit values into that concat's
@@ -724,13 +759,14 @@ class UNetModel(nn.Module):
                 if cat_ok and nxt is None and ops.gn_apply16c_x16_ok(layer.out_channels, next_skip_c):
                     ncat = layer.out_channels + next_skip_c
                 h = self._res(ltag, layer, h, skip, emb_all, self._emb_off[id(layer)], emb_bstride, x2_bmod=skip_bmod,
-                              want16=isinstance(nxt, Upsample), next_cat=ncat)
+                              want16=isinstance(nxt, Upsample), next_cat=ncat, next_norm=self._first_norm(nxt if nxt is not None else next_layer))
                 if self._tape is not None:
                     self._tape.append(("res", layer, x1, skip, self._last_h, h, self._emb_off[id(layer)]))
                 skip = None
             elif isinstance(layer, ResBlockStyle):
                 x1 = h
-                h = self._res(ltag, layer.block, h, None, style_all, 0, style_all.shape[1])      # (never the last layer of its block: no next_cat)
+                h = self._res(ltag, layer.block, h, None, style_all, 0, style_all.shape[1],       # (never the last layer of its block: no next_cat)
+                              next_norm=self._first_norm(nxt if nxt is not None else next_layer))
                 if self._tape is not None:
                     self._tape.append(("res", layer.block, x1, None, self._last_h, h, None))
             elif isinstance(layer, AttentionBlock):
@@ -869,6 +905,7 @@ class UNetModel(nn.Module):
         self._raw16 = {}
         self._x16 = {}          # fp32 handle -> (raw plane of the next block's concat, channels): tensors that exist in 16 bits only
         self._catpp = 0
+        self._pre16 = {}        # fp32 handle -> (id(norm), act, planes): GroupNorm planes written ahead by the producing convolution's call
         if getattr(self, "_coop_state", None) is None or self._coop_state.device != x.device:
             self._coop_bufs, self._coop_state = {}, ops.coop_words_new()
         self._coop_advanced = False
@@ -917,12 +954,15 @@ class UNetModel(nn.Module):
             self._tape.append(("conv_in", x, c_concat, h))
             self._tape_emb = (timesteps, emb, contexts[0])
         hs = [h]
+        mid = list(self.middle_block)
+        nblk = len(self.input_blocks)
         for i, blk in enumerate(self.input_blocks[1:], start=1):
-            h = self._run_block(f"in{i}", blk, h, None, emb_e, emb_stride, None)
+            # (the layer that reads this block's output alone, if any: its GroupNorm may ride on this block's tail convolution)
+            nl = list(self.input_blocks[i + 1])[0] if i + 1 < nblk else mid[0]
+            h = self._run_block(f"in{i}", blk, h, None, emb_e, emb_stride, None, next_layer=nl)
             hs.append(h)
         # middle block: [0] shared, then replicate the batch for the style-conditioned remainder
-        mid = list(self.middle_block)
-        h = self._run_block("mid.a", mid[:1], h, None, emb_e, emb_stride, None)
+        h = self._run_block("mid.a", mid[:1], h, None, emb_e, emb_stride, None, next_layer=mid[1] if nrep == 1 and len(mid) > 1 else None)
         if nrep > 1:
             h2 = self._buf("mid.rep", (Bd,) + tuple(h.shape[1:]))
             cs1 = self._cs.get(h.data_ptr())

@@ -920,6 +920,21 @@ def test_conv_fused_skip(dev, prec, tol, B, H, W, cin, cb, cout, emb, m16):
     for k in range(cs.shape[1]):
         sl = flat[:, k * 256:(k + 1) * 256]
         assert torch.allclose(cs[:, k, :, 0].double(), sl.sum(1), rtol=1e-4, atol=2e-3)
+    if cout % 32 == 0:
+        # round 5: the NEXT block's in_layers GroupNorm + SiLU riding on this call (gn_next; in the epilogue where a tile holds whole samples and
+        # whole groups - also behind the fused phase now - by the trailing pass otherwise): same fp32 output and statistics, planes equal to
+        # the separate stedm_gn_apply16c pass to one unit of the 16-bit format
+        gamma = (1.0 + 0.3 * prng.normal(21, "fs.g", (cout,))).to(dev); beta = (0.2 * prng.normal(21, "fs.bt", (cout,))).to(dev)
+        ref16 = torch.empty((B, H, W, cout), dtype=torch.int16, device=dev)
+        ops.gn_apply16c(out, cs, None, None, ref16, None, pr, gamma, beta, 1e-5, 32, 1)
+        out2 = torch.full_like(out, float("nan")); cs2 = torch.full_like(cs, float("nan"))
+        planes = torch.full((B, H, W, cout), 0x7e7e, dtype=torch.int16, device=dev)
+        ops.conv_igemm(None, whi, wlo, out2, gn_next=(gamma, beta, 1e-5, 32, 1, planes, None, False), **dict(kw, chan_stats=cs2))
+        assert torch.equal(out2, out) and torch.equal(cs2, cs)
+        asf = lambda t: t.view(torch.float16 if pr.label == "f16" else torch.bfloat16).float()
+        unit = 2.0 ** (-10 if pr.label == "f16" else -7)
+        d = (asf(planes) - asf(ref16)).abs()
+        assert bool((d <= unit * asf(ref16).abs().clamp_min(2.0 ** -14) * 1.01).all()), float(d.max())
 
 
 @pytest.mark.parametrize("prec,tol", PRECS[1:])
